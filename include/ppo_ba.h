@@ -1,0 +1,278 @@
+/*
+ * ppo_ba.h -- C ABI of libppo_ba.so, the MI355X-native local bundle adjustment that replaces the
+ * g2o section of Optimizer::LocalBACameraPlaneCuboids.
+ *
+ * Reference seam (paths relative to the reference checkout):
+ *   include/Optimizer.h:62          static void LocalBACameraPlaneCuboids(KeyFrame*, bool*, Map*, bool, bool)
+ *   src/LocalMapping.cc:100         the only call site
+ *   src/Optimizer.cc:2108-2116      g2o solver set-up                      -> ppo_ba_create()
+ *   src/Optimizer.cc:2120-2714      vertex / edge construction             -> the arrays of ppo_ba_problem
+ *   src/Optimizer.cc:2723-2838      5 LM iterations, outlier pass, 10 more -> ppo_ba_run()
+ *   src/Optimizer.cc:2840-2966      erase lists + write-back               <- ppo_ba_read()
+ *
+ * Everything is plain C: caller-owned pointers and sizes, no C++ types, no exceptions.  The library
+ * copies what it needs inside ppo_ba_create(); no caller pointer is retained after it returns.
+ *
+ * Conventions (each cites the reference):
+ *   pose     world->camera, (qx,qy,qz,qw,tx,ty,tz); update [omega(3), upsilon(3)], T <- exp(d)*T
+ *            (Thirdparty/g2o/g2o/types/se3quat.h:274-308, types_six_dof_expmap.h:73-91)
+ *   point    xyz, additive update (Thirdparty/g2o/g2o/types/types_sba.h:52-56)
+ *   plane    (nx,ny,nz,d), |n|=1, d>=0; 3-DoF update (azimuth, elevation, distance)
+ *            (include/G2O_Plane3D.h:45-87,120-125)
+ *   cuboid   object->world (qx,qy,qz,qw,tx,ty,tz) + half extents; 9-DoF update
+ *            [omega(3), upsilon(3), dscale(3)], right-multiplicative (src/g2o_cuboid.cc:39-67)
+ */
+#ifndef PPO_BA_H
+#define PPO_BA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPO_BA_ABI_VERSION 1
+
+/* return codes: 0 ok, <0 error, >0 early termination */
+enum {
+  PPO_BA_OK = 0,
+  PPO_BA_ABORTED = 1,        /* *stop_flag became non-zero (Optimizer.cc:2723-2725, 2732-2734) */
+  PPO_BA_ERR_ARG = -1,       /* null pointer, negative size, index out of range */
+  PPO_BA_ERR_NONFINITE = -2, /* NaN/Inf in the inputs */
+  PPO_BA_ERR_NOMEM = -3,
+  PPO_BA_ERR_HIP = -4,       /* no device, kernel or runtime failure */
+  PPO_BA_ERR_SOLVER = -5,    /* dense factorisation backend failure (not "matrix not positive") */
+  PPO_BA_ERR_COMM = -6,      /* RCCL failure */
+  PPO_BA_ERR_STATE = -7      /* call order (read before run, ...) */
+};
+
+/* cuboid vertex mode bits (include/g2o_cuboid.h:284-287; set at Optimizer.cc:2167-2168) */
+enum { PPO_CUBOID_FIX_ROLLPITCH = 1, PPO_CUBOID_FIX_HEIGHT = 2, PPO_CUBOID_FIX_ROTATION = 4 };
+
+/* Jacobian mode for the edges g2o differentiates numerically */
+enum { PPO_JAC_NUMERIC = 0 /* central differences, delta = numeric_delta, as the reference */ };
+
+/* dense reduced-system backend */
+enum { PPO_SOLVER_AUTO = 0, PPO_SOLVER_ROCSOLVER = 1, PPO_SOLVER_NATIVE = 2 };
+
+/*
+ * The flattened factor graph.  All arrays are caller-owned and read-only.  Index arrays are 0-based
+ * dense per-type indices (the reference's colliding graph ids, Optimizer.cc:2125,2170,2214,2342, are
+ * not reproduced).  Edge blocks may be given in any order; order inside a block = the reference's
+ * addEdge order and defines the deterministic summation order of the oracle.
+ * info arrays hold the DIAGONAL of the information matrix (every information matrix built by
+ * Optimizer.cc:2240-2244, 2273-2276, 2297-2300, 2377, 2405, 2465, 2533, 2645-2647, 2696-2700 is diagonal).
+ * huber = RobustKernelHuber delta (residual-norm units, compared against chi2 as delta^2,
+ * Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:78-91); huber <= 0 means "no robust kernel".
+ */
+typedef struct ppo_ba_problem {
+  /* -- vertices ------------------------------------------------------------------------------- */
+  int32_t n_poses;            /* local + fixed keyframes (Optimizer.cc:2120-2145) */
+  const double* pose_qt;      /* [n_poses][7] qx qy qz qw tx ty tz */
+  const uint8_t* pose_fixed;  /* [n_poses] 1 = setFixed(true) */
+  const double* pose_cam;     /* [n_poses][5] fx fy cx cy bf (Optimizer.cc:2383-2386, 2412-2416) */
+
+  int32_t n_points;           /* Optimizer.cc:2332-2348 */
+  const double* point_xyz;    /* [n_points][3] */
+  const uint8_t* point_fixed; /* [n_points] or NULL (= all free, marginalised) */
+
+  int32_t n_planes;           /* Optimizer.cc:2208-2219 */
+  const double* plane_coef;   /* [n_planes][4], any scale/sign: normalised as Plane3D::fromVector */
+
+  int32_t n_cuboids;          /* Optimizer.cc:2150-2179; never marginalised */
+  const double* cuboid_qt;    /* [n_cuboids][7] */
+  const double* cuboid_scale; /* [n_cuboids][3] half extents */
+  const uint8_t* cuboid_flags;      /* [n_cuboids] PPO_CUBOID_* bits, or NULL (= ROLLPITCH|HEIGHT) */
+  const double* cuboid_fixedscale;  /* [n_cuboids][3] or NULL; [0]>0 pins the scale (g2o_cuboid.cc:61-62) */
+
+  /* -- EdgeSE3ProjectXYZ (types_six_dof_expmap.h:164-193), Optimizer.cc:2366-2392 -------------- */
+  int32_t n_mono;
+  const int32_t* mono_point;  /* vertex slot 0 */
+  const int32_t* mono_pose;   /* vertex slot 1 */
+  const double* mono_obs;     /* [n_mono][2] */
+  const double* mono_info;    /* [n_mono] invSigma2 (information = invSigma2 * I2) */
+  const double* mono_huber;   /* [n_mono] */
+
+  /* -- EdgeStereoSE3ProjectXYZ (types_six_dof_expmap.h:196-225), Optimizer.cc:2393-2422 --------- */
+  int32_t n_stereo;
+  const int32_t* stereo_point;
+  const int32_t* stereo_pose;
+  const double* stereo_obs;   /* [n_stereo][3] u v u_right */
+  const double* stereo_info;  /* [n_stereo] */
+  const double* stereo_huber; /* [n_stereo] */
+
+  /* -- EdgePlane / EdgeVerticalPlane / EdgeParallelPlane (G2O_Plane3D.h:176-310),
+   *    Optimizer.cc:2229-2307.  kind: 0 = EdgePlane (3-D), 1 = vertical (2-D), 2 = parallel (2-D) */
+  int32_t n_plane_edges;
+  const int32_t* pl_plane;    /* slot 0 */
+  const int32_t* pl_pose;     /* slot 1 */
+  const uint8_t* pl_kind;     /* [n] or NULL (= all 0) */
+  const double* pl_meas;      /* [n][4] camera-frame plane, normalised on ingest like toPlane3D */
+  const double* pl_info;      /* [n][3] (third entry unused for kind 1,2) */
+  const double* pl_huber;     /* [n] */
+
+  /* -- EdgeSE3CuboidProj (g2o_cuboid.h:291-303), Optimizer.cc:2433-2487 ------------------------- */
+  int32_t n_bbox;
+  const int32_t* bbox_pose;   /* slot 0 */
+  const int32_t* bbox_cuboid; /* slot 1 */
+  const double* bbox_meas;    /* [n][4] cx cy w h */
+  const double* bbox_info;    /* [n][4] */
+  const double* bbox_huber;   /* [n] */
+  const double* bbox_K;       /* [n][9] row-major Kalib */
+
+  /* -- EdgeSE3CuboidCornerProj (g2o_cuboid.h:306-318), Optimizer.cc:2493-2551 ------------------- */
+  int32_t n_corner;
+  const int32_t* corner_pose;
+  const int32_t* corner_cuboid;
+  const double* corner_meas;  /* [n][16] u0 v0 ... u7 v7 */
+  const double* corner_info;  /* [n][16] */
+  const double* corner_huber; /* [n] */
+  const double* corner_K;     /* [n][9] */
+
+  /* -- EdgePointCuboidOnlyObject (g2o_cuboid.h:355-376), Optimizer.cc:2556-2655: unary ---------- */
+  int32_t n_ptcub;
+  const int32_t* ptcub_cuboid;
+  const int32_t* ptcub_offsets;     /* [n_ptcub+1] CSR into ptcub_points */
+  const double* ptcub_points;       /* [offsets[n]][3] world points frozen at build time */
+  const double* ptcub_margin_ratio; /* [n] max_outside_margin_ratio */
+  const double* ptcub_prior_half;   /* [n][3] prior_object_half_size, [0]<=0 = unset; or NULL */
+  const double* ptcub_info;         /* [n][3] */
+  const double* ptcub_huber;        /* [n] or NULL (= none, as the reference) */
+
+  /* -- EdgeCuboidPlane (G2O_Plane3D.h:332-474), Optimizer.cc:2662-2714: error == measurement ----- */
+  int32_t n_cubpl;
+  const int32_t* cubpl_cuboid; /* slot 0 */
+  const int32_t* cubpl_plane;  /* slot 1 */
+  const double* cubpl_meas;    /* [n][3] */
+  const double* cubpl_info;    /* [n][3] */
+  const double* cubpl_huber;   /* [n] */
+} ppo_ba_problem;
+
+typedef struct ppo_ba_options {
+  int32_t abi_version;      /* PPO_BA_ABI_VERSION */
+  int32_t iters_pass1;      /* 5   Optimizer.cc:2728 */
+  int32_t iters_pass2;      /* 10  Optimizer.cc:2837; 0 skips the outlier pass entirely */
+  double lm_tau;            /* 1e-5 optimization_algorithm_levenberg.cpp:47 */
+  int32_t lm_max_trials;    /* 10  :51 */
+  double lm_lower;          /* 1/3 :49 */
+  double lm_upper;          /* 2/3 :48 */
+  double numeric_delta;     /* 1e-9 base_binary_edge.hpp:232 */
+  int32_t jacobian_mode;    /* PPO_JAC_* */
+  /* outlier thresholds of the between-pass classification, Optimizer.cc:2739-2833 */
+  double chi2_mono;         /* 5.991 */
+  double chi2_stereo;       /* 7.815 */
+  double chi2_plane;        /* plane_chi */
+  double chi2_plane_vp;     /* 200 */
+  double th_bbox_norm;      /* thHuberBbox2d, compared with |e| (not chi2) Optimizer.cc:2774 */
+  double th_corner_norm;    /* thHuberConer2d Optimizer.cc:2783 */
+  int32_t deterministic;    /* 1 = order-stable reductions where the backend has them (debug) */
+  int32_t solver;           /* PPO_SOLVER_* */
+  /* multi-GPU (one process per GPU).  world_size<=1 = single GPU.  The 128-byte RCCL unique id is
+   * created by rank 0 with ppo_ba_comm_unique_id() and broadcast by the caller. */
+  int32_t device_id;        /* HIP device ordinal for this process */
+  int32_t rank, world_size;
+  uint8_t comm_id[128];
+  int32_t verbose;
+} ppo_ba_options;
+
+/* one record per LM iteration (one OptimizationAlgorithmLevenberg::solve call) */
+typedef struct ppo_ba_iter_stat {
+  int32_t pass;        /* 0 or 1 */
+  int32_t iteration;   /* index inside the pass */
+  int32_t trials;      /* qmax, levenberg.cpp:100-149 */
+  int32_t accepted;    /* last trial accepted */
+  double chi2_before;  /* currentChi at entry (robustified) */
+  double chi2_after;   /* currentChi at exit */
+  double lambda;       /* lambda used by the last trial */
+  int32_t result;      /* 0 OK, 1 Terminate, 2 aborted */
+  int32_t pad_;
+} ppo_ba_iter_stat;
+
+#define PPO_BA_MAX_ITER_STATS 64
+
+typedef struct ppo_ba_stats {
+  int32_t n_iters;                                  /* LM iterations actually run (both passes) */
+  int32_t n_trials;                                 /* solve attempts */
+  ppo_ba_iter_stat iters[PPO_BA_MAX_ITER_STATS];
+  int32_t n_reduced;                                /* dimension of the dense reduced system */
+  int32_t n_active_edges_pass1, n_active_edges_pass2;
+  double wall_ms_total;                             /* host steady_clock around run() */
+  double wall_ms_pass1, wall_ms_pass2, wall_ms_classify;
+  /* device time per phase summed over the run, from HIP events (0 when not collected) */
+  double ms_linearize, ms_schur, ms_factor, ms_backsub, ms_chi2;
+} ppo_ba_stats;
+
+/* caller-allocated output buffers; any pointer may be NULL to skip that output */
+typedef struct ppo_ba_result {
+  double* pose_qt;        /* [n_poses][7] */
+  double* point_xyz;      /* [n_points][3] */
+  double* plane_coef;     /* [n_planes][4] */
+  double* cuboid_qt;      /* [n_cuboids][7] */
+  double* cuboid_scale;   /* [n_cuboids][3] */
+  /* per-edge chi2 = e' * Omega * e of the LAST evaluated error (the semantics of g2o's stored _error,
+   * SURVEY.md 8(a) note under A27), level (1 = classified outlier between the passes) and depth test */
+  double* mono_chi2;      uint8_t* mono_level;    uint8_t* mono_depth_positive;
+  double* stereo_chi2;    uint8_t* stereo_level;  uint8_t* stereo_depth_positive;
+  double* pl_chi2;        uint8_t* pl_level;
+  double* bbox_chi2;      double* bbox_errnorm;   uint8_t* bbox_level;
+  double* corner_chi2;    double* corner_errnorm; uint8_t* corner_level;
+  double* ptcub_chi2;
+  double* cubpl_chi2;
+} ppo_ba_result;
+
+typedef struct ppo_ba_solver* ppo_ba_handle;
+
+int ppo_ba_version(void);
+const char* ppo_ba_strerror(int code);
+
+/* fills *o with the reference's constants (the comments on ppo_ba_options) */
+void ppo_ba_default_options(ppo_ba_options* o);
+
+/* validate + copy + upload once.  Fails with PPO_BA_ERR_HIP when no gfx950 device is usable. */
+int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handle* out);
+
+/* pass 1, outlier classification, pass 2.  stop_flag (may be NULL) is polled before the start,
+ * between the passes, before every LM iteration and every LM trial, like g2o's _forceStopFlag. */
+int ppo_ba_run(ppo_ba_handle h, const volatile uint8_t* stop_flag, ppo_ba_stats* stats);
+
+int ppo_ba_read(ppo_ba_handle h, ppo_ba_result* r);
+
+void ppo_ba_destroy(ppo_ba_handle h); /* NULL-safe */
+
+/* -- measurement and test hooks (not part of the reference seam) ---------------------------------- */
+
+/* Re-upload the initial estimates and reset edge levels / robust kernels, so that run() can be timed
+ * repeatedly on one handle with inputs already resident in HBM. */
+int ppo_ba_reset(ppo_ba_handle h);
+
+/* One linearisation of the current state: fills the block-sparse system and returns sum(rho0).
+ * Used by bench.py to time the Jacobian/assembly kernels in isolation and by the parity tests. */
+int ppo_ba_linearize(ppo_ba_handle h, double* robust_chi2);
+
+/* Time `reps` back-to-back launches of the linearise/assemble kernel group with HIP events on the
+ * library's own stream; returns average milliseconds per linearisation in *ms. */
+int ppo_ba_time_linearize(ppo_ba_handle h, int reps, double* ms);
+
+/* Time `reps` factorisations of the current reduced system (HIP events); average ms in *ms. */
+int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
+
+/* Re-linearise the current state and build the reduced system for the damping set with
+ * ppo_ba_debug_set_lambda(): S is n*n column-major (returned symmetric), b the Schur right-hand side, x the
+ * solution of S x = b.  n = ppo_ba_stats.n_reduced.  Any pointer may be NULL. */
+int ppo_ba_debug_set_lambda(ppo_ba_handle h, double lambda);
+int ppo_ba_debug_reduced(ppo_ba_handle h, double* S, double* b, double* x, int32_t* n);
+
+/* Algorithmic bytes of one linearisation (SURVEY.md 8(d) formula) for the problem in h. */
+int64_t ppo_ba_linearize_bytes(ppo_ba_handle h);
+
+/* Host-only helpers (no GPU needed). */
+/* Range-partition landmarks (points then planes) into world_size contiguous edge-balanced ranges:
+ * fills first_point[world_size+1], first_plane[world_size+1]. */
+int ppo_ba_partition(const ppo_ba_problem* p, int32_t world_size, int32_t* first_point, int32_t* first_plane);
+/* 128-byte RCCL unique id for ppo_ba_options.comm_id (call on rank 0, broadcast to the others). */
+int ppo_ba_comm_unique_id(uint8_t id[128]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPO_BA_H */

@@ -1,0 +1,1146 @@
+// ppo_oracle.cpp -- TEST INFRASTRUCTURE ONLY (see oracle/README.md): single-threaded CPU restatement of
+// the reference's local bundle adjustment, used as parity checker and as bench.py's cpu_baseline leg.
+// Nothing in the product path (libppo_ba.so, the host adapter) links, includes or calls this file.
+//
+// Parity status: the reference cannot be compiled here (Eigen3/OpenCV/PCL/Pangolin absent) and ships no
+// tests for this path, so this restatement is pinned by (a) golden vectors produced by the reference's
+// OWN prebuilt Thirdparty/g2o/lib/libg2o.so for the pieces that library exports (oracle/pin_g2o_prebuilt.py
+// -> tests/golden/g2o_prebuilt.json) and (b) analytic known-answer tests.  The custom plane/cuboid edges
+// live only in lib/libORB_SLAM2.so, which does not load here: for them parity is UNPINNED.
+//
+// What is restated, in the reference's own order (paths relative to the reference checkout, G2O =
+// Thirdparty/g2o/g2o):
+//   graph activation / index mapping   G2O/core/sparse_optimizer.cpp:166-267
+//   structure                          G2O/core/block_solver.hpp:143-295
+//   residuals                          types_six_dof_expmap.{h,cpp}, include/G2O_Plane3D.h, src/g2o_cuboid.cc
+//   numeric Jacobians (delta 1e-9)     G2O/core/base_binary_edge.hpp:217-320, base_unary_edge.hpp:82-123
+//   quadratic form + Huber             G2O/core/base_binary_edge.hpp:55-120, base_unary_edge.hpp:43-72,
+//                                      base_edge.h:96-102, robust_kernel_impl.cpp:78-91
+//   Schur complement + back-subst.     G2O/core/block_solver.hpp:354-486
+//   dense LDLT with positivity gate    G2O/solvers/linear_solver_dense.h:65-113 (Eigen::LDLT restated)
+//   Levenberg-Marquardt                G2O/core/optimization_algorithm_levenberg.cpp:61-189
+//   outer loop                         G2O/core/sparse_optimizer.cpp:354-419
+//   two-pass protocol + classification src/Optimizer.cc:2723-2838
+#include "../include/ppo_ba.h"
+#include "oracle_math.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <vector>
+
+using namespace orc;
+
+namespace {
+
+enum VType { V_POSE = 0, V_POINT = 1, V_PLANE = 2, V_CUBOID = 3, V_NONE = -1 };
+enum EType { E_PLANE = 0, E_MONO, E_STEREO, E_BBOX, E_CORNER, E_PTCUB, E_CUBPL, E_NTYPES };
+static const int kVDim[4] = {6, 3, 3, 9};
+static const int kMaxDim = 16;
+
+struct EdgeRef {
+  int type, idx;
+};
+
+struct Oracle {
+  ppo_ba_options opt;
+  // ---- problem copy ----
+  int n_poses = 0, n_points = 0, n_planes = 0, n_cuboids = 0;
+  std::vector<SE3> pose0;
+  std::vector<uint8_t> pose_fixed;
+  std::vector<double> pose_cam;
+  std::vector<V3> point0;
+  std::vector<uint8_t> point_fixed;
+  std::vector<Plane> plane0;
+  std::vector<Cuboid> cuboid0;
+  std::vector<uint8_t> cuboid_flags;
+  std::vector<double> cuboid_fixedscale;
+  int n_edges[E_NTYPES] = {0};
+  std::vector<int> e_v0[E_NTYPES], e_v1[E_NTYPES];
+  std::vector<double> e_meas[E_NTYPES], e_info[E_NTYPES], e_huber[E_NTYPES];
+  std::vector<uint8_t> pl_kind;
+  std::vector<Plane> pl_meas_plane;
+  std::vector<double> bbox_K, corner_K;
+  std::vector<int> ptcub_off;
+  std::vector<double> ptcub_pts, ptcub_margin, ptcub_prior;
+  // ---- state ----
+  std::vector<SE3> pose;
+  std::vector<V3> point;
+  std::vector<Plane> plane;
+  std::vector<Cuboid> cuboid;
+  std::vector<uint8_t> level[E_NTYPES], robust[E_NTYPES];
+  std::vector<double> err[E_NTYPES];  // stored _error, kMaxDim per edge
+  // ---- active sets / index mapping (rebuilt per pass) ----
+  std::vector<EdgeRef> active;
+  std::vector<int> hidx[4];   // per vertex: -1 or block index (reduced for pose/cuboid, landmark index else)
+  std::vector<int> col0[4];   // column of the block inside its partition
+  int n_red_blocks = 0, n_red = 0, n_lm = 0;
+  std::vector<int> red_col0, red_dim;  // per reduced block
+  std::vector<int> lm_type, lm_vidx;   // per landmark block
+  // ---- linear system ----
+  std::vector<double> Hpp;  // n_red x n_red, column-major, upper blocks filled
+  std::vector<double> Hll;  // n_lm x 9 (row-major 3x3)
+  std::vector<double> b;    // n_red + 3 n_lm
+  std::vector<int> hpl_start;                 // per landmark: first block slot
+  std::vector<int> hpl_rb;                    // per slot: reduced block id (sorted inside a landmark)
+  std::vector<double> hpl;                    // per slot: 6x3 row-major (pose rows)
+  std::vector<int> edge_slot[E_NTYPES];       // per landmark-pose edge: slot (or -1)
+  std::vector<double> S, bs, x, coeff, Dinv;  // Schur workspace; x is n_red + 3 n_lm
+  std::vector<double> diag_backup_p, diag_backup_l;
+  bool do_schur = false;
+  // ---- LM ----
+  double lambda = -1, ni = 2;
+  int nBad = 0;
+  // ---- bookkeeping ----
+  ppo_ba_stats stats;
+  bool ran = false;
+};
+
+int edge_dim(const Oracle& o, int type, int idx) {
+  switch (type) {
+    case E_PLANE: return o.pl_kind[idx] == 0 ? 3 : 2;
+    case E_MONO: return 2;
+    case E_STEREO: return 3;
+    case E_BBOX: return 4;
+    case E_CORNER: return 16;
+    case E_PTCUB: return 3;
+    case E_CUBPL: return 3;
+  }
+  return 0;
+}
+// vertex slots, SURVEY.md appendix A "Edge vertex slots" (Optimizer.cc:2237-2238,2373-2374,2445-2446,2644,2691-2692)
+void edge_vertices(const Oracle& o, int type, int idx, int& t0, int& i0, int& t1, int& i1) {
+  i0 = o.e_v0[type][idx];
+  i1 = o.e_v1[type].empty() ? -1 : o.e_v1[type][idx];
+  t0 = V_POSE;
+  t1 = V_NONE;
+  switch (type) {
+    case E_PLANE: t0 = V_PLANE; t1 = V_POSE; break;
+    case E_MONO: case E_STEREO: t0 = V_POINT; t1 = V_POSE; break;
+    case E_BBOX: case E_CORNER: t0 = V_POSE; t1 = V_CUBOID; break;
+    case E_PTCUB: t0 = V_CUBOID; t1 = V_NONE; i1 = -1; break;
+    case E_CUBPL: t0 = V_CUBOID; t1 = V_PLANE; break;
+  }
+}
+bool vertex_fixed(const Oracle& o, int t, int i) {
+  if (t == V_POSE) return o.pose_fixed[i] != 0;
+  if (t == V_POINT) return o.point_fixed[i] != 0;
+  return false;
+}
+const void* vertex_ptr(const Oracle& o, int t, int i) {
+  switch (t) {
+    case V_POSE: return &o.pose[i];
+    case V_POINT: return &o.point[i];
+    case V_PLANE: return &o.plane[i];
+    case V_CUBOID: return &o.cuboid[i];
+  }
+  return nullptr;
+}
+
+// computeError() of every edge class; a/b are the estimates of vertex slot 0 / 1.
+void compute_error(const Oracle& o, int type, int idx, const void* a, const void* bptr, double* e) {
+  switch (type) {
+    case E_MONO: {  // types_six_dof_expmap.h:174-179, .cpp:173-179
+      const V3& X = *static_cast<const V3*>(a);
+      const SE3& T = *static_cast<const SE3*>(bptr);
+      const double* cam = &o.pose_cam[5 * o.e_v1[type][idx]];
+      const double* obs = &o.e_meas[type][2 * idx];
+      const V3 pc = se3_map(T, X);
+      const double px = pc[0] / pc[2], py = pc[1] / pc[2];
+      e[0] = obs[0] - (px * cam[0] + cam[2]);
+      e[1] = obs[1] - (py * cam[1] + cam[3]);
+      break;
+    }
+    case E_STEREO: {  // types_six_dof_expmap.h:206-211, .cpp:182-189 (invz and bf are float there)
+      const V3& X = *static_cast<const V3*>(a);
+      const SE3& T = *static_cast<const SE3*>(bptr);
+      const double* cam = &o.pose_cam[5 * o.e_v1[type][idx]];
+      const double* obs = &o.e_meas[type][3 * idx];
+      const V3 pc = se3_map(T, X);
+      const float bf = (float)cam[4];
+      const float invz = 1.0f / (float)pc[2];
+      const double r0 = pc[0] * invz * cam[0] + cam[2];
+      const double r1 = pc[1] * invz * cam[1] + cam[3];
+      const double r2 = r0 - (double)(bf * invz);
+      e[0] = obs[0] - r0;
+      e[1] = obs[1] - r1;
+      e[2] = obs[2] - r2;
+      break;
+    }
+    case E_PLANE: {  // G2O_Plane3D.h:181-192, 220-231, 279-290
+      const Plane& pl = *static_cast<const Plane*>(a);
+      const SE3& T = *static_cast<const SE3*>(bptr);
+      const Plane local = plane_transform(T, pl);
+      const Plane& m = o.pl_meas_plane[idx];
+      if (o.pl_kind[idx] == 0) plane_ominus(local, m, e);
+      else if (o.pl_kind[idx] == 1) plane_ominus_ver(local, m, e);
+      else plane_ominus_par(local, m, e);
+      break;
+    }
+    case E_BBOX: {  // src/g2o_cuboid.cc:70-81
+      const SE3& T = *static_cast<const SE3*>(a);
+      const Cuboid& c = *static_cast<const Cuboid*>(bptr);
+      double bb[4];
+      cuboid_project_bbox(c, T, &o.bbox_K[9 * idx], bb);
+      for (int i = 0; i < 4; ++i) e[i] = bb[i] - o.e_meas[type][4 * idx + i];
+      break;
+    }
+    case E_CORNER: {  // src/g2o_cuboid.cc:103-120
+      const SE3& T = *static_cast<const SE3*>(a);
+      const Cuboid& c = *static_cast<const Cuboid*>(bptr);
+      double uv[8][2];
+      cuboid_project_corners(c, T, &o.corner_K[9 * idx], uv);
+      for (int k = 0; k < 8; ++k) {
+        e[2 * k] = uv[k][0] - o.e_meas[type][16 * idx + 2 * k];
+        e[2 * k + 1] = uv[k][1] - o.e_meas[type][16 * idx + 2 * k + 1];
+      }
+      break;
+    }
+    case E_PTCUB: {  // src/g2o_cuboid.cc:132-160
+      const Cuboid& c = *static_cast<const Cuboid*>(a);
+      V3 acc = mk(0, 0, 0);
+      const int p0 = o.ptcub_off[idx], p1 = o.ptcub_off[idx + 1];
+      for (int p = p0; p < p1; ++p) {
+        const V3 pe = cuboid_point_boundary_error(c, mk(o.ptcub_pts[3 * p], o.ptcub_pts[3 * p + 1], o.ptcub_pts[3 * p + 2]),
+                                                  o.ptcub_margin[idx]);
+        for (int i = 0; i < 3; ++i) acc[i] += std::fabs(pe[i]);
+      }
+      if (p1 > p0)
+        for (int i = 0; i < 3; ++i) acc[i] = acc[i] / (double)(p1 - p0);
+      for (int i = 0; i < 3; ++i) acc[i] = acc[i] / c.scale[i];
+      double prior_weight = 0.2;
+      V3 prior = c.scale;
+      const double* ph = &o.ptcub_prior[3 * idx];
+      if (ph[0] > 0) {
+        prior_weight = 50.0;
+        for (int i = 0; i < 3; ++i) prior[i] = std::fabs((c.scale[i] - ph[i]) / ph[i]);
+      }
+      for (int i = 0; i < 3; ++i) e[i] = 1.0 * acc[i] + prior_weight * prior[i];
+      break;
+    }
+    case E_CUBPL: {  // G2O_Plane3D.h:470-473: _error = _measurement
+      for (int i = 0; i < 3; ++i) e[i] = o.e_meas[type][3 * idx + i];
+      break;
+    }
+  }
+}
+
+// oplus on a copy of one vertex estimate (push / oplus / ... / pop of base_vertex.h:96-97)
+struct VTemp {
+  SE3 pose;
+  V3 point;
+  Plane plane;
+  Cuboid cuboid;
+};
+const void* oplus_copy(const Oracle& o, int t, int i, const double* upd, VTemp& tmp) {
+  switch (t) {
+    case V_POSE: tmp.pose = pose_oplus(o.pose[i], upd); return &tmp.pose;
+    case V_POINT: tmp.point = add(o.point[i], mk(upd[0], upd[1], upd[2])); return &tmp.point;  // types_sba.h:52-56
+    case V_PLANE: tmp.plane = plane_oplus(o.plane[i], upd); return &tmp.plane;
+    case V_CUBOID:
+      tmp.cuboid = cuboid_oplus(o.cuboid[i], upd, o.cuboid_flags[i], &o.cuboid_fixedscale[3 * i]);
+      return &tmp.cuboid;
+  }
+  return nullptr;
+}
+
+// linearizeOplus: analytic for the two reprojection edges, central differences otherwise.
+// J0 is dim x d0 (row-major), J1 is dim x d1.
+void linearize(const Oracle& o, int type, int idx, double* J0, double* J1) {
+  int t0, i0, t1, i1;
+  edge_vertices(o, type, idx, t0, i0, t1, i1);
+  const int dim = edge_dim(o, type, idx);
+  if (type == E_MONO || type == E_STEREO) {
+    // types_six_dof_expmap.cpp:135-171 and :220-266
+    const V3& X = o.point[i0];
+    const SE3& T = o.pose[i1];
+    const double* cam = &o.pose_cam[5 * i1];
+    const double fx = cam[0], fy = cam[1], bf = cam[4];
+    const V3 pc = se3_map(T, X);
+    const M3 R = quat_to_matrix(T.r);
+    const double x = pc[0], y = pc[1], z = pc[2], z_2 = z * z;
+    if (type == E_MONO) {
+      double tmp[2][3] = {{fx, 0, -x / z * fx}, {0, fy, -y / z * fy}};
+      for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c) {
+          const double s = -1. / z;
+          J0[r * 3 + c] = (s * tmp[r][0]) * R.m[0][c] + (s * tmp[r][1]) * R.m[1][c] + (s * tmp[r][2]) * R.m[2][c];
+        }
+    } else {
+      for (int c = 0; c < 3; ++c) {
+        J0[0 * 3 + c] = -fx * R.m[0][c] / z + fx * x * R.m[2][c] / z_2;
+        J0[1 * 3 + c] = -fy * R.m[1][c] / z + fy * y * R.m[2][c] / z_2;
+        J0[2 * 3 + c] = J0[0 * 3 + c] - bf * R.m[2][c] / z_2;
+      }
+    }
+    J1[0] = x * y / z_2 * fx;
+    J1[1] = -(1 + (x * x / z_2)) * fx;
+    J1[2] = y / z * fx;
+    J1[3] = -1. / z * fx;
+    J1[4] = 0;
+    J1[5] = x / z_2 * fx;
+    J1[6] = (1 + y * y / z_2) * fy;
+    J1[7] = -x * y / z_2 * fy;
+    J1[8] = -x / z * fy;
+    J1[9] = 0;
+    J1[10] = -1. / z * fy;
+    J1[11] = y / z_2 * fy;
+    if (type == E_STEREO) {
+      J1[12] = J1[0] - bf * y / z_2;
+      J1[13] = J1[1] + bf * x / z_2;
+      J1[14] = J1[2];
+      J1[15] = J1[3];
+      J1[16] = 0;
+      J1[17] = J1[5] - bf / z_2;
+    }
+    return;
+  }
+  // base_binary_edge.hpp:217-320 / base_unary_edge.hpp:82-123
+  const double delta = o.opt.numeric_delta;
+  const double scalar = 1.0 / (2 * delta);
+  VTemp tmp;
+  double ep[kMaxDim], em[kMaxDim];
+  for (int side = 0; side < 2; ++side) {
+    const int t = side == 0 ? t0 : t1, i = side == 0 ? i0 : i1;
+    double* J = side == 0 ? J0 : J1;
+    if (t == V_NONE || vertex_fixed(o, t, i)) continue;
+    const int d = kVDim[t];
+    double addv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < d; ++c) {
+      addv[c] = delta;
+      const void* vp = oplus_copy(o, t, i, addv, tmp);
+      compute_error(o, type, idx, side == 0 ? vp : vertex_ptr(o, t0, i0), side == 1 ? vp : (t1 == V_NONE ? nullptr : vertex_ptr(o, t1, i1)), ep);
+      addv[c] = -delta;
+      vp = oplus_copy(o, t, i, addv, tmp);
+      compute_error(o, type, idx, side == 0 ? vp : vertex_ptr(o, t0, i0), side == 1 ? vp : (t1 == V_NONE ? nullptr : vertex_ptr(o, t1, i1)), em);
+      addv[c] = 0.0;
+      for (int r = 0; r < dim; ++r) J[r * d + c] = scalar * (ep[r] - em[r]);
+    }
+  }
+}
+
+double edge_chi2(const Oracle& o, int type, int idx) {  // base_edge.h:58-61 with a diagonal information matrix
+  const int dim = edge_dim(o, type, idx);
+  const double* e = &o.err[type][(size_t)kMaxDim * idx];
+  double s = 0;
+  if (type == E_MONO || type == E_STEREO) {
+    const double w = o.e_info[type][idx];
+    for (int i = 0; i < dim; ++i) s += e[i] * (w * e[i]);
+  } else {
+    const int stride = (type == E_BBOX) ? 4 : (type == E_CORNER ? 16 : 3);
+    const double* w = &o.e_info[type][(size_t)stride * idx];
+    for (int i = 0; i < dim; ++i) s += e[i] * (w[i] * e[i]);
+  }
+  return s;
+}
+double info_at(const Oracle& o, int type, int idx, int i) {
+  if (type == E_MONO || type == E_STEREO) return o.e_info[type][idx];
+  const int stride = (type == E_BBOX) ? 4 : (type == E_CORNER ? 16 : 3);
+  return o.e_info[type][(size_t)stride * idx + i];
+}
+
+// SparseOptimizer::initializeOptimization(level) + buildIndexMapping, sparse_optimizer.cpp:166-267,
+// followed by BlockSolver::buildStructure, block_solver.hpp:143-295.
+void initialize_optimization(Oracle& o, int lvl) {
+  o.active.clear();
+  std::vector<uint8_t> vact[4];
+  vact[V_POSE].assign(o.n_poses, 0);
+  vact[V_POINT].assign(o.n_points, 0);
+  vact[V_PLANE].assign(o.n_planes, 0);
+  vact[V_CUBOID].assign(o.n_cuboids, 0);
+  for (int type = 0; type < E_NTYPES; ++type)  // addEdge order, SURVEY.md appendix A "Edge evaluation order"
+    for (int idx = 0; idx < o.n_edges[type]; ++idx) {
+      if (o.level[type][idx] != lvl) continue;
+      int t0, i0, t1, i1;
+      edge_vertices(o, type, idx, t0, i0, t1, i1);
+      const bool all_fixed = vertex_fixed(o, t0, i0) && (t1 == V_NONE || vertex_fixed(o, t1, i1));
+      if (all_fixed) continue;
+      o.active.push_back(EdgeRef{type, idx});
+      vact[t0][i0] = 1;
+      if (t1 != V_NONE) vact[t1][i1] = 1;
+    }
+  for (int t = 0; t < 4; ++t) {
+    const int n = (int)vact[t].size();
+    o.hidx[t].assign(n, -1);
+    o.col0[t].assign(n, -1);
+  }
+  // non-marginalised first (poses, cuboids), then marginalised (planes, points)
+  o.red_col0.clear(); o.red_dim.clear();
+  o.n_red = 0;
+  for (int t : {V_POSE, V_CUBOID})
+    for (int i = 0; i < (int)vact[t].size(); ++i)
+      if (vact[t][i] && !vertex_fixed(o, t, i)) {
+        o.hidx[t][i] = (int)o.red_col0.size();
+        o.col0[t][i] = o.n_red;
+        o.red_col0.push_back(o.n_red);
+        o.red_dim.push_back(kVDim[t]);
+        o.n_red += kVDim[t];
+      }
+  o.n_red_blocks = (int)o.red_col0.size();
+  o.lm_type.clear(); o.lm_vidx.clear();
+  for (int t : {V_PLANE, V_POINT})
+    for (int i = 0; i < (int)vact[t].size(); ++i)
+      if (vact[t][i] && !vertex_fixed(o, t, i)) {
+        o.hidx[t][i] = (int)o.lm_type.size();
+        o.col0[t][i] = 3 * (int)o.lm_type.size();
+        o.lm_type.push_back(t);
+        o.lm_vidx.push_back(i);
+      }
+  o.n_lm = (int)o.lm_type.size();
+  o.do_schur = o.n_lm > 0;  // optimization_algorithm_with_hessian.cpp:50-73
+  // Hpl structure: per landmark the sorted set of reduced blocks it touches
+  std::vector<std::vector<int>> touch(o.n_lm);
+  for (const EdgeRef& er : o.active) {
+    if (er.type != E_PLANE && er.type != E_MONO && er.type != E_STEREO) continue;
+    int t0, i0, t1, i1;
+    edge_vertices(o, er.type, er.idx, t0, i0, t1, i1);
+    const int l = o.hidx[t0][i0], rb = o.hidx[t1][i1];
+    if (l >= 0 && rb >= 0) touch[l].push_back(rb);
+  }
+  o.hpl_start.assign(o.n_lm + 1, 0);
+  o.hpl_rb.clear();
+  for (int l = 0; l < o.n_lm; ++l) {
+    std::sort(touch[l].begin(), touch[l].end());
+    touch[l].erase(std::unique(touch[l].begin(), touch[l].end()), touch[l].end());
+    o.hpl_start[l] = (int)o.hpl_rb.size();
+    o.hpl_rb.insert(o.hpl_rb.end(), touch[l].begin(), touch[l].end());
+  }
+  o.hpl_start[o.n_lm] = (int)o.hpl_rb.size();
+  o.hpl.assign(o.hpl_rb.size() * 18, 0.0);
+  for (int type : {E_PLANE, E_MONO, E_STEREO}) o.edge_slot[type].assign(o.n_edges[type], -1);
+  for (const EdgeRef& er : o.active) {
+    if (er.type != E_PLANE && er.type != E_MONO && er.type != E_STEREO) continue;
+    int t0, i0, t1, i1;
+    edge_vertices(o, er.type, er.idx, t0, i0, t1, i1);
+    const int l = o.hidx[t0][i0], rb = o.hidx[t1][i1];
+    if (l < 0 || rb < 0) continue;
+    const int* first = &o.hpl_rb[o.hpl_start[l]];
+    const int* last = &o.hpl_rb[0] + o.hpl_start[l + 1];
+    o.edge_slot[er.type][er.idx] = (int)(std::lower_bound(first, last, rb) - &o.hpl_rb[0]);
+  }
+  o.Hpp.assign((size_t)o.n_red * o.n_red, 0.0);
+  o.Hll.assign((size_t)o.n_lm * 9, 0.0);
+  o.b.assign((size_t)o.n_red + 3 * (size_t)o.n_lm, 0.0);
+  o.x.assign(o.b.size(), 0.0);
+  o.S.assign(o.do_schur ? o.Hpp.size() : 0, 0.0);
+  o.bs.assign(o.n_red, 0.0);
+  o.coeff.assign(o.b.size(), 0.0);
+  o.Dinv.assign((size_t)o.n_lm * 9, 0.0);
+}
+
+// SparseOptimizer::computeActiveErrors, sparse_optimizer.cpp:61-76
+void compute_active_errors(Oracle& o) {
+  for (const EdgeRef& er : o.active) {
+    int t0, i0, t1, i1;
+    edge_vertices(o, er.type, er.idx, t0, i0, t1, i1);
+    compute_error(o, er.type, er.idx, vertex_ptr(o, t0, i0), t1 == V_NONE ? nullptr : vertex_ptr(o, t1, i1),
+                  &o.err[er.type][(size_t)kMaxDim * er.idx]);
+  }
+}
+// SparseOptimizer::activeRobustChi2, sparse_optimizer.cpp:100-114
+double active_robust_chi2(const Oracle& o) {
+  double chi = 0.0, rho[3];
+  for (const EdgeRef& er : o.active) {
+    const double c = edge_chi2(o, er.type, er.idx);
+    const double hub = o.e_huber[er.type][er.idx];
+    if (o.robust[er.type][er.idx] && hub > 0) {
+      huber_robustify(c, hub, rho);
+      chi += rho[0];
+    } else {
+      chi += c;
+    }
+  }
+  return chi;
+}
+
+inline double& HPP(Oracle& o, int r, int c) { return o.Hpp[(size_t)c * o.n_red + r]; }
+
+// BlockSolver::buildSystem, block_solver.hpp:502-560 with constructQuadraticForm of
+// base_binary_edge.hpp:55-120 / base_unary_edge.hpp:43-72.
+void build_system(Oracle& o) {
+  std::fill(o.Hpp.begin(), o.Hpp.end(), 0.0);
+  std::fill(o.Hll.begin(), o.Hll.end(), 0.0);
+  std::fill(o.hpl.begin(), o.hpl.end(), 0.0);
+  std::fill(o.b.begin(), o.b.end(), 0.0);
+  double J0[kMaxDim * 9], J1[kMaxDim * 9];
+  for (const EdgeRef& er : o.active) {
+    int t0, i0, t1, i1;
+    edge_vertices(o, er.type, er.idx, t0, i0, t1, i1);
+    const int dim = edge_dim(o, er.type, er.idx);
+    linearize(o, er.type, er.idx, J0, J1);
+    const double* e = &o.err[er.type][(size_t)kMaxDim * er.idx];
+    // omega_r = -rho1 * Omega * e ; weightedOmega = rho1 * Omega (base_edge.h:96-102: rho2 term dropped)
+    double rho1 = 1.0;
+    const double hub = o.e_huber[er.type][er.idx];
+    if (o.robust[er.type][er.idx] && hub > 0) {
+      double rho[3];
+      huber_robustify(edge_chi2(o, er.type, er.idx), hub, rho);
+      rho1 = rho[1];
+    }
+    double w[kMaxDim], omega_r[kMaxDim];
+    for (int r = 0; r < dim; ++r) {
+      const double om = info_at(o, er.type, er.idx, r);
+      w[r] = rho1 * om;
+      omega_r[r] = -(om * e[r]) * rho1;
+    }
+    const bool free0 = !vertex_fixed(o, t0, i0) && o.hidx[t0][i0] >= 0;
+    const bool free1 = t1 != V_NONE && !vertex_fixed(o, t1, i1) && o.hidx[t1][i1] >= 0;
+    const int d0 = kVDim[t0], d1 = t1 == V_NONE ? 0 : kVDim[t1];
+    auto add_diag = [&](int t, int i, const double* J, int d) {
+      const bool marg = (t == V_POINT || t == V_PLANE);
+      if (marg) {
+        double* D = &o.Hll[(size_t)9 * o.hidx[t][i]];
+        double* bl = &o.b[(size_t)o.n_red + o.col0[t][i]];
+        for (int a = 0; a < 3; ++a) {
+          double sb = 0;
+          for (int r = 0; r < dim; ++r) sb += J[r * d + a] * omega_r[r];
+          bl[a] += sb;
+          for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int r = 0; r < dim; ++r) s += J[r * d + a] * w[r] * J[r * d + c];
+            D[a * 3 + c] += s;
+          }
+        }
+      } else {
+        const int c0 = o.col0[t][i];
+        for (int a = 0; a < d; ++a) {
+          double sb = 0;
+          for (int r = 0; r < dim; ++r) sb += J[r * d + a] * omega_r[r];
+          o.b[c0 + a] += sb;
+          for (int c = 0; c < d; ++c) {
+            double s = 0;
+            for (int r = 0; r < dim; ++r) s += J[r * d + a] * w[r] * J[r * d + c];
+            HPP(o, c0 + a, c0 + c) += s;
+          }
+        }
+      }
+    };
+    if (free0) add_diag(t0, i0, J0, d0);
+    if (free1) add_diag(t1, i1, J1, d1);
+    if (free0 && free1) {
+      if (er.type == E_BBOX || er.type == E_CORNER) {  // pose (slot 0) x cuboid (slot 1): upper block of Hpp
+        const int r0 = o.col0[t0][i0], c0 = o.col0[t1][i1];
+        for (int a = 0; a < d0; ++a)
+          for (int c = 0; c < d1; ++c) {
+            double s = 0;
+            for (int r = 0; r < dim; ++r) s += J0[r * d0 + a] * w[r] * J1[r * d1 + c];
+            HPP(o, r0 + a, c0 + c) += s;
+          }
+      } else if (er.type == E_PLANE || er.type == E_MONO || er.type == E_STEREO) {
+        // landmark (slot 0) x pose (slot 1): Hpl(pose, landmark) += B' W A  (block_solver.hpp:240-244)
+        double* blk = &o.hpl[(size_t)18 * o.edge_slot[er.type][er.idx]];
+        for (int a = 0; a < 6; ++a)
+          for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int r = 0; r < dim; ++r) s += J1[r * 6 + a] * w[r] * J0[r * 3 + c];
+            blk[a * 3 + c] += s;
+          }
+      }
+      // E_CUBPL: cuboid x plane block exists structurally in g2o but its Jacobians are identically zero
+      // (constant error differentiated numerically), so nothing is accumulated.
+    }
+  }
+}
+
+// PartialPivLU-based inverse of a 3x3 block: MatrixXd::inverse() on a dynamic matrix, block_solver.hpp:389
+bool inverse3(const double* A, double* inv) {
+  double lu[3][3];
+  int perm[3] = {0, 1, 2};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) lu[i][j] = A[i * 3 + j];
+  for (int k = 0; k < 3; ++k) {
+    int piv = k;
+    double best = std::fabs(lu[k][k]);
+    for (int i = k + 1; i < 3; ++i)
+      if (std::fabs(lu[i][k]) > best) { best = std::fabs(lu[i][k]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < 3; ++j) std::swap(lu[k][j], lu[piv][j]);
+      std::swap(perm[k], perm[piv]);
+    }
+    if (lu[k][k] != 0.0)
+      for (int i = k + 1; i < 3; ++i) lu[i][k] /= lu[k][k];
+    for (int i = k + 1; i < 3; ++i)
+      for (int j = k + 1; j < 3; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+  }
+  for (int c = 0; c < 3; ++c) {  // solve L U x = P e_c
+    double y[3];
+    for (int i = 0; i < 3; ++i) {
+      double s = (perm[i] == c) ? 1.0 : 0.0;
+      for (int j = 0; j < i; ++j) s -= lu[i][j] * y[j];
+      y[i] = s;
+    }
+    for (int i = 2; i >= 0; --i) {
+      double s = y[i];
+      for (int j = i + 1; j < 3; ++j) s -= lu[i][j] * inv[j * 3 + c];
+      inv[i * 3 + c] = s / lu[i][i];
+    }
+  }
+  return true;
+}
+
+// Eigen::LDLT<MatrixXd>::compute + isPositive + solve as used by linear_solver_dense.h:104-112.
+// Restated from Eigen 3.3's published algorithm: left-looking unblocked L D L^T on the lower triangle with
+// symmetric pivoting on the largest remaining |diagonal|, sign tracking for isPositive(), and a solve that
+// treats |d_i| <= DBL_MIN as zero.  A is n x n column-major and is overwritten.
+bool ldlt_solve(std::vector<double>& A, int n, const double* rhs, double* xout) {
+  std::vector<int> tr(n);
+  std::vector<double> temp(n);
+  enum { ZeroSign, PositiveSemiDef, NegativeSemiDef, Indefinite } sign = ZeroSign;
+  auto M = [&](int r, int c) -> double& { return A[(size_t)c * n + r]; };
+  bool all_zero_diag = false;
+  for (int k = 0; k < n && !all_zero_diag; ++k) {
+    int big = k;
+    double best = std::fabs(M(k, k));
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(M(i, i)) > best) { best = std::fabs(M(i, i)); big = i; }
+    tr[k] = big;
+    if (k != big) {
+      const int s = n - big - 1;
+      for (int j = 0; j < k; ++j) std::swap(M(k, j), M(big, j));
+      for (int i = 0; i < s; ++i) std::swap(M(big + 1 + i, k), M(big + 1 + i, big));
+      std::swap(M(k, k), M(big, big));
+      for (int i = k + 1; i < big; ++i) std::swap(M(i, k), M(big, i));
+    }
+    const int rs = n - k - 1;
+    if (k > 0) {
+      for (int j = 0; j < k; ++j) temp[j] = M(j, j) * M(k, j);
+      double s = 0;
+      for (int j = 0; j < k; ++j) s += M(k, j) * temp[j];
+      M(k, k) -= s;
+      if (rs > 0)
+        for (int j = 0; j < k; ++j) {
+          const double tj = temp[j];
+          if (tj == 0.0) continue;
+          double* colj = &A[(size_t)j * n + k + 1];
+          double* colk = &A[(size_t)k * n + k + 1];
+          for (int i = 0; i < rs; ++i) colk[i] -= colj[i] * tj;
+        }
+    }
+    const double akk = M(k, k);
+    const bool pivot_ok = std::fabs(akk) > 0.0;
+    if (k == 0 && !pivot_ok) {
+      for (int j = 0; j < n; ++j) tr[j] = j;
+      all_zero_diag = true;
+      break;
+    }
+    if (rs > 0 && pivot_ok) {
+      double* colk = &A[(size_t)k * n + k + 1];
+      for (int i = 0; i < rs; ++i) colk[i] /= akk;
+    }
+    if (sign == PositiveSemiDef) {
+      if (akk < 0) sign = Indefinite;
+    } else if (sign == NegativeSemiDef) {
+      if (akk > 0) sign = Indefinite;
+    } else if (sign == ZeroSign) {
+      if (akk > 0) sign = PositiveSemiDef;
+      else if (akk < 0) sign = NegativeSemiDef;
+    }
+  }
+  const bool positive = (sign == PositiveSemiDef || sign == ZeroSign);
+  if (!positive) return false;
+  std::vector<double> y(rhs, rhs + n);
+  for (int k = 0; k < n; ++k) std::swap(y[k], y[tr[k]]);
+  for (int j = 0; j < n; ++j) {  // L y = P b
+    const double yj = y[j];
+    const double* col = &A[(size_t)j * n];
+    for (int i = j + 1; i < n; ++i) y[i] -= col[i] * yj;
+  }
+  const double tol = std::numeric_limits<double>::min();
+  for (int i = 0; i < n; ++i) {
+    const double d = M(i, i);
+    y[i] = std::fabs(d) > tol ? y[i] / d : 0.0;
+  }
+  for (int j = n - 1; j >= 0; --j) {  // L' z = y
+    const double* col = &A[(size_t)j * n];
+    double s = y[j];
+    for (int i = j + 1; i < n; ++i) s -= col[i] * y[i];
+    y[j] = s;
+  }
+  for (int k = n - 1; k >= 0; --k) std::swap(y[k], y[tr[k]]);
+  std::copy(y.begin(), y.end(), xout);
+  return true;
+}
+
+// LinearSolverDense::solve, linear_solver_dense.h:65-113: mirror the upper blocks, factor, gate on isPositive
+bool dense_solve(Oracle& o, std::vector<double>& Aupper, const double* rhs, double* xout) {
+  const int n = o.n_red;
+  std::vector<double> H(Aupper);
+  for (int c = 0; c < n; ++c)
+    for (int r = 0; r < c; ++r) H[(size_t)r * n + c] = H[(size_t)c * n + r];  // lower(c,r) = upper(r,c)
+  return ldlt_solve(H, n, rhs, xout);
+}
+
+// BlockSolver::setLambda / restoreDiagonal, block_solver.hpp:564-604
+void set_lambda(Oracle& o, double lambda) {
+  o.diag_backup_p.resize(o.n_red);
+  o.diag_backup_l.resize((size_t)3 * o.n_lm);
+  for (int i = 0; i < o.n_red; ++i) {
+    o.diag_backup_p[i] = HPP(o, i, i);
+    HPP(o, i, i) += lambda;
+  }
+  for (int l = 0; l < o.n_lm; ++l)
+    for (int a = 0; a < 3; ++a) {
+      o.diag_backup_l[3 * l + a] = o.Hll[(size_t)9 * l + 4 * a];
+      o.Hll[(size_t)9 * l + 4 * a] += lambda;
+    }
+}
+void restore_diagonal(Oracle& o) {
+  for (int i = 0; i < o.n_red; ++i) HPP(o, i, i) = o.diag_backup_p[i];
+  for (int l = 0; l < o.n_lm; ++l)
+    for (int a = 0; a < 3; ++a) o.Hll[(size_t)9 * l + 4 * a] = o.diag_backup_l[3 * l + a];
+}
+
+// BlockSolver::solve, block_solver.hpp:354-486
+bool block_solve(Oracle& o) {
+  const int n = o.n_red;
+  if (!o.do_schur) return dense_solve(o, o.Hpp, o.b.data(), o.x.data());
+  o.S = o.Hpp;
+  std::fill(o.coeff.begin(), o.coeff.begin() + n, 0.0);
+  for (int l = 0; l < o.n_lm; ++l) {
+    double* Dinv = &o.Dinv[(size_t)9 * l];
+    inverse3(&o.Hll[(size_t)9 * l], Dinv);
+    const double* bl = &o.b[(size_t)n + 3 * l];
+    double db[3];
+    for (int a = 0; a < 3; ++a) db[a] = Dinv[a * 3] * bl[0] + Dinv[a * 3 + 1] * bl[1] + Dinv[a * 3 + 2] * bl[2];
+    for (int s1 = o.hpl_start[l]; s1 < o.hpl_start[l + 1]; ++s1) {
+      const double* Bi = &o.hpl[(size_t)18 * s1];
+      const int r0 = o.red_col0[o.hpl_rb[s1]];
+      double BDinv[18];
+      for (int a = 0; a < 6; ++a)
+        for (int c = 0; c < 3; ++c)
+          BDinv[a * 3 + c] = Bi[a * 3] * Dinv[c] + Bi[a * 3 + 1] * Dinv[3 + c] + Bi[a * 3 + 2] * Dinv[6 + c];
+      for (int a = 0; a < 6; ++a) o.coeff[r0 + a] += Bi[a * 3] * db[0] + Bi[a * 3 + 1] * db[1] + Bi[a * 3 + 2] * db[2];
+      for (int s2 = s1; s2 < o.hpl_start[l + 1]; ++s2) {
+        const double* Bj = &o.hpl[(size_t)18 * s2];
+        const int c0 = o.red_col0[o.hpl_rb[s2]];
+        for (int a = 0; a < 6; ++a)
+          for (int c = 0; c < 6; ++c)
+            o.S[(size_t)(c0 + c) * n + r0 + a] -= BDinv[a * 3] * Bj[c * 3] + BDinv[a * 3 + 1] * Bj[c * 3 + 1] + BDinv[a * 3 + 2] * Bj[c * 3 + 2];
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) o.bs[i] = o.b[i] - o.coeff[i];
+  if (!dense_solve(o, o.S, o.bs.data(), o.x.data())) return false;
+  for (int l = 0; l < o.n_lm; ++l) {  // x_l = Dinv (b_l - B' x_p), :461-481
+    double cl[3] = {o.b[(size_t)n + 3 * l], o.b[(size_t)n + 3 * l + 1], o.b[(size_t)n + 3 * l + 2]};
+    for (int s1 = o.hpl_start[l]; s1 < o.hpl_start[l + 1]; ++s1) {
+      const double* Bi = &o.hpl[(size_t)18 * s1];
+      const int r0 = o.red_col0[o.hpl_rb[s1]];
+      for (int c = 0; c < 3; ++c)
+        for (int a = 0; a < 6; ++a) cl[c] += Bi[a * 3 + c] * (-o.x[r0 + a]);
+    }
+    const double* Dinv = &o.Dinv[(size_t)9 * l];
+    for (int a = 0; a < 3; ++a) o.x[(size_t)n + 3 * l + a] = Dinv[a * 3] * cl[0] + Dinv[a * 3 + 1] * cl[1] + Dinv[a * 3 + 2] * cl[2];
+  }
+  return true;
+}
+
+// SparseOptimizer::update, sparse_optimizer.cpp:422-435
+void apply_update(Oracle& o) {
+  for (int i = 0; i < o.n_poses; ++i)
+    if (o.hidx[V_POSE][i] >= 0) o.pose[i] = pose_oplus(o.pose[i], &o.x[o.col0[V_POSE][i]]);
+  for (int i = 0; i < o.n_cuboids; ++i)
+    if (o.hidx[V_CUBOID][i] >= 0)
+      o.cuboid[i] = cuboid_oplus(o.cuboid[i], &o.x[o.col0[V_CUBOID][i]], o.cuboid_flags[i], &o.cuboid_fixedscale[3 * i]);
+  for (int i = 0; i < o.n_planes; ++i)
+    if (o.hidx[V_PLANE][i] >= 0) o.plane[i] = plane_oplus(o.plane[i], &o.x[(size_t)o.n_red + o.col0[V_PLANE][i]]);
+  for (int i = 0; i < o.n_points; ++i)
+    if (o.hidx[V_POINT][i] >= 0) {
+      const double* u = &o.x[(size_t)o.n_red + o.col0[V_POINT][i]];
+      o.point[i] = add(o.point[i], mk(u[0], u[1], u[2]));
+    }
+}
+
+bool stop_requested(const volatile uint8_t* f) { return f && *f; }
+
+// OptimizationAlgorithmLevenberg::solve, optimization_algorithm_levenberg.cpp:61-164.
+// returns 0 OK, 1 Terminate
+int lm_solve(Oracle& o, int iteration, const volatile uint8_t* stop, ppo_ba_iter_stat& st) {
+  compute_active_errors(o);
+  double currentChi = active_robust_chi2(o);
+  double tempChi = currentChi;
+  const double iniChi = currentChi;
+  st.chi2_before = currentChi;
+  build_system(o);
+  if (iteration == 0) {  // computeLambdaInit, :166-180
+    double maxDiagonal = 0.;
+    for (int i = 0; i < o.n_red; ++i) maxDiagonal = std::max(std::fabs(HPP(o, i, i)), maxDiagonal);
+    for (int l = 0; l < o.n_lm; ++l)
+      for (int a = 0; a < 3; ++a) maxDiagonal = std::max(std::fabs(o.Hll[(size_t)9 * l + 4 * a]), maxDiagonal);
+    o.lambda = o.opt.lm_tau * maxDiagonal;
+    o.ni = 2;
+    o.nBad = 0;
+  }
+  double rho = 0;
+  int qmax = 0;
+  std::vector<SE3> pose_bak;
+  std::vector<V3> point_bak;
+  std::vector<Plane> plane_bak;
+  std::vector<Cuboid> cuboid_bak;
+  do {
+    pose_bak = o.pose; point_bak = o.point; plane_bak = o.plane; cuboid_bak = o.cuboid;  // push()
+    set_lambda(o, o.lambda);
+    const bool ok2 = block_solve(o);
+    apply_update(o);
+    restore_diagonal(o);
+    compute_active_errors(o);
+    tempChi = active_robust_chi2(o);
+    if (!ok2) tempChi = std::numeric_limits<double>::max();
+    rho = (currentChi - tempChi);
+    double scale = 0.;  // computeScale, :182-189
+    for (size_t j = 0; j < o.x.size(); ++j) scale += o.x[j] * (o.lambda * o.x[j] + o.b[j]);
+    scale += 1e-3;
+    rho /= scale;
+    st.lambda = o.lambda;
+    if (rho > 0 && std::isfinite(tempChi)) {
+      double alpha = 1. - std::pow((2 * rho - 1), 3);
+      alpha = std::min(alpha, o.opt.lm_upper);
+      const double scaleFactor = std::max(o.opt.lm_lower, alpha);
+      o.lambda *= scaleFactor;
+      o.ni = 2;
+      currentChi = tempChi;
+      st.accepted = 1;
+    } else {
+      o.lambda *= o.ni;
+      o.ni *= 2;
+      o.pose.swap(pose_bak); o.point.swap(point_bak); o.plane.swap(plane_bak); o.cuboid.swap(cuboid_bak);  // pop()
+      st.accepted = 0;
+    }
+    qmax++;
+    o.stats.n_trials++;
+  } while (rho < 0 && qmax < o.opt.lm_max_trials && !stop_requested(stop));
+  st.trials = qmax;
+  st.chi2_after = currentChi;
+  if (qmax == o.opt.lm_max_trials || rho == 0) return 1;
+  if ((iniChi - currentChi) * 1e3 < iniChi) o.nBad++;
+  else o.nBad = 0;
+  if (o.nBad >= 3) return 1;
+  return 0;
+}
+
+// SparseOptimizer::optimize, sparse_optimizer.cpp:354-419
+void optimize(Oracle& o, int pass, int iterations, const volatile uint8_t* stop) {
+  if (o.n_red == 0) return;  // "0 vertices to optimize"
+  bool ok = true;
+  for (int i = 0; i < iterations && !stop_requested(stop) && ok; ++i) {
+    ppo_ba_iter_stat st{};
+    st.pass = pass;
+    st.iteration = i;
+    const int res = lm_solve(o, i, stop, st);
+    st.result = res;
+    ok = (res == 0);
+    if (o.stats.n_iters < PPO_BA_MAX_ITER_STATS) o.stats.iters[o.stats.n_iters] = st;
+    o.stats.n_iters++;
+  }
+}
+
+bool depth_positive(const Oracle& o, int type, int idx) {  // types_six_dof_expmap.h:181-185, 213-217
+  const V3 pc = se3_map(o.pose[o.e_v1[type][idx]], o.point[o.e_v0[type][idx]]);
+  return pc[2] > 0.0;
+}
+double err_norm(const Oracle& o, int type, int idx) {
+  const int dim = edge_dim(o, type, idx);
+  const double* e = &o.err[type][(size_t)kMaxDim * idx];
+  double s = 0;
+  for (int i = 0; i < dim; ++i) s += e[i] * e[i];
+  return std::sqrt(s);
+}
+
+// Optimizer.cc:2736-2833
+void classify_outliers(Oracle& o) {
+  for (int i = 0; i < o.n_edges[E_MONO]; ++i) {
+    if (edge_chi2(o, E_MONO, i) > o.opt.chi2_mono || !depth_positive(o, E_MONO, i)) o.level[E_MONO][i] = 1;
+    o.robust[E_MONO][i] = 0;
+  }
+  for (int i = 0; i < o.n_edges[E_STEREO]; ++i) {
+    if (edge_chi2(o, E_STEREO, i) > o.opt.chi2_stereo || !depth_positive(o, E_STEREO, i)) o.level[E_STEREO][i] = 1;
+    o.robust[E_STEREO][i] = 0;
+  }
+  for (int i = 0; i < o.n_edges[E_BBOX]; ++i)
+    if (err_norm(o, E_BBOX, i) > o.opt.th_bbox_norm) o.level[E_BBOX][i] = 1;
+  for (int i = 0; i < o.n_edges[E_CORNER]; ++i)
+    if (err_norm(o, E_CORNER, i) > o.opt.th_corner_norm) o.level[E_CORNER][i] = 1;
+  for (int i = 0; i < o.n_edges[E_PLANE]; ++i) {
+    const double th = o.pl_kind[i] == 0 ? o.opt.chi2_plane : o.opt.chi2_plane_vp;
+    if (edge_chi2(o, E_PLANE, i) > th) o.level[E_PLANE][i] = 1;
+    o.robust[E_PLANE][i] = 0;
+  }
+  // point-cuboid: no filter (:2816-2824); cuboid-plane: vpEdgesCuboidPlane is never filled (:2660, 2826-2833)
+}
+
+void reset_state(Oracle& o) {
+  o.pose = o.pose0; o.point = o.point0; o.plane = o.plane0; o.cuboid = o.cuboid0;
+  for (int t = 0; t < E_NTYPES; ++t) {
+    o.level[t].assign(o.n_edges[t], 0);
+    o.robust[t].assign(o.n_edges[t], 1);
+    o.err[t].assign((size_t)kMaxDim * o.n_edges[t], 0.0);
+  }
+  o.ran = false;
+}
+
+template <class T>
+void copy_in(std::vector<T>& dst, const T* src, size_t n, T fill = T()) {
+  if (src) dst.assign(src, src + n);
+  else dst.assign(n, fill);
+}
+
+}  // namespace
+
+extern "C" {
+
+typedef struct Oracle* oracle_handle;
+
+int oracle_ba_create(const ppo_ba_problem* p, const ppo_ba_options* opt, oracle_handle* out) {
+  if (!p || !opt || !out) return PPO_BA_ERR_ARG;
+  Oracle* o = new Oracle();
+  o->opt = *opt;
+  o->n_poses = p->n_poses; o->n_points = p->n_points; o->n_planes = p->n_planes; o->n_cuboids = p->n_cuboids;
+  o->pose0.resize(p->n_poses);
+  for (int i = 0; i < p->n_poses; ++i) {
+    const double* q = &p->pose_qt[7 * i];
+    // Converter::toSE3Quat builds SE3Quat(R,t) whose ctor normalises (se3quat.h:58-60)
+    o->pose0[i] = se3_make(Quat{q[0], q[1], q[2], q[3]}, mk(q[4], q[5], q[6]));
+  }
+  copy_in(o->pose_fixed, p->pose_fixed, (size_t)p->n_poses, (uint8_t)0);
+  copy_in(o->pose_cam, p->pose_cam, (size_t)5 * p->n_poses, 0.0);
+  o->point0.resize(p->n_points);
+  for (int i = 0; i < p->n_points; ++i) o->point0[i] = mk(p->point_xyz[3 * i], p->point_xyz[3 * i + 1], p->point_xyz[3 * i + 2]);
+  copy_in(o->point_fixed, p->point_fixed, (size_t)p->n_points, (uint8_t)0);
+  o->plane0.resize(p->n_planes);
+  for (int i = 0; i < p->n_planes; ++i) o->plane0[i] = plane_from_cv(&p->plane_coef[4 * i]);
+  o->cuboid0.resize(p->n_cuboids);
+  for (int i = 0; i < p->n_cuboids; ++i) {
+    const double* q = &p->cuboid_qt[7 * i];
+    o->cuboid0[i].pose = se3_make(Quat{q[0], q[1], q[2], q[3]}, mk(q[4], q[5], q[6]));
+    o->cuboid0[i].scale = mk(p->cuboid_scale[3 * i], p->cuboid_scale[3 * i + 1], p->cuboid_scale[3 * i + 2]);
+  }
+  copy_in(o->cuboid_flags, p->cuboid_flags, (size_t)p->n_cuboids, (uint8_t)(PPO_CUBOID_FIX_ROLLPITCH | PPO_CUBOID_FIX_HEIGHT));
+  copy_in(o->cuboid_fixedscale, p->cuboid_fixedscale, (size_t)3 * p->n_cuboids, 0.0);
+
+  auto set_edges = [&](int t, int n, const int32_t* v0, const int32_t* v1, const double* meas, int mdim, const double* info,
+                       int idim, const double* huber) {
+    o->n_edges[t] = n;
+    copy_in(o->e_v0[t], v0, (size_t)n, 0);
+    if (v1) copy_in(o->e_v1[t], v1, (size_t)n, 0);
+    copy_in(o->e_meas[t], meas, (size_t)mdim * n, 0.0);
+    copy_in(o->e_info[t], info, (size_t)idim * n, 1.0);
+    copy_in(o->e_huber[t], huber, (size_t)n, 0.0);
+  };
+  set_edges(E_MONO, p->n_mono, p->mono_point, p->mono_pose, p->mono_obs, 2, p->mono_info, 1, p->mono_huber);
+  set_edges(E_STEREO, p->n_stereo, p->stereo_point, p->stereo_pose, p->stereo_obs, 3, p->stereo_info, 1, p->stereo_huber);
+  set_edges(E_PLANE, p->n_plane_edges, p->pl_plane, p->pl_pose, p->pl_meas, 4, p->pl_info, 3, p->pl_huber);
+  copy_in(o->pl_kind, p->pl_kind, (size_t)p->n_plane_edges, (uint8_t)0);
+  o->pl_meas_plane.resize(p->n_plane_edges);
+  for (int i = 0; i < p->n_plane_edges; ++i) o->pl_meas_plane[i] = plane_from_cv(&p->pl_meas[4 * i]);
+  set_edges(E_BBOX, p->n_bbox, p->bbox_pose, p->bbox_cuboid, p->bbox_meas, 4, p->bbox_info, 4, p->bbox_huber);
+  copy_in(o->bbox_K, p->bbox_K, (size_t)9 * p->n_bbox, 0.0);
+  set_edges(E_CORNER, p->n_corner, p->corner_pose, p->corner_cuboid, p->corner_meas, 16, p->corner_info, 16, p->corner_huber);
+  copy_in(o->corner_K, p->corner_K, (size_t)9 * p->n_corner, 0.0);
+  set_edges(E_PTCUB, p->n_ptcub, p->ptcub_cuboid, nullptr, nullptr, 0, p->ptcub_info, 3, p->ptcub_huber);
+  copy_in(o->ptcub_off, p->ptcub_offsets, (size_t)p->n_ptcub + 1, 0);
+  copy_in(o->ptcub_pts, p->ptcub_points, (size_t)3 * (p->n_ptcub ? o->ptcub_off[p->n_ptcub] : 0), 0.0);
+  copy_in(o->ptcub_margin, p->ptcub_margin_ratio, (size_t)p->n_ptcub, 1.0);
+  copy_in(o->ptcub_prior, p->ptcub_prior_half, (size_t)3 * p->n_ptcub, 0.0);
+  set_edges(E_CUBPL, p->n_cubpl, p->cubpl_cuboid, p->cubpl_plane, p->cubpl_meas, 3, p->cubpl_info, 3, p->cubpl_huber);
+  reset_state(*o);
+  *out = o;
+  return PPO_BA_OK;
+}
+
+int oracle_ba_reset(oracle_handle o) {
+  if (!o) return PPO_BA_ERR_ARG;
+  reset_state(*o);
+  return PPO_BA_OK;
+}
+
+// Optimizer.cc:2723-2838
+int oracle_ba_run(oracle_handle o, const volatile uint8_t* stop, ppo_ba_stats* stats) {
+  if (!o) return PPO_BA_ERR_ARG;
+  std::memset(&o->stats, 0, sizeof(o->stats));
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = PPO_BA_OK;
+  if (stop_requested(stop)) return PPO_BA_ABORTED;
+  initialize_optimization(*o, 0);
+  o->stats.n_reduced = o->n_red;
+  o->stats.n_active_edges_pass1 = (int)o->active.size();
+  optimize(*o, 0, o->opt.iters_pass1, stop);
+  const auto t1 = std::chrono::steady_clock::now();
+  bool more = !stop_requested(stop) && o->opt.iters_pass2 > 0;
+  if (stop_requested(stop)) rc = PPO_BA_ABORTED;
+  auto t2 = t1;
+  if (more) {
+    classify_outliers(*o);
+    t2 = std::chrono::steady_clock::now();
+    initialize_optimization(*o, 0);
+    o->stats.n_active_edges_pass2 = (int)o->active.size();
+    optimize(*o, 1, o->opt.iters_pass2, stop);
+    if (stop_requested(stop)) rc = PPO_BA_ABORTED;
+  }
+  const auto t3 = std::chrono::steady_clock::now();
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  o->stats.wall_ms_total = ms(t0, t3);
+  o->stats.wall_ms_pass1 = ms(t0, t1);
+  o->stats.wall_ms_classify = ms(t1, t2);
+  o->stats.wall_ms_pass2 = ms(t2, t3);
+  o->ran = true;
+  if (stats) *stats = o->stats;
+  return rc;
+}
+
+int oracle_ba_read(oracle_handle o, ppo_ba_result* r) {
+  if (!o || !r) return PPO_BA_ERR_ARG;
+  auto put_se3 = [](double* dst, const SE3& T) {
+    dst[0] = T.r.x; dst[1] = T.r.y; dst[2] = T.r.z; dst[3] = T.r.w; dst[4] = T.t[0]; dst[5] = T.t[1]; dst[6] = T.t[2];
+  };
+  if (r->pose_qt) for (int i = 0; i < o->n_poses; ++i) put_se3(&r->pose_qt[7 * i], o->pose[i]);
+  if (r->point_xyz) for (int i = 0; i < o->n_points; ++i) for (int a = 0; a < 3; ++a) r->point_xyz[3 * i + a] = o->point[i][a];
+  if (r->plane_coef) for (int i = 0; i < o->n_planes; ++i) for (int a = 0; a < 4; ++a) r->plane_coef[4 * i + a] = o->plane[i].c[a];
+  if (r->cuboid_qt) for (int i = 0; i < o->n_cuboids; ++i) put_se3(&r->cuboid_qt[7 * i], o->cuboid[i].pose);
+  if (r->cuboid_scale) for (int i = 0; i < o->n_cuboids; ++i) for (int a = 0; a < 3; ++a) r->cuboid_scale[3 * i + a] = o->cuboid[i].scale[a];
+  auto put_chi = [&](int t, double* chi, uint8_t* lvl) {
+    for (int i = 0; i < o->n_edges[t]; ++i) {
+      if (chi) chi[i] = edge_chi2(*o, t, i);
+      if (lvl) lvl[i] = o->level[t][i];
+    }
+  };
+  put_chi(E_MONO, r->mono_chi2, r->mono_level);
+  put_chi(E_STEREO, r->stereo_chi2, r->stereo_level);
+  put_chi(E_PLANE, r->pl_chi2, r->pl_level);
+  put_chi(E_BBOX, r->bbox_chi2, r->bbox_level);
+  put_chi(E_CORNER, r->corner_chi2, r->corner_level);
+  put_chi(E_PTCUB, r->ptcub_chi2, nullptr);
+  put_chi(E_CUBPL, r->cubpl_chi2, nullptr);
+  if (r->mono_depth_positive) for (int i = 0; i < o->n_edges[E_MONO]; ++i) r->mono_depth_positive[i] = depth_positive(*o, E_MONO, i);
+  if (r->stereo_depth_positive) for (int i = 0; i < o->n_edges[E_STEREO]; ++i) r->stereo_depth_positive[i] = depth_positive(*o, E_STEREO, i);
+  if (r->bbox_errnorm) for (int i = 0; i < o->n_edges[E_BBOX]; ++i) r->bbox_errnorm[i] = err_norm(*o, E_BBOX, i);
+  if (r->corner_errnorm) for (int i = 0; i < o->n_edges[E_CORNER]; ++i) r->corner_errnorm[i] = err_norm(*o, E_CORNER, i);
+  return PPO_BA_OK;
+}
+
+void oracle_ba_destroy(oracle_handle o) { delete o; }
+
+// ---- step-level hooks for the parity tests ------------------------------------------------------
+// One linearisation of the current state at level 0: errors, robust chi2, block system.
+int oracle_ba_linearize(oracle_handle o, double* robust_chi2) {
+  if (!o) return PPO_BA_ERR_ARG;
+  initialize_optimization(*o, 0);
+  compute_active_errors(*o);
+  if (robust_chi2) *robust_chi2 = active_robust_chi2(*o);
+  build_system(*o);
+  o->stats.n_reduced = o->n_red;
+  return PPO_BA_OK;
+}
+// Reduced system for a given lambda after oracle_ba_linearize: S (n x n column-major, full symmetric),
+// b_schur and the solution x_p.  Landmark range [lm_first, lm_last) restricts the Schur sum (for the
+// sharding tests: partial systems of disjoint ranges sum to the full one when add_hpp is set on one rank).
+int oracle_ba_reduced(oracle_handle o, double lambda, int lm_first, int lm_last, int add_hpp, double* S, double* bsch, int32_t* n_out) {
+  if (!o) return PPO_BA_ERR_ARG;
+  const int n = o->n_red;
+  if (n_out) *n_out = n;
+  if (lm_last < 0 || lm_last > o->n_lm) lm_last = o->n_lm;
+  std::vector<double> Sm((size_t)n * n, 0.0), bb(n, 0.0);
+  if (add_hpp) {
+    for (int c = 0; c < n; ++c)
+      for (int r = 0; r <= c; ++r) Sm[(size_t)c * n + r] = o->Hpp[(size_t)c * n + r];
+    for (int i = 0; i < n; ++i) { Sm[(size_t)i * n + i] += lambda; bb[i] = o->b[i]; }
+  }
+  for (int l = lm_first; l < lm_last; ++l) {
+    double D[9], Dinv[9];
+    for (int k = 0; k < 9; ++k) D[k] = o->Hll[(size_t)9 * l + k];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    inverse3(D, Dinv);
+    const double* bl = &o->b[(size_t)n + 3 * l];
+    double db[3];
+    for (int a = 0; a < 3; ++a) db[a] = Dinv[a * 3] * bl[0] + Dinv[a * 3 + 1] * bl[1] + Dinv[a * 3 + 2] * bl[2];
+    for (int s1 = o->hpl_start[l]; s1 < o->hpl_start[l + 1]; ++s1) {
+      const double* Bi = &o->hpl[(size_t)18 * s1];
+      const int r0 = o->red_col0[o->hpl_rb[s1]];
+      double BDinv[18];
+      for (int a = 0; a < 6; ++a)
+        for (int c = 0; c < 3; ++c) BDinv[a * 3 + c] = Bi[a * 3] * Dinv[c] + Bi[a * 3 + 1] * Dinv[3 + c] + Bi[a * 3 + 2] * Dinv[6 + c];
+      for (int a = 0; a < 6; ++a) bb[r0 + a] -= Bi[a * 3] * db[0] + Bi[a * 3 + 1] * db[1] + Bi[a * 3 + 2] * db[2];
+      for (int s2 = s1; s2 < o->hpl_start[l + 1]; ++s2) {
+        const double* Bj = &o->hpl[(size_t)18 * s2];
+        const int c0 = o->red_col0[o->hpl_rb[s2]];
+        for (int a = 0; a < 6; ++a)
+          for (int c = 0; c < 6; ++c)
+            Sm[(size_t)(c0 + c) * n + r0 + a] -= BDinv[a * 3] * Bj[c * 3] + BDinv[a * 3 + 1] * Bj[c * 3 + 1] + BDinv[a * 3 + 2] * Bj[c * 3 + 2];
+      }
+    }
+  }
+  for (int c = 0; c < n; ++c)
+    for (int r = 0; r < c; ++r) Sm[(size_t)r * n + c] = Sm[(size_t)c * n + r];
+  if (S) std::copy(Sm.begin(), Sm.end(), S);
+  if (bsch) std::copy(bb.begin(), bb.end(), bsch);
+  return PPO_BA_OK;
+}
+int oracle_ba_num_landmarks(oracle_handle o) { return o ? o->n_lm : -1; }
+// dense symmetric solve through the restated LDLT (column-major full matrix in, lower triangle used)
+int oracle_ldlt_solve(const double* A, int n, const double* rhs, double* x) {
+  std::vector<double> M(A, A + (size_t)n * n);
+  return ldlt_solve(M, n, rhs, x) ? 1 : 0;
+}
+// per-edge residual and Jacobians at the current state.  type: 0 plane,1 mono,2 stereo,3 bbox,4 corner,5 ptcub,6 cubpl
+int oracle_edge_eval(oracle_handle o, int type, int idx, double* e, double* J0, double* J1) {
+  if (!o || type < 0 || type >= E_NTYPES || idx < 0 || idx >= o->n_edges[type]) return PPO_BA_ERR_ARG;
+  int t0, i0, t1, i1;
+  edge_vertices(*o, type, idx, t0, i0, t1, i1);
+  double ee[kMaxDim], j0[kMaxDim * 9] = {0}, j1[kMaxDim * 9] = {0};
+  compute_error(*o, type, idx, vertex_ptr(*o, t0, i0), t1 == V_NONE ? nullptr : vertex_ptr(*o, t1, i1), ee);
+  linearize(*o, type, idx, j0, j1);
+  const int dim = edge_dim(*o, type, idx);
+  if (e) std::copy(ee, ee + dim, e);
+  if (J0) std::copy(j0, j0 + dim * kVDim[t0], J0);
+  if (J1 && t1 != V_NONE) std::copy(j1, j1 + dim * kVDim[t1], J1);
+  return dim;
+}
+
+// ---- leaf functions for the known-answer / golden tests ------------------------------------------
+void oracle_se3_exp(const double upd[6], double qt[7]) {
+  const SE3 T = se3_exp(upd);
+  qt[0] = T.r.x; qt[1] = T.r.y; qt[2] = T.r.z; qt[3] = T.r.w; qt[4] = T.t[0]; qt[5] = T.t[1]; qt[6] = T.t[2];
+}
+void oracle_pose_oplus(const double qt[7], const double upd[6], double out[7]) {
+  const SE3 T = pose_oplus(se3_make(Quat{qt[0], qt[1], qt[2], qt[3]}, mk(qt[4], qt[5], qt[6])), upd);
+  out[0] = T.r.x; out[1] = T.r.y; out[2] = T.r.z; out[3] = T.r.w; out[4] = T.t[0]; out[5] = T.t[1]; out[6] = T.t[2];
+}
+void oracle_plane_oplus(const double c[4], const double upd[3], double out[4]) {
+  const Plane p = plane_oplus(plane_from_vector(c), upd);
+  std::memcpy(out, p.c, sizeof(p.c));
+}
+void oracle_plane_ominus(const double a[4], const double b[4], int kind, double* e) {
+  const Plane pa = plane_from_vector(a), pb = plane_from_vector(b);
+  if (kind == 0) plane_ominus(pa, pb, e);
+  else if (kind == 1) plane_ominus_ver(pa, pb, e);
+  else plane_ominus_par(pa, pb, e);
+}
+void oracle_plane_transform(const double qt[7], const double c[4], double out[4]) {
+  const Plane p = plane_transform(se3_make(Quat{qt[0], qt[1], qt[2], qt[3]}, mk(qt[4], qt[5], qt[6])), plane_from_vector(c));
+  std::memcpy(out, p.c, sizeof(p.c));
+}
+void oracle_cuboid_oplus(const double qt[7], const double scale[3], const double upd[9], unsigned flags, const double* fixedscale,
+                         double out_qt[7], double out_scale[3]) {
+  Cuboid c;
+  c.pose = se3_make(Quat{qt[0], qt[1], qt[2], qt[3]}, mk(qt[4], qt[5], qt[6]));
+  c.scale = mk(scale[0], scale[1], scale[2]);
+  const Cuboid n = cuboid_oplus(c, upd, flags, fixedscale);
+  out_qt[0] = n.pose.r.x; out_qt[1] = n.pose.r.y; out_qt[2] = n.pose.r.z; out_qt[3] = n.pose.r.w;
+  out_qt[4] = n.pose.t[0]; out_qt[5] = n.pose.t[1]; out_qt[6] = n.pose.t[2];
+  for (int i = 0; i < 3; ++i) out_scale[i] = n.scale[i];
+}
+void oracle_cuboid_project(const double cqt[7], const double scale[3], const double pose_qt[7], const double K[9], double uv[16], double bbox[4]) {
+  Cuboid c;
+  c.pose = se3_make(Quat{cqt[0], cqt[1], cqt[2], cqt[3]}, mk(cqt[4], cqt[5], cqt[6]));
+  c.scale = mk(scale[0], scale[1], scale[2]);
+  const SE3 T = se3_make(Quat{pose_qt[0], pose_qt[1], pose_qt[2], pose_qt[3]}, mk(pose_qt[4], pose_qt[5], pose_qt[6]));
+  double c2[8][2];
+  cuboid_project_corners(c, T, K, c2);
+  for (int k = 0; k < 8; ++k) { uv[2 * k] = c2[k][0]; uv[2 * k + 1] = c2[k][1]; }
+  cuboid_project_bbox(c, T, K, bbox);
+}
+void oracle_huber(double e, double delta, double rho[3]) { huber_robustify(e, delta, rho); }
+
+}  // extern "C"

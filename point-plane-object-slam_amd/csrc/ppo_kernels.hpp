@@ -1,0 +1,728 @@
+// ppo_kernels.hpp -- CDNA4 (gfx950, wave64) kernels of one Levenberg-Marquardt iteration.
+//
+// Data flow per LM iteration (DESIGN.md has the byte accounting):
+//   k_lin_points      thread per point, its mono/stereo edges in registers: residual, analytic Jacobians, Huber,
+//                     D_l / b_l written once, W = Jp' w Jl written once per edge, pose blocks accumulated in LDS
+//                     (the camera table is staged in LDS too) and flushed with one global atomic per entry.
+//   k_lin_numeric<M>  16-lane group per plane / bbox / corner / point-cuboid edge, one lane per Jacobian column,
+//                     central differences through the vertex box-plus exactly like g2o (delta = 1e-9).
+//   k_assemble        reduced system S (lower) <- Hpp + lambda I, Hcc + lambda I, pose-cuboid blocks; bs <- b.
+//   k_schur_prep      thread per landmark: (D + lambda I)^-1, y = Dinv b_l, Y = W Dinv, bs -= W y.
+//   k_schur_accum     8-lane group per (landmark, pose) slot: S(pj, pi) -= W_j Y_i' with row-contiguous atomics.
+//   [dense Cholesky of S: rocSOLVER or ppo_chol.hpp]
+//   k_update_reduced  poses / cuboids: trial = cur [+] x.      k_backsub: x_l = Dinv (b_l - W' x_p), trial landmarks.
+//   k_chi2_points / k_chi2_numeric<M>   residual-only pass on the trial state, per-edge chi2 kept (g2o's stored _error).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ppo_math.hpp"
+
+namespace ppo {
+
+// ---- device-resident graph -----------------------------------------------------------------------------
+struct MonoEdge {  // 48 B
+  double u, v, info, huber;
+  int32_t pose, slot;
+  uint32_t flags;  // bit0 active (level 0), bit1 robust kernel on
+  int32_t pad;
+};
+struct StereoEdge {  // 64 B
+  double u, v, ur, info, huber;
+  int32_t pose, slot;
+  uint32_t flags;
+  int32_t pad[3];
+};
+struct PlaneEdge {  // 88 B
+  double meas[4], info[3], huber;
+  int32_t plane, pose, slot;
+  uint32_t flags;  // bit0 active, bit1 robust, bits 8..9 kind
+  int32_t pad[2];
+};
+struct CubEdge {  // bbox (dim 4) and corner (dim 16) edges share one record
+  double meas[16], info[16], huber, K[9];
+  int32_t pose, cuboid;
+  uint32_t flags;
+  int32_t dim;
+};
+struct PtCubEdge {
+  double margin, prior[3], info[3], huber;
+  int32_t cuboid, p0, p1;
+  uint32_t flags;
+};
+
+enum { F_ACTIVE = 1u, F_ROBUST = 2u };
+enum { ACC_CHI2 = 0, ACC_SCALE = 1, ACC_MAXDIAG = 2, ACC_N = 8 };
+
+struct State {       // one copy of all estimates
+  double* pose_qt;   // [Np][7]
+  double* pose_rt;   // [Np][12] rotation matrix (row-major) + translation, derived from pose_qt
+  double* point;     // [Npt][3]
+  double* plane;     // [Npl][4]
+  double* cub;       // [Nc][10] qx qy qz qw tx ty tz sx sy sz
+};
+
+struct Graph {
+  int n_poses, n_points, n_planes, n_cuboids, n_pose_free, n_red, n_lm, n_slots;
+  int n_mono, n_stereo, n_pl, n_bbox, n_corner, n_ptcub;
+  const double* pose_cam;      // [Np][5]
+  const int32_t* pose_col;     // [Np] column of the pose block in the reduced system, -1 fixed / unused
+  const int32_t* pose_free_id; // [Np] dense id among free poses (index into HB), -1 otherwise
+  const int32_t* cub_col;      // [Nc]
+  const uint8_t* point_fixed;  // [Npt]
+  const uint8_t* cub_flags;    // [Nc]
+  const double* cub_fixedscale;  // [Nc][3]
+  const int32_t* mo_off;       // [Npt+1] mono edges of a point (edges sorted by point)
+  const int32_t* st_off;       // [Npt+1]
+  MonoEdge* mono;
+  StereoEdge* stereo;
+  PlaneEdge* pl;
+  CubEdge* bbox;
+  CubEdge* corner;
+  PtCubEdge* ptcub;
+  const double* ptcub_pts;
+  const int32_t* slot_off;     // [n_lm+1] slots of a landmark (landmark = point id, or n_points + plane id)
+  const int32_t* slot_col;     // [n_slots] reduced column of the slot's pose
+  const int32_t* slot_lm;      // [n_slots]
+  // per-edge outputs (stored-_error semantics)
+  double* mono_chi2;  double* stereo_chi2;  double* pl_chi2;
+  double* bbox_chi2;  double* bbox_norm;    double* corner_chi2;  double* corner_norm;  double* ptcub_chi2;
+  // linear system
+  double* HB;    // [n_pose_free][27]: 21 packed lower entries of the 6x6 block, then b (6)
+  double* HC;    // [Nc][54]: 45 packed lower entries of the 9x9 block, then b (9)
+  double* D;     // [n_lm][6] packed upper (00,01,02,11,12,22)
+  double* bl;    // [n_lm][3]
+  double* W;     // [n_slots][18] pose rows x landmark cols, row-major
+  double* Wpc_bbox;    // [n_bbox][54] pose rows x cuboid cols
+  double* Wpc_corner;  // [n_corner][54]
+  double* Dinv;  // [n_lm][6]
+  double* yl;    // [n_lm][3]
+  double* Y;     // [n_slots][18]
+  double* S;     // [n_red][n_red] column-major, lower triangle
+  double* bs;    // [n_red]
+  double* xr;    // [n_red]
+  double* acc;   // [ACC_N]
+  // landmark range owned by this rank (multi-GPU) -- single GPU: [0, n_points) and [0, n_planes)
+  int pt_first, pt_last, plane_first, plane_last;
+  int owns_reduced;  // 1 on the rank that adds Hcc / lambda / cuboid terms
+};
+
+__device__ __forceinline__ int packed_lower(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+// block-wide sum to one global atomic (blockDim.x multiple of 64, <= 1024)
+__device__ __forceinline__ void block_atomic_add(double v, double* dst, double* s_red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) s_red[wid] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_red[i];
+    if (t != 0.0) atomicAdd(dst, t);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void atomic_max_pos(double* dst, double v) {  // v >= 0: IEEE order == integer order
+  atomicMax(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v));
+}
+
+__device__ __forceinline__ Pose load_pose(const double* qt) { return Pose{Quat{qt[0], qt[1], qt[2], qt[3]}, Vec3{qt[4], qt[5], qt[6]}}; }
+__device__ __forceinline__ void store_pose(double* qt, double* rt, const Pose& P) {
+  qt[0] = P.q.x; qt[1] = P.q.y; qt[2] = P.q.z; qt[3] = P.q.w; qt[4] = P.t.x; qt[5] = P.t.y; qt[6] = P.t.z;
+  const Mat3 R = rotmat(P.q);
+  for (int i = 0; i < 9; ++i) rt[i] = R.a[i];
+  rt[9] = P.t.x; rt[10] = P.t.y; rt[11] = P.t.z;
+}
+__device__ __forceinline__ Cub load_cub(const double* c) {
+  return Cub{Pose{Quat{c[0], c[1], c[2], c[3]}, Vec3{c[4], c[5], c[6]}}, Vec3{c[7], c[8], c[9]}};
+}
+__device__ __forceinline__ PlaneC load_plane(const double* p) { return PlaneC{p[0], p[1], p[2], p[3]}; }
+
+// ======================================================================================================
+// k_lin_points: reprojection edges.  LDS layout: [n_poses][16] camera table (R, t, fx fy cx cy) followed by
+// [n_pose_free][27] pose-block accumulators.  USE_LDS=false falls back to global atomics and global camera reads
+// when the window has too many keyframes for 160 KB.
+// ======================================================================================================
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
+  extern __shared__ double smem[];
+  __shared__ double s_red[4];
+  double* s_cam = smem;
+  const int acc0 = g.n_poses * 16;
+  double* s_acc = smem + acc0;
+  if (USE_LDS) {
+    for (int i = threadIdx.x; i < g.n_poses * 16; i += blockDim.x) {
+      const int p = i >> 4, k = i & 15;
+      s_cam[i] = k < 12 ? st.pose_rt[p * 12 + k] : g.pose_cam[p * 5 + (k - 12)];
+    }
+    for (int i = threadIdx.x; i < g.n_pose_free * 27; i += blockDim.x) s_acc[i] = 0.0;
+    __syncthreads();
+  }
+  double chi_local = 0.0;
+  for (int p = g.pt_first + blockIdx.x * blockDim.x + threadIdx.x; p < g.pt_last; p += gridDim.x * blockDim.x) {
+    const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
+    const bool lm_free = !g.point_fixed[p];
+    double D[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+    const int m0 = g.mo_off[p], m1 = g.mo_off[p + 1], s0 = g.st_off[p], s1 = g.st_off[p + 1];
+    for (int ei = m0; ei < m1 + (s1 - s0); ++ei) {
+      const bool is_st = ei >= m1;
+      const int e = is_st ? s0 + (ei - m1) : ei;
+      double ev[3], Jl[9], Jp[18], info, hub, zc;
+      int pose, slot, dim;
+      uint32_t flags;
+      if (!is_st) {
+        const MonoEdge ed = g.mono[e];
+        pose = ed.pose; slot = ed.slot; flags = ed.flags; info = ed.info; hub = ed.huber; dim = 2;
+        if (!(flags & F_ACTIVE)) {
+          if (slot >= 0) for (int k = 0; k < 18; ++k) g.W[(size_t)slot * 18 + k] = 0.0;
+          continue;
+        }
+        const double* c = USE_LDS ? &s_cam[pose * 16] : nullptr;
+        Mat3 R; Vec3 t; double fx, fy, cx, cy;
+        if (USE_LDS) { for (int k = 0; k < 9; ++k) R.a[k] = c[k]; t = v3(c[9], c[10], c[11]); fx = c[12]; fy = c[13]; cx = c[14]; cy = c[15]; }
+        else { const double* rt = &st.pose_rt[pose * 12]; for (int k = 0; k < 9; ++k) R.a[k] = rt[k]; t = v3(rt[9], rt[10], rt[11]);
+               const double* cm = &g.pose_cam[pose * 5]; fx = cm[0]; fy = cm[1]; cx = cm[2]; cy = cm[3]; }
+        mono_eval(R, t, X, fx, fy, cx, cy, ed.u, ed.v, ev, Jl, Jp, zc);
+      } else {
+        const StereoEdge ed = g.stereo[e];
+        pose = ed.pose; slot = ed.slot; flags = ed.flags; info = ed.info; hub = ed.huber; dim = 3;
+        if (!(flags & F_ACTIVE)) {
+          if (slot >= 0) for (int k = 0; k < 18; ++k) g.W[(size_t)slot * 18 + k] = 0.0;
+          continue;
+        }
+        const double* rt = &st.pose_rt[pose * 12];
+        Mat3 R; for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
+        const double* cm = &g.pose_cam[pose * 5];
+        stereo_eval(R, v3(rt[9], rt[10], rt[11]), X, cm[0], cm[1], cm[2], cm[3], cm[4], ed.u, ed.v, ed.ur, ev, Jl, Jp, zc);
+      }
+      double chi2 = 0;
+      for (int r = 0; r < dim; ++r) chi2 += ev[r] * (info * ev[r]);
+      if (is_st) g.stereo_chi2[e] = chi2; else g.mono_chi2[e] = chi2;
+      double rho0, rho1;
+      huber(chi2, (flags & F_ROBUST) ? hub : 0.0, rho0, rho1);
+      chi_local += rho0;
+      const double w = rho1 * info;
+      double gr[3];  // -rho1 * Omega * e
+      for (int r = 0; r < dim; ++r) gr[r] = -(info * ev[r]) * rho1;
+      if (lm_free) {
+        for (int r = 0; r < dim; ++r) {
+          const double* j = &Jl[3 * r];
+          D[0] += j[0] * w * j[0]; D[1] += j[0] * w * j[1]; D[2] += j[0] * w * j[2];
+          D[3] += j[1] * w * j[1]; D[4] += j[1] * w * j[2]; D[5] += j[2] * w * j[2];
+          bl[0] += j[0] * gr[r]; bl[1] += j[1] * gr[r]; bl[2] += j[2] * gr[r];
+        }
+      }
+      const int fid = g.pose_free_id[pose];
+      if (fid >= 0) {
+        const int base = fid * 27;
+        for (int a = 0; a < 6; ++a) {
+          double ba = 0;
+          for (int r = 0; r < dim; ++r) ba += Jp[6 * r + a] * gr[r];
+          if constexpr (USE_LDS) atomicAdd(&smem[acc0 + base + 21 + a], ba); else atomicAdd(&g.HB[base + 21 + a], ba);
+          for (int c = 0; c <= a; ++c) {
+            double h = 0;
+            for (int r = 0; r < dim; ++r) h += Jp[6 * r + a] * w * Jp[6 * r + c];
+            if constexpr (USE_LDS) atomicAdd(&smem[acc0 + base + packed_lower(a, c)], h); else atomicAdd(&g.HB[base + packed_lower(a, c)], h);
+          }
+        }
+        if (slot >= 0) {
+          double* Wd = &g.W[(size_t)slot * 18];
+          for (int a = 0; a < 6; ++a)
+            for (int c = 0; c < 3; ++c) {
+              double h = 0;
+              for (int r = 0; r < dim; ++r) h += Jp[6 * r + a] * w * Jl[3 * r + c];
+              Wd[a * 3 + c] = h;
+            }
+        }
+      }
+    }
+    if (lm_free) {
+      for (int k = 0; k < 6; ++k) g.D[(size_t)p * 6 + k] = D[k];
+      for (int k = 0; k < 3; ++k) g.bl[(size_t)p * 3 + k] = bl[k];
+    }
+  }
+  block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+  if (USE_LDS) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.n_pose_free * 27; i += blockDim.x) {
+      const double v = s_acc[i];
+      if (v != 0.0) atomicAdd(&g.HB[i], v);
+    }
+  }
+}
+
+// residual-only pass over the reprojection edges (trial state)
+__global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
+  __shared__ double s_red[4];
+  double chi_local = 0.0;
+  for (int p = g.pt_first + blockIdx.x * blockDim.x + threadIdx.x; p < g.pt_last; p += gridDim.x * blockDim.x) {
+    const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
+    for (int e = g.mo_off[p]; e < g.mo_off[p + 1]; ++e) {
+      const MonoEdge ed = g.mono[e];
+      if (!(ed.flags & F_ACTIVE)) continue;
+      const double* rt = &st.pose_rt[ed.pose * 12];
+      const double* cm = &g.pose_cam[ed.pose * 5];
+      Mat3 R; for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
+      double ev[2], zc;
+      mono_residual(R, v3(rt[9], rt[10], rt[11]), X, cm[0], cm[1], cm[2], cm[3], ed.u, ed.v, ev, zc);
+      const double chi2 = ev[0] * (ed.info * ev[0]) + ev[1] * (ed.info * ev[1]);
+      g.mono_chi2[e] = chi2;
+      double rho0, rho1;
+      huber(chi2, (ed.flags & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      chi_local += rho0;
+    }
+    for (int e = g.st_off[p]; e < g.st_off[p + 1]; ++e) {
+      const StereoEdge ed = g.stereo[e];
+      if (!(ed.flags & F_ACTIVE)) continue;
+      const double* rt = &st.pose_rt[ed.pose * 12];
+      const double* cm = &g.pose_cam[ed.pose * 5];
+      Mat3 R; for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
+      double ev[3], zc;
+      stereo_residual(R, v3(rt[9], rt[10], rt[11]), X, cm[0], cm[1], cm[2], cm[3], cm[4], ed.u, ed.v, ed.ur, ev, zc);
+      double chi2 = 0;
+      for (int r = 0; r < 3; ++r) chi2 += ev[r] * (ed.info * ev[r]);
+      g.stereo_chi2[e] = chi2;
+      double rho0, rho1;
+      huber(chi2, (ed.flags & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      chi_local += rho0;
+    }
+  }
+  block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+}
+
+// Optimizer.cc:2739-2769: level 1 if chi2 > threshold or depth <= 0 (depth from the CURRENT estimates), kernel off
+__global__ void k_classify_points(Graph g, State st, double th_mono, double th_stereo) {
+  for (int p = g.pt_first + blockIdx.x * blockDim.x + threadIdx.x; p < g.pt_last; p += gridDim.x * blockDim.x) {
+    const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
+    for (int e = g.mo_off[p]; e < g.mo_off[p + 1]; ++e) {
+      const int pose = g.mono[e].pose;
+      const double* rt = &st.pose_rt[pose * 12];
+      const double z = rt[6] * X.x + rt[7] * X.y + rt[8] * X.z + rt[11];
+      uint32_t f = g.mono[e].flags;
+      if (g.mono_chi2[e] > th_mono || !(z > 0.0)) f &= ~F_ACTIVE;
+      f &= ~F_ROBUST;
+      g.mono[e].flags = f;
+    }
+    for (int e = g.st_off[p]; e < g.st_off[p + 1]; ++e) {
+      const int pose = g.stereo[e].pose;
+      const double* rt = &st.pose_rt[pose * 12];
+      const double z = rt[6] * X.x + rt[7] * X.y + rt[8] * X.z + rt[11];
+      uint32_t f = g.stereo[e].flags;
+      if (g.stereo_chi2[e] > th_stereo || !(z > 0.0)) f &= ~F_ACTIVE;
+      f &= ~F_ROBUST;
+      g.stereo[e].flags = f;
+    }
+  }
+}
+// Optimizer.cc:2771-2814 for the plane and cuboid-projection edges
+__global__ void k_classify_small(Graph g, double th_plane, double th_vp, double th_bbox, double th_corner) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < g.n_pl) {
+    uint32_t f = g.pl[i].flags;
+    const int kind = (f >> 8) & 3;
+    if (g.pl_chi2[i] > (kind == 0 ? th_plane : th_vp)) f &= ~F_ACTIVE;
+    f &= ~F_ROBUST;
+    g.pl[i].flags = f;
+  }
+  if (i < g.n_bbox && g.bbox_norm[i] > th_bbox) g.bbox[i].flags &= ~F_ACTIVE;      // kernel stays on
+  if (i < g.n_corner && g.corner_norm[i] > th_corner) g.corner[i].flags &= ~F_ACTIVE;
+}
+
+// ======================================================================================================
+// Numerically differentiated edges.  A model provides: DIM_MAX, NCOL, and
+//   bool  active(i), int dim(i)
+//   void  residual(i, column c or -1, sign, delta, st, e)   -- residual with vertex column c perturbed by sign*delta
+//   scatter of the quadratic form.
+// ======================================================================================================
+struct PlaneModel {
+  static constexpr int DIM_MAX = 3, NCOL = 9;  // cols 0-2 plane, 3-8 pose
+  const Graph& g;
+  bool corner;  // unused
+  __device__ bool active(int i) const { return g.pl[i].flags & F_ACTIVE; }
+  __device__ int dim(int i) const { return ((g.pl[i].flags >> 8) & 3) == 0 ? 3 : 2; }
+  __device__ bool col_free(int i, int c) const { return c < 3 || g.pose_col[g.pl[i].pose] >= 0; }
+  __device__ void residual(int i, int c, double step, const State& st, double* e) const {
+    const PlaneEdge& ed = g.pl[i];
+    PlaneC pl = load_plane(&st.plane[4 * ed.plane]);
+    Pose T = load_pose(&st.pose_qt[7 * ed.pose]);
+    double u[6] = {0, 0, 0, 0, 0, 0};
+    if (c >= 0 && c < 3) { u[c] = step; pl = plane_boxplus(pl, u); }
+    else if (c >= 3) { u[c - 3] = step; T = pose_boxplus(T, u); }
+    const PlaneC local = plane_into_camera(T, pl);
+    plane_residual(local, PlaneC{ed.meas[0], ed.meas[1], ed.meas[2], ed.meas[3]}, (ed.flags >> 8) & 3, e);
+  }
+  __device__ double info(int i, int r) const { return g.pl[i].info[r]; }
+  __device__ double huber_delta(int i) const { return (g.pl[i].flags & F_ROBUST) ? g.pl[i].huber : 0.0; }
+  __device__ void store_chi2(int i, double chi2, double) const { g.pl_chi2[i] = chi2; }
+  // row c of H (ncol entries) and b[c]
+  __device__ void scatter(int i, int c, const double* Hrow, double bc) const {
+    const PlaneEdge& ed = g.pl[i];
+    const int l = g.n_points + ed.plane;
+    if (c < 3) {
+      for (int c2 = c; c2 < 3; ++c2) atomicAdd(&g.D[(size_t)l * 6 + (c == 0 ? c2 : (c == 1 ? 2 + c2 : 5))], Hrow[c2]);
+      atomicAdd(&g.bl[(size_t)l * 3 + c], bc);
+    } else {
+      const int fid = g.pose_free_id[ed.pose];
+      if (fid < 0) return;
+      const int a = c - 3;
+      double* hb = &g.HB[(size_t)fid * 27];
+      for (int c2 = 0; c2 <= a; ++c2) atomicAdd(&hb[packed_lower(a, c2)], Hrow[3 + c2]);
+      atomicAdd(&hb[21 + a], bc);
+      if (ed.slot >= 0)
+        for (int c2 = 0; c2 < 3; ++c2) atomicAdd(&g.W[(size_t)ed.slot * 18 + a * 3 + c2], Hrow[c2]);
+    }
+  }
+};
+
+struct CubProjModel {  // bbox (corner = false) or corner edges: cols 0-5 pose, 6-14 cuboid
+  static constexpr int DIM_MAX = 16, NCOL = 15;
+  const Graph& g;
+  bool corner;
+  __device__ const CubEdge& E(int i) const { return corner ? g.corner[i] : g.bbox[i]; }
+  __device__ bool active(int i) const { return E(i).flags & F_ACTIVE; }
+  __device__ int dim(int i) const { return E(i).dim; }
+  __device__ bool col_free(int i, int c) const { return c >= 6 || g.pose_col[E(i).pose] >= 0; }
+  __device__ void residual(int i, int c, double step, const State& st, double* e) const {
+    const CubEdge& ed = E(i);
+    Pose T = load_pose(&st.pose_qt[7 * ed.pose]);
+    Cub cb = load_cub(&st.cub[10 * ed.cuboid]);
+    double u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (c >= 0 && c < 6) { u[c] = step; T = pose_boxplus(T, u); }
+    else if (c >= 6) {
+      u[c - 6] = step;
+      const double* fs = &g.cub_fixedscale[3 * ed.cuboid];
+      cb = cuboid_boxplus(cb, u, g.cub_flags[ed.cuboid], fs[0], fs[1], fs[2]);
+    }
+    if (corner) corner_residual(T, cb, ed.K, ed.meas, e);
+    else bbox_residual(T, cb, ed.K, ed.meas, e);
+  }
+  __device__ double info(int i, int r) const { return E(i).info[r]; }
+  __device__ double huber_delta(int i) const { return (E(i).flags & F_ROBUST) ? E(i).huber : 0.0; }
+  __device__ void store_chi2(int i, double chi2, double nrm) const {
+    if (corner) { g.corner_chi2[i] = chi2; g.corner_norm[i] = nrm; } else { g.bbox_chi2[i] = chi2; g.bbox_norm[i] = nrm; }
+  }
+  __device__ void scatter(int i, int c, const double* Hrow, double bc) const {
+    const CubEdge& ed = E(i);
+    if (c < 6) {
+      const int fid = g.pose_free_id[ed.pose];
+      if (fid < 0) return;
+      double* hb = &g.HB[(size_t)fid * 27];
+      for (int c2 = 0; c2 <= c; ++c2) atomicAdd(&hb[packed_lower(c, c2)], Hrow[c2]);
+      atomicAdd(&hb[21 + c], bc);
+      double* w = (corner ? g.Wpc_corner : g.Wpc_bbox) + (size_t)i * 54 + c * 9;
+      for (int c2 = 0; c2 < 9; ++c2) w[c2] = Hrow[6 + c2];
+    } else {
+      const int a = c - 6;
+      double* hc = &g.HC[(size_t)ed.cuboid * 54];
+      for (int c2 = 0; c2 <= a; ++c2) atomicAdd(&hc[packed_lower(a, c2)], Hrow[6 + c2]);
+      atomicAdd(&hc[45 + a], bc);
+    }
+  }
+};
+
+struct PtCubModel {  // unary: cols 0-8 cuboid
+  static constexpr int DIM_MAX = 3, NCOL = 9;
+  const Graph& g;
+  bool corner;  // unused
+  __device__ bool active(int i) const { return g.ptcub[i].flags & F_ACTIVE; }
+  __device__ int dim(int) const { return 3; }
+  __device__ bool col_free(int, int) const { return true; }
+  __device__ void residual(int i, int c, double step, const State& st, double* e) const {
+    const PtCubEdge& ed = g.ptcub[i];
+    Cub cb = load_cub(&st.cub[10 * ed.cuboid]);
+    if (c >= 0) {
+      double u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      u[c] = step;
+      const double* fs = &g.cub_fixedscale[3 * ed.cuboid];
+      cb = cuboid_boxplus(cb, u, g.cub_flags[ed.cuboid], fs[0], fs[1], fs[2]);
+    }
+    ptcub_residual(cb, &g.ptcub_pts[3 * (size_t)ed.p0], ed.p1 - ed.p0, ed.margin, ed.prior, e);
+  }
+  __device__ double info(int i, int r) const { return g.ptcub[i].info[r]; }
+  __device__ double huber_delta(int i) const { return (g.ptcub[i].flags & F_ROBUST) ? g.ptcub[i].huber : 0.0; }
+  __device__ void store_chi2(int i, double chi2, double) const { g.ptcub_chi2[i] = chi2; }
+  __device__ void scatter(int i, int c, const double* Hrow, double bc) const {
+    double* hc = &g.HC[(size_t)g.ptcub[i].cuboid * 54];
+    for (int c2 = 0; c2 <= c; ++c2) atomicAdd(&hc[packed_lower(c, c2)], Hrow[c2]);
+    atomicAdd(&hc[45 + c], bc);
+  }
+};
+
+// 16 lanes per edge, 16 edges per 256-thread block; lane c < NCOL differentiates column c, lane 15 evaluates the
+// base residual (base_binary_edge.hpp:217-320, base_unary_edge.hpp:82-123, then :55-120 / :43-72).
+template <class Model>
+__global__ __launch_bounds__(256) void k_lin_numeric(Graph g, State st, int n_edges, bool corner, double delta) {
+  constexpr int DM = Model::DIM_MAX, NC = Model::NCOL;
+  __shared__ double sJ[16][DM][16];  // [group][row][col]
+  __shared__ double sW[16][DM], sG[16][DM];
+  __shared__ double s_red[4];
+  const Model m{g, corner};
+  const int grp = threadIdx.x >> 4, lane = threadIdx.x & 15;
+  const int i = blockIdx.x * 16 + grp;
+  const bool act = i < n_edges && m.active(i);
+  const int dim = act ? m.dim(i) : 0;
+  double chi_local = 0.0;
+  if (act) {
+    if (lane < NC) {
+      double ep[DM], em[DM];
+      const bool fr = m.col_free(i, lane);
+      if (fr) {
+        m.residual(i, lane, delta, st, ep);
+        m.residual(i, lane, -delta, st, em);
+      }
+      const double scalar = 1.0 / (2 * delta);
+      for (int r = 0; r < dim; ++r) sJ[grp][r][lane] = fr ? scalar * (ep[r] - em[r]) : 0.0;
+    } else if (lane == 15) {
+      double e0[DM];
+      m.residual(i, -1, 0.0, st, e0);
+      double chi2 = 0, nrm = 0;
+      for (int r = 0; r < dim; ++r) { chi2 += e0[r] * (m.info(i, r) * e0[r]); nrm += e0[r] * e0[r]; }
+      m.store_chi2(i, chi2, sqrt(nrm));
+      double rho0, rho1;
+      huber(chi2, m.huber_delta(i), rho0, rho1);
+      chi_local = rho0;
+      for (int r = 0; r < dim; ++r) { sW[grp][r] = rho1 * m.info(i, r); sG[grp][r] = -(m.info(i, r) * e0[r]) * rho1; }
+    }
+  }
+  __syncthreads();
+  if (act && lane < NC && m.col_free(i, lane)) {
+    double Hrow[NC], bc = 0;
+    for (int r = 0; r < dim; ++r) bc += sJ[grp][r][lane] * sG[grp][r];
+    for (int c2 = 0; c2 < NC; ++c2) {
+      double h = 0;
+      for (int r = 0; r < dim; ++r) h += sJ[grp][r][lane] * sW[grp][r] * sJ[grp][r][c2];
+      Hrow[c2] = h;
+    }
+    m.scatter(i, lane, Hrow, bc);
+  }
+  block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+}
+
+template <class Model>
+__global__ __launch_bounds__(256) void k_chi2_numeric(Graph g, State st, int n_edges, bool corner) {
+  constexpr int DM = Model::DIM_MAX;
+  __shared__ double s_red[4];
+  const Model m{g, corner};
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double chi_local = 0.0;
+  if (i < n_edges && m.active(i)) {
+    double e0[DM];
+    const int dim = m.dim(i);
+    m.residual(i, -1, 0.0, st, e0);
+    double chi2 = 0, nrm = 0;
+    for (int r = 0; r < dim; ++r) { chi2 += e0[r] * (m.info(i, r) * e0[r]); nrm += e0[r] * e0[r]; }
+    m.store_chi2(i, chi2, sqrt(nrm));
+    double rho0, rho1;
+    huber(chi2, m.huber_delta(i), rho0, rho1);
+    chi_local = rho0;
+  }
+  block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+}
+
+// max |H_jj| over every active diagonal (computeLambdaInit, levenberg.cpp:166-180)
+__global__ void k_maxdiag(Graph g) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double m = 0.0;
+  if (i < g.n_pose_free * 6) m = fabs(g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)]);
+  if (i < g.n_cuboids * 9 && g.owns_reduced) m = fmax(m, fabs(g.HC[(size_t)(i / 9) * 54 + packed_lower(i % 9, i % 9)]));
+  const int nl_owned = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
+  if (i < nl_owned * 3) {
+    const int k = i / 3, a = i % 3;
+    const int l = k < (g.pt_last - g.pt_first) ? g.pt_first + k : g.n_points + g.plane_first + (k - (g.pt_last - g.pt_first));
+    const bool fixed = l < g.n_points && g.point_fixed[l];
+    if (!fixed) m = fmax(m, fabs(g.D[(size_t)l * 6 + (a == 0 ? 0 : (a == 1 ? 3 : 5))]));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomic_max_pos(&g.acc[ACC_MAXDIAG], m);
+}
+
+// S(lower) += Hpp (+ lambda), Hcc (+ lambda), pose-cuboid blocks; bs = b.   S was zeroed beforehand.
+__global__ void k_assemble(Graph g, double lambda) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = g.n_red;
+  const int nP = g.n_pose_free * 27, nC = g.n_cuboids * 54, nB = g.n_bbox * 54, nK = g.n_corner * 54;
+  if (!g.owns_reduced) return;  // multi-GPU: HB is already summed over ranks, one rank contributes it
+  if (i < nP) {
+    const int f = i / 27, k = i % 27;
+    const int col0 = f * 6;  // free poses occupy the leading 6*n_pose_free columns in free-id order
+    const double v = g.HB[i];
+    if (k < 21) {
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= k) ++r;
+      const int c = k - r * (r + 1) / 2;
+      const double add = v + ((r == c && g.owns_reduced) ? lambda : 0.0);
+      atomicAdd(&g.S[(size_t)(col0 + c) * n + col0 + r], add);
+    } else {
+      atomicAdd(&g.bs[col0 + (k - 21)], v);
+    }
+    return;
+  }
+  int j = i - nP;
+  if (j < nC) {
+    if (!g.owns_reduced) return;
+    const int cb = j / 54, k = j % 54;
+    const int col0 = g.cub_col[cb];
+    if (col0 < 0) return;
+    const double v = g.HC[j];
+    if (k < 45) {
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= k) ++r;
+      const int c = k - r * (r + 1) / 2;
+      atomicAdd(&g.S[(size_t)(col0 + c) * n + col0 + r], v + (r == c ? lambda : 0.0));
+    } else {
+      atomicAdd(&g.bs[col0 + (k - 45)], v);
+    }
+    return;
+  }
+  j -= nC;
+  if (j < nB + nK) {
+    if (!g.owns_reduced) return;
+    const bool corner = j >= nB;
+    const int jj = corner ? j - nB : j;
+    const int e = jj / 54, k = jj % 54, a = k / 9, c = k % 9;
+    const CubEdge& ed = corner ? g.corner[e] : g.bbox[e];
+    if (!(ed.flags & F_ACTIVE)) return;
+    const int pc = g.pose_col[ed.pose], cc = g.cub_col[ed.cuboid];
+    if (pc < 0 || cc < 0) return;
+    const double v = (corner ? g.Wpc_corner : g.Wpc_bbox)[(size_t)e * 54 + k];
+    atomicAdd(&g.S[(size_t)(pc + a) * n + cc + c], v);  // row = cuboid column (cuboids come after poses)
+  }
+}
+
+__global__ void k_schur_prep(Graph g, double lambda) {
+  const int nl_pts = g.pt_last - g.pt_first;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nl_pts + (g.plane_last - g.plane_first)) return;
+  const int l = k < nl_pts ? g.pt_first + k : g.n_points + g.plane_first + (k - nl_pts);
+  if (l < g.n_points && g.point_fixed[l]) return;
+  double D[6], I[6];
+  for (int q = 0; q < 6; ++q) D[q] = g.D[(size_t)l * 6 + q];
+  D[0] += lambda; D[3] += lambda; D[5] += lambda;
+  sym3_inverse(D, I);
+  for (int q = 0; q < 6; ++q) g.Dinv[(size_t)l * 6 + q] = I[q];
+  const double b0 = g.bl[(size_t)l * 3], b1 = g.bl[(size_t)l * 3 + 1], b2 = g.bl[(size_t)l * 3 + 2];
+  const double y0 = I[0] * b0 + I[1] * b1 + I[2] * b2;
+  const double y1 = I[1] * b0 + I[3] * b1 + I[4] * b2;
+  const double y2 = I[2] * b0 + I[4] * b1 + I[5] * b2;
+  g.yl[(size_t)l * 3] = y0; g.yl[(size_t)l * 3 + 1] = y1; g.yl[(size_t)l * 3 + 2] = y2;
+  for (int s = g.slot_off[l]; s < g.slot_off[l + 1]; ++s) {
+    const double* w = &g.W[(size_t)s * 18];
+    double* y = &g.Y[(size_t)s * 18];
+    const int col = g.slot_col[s];
+    for (int a = 0; a < 6; ++a) {
+      const double w0 = w[a * 3], w1 = w[a * 3 + 1], w2 = w[a * 3 + 2];
+      y[a * 3] = w0 * I[0] + w1 * I[1] + w2 * I[2];
+      y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
+      y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
+      const double d = w0 * y0 + w1 * y1 + w2 * y2;
+      if (d != 0.0) atomicAdd(&g.bs[col + a], -d);
+    }
+  }
+}
+
+// One 8-lane group per slot j (lanes 0..5 active = rows of the pose block).  For every slot i <= j of the same
+// landmark: S(col_j + c, col_i + r) -= W_j[c,:] . Y_i[r,:]; six consecutive rows per column => one 48-byte segment
+// per atomic instruction group.
+__global__ __launch_bounds__(256) void k_schur_accum(Graph g, int slot_first, int slot_last) {
+  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, c = threadIdx.x & 7;
+  const int sj = slot_first + grp;
+  if (sj >= slot_last || c >= 6) return;
+  const int l = g.slot_lm[sj];
+  const int colj = g.slot_col[sj];
+  const double w0 = g.W[(size_t)sj * 18 + c * 3], w1 = g.W[(size_t)sj * 18 + c * 3 + 1], w2 = g.W[(size_t)sj * 18 + c * 3 + 2];
+  const int n = g.n_red;
+  for (int si = g.slot_off[l]; si <= sj; ++si) {
+    const int coli = g.slot_col[si];
+    const double* y = &g.Y[(size_t)si * 18];
+    const int rmax = (si == sj) ? c : 5;  // diagonal block: lower part only
+    for (int r = 0; r <= rmax; ++r) {
+      const double v = w0 * y[r * 3] + w1 * y[r * 3 + 1] + w2 * y[r * 3 + 2];
+      if (v != 0.0) atomicAdd(&g.S[(size_t)(coli + r) * n + colj + c], -v);
+    }
+  }
+}
+
+// poses and cuboids: trial = cur [+] x ; scale += x (lambda x + b)   (computeScale, levenberg.cpp:182-189)
+__global__ void k_update_reduced(Graph g, State cur, State trial, double lambda) {
+  __shared__ double s_red[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sc = 0.0;
+  if (i < g.n_poses) {
+    const int col = g.pose_col[i];
+    Pose T = load_pose(&cur.pose_qt[7 * i]);
+    if (col >= 0) {
+      const double* x = &g.xr[col];
+      T = pose_boxplus(T, x);
+      if (g.owns_reduced) {
+        const double* b = &g.HB[(size_t)g.pose_free_id[i] * 27 + 21];
+        for (int a = 0; a < 6; ++a) sc += x[a] * (lambda * x[a] + b[a]);
+      }
+    }
+    store_pose(&trial.pose_qt[7 * i], &trial.pose_rt[12 * i], T);
+  } else if (i < g.n_poses + g.n_cuboids) {
+    const int k = i - g.n_poses;
+    const int col = g.cub_col[k];
+    Cub c = load_cub(&cur.cub[10 * k]);
+    if (col >= 0) {
+      const double* x = &g.xr[col];
+      const double* fs = &g.cub_fixedscale[3 * k];
+      c = cuboid_boxplus(c, x, g.cub_flags[k], fs[0], fs[1], fs[2]);
+      if (g.owns_reduced) {
+        const double* b = &g.HC[(size_t)k * 54 + 45];
+        for (int a = 0; a < 9; ++a) sc += x[a] * (lambda * x[a] + b[a]);
+      }
+    }
+    double* o = &trial.cub[10 * k];
+    o[0] = c.T.q.x; o[1] = c.T.q.y; o[2] = c.T.q.z; o[3] = c.T.q.w; o[4] = c.T.t.x; o[5] = c.T.t.y; o[6] = c.T.t.z;
+    o[7] = c.s.x; o[8] = c.s.y; o[9] = c.s.z;
+  }
+  block_atomic_add(sc, &g.acc[ACC_SCALE], s_red);
+}
+
+// landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term
+__global__ void k_backsub(Graph g, State cur, State trial, double lambda) {
+  __shared__ double s_red[4];
+  const int nl_pts = g.pt_last - g.pt_first;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  double sc = 0.0;
+  if (k < nl_pts + (g.plane_last - g.plane_first)) {
+    const int l = k < nl_pts ? g.pt_first + k : g.n_points + g.plane_first + (k - nl_pts);
+    const bool fixed = l < g.n_points && g.point_fixed[l];
+    double xl[3] = {0, 0, 0};
+    if (!fixed) {
+      const double b0 = g.bl[(size_t)l * 3], b1 = g.bl[(size_t)l * 3 + 1], b2 = g.bl[(size_t)l * 3 + 2];
+      double c0 = b0, c1 = b1, c2 = b2;
+      for (int s = g.slot_off[l]; s < g.slot_off[l + 1]; ++s) {
+        const double* w = &g.W[(size_t)s * 18];
+        const double* x = &g.xr[g.slot_col[s]];
+        for (int a = 0; a < 6; ++a) {
+          c0 -= w[a * 3] * x[a]; c1 -= w[a * 3 + 1] * x[a]; c2 -= w[a * 3 + 2] * x[a];
+        }
+      }
+      const double* I = &g.Dinv[(size_t)l * 6];
+      xl[0] = I[0] * c0 + I[1] * c1 + I[2] * c2;
+      xl[1] = I[1] * c0 + I[3] * c1 + I[4] * c2;
+      xl[2] = I[2] * c0 + I[4] * c1 + I[5] * c2;
+      sc = xl[0] * (lambda * xl[0] + b0) + xl[1] * (lambda * xl[1] + b1) + xl[2] * (lambda * xl[2] + b2);
+    }
+    if (l < g.n_points) {
+      for (int a = 0; a < 3; ++a) trial.point[3 * l + a] = cur.point[3 * l + a] + xl[a];
+    } else {
+      const int j = l - g.n_points;
+      const PlaneC p = plane_boxplus(load_plane(&cur.plane[4 * j]), xl);
+      trial.plane[4 * j] = p.nx; trial.plane[4 * j + 1] = p.ny; trial.plane[4 * j + 2] = p.nz; trial.plane[4 * j + 3] = p.d;
+    }
+  }
+  block_atomic_add(sc, &g.acc[ACC_SCALE], s_red);
+}
+
+__global__ void k_pose_rt(State st, int n_poses) {  // derive rotation matrices after an upload
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_poses) store_pose(&st.pose_qt[7 * i], &st.pose_rt[12 * i], load_pose(&st.pose_qt[7 * i]));
+}
+
+}  // namespace ppo

@@ -1,0 +1,413 @@
+// ppo_math.hpp -- FP64 geometry used by the HIP kernels of libppo_ba.so.
+//
+// Every function is __host__ __device__ so that tests can exercise the exact device formulas on the CPU
+// (csrc/hostcheck.cpp); the product path only ever calls them from kernels.
+// Semantics follow the reference (paths relative to the reference checkout, G2O = Thirdparty/g2o/g2o):
+//   SE3 exp / compose / normalise    G2O/types/se3quat.h:110-134,274-336
+//   pose update                      G2O/types/types_six_dof_expmap.h:73-91
+//   plane algebra                    include/G2O_Plane3D.h:45-140
+//   cuboid update / projection       src/g2o_cuboid.cc:6-67, include/g2o_cuboid.h:173-255
+//   Huber                            G2O/core/robust_kernel_impl.cpp:78-91
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define PPO_HD __host__ __device__ __forceinline__
+#else
+#define PPO_HD inline
+#endif
+
+namespace ppo {
+
+struct Vec3 {
+  double x, y, z;
+};
+struct Mat3 {  // row-major
+  double a[9];
+};
+struct Quat {
+  double x, y, z, w;
+};
+struct Pose {  // rigid transform as unit quaternion (w >= 0) + translation
+  Quat q;
+  Vec3 t;
+};
+struct PlaneC {  // (n, d) with |n| = 1 and d >= 0
+  double nx, ny, nz, d;
+};
+struct Cub {
+  Pose T;  // object -> world
+  Vec3 s;  // half extents
+};
+
+PPO_HD Vec3 v3(double x, double y, double z) { return Vec3{x, y, z}; }
+PPO_HD Vec3 operator+(Vec3 a, Vec3 b) { return Vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+PPO_HD Vec3 operator-(Vec3 a, Vec3 b) { return Vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+PPO_HD Vec3 operator*(Vec3 a, double s) { return Vec3{a.x * s, a.y * s, a.z * s}; }
+PPO_HD double dot3(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PPO_HD Vec3 cross3(Vec3 a, Vec3 b) { return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+PPO_HD Vec3 matvec(const Mat3& M, Vec3 v) {
+  return Vec3{M.a[0] * v.x + M.a[1] * v.y + M.a[2] * v.z, M.a[3] * v.x + M.a[4] * v.y + M.a[5] * v.z,
+              M.a[6] * v.x + M.a[7] * v.y + M.a[8] * v.z};
+}
+PPO_HD Vec3 matTvec(const Mat3& M, Vec3 v) {
+  return Vec3{M.a[0] * v.x + M.a[3] * v.y + M.a[6] * v.z, M.a[1] * v.x + M.a[4] * v.y + M.a[7] * v.z,
+              M.a[2] * v.x + M.a[5] * v.y + M.a[8] * v.z};
+}
+
+// unit quaternion -> rotation matrix (the expansion Eigen uses, so products round alike)
+PPO_HD Mat3 rotmat(Quat q) {
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  Mat3 R;
+  R.a[0] = 1 - (tyy + tzz); R.a[1] = txy - twz;       R.a[2] = txz + twy;
+  R.a[3] = txy + twz;       R.a[4] = 1 - (txx + tzz); R.a[5] = tyz - twx;
+  R.a[6] = txz - twy;       R.a[7] = tyz + twx;       R.a[8] = 1 - (txx + tyy);
+  return R;
+}
+// rotation(-like) matrix -> quaternion, largest-component branch selection (Shoemake)
+PPO_HD Quat quat_of(const Mat3& R) {
+  Quat q;
+  const double tr = R.a[0] + R.a[4] + R.a[8];
+  if (tr > 0) {
+    double s = sqrt(tr + 1.0);
+    q.w = 0.5 * s;
+    s = 0.5 / s;
+    q.x = (R.a[7] - R.a[5]) * s;
+    q.y = (R.a[2] - R.a[6]) * s;
+    q.z = (R.a[3] - R.a[1]) * s;
+  } else if (R.a[0] >= R.a[4] && R.a[0] >= R.a[8]) {  // i = 0
+    double s = sqrt(R.a[0] - R.a[4] - R.a[8] + 1.0);
+    q.x = 0.5 * s;
+    s = 0.5 / s;
+    q.w = (R.a[7] - R.a[5]) * s;
+    q.y = (R.a[3] + R.a[1]) * s;
+    q.z = (R.a[6] + R.a[2]) * s;
+  } else if (R.a[4] > R.a[0] && R.a[4] >= R.a[8]) {  // i = 1
+    double s = sqrt(R.a[4] - R.a[8] - R.a[0] + 1.0);
+    q.y = 0.5 * s;
+    s = 0.5 / s;
+    q.w = (R.a[2] - R.a[6]) * s;
+    q.z = (R.a[7] + R.a[5]) * s;
+    q.x = (R.a[1] + R.a[3]) * s;
+  } else {  // i = 2
+    double s = sqrt(R.a[8] - R.a[0] - R.a[4] + 1.0);
+    q.z = 0.5 * s;
+    s = 0.5 / s;
+    q.w = (R.a[3] - R.a[1]) * s;
+    q.x = (R.a[6] + R.a[2]) * s;
+    q.y = (R.a[5] + R.a[7]) * s;
+  }
+  return q;
+}
+PPO_HD Quat qmul(Quat a, Quat b) {
+  return Quat{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+              a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+PPO_HD Vec3 qrot(Quat q, Vec3 v) {  // v + 2w (u x v) + 2 u x (u x v)
+  const Vec3 u = v3(q.x, q.y, q.z);
+  Vec3 uv = cross3(u, v);
+  uv = uv + uv;
+  return v + uv * q.w + cross3(u, uv);
+}
+PPO_HD Quat canon(Quat q) {  // g2o normalizeRotation: w >= 0, unit norm
+  if (q.w < 0) q = Quat{-q.x, -q.y, -q.z, -q.w};
+  const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  return Quat{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+PPO_HD Pose compose(const Pose& A, const Pose& B) {  // A * B
+  Pose r;
+  r.t = A.t + qrot(A.q, B.t);
+  r.q = canon(qmul(A.q, B.q));
+  return r;
+}
+PPO_HD Pose inverse(const Pose& A) {
+  Pose r;
+  r.q = Quat{-A.q.x, -A.q.y, -A.q.z, A.q.w};
+  r.t = qrot(r.q, A.t * -1.0);
+  return r;
+}
+PPO_HD Vec3 apply(const Pose& A, Vec3 p) { return qrot(A.q, p) + A.t; }
+
+// W = [w]_x and W^2 in closed form
+PPO_HD void skew_sq(Vec3 w, Mat3& W, Mat3& W2) {
+  W = Mat3{{0, -w.z, w.y, w.z, 0, -w.x, -w.y, w.x, 0}};
+  W2 = Mat3{{-(w.y * w.y) - w.z * w.z, w.x * w.y, w.x * w.z,
+             w.x * w.y, -(w.z * w.z) - w.x * w.x, w.y * w.z,
+             w.x * w.z, w.y * w.z, -(w.x * w.x) - w.y * w.y}};
+}
+// SE3 exponential with g2o's branches: below 1e-5 rad R = V = I + W + W^2 (not I + W + W^2/2)
+PPO_HD Pose exp_se3(const double* u) {
+  const Vec3 om = v3(u[0], u[1], u[2]), up = v3(u[3], u[4], u[5]);
+  const double th = sqrt(dot3(om, om));
+  Mat3 W, W2, R, V;
+  skew_sq(om, W, W2);
+  // g2o forms Omega*Omega by a matrix product; the closed form above has the same terms but may round
+  // differently in the last bit -- irrelevant at |omega|^2 ~ 1e-18 next to 1.
+  double a = 1.0, b = 1.0, c = 1.0;
+  const bool small = th < 0.00001;
+  if (!small) {
+    a = sin(th) / th;
+    b = (1 - cos(th)) / (th * th);
+    c = (th - sin(th)) / (th * th * th);
+  }
+  for (int i = 0; i < 9; ++i) {
+    const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+    R.a[i] = id + a * W.a[i] + b * W2.a[i];
+    V.a[i] = small ? R.a[i] : id + b * W.a[i] + c * W2.a[i];
+  }
+  Pose P;
+  P.q = canon(quat_of(R));
+  P.t = matvec(V, up);
+  return P;
+}
+PPO_HD Pose pose_boxplus(const Pose& T, const double* u) { return compose(exp_se3(u), T); }
+
+// ---- planes ------------------------------------------------------------------------------------------
+PPO_HD PlaneC plane_canon(double nx, double ny, double nz, double d) {
+  const double inv = 1. / sqrt(nx * nx + ny * ny + nz * nz);
+  nx *= inv; ny *= inv; nz *= inv; d *= inv;
+  if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }
+  return PlaneC{nx, ny, nz, d};
+}
+PPO_HD double az_of(Vec3 v) { return atan2(v.y, v.x); }
+PPO_HD double el_of(Vec3 v) { return atan2(v.z, sqrt(v.x * v.x + v.y * v.y)); }
+// Rz(azimuth) * Ry(-elevation) through the half-angle quaternion product, like Eigen's AngleAxis * AngleAxis
+PPO_HD Mat3 plane_frame(Vec3 n) {
+  const double ha = 0.5 * az_of(n), he = 0.5 * -el_of(n);
+  const Quat qa = Quat{0, 0, sin(ha), cos(ha)};
+  const Quat qe = Quat{0, sin(he), 0, cos(he)};
+  return rotmat(qmul(qa, qe));
+}
+PPO_HD PlaneC plane_boxplus(const PlaneC& p, const double* u) {
+  const double s = sin(u[1]), c = cos(u[1]);
+  const Vec3 n = v3(c * cos(u[0]), c * sin(u[0]), s);
+  const Vec3 rn = matvec(plane_frame(v3(p.nx, p.ny, p.nz)), n);
+  const double dist = -p.d + u[2];
+  return plane_canon(rn.x, rn.y, rn.z, -dist);
+}
+PPO_HD PlaneC plane_into_camera(const Pose& Tcw, const PlaneC& p) {
+  const Vec3 n2 = matvec(rotmat(Tcw.q), v3(p.nx, p.ny, p.nz));
+  double d2 = p.d - dot3(Tcw.t, n2);
+  if (d2 < 0.0) return plane_canon(-n2.x, -n2.y, -n2.z, -d2);
+  return plane_canon(n2.x, n2.y, n2.z, d2);
+}
+// kind 0: Plane3D::ominus (3), kind 1: ominus_ver (2), kind 2: ominus_par (2).  a = transformed estimate, m = measurement
+PPO_HD void plane_residual(const PlaneC& a, const PlaneC& m, int kind, double* e) {
+  const Vec3 na = v3(a.nx, a.ny, a.nz), nm = v3(m.nx, m.ny, m.nz);
+  Vec3 ref = na;
+  if (kind == 1) {
+    Vec3 ax = cross3(na, nm);
+    const double an = sqrt(dot3(ax, ax));
+    ax = v3(ax.x / an, ax.y / an, ax.z / an);
+    // rotate na by +90 degrees about ax (Rodrigues with the constants Eigen would compute for M_PI/2)
+    const double s = sin(M_PI / 2), c = cos(M_PI / 2);
+    const Vec3 sa = ax * s, ca = ax * (1.0 - c);
+    Mat3 R;
+    double t;
+    t = ca.x * ax.y; R.a[1] = t - sa.z; R.a[3] = t + sa.z;
+    t = ca.x * ax.z; R.a[2] = t + sa.y; R.a[6] = t - sa.y;
+    t = ca.y * ax.z; R.a[5] = t - sa.x; R.a[7] = t + sa.x;
+    R.a[0] = ca.x * ax.x + c; R.a[4] = ca.y * ax.y + c; R.a[8] = ca.z * ax.z + c;
+    ref = matvec(R, na);
+  } else if (kind == 2) {
+    if (dot3(nm, na) < 0) ref = na * -1.0;
+  }
+  const Vec3 n = matTvec(plane_frame(ref), nm);
+  e[0] = az_of(n);
+  e[1] = el_of(n);
+  if (kind == 0) e[2] = (-a.d) - (-m.d);
+}
+
+// ---- cuboids -----------------------------------------------------------------------------------------
+PPO_HD Pose exp_yaw_only(const double* u) {  // src/g2o_cuboid.cc:6-36
+  const Vec3 om = v3(u[0], u[1], u[2]), up = v3(u[3], u[4], u[5]);
+  const double th = sqrt(dot3(om, om));
+  const double cz = cos(om.z), sz = sin(om.z);
+  const Mat3 R = Mat3{{cz, -sz, 0, sz, cz, 0, 0, 0, 1}};
+  Mat3 V = R;
+  if (!(th < 0.00001)) {
+    Mat3 W, W2;
+    skew_sq(om, W, W2);
+    const double b = (1 - cos(th)) / (th * th), c = (th - sin(th)) / (th * th * th);
+    for (int i = 0; i < 9; ++i) V.a[i] = ((i == 0 || i == 4 || i == 8) ? 1.0 : 0.0) + b * W.a[i] + c * W2.a[i];
+  }
+  Pose P;
+  P.q = canon(quat_of(R));
+  P.t = matvec(V, up);
+  return P;
+}
+PPO_HD Cub cuboid_boxplus(const Cub& c, const double* u, unsigned flags, double fsx, double fsy, double fsz) {
+  Cub n;
+  if (flags & 4u) {
+    n.T.q = Quat{0, 0, 0, 1};
+    n.T.t = c.T.t + v3(u[3], u[4], u[5]);
+  } else if (flags & 1u) {
+    const double u2[6] = {0, 0, u[2], u[3], u[4], u[5]};
+    n.T = compose(c.T, exp_yaw_only(u2));
+  } else {
+    n.T = compose(c.T, exp_se3(u));
+  }
+  if (flags & 2u) n.T.t.y = c.T.t.y;
+  if (fsx > 0) n.s = v3(fsx, fsy, fsz);
+  else n.s = c.s + v3(u[6], u[7], u[8]);
+  return n;
+}
+// corner k of the body frame: signs (x,y,z) of include/g2o_cuboid.h:202-204
+PPO_HD void corner_sign(int k, double& sx, double& sy, double& sz) {
+  sx = ((k & 3) == 0 || (k & 3) == 1) ? 1.0 : -1.0;
+  sy = ((k & 3) == 0 || (k & 3) == 3) ? 1.0 : -1.0;
+  sz = (k < 4) ? -1.0 : 1.0;
+}
+PPO_HD void cuboid_corner_px(const Cub& c, const Mat3& Rwo, const Mat3& Rcw, Vec3 tcw, const double* K, int k, double& u, double& v) {
+  double sx, sy, sz;
+  corner_sign(k, sx, sy, sz);
+  Vec3 pw;
+  pw.x = (Rwo.a[0] * c.s.x) * sx + (Rwo.a[1] * c.s.y) * sy + (Rwo.a[2] * c.s.z) * sz + c.T.t.x;
+  pw.y = (Rwo.a[3] * c.s.x) * sx + (Rwo.a[4] * c.s.y) * sy + (Rwo.a[5] * c.s.z) * sz + c.T.t.y;
+  pw.z = (Rwo.a[6] * c.s.x) * sx + (Rwo.a[7] * c.s.y) * sy + (Rwo.a[8] * c.s.z) * sz + c.T.t.z;
+  const Vec3 pc = matvec(Rcw, pw) + tcw;
+  const double hx = K[0] * pc.x + K[1] * pc.y + K[2] * pc.z;
+  const double hy = K[3] * pc.x + K[4] * pc.y + K[5] * pc.z;
+  const double hz = K[6] * pc.x + K[7] * pc.y + K[8] * pc.z;
+  u = hx / hz;
+  v = hy / hz;
+}
+// e[0..3] = projected (cx, cy, w, h) - meas
+PPO_HD void bbox_residual(const Pose& Tcw, const Cub& c, const double* K, const double* meas, double* e) {
+  const Mat3 Rwo = rotmat(c.T.q), Rcw = rotmat(Tcw.q);
+  double ulo = 0, uhi = 0, vlo = 0, vhi = 0;
+  for (int k = 0; k < 8; ++k) {
+    double u, v;
+    cuboid_corner_px(c, Rwo, Rcw, Tcw.t, K, k, u, v);
+    if (k == 0) { ulo = uhi = u; vlo = vhi = v; }
+    else { ulo = fmin(ulo, u); uhi = fmax(uhi, u); vlo = fmin(vlo, v); vhi = fmax(vhi, v); }
+  }
+  e[0] = (uhi + ulo) / 2 - meas[0];
+  e[1] = (vhi + vlo) / 2 - meas[1];
+  e[2] = (uhi - ulo) - meas[2];
+  e[3] = (vhi - vlo) - meas[3];
+}
+PPO_HD void corner_residual(const Pose& Tcw, const Cub& c, const double* K, const double* meas, double* e) {
+  const Mat3 Rwo = rotmat(c.T.q), Rcw = rotmat(Tcw.q);
+  for (int k = 0; k < 8; ++k) {
+    double u, v;
+    cuboid_corner_px(c, Rwo, Rcw, Tcw.t, K, k, u, v);
+    e[2 * k] = u - meas[2 * k];
+    e[2 * k + 1] = v - meas[2 * k + 1];
+  }
+}
+// EdgePointCuboidOnlyObject::computeError, src/g2o_cuboid.cc:132-160
+PPO_HD void ptcub_residual(const Cub& c, const double* pts, int npts, double margin, const double* prior_half, double* e) {
+  const Pose inv = inverse(c.T);
+  double acc[3] = {0, 0, 0};
+  const double s[3] = {c.s.x, c.s.y, c.s.z};
+  for (int p = 0; p < npts; ++p) {
+    const Vec3 l = apply(inv, v3(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]));
+    const double a[3] = {fabs(l.x), fabs(l.y), fabs(l.z)};
+    for (int i = 0; i < 3; ++i) {
+      double pe;
+      if (a[i] < s[i]) pe = 0;
+      else if (a[i] < (margin + 1) * s[i]) pe = a[i] - s[i];
+      else pe = margin * s[i];
+      acc[i] += fabs(pe);
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (npts > 0) acc[i] = acc[i] / (double)npts;
+    acc[i] = acc[i] / s[i];
+    double pw = 0.2, pr = s[i];
+    if (prior_half[0] > 0) { pw = 50.0; pr = fabs((s[i] - prior_half[i]) / prior_half[i]); }
+    e[i] = 1.0 * acc[i] + pw * pr;
+  }
+}
+
+// ---- reprojection edges ------------------------------------------------------------------------------
+// EdgeSE3ProjectXYZ: residual (2) and Jacobians wrt point (2x3, row-major) and pose (2x6)
+PPO_HD void mono_eval(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy, double cx, double cy, double ou, double ov,
+                      double* e, double* Jl, double* Jp, double& zc) {
+  const Vec3 pc = matvec(R, X) + t;
+  const double x = pc.x, y = pc.y, z = pc.z, z2 = z * z;
+  zc = z;
+  e[0] = ou - (x / z * fx + cx);
+  e[1] = ov - (y / z * fy + cy);
+  const double s = -1. / z;
+  const double r0[3] = {s * fx, s * 0.0, s * (-x / z * fx)};
+  const double r1[3] = {s * 0.0, s * fy, s * (-y / z * fy)};
+  for (int c = 0; c < 3; ++c) {
+    Jl[c] = r0[0] * R.a[c] + r0[1] * R.a[3 + c] + r0[2] * R.a[6 + c];
+    Jl[3 + c] = r1[0] * R.a[c] + r1[1] * R.a[3 + c] + r1[2] * R.a[6 + c];
+  }
+  Jp[0] = x * y / z2 * fx; Jp[1] = -(1 + (x * x / z2)) * fx; Jp[2] = y / z * fx;
+  Jp[3] = -1. / z * fx;    Jp[4] = 0;                        Jp[5] = x / z2 * fx;
+  Jp[6] = (1 + y * y / z2) * fy; Jp[7] = -x * y / z2 * fy;   Jp[8] = -x / z * fy;
+  Jp[9] = 0;               Jp[10] = -1. / z * fy;            Jp[11] = y / z2 * fy;
+}
+PPO_HD void mono_residual(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy, double cx, double cy, double ou, double ov, double* e, double& zc) {
+  const Vec3 pc = matvec(R, X) + t;
+  zc = pc.z;
+  e[0] = ou - (pc.x / pc.z * fx + cx);
+  e[1] = ov - (pc.y / pc.z * fy + cy);
+}
+// EdgeStereoSE3ProjectXYZ (1/z and bf pass through float, types_six_dof_expmap.cpp:182-189)
+PPO_HD void stereo_residual(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy, double cx, double cy, double bfd,
+                            double ou, double ov, double our, double* e, double& zc) {
+  const Vec3 pc = matvec(R, X) + t;
+  zc = pc.z;
+  const float bf = (float)bfd;
+  const float invz = 1.0f / (float)pc.z;
+  const double r0 = pc.x * invz * fx + cx;
+  const double r1 = pc.y * invz * fy + cy;
+  const double r2 = r0 - (double)(bf * invz);
+  e[0] = ou - r0; e[1] = ov - r1; e[2] = our - r2;
+}
+PPO_HD void stereo_eval(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy, double cx, double cy, double bf,
+                        double ou, double ov, double our, double* e, double* Jl, double* Jp, double& zc) {
+  stereo_residual(R, t, X, fx, fy, cx, cy, bf, ou, ov, our, e, zc);
+  const Vec3 pc = matvec(R, X) + t;
+  const double x = pc.x, y = pc.y, z = pc.z, z2 = z * z;
+  for (int c = 0; c < 3; ++c) {
+    Jl[c] = -fx * R.a[c] / z + fx * x * R.a[6 + c] / z2;
+    Jl[3 + c] = -fy * R.a[3 + c] / z + fy * y * R.a[6 + c] / z2;
+    Jl[6 + c] = Jl[c] - bf * R.a[6 + c] / z2;
+  }
+  Jp[0] = x * y / z2 * fx; Jp[1] = -(1 + (x * x / z2)) * fx; Jp[2] = y / z * fx;
+  Jp[3] = -1. / z * fx;    Jp[4] = 0;                        Jp[5] = x / z2 * fx;
+  Jp[6] = (1 + y * y / z2) * fy; Jp[7] = -x * y / z2 * fy;   Jp[8] = -x / z * fy;
+  Jp[9] = 0;               Jp[10] = -1. / z * fy;            Jp[11] = y / z2 * fy;
+  Jp[12] = Jp[0] - bf * y / z2; Jp[13] = Jp[1] + bf * x / z2; Jp[14] = Jp[2];
+  Jp[15] = Jp[3];          Jp[16] = 0;                       Jp[17] = Jp[5] - bf / z2;
+}
+
+// Huber weight: rho0 (robustified chi2) and rho1 (weight); delta <= 0 disables the kernel
+PPO_HD void huber(double chi2, double delta, double& rho0, double& rho1) {
+  rho0 = chi2;
+  rho1 = 1.0;
+  if (delta > 0) {
+    const double dsqr = delta * delta;
+    if (!(chi2 <= dsqr)) {
+      const double sq = sqrt(chi2);
+      rho0 = 2 * sq * delta - dsqr;
+      rho1 = delta / sq;
+    }
+  }
+}
+
+// inverse of a symmetric 3x3 given as (d00,d01,d02,d11,d12,d22) by cofactors; returns the same packing
+PPO_HD void sym3_inverse(const double* D, double* I) {
+  const double c00 = D[3] * D[5] - D[4] * D[4];
+  const double c01 = D[2] * D[4] - D[1] * D[5];
+  const double c02 = D[1] * D[4] - D[2] * D[3];
+  const double det = D[0] * c00 + D[1] * c01 + D[2] * c02;
+  const double id = 1.0 / det;
+  I[0] = c00 * id;
+  I[1] = c01 * id;
+  I[2] = c02 * id;
+  I[3] = (D[0] * D[5] - D[2] * D[2]) * id;
+  I[4] = (D[1] * D[2] - D[0] * D[4]) * id;
+  I[5] = (D[0] * D[3] - D[1] * D[1]) * id;
+}
+
+}  // namespace ppo

@@ -1,0 +1,998 @@
+// ppo_solver.hip -- C ABI of libppo_ba.so (include/ppo_ba.h): graph ingest, device upload, the
+// Levenberg-Marquardt control loop of Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-164
+// driving the kernels of ppo_kernels.hpp, the two-pass protocol of src/Optimizer.cc:2723-2838, read-back.
+//
+// There is no CPU fallback: without a usable HIP device ppo_ba_create() returns PPO_BA_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/ppo_ba.h"
+#include "ppo_chol.hpp"
+#include "ppo_comm.hpp"
+#include "ppo_kernels.hpp"
+
+using namespace ppo;
+
+#define HIP_TRY(expr)                                                                                            \
+  do {                                                                                                           \
+    hipError_t e_ = (expr);                                                                                      \
+    if (e_ != hipSuccess) {                                                                                      \
+      std::fprintf(stderr, "[ppo_ba] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return PPO_BA_ERR_HIP;                                                                                     \
+    }                                                                                                            \
+  } while (0)
+#define RC_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ < 0) return rc_;    \
+  } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  bool alloc(size_t count) {
+    n = count;
+    p = nullptr;
+    if (count == 0) return true;
+    return hipMalloc((void**)&p, count * sizeof(T)) == hipSuccess;
+  }
+  bool upload(const std::vector<T>& h, hipStream_t s) {
+    if (!alloc(h.size())) return false;
+    if (h.empty()) return true;
+    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct ppo_ba_solver {
+  ppo_ba_options opt;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  rocblas_handle blas = nullptr;
+  Comm comm;
+  int n_cubpl = 0;
+  // host copies kept after create
+  std::vector<int32_t> mono_perm, stereo_perm;  // sorted position -> caller index
+  std::vector<MonoEdge> h_mono;
+  std::vector<StereoEdge> h_stereo;
+  std::vector<PlaneEdge> h_pl;
+  std::vector<CubEdge> h_bbox, h_corner;
+  std::vector<PtCubEdge> h_ptcub;
+  std::vector<double> cubpl_chi2;  // EdgeCuboidPlane: error == measurement, so chi2 is a constant
+  double cubpl_rho_sum = 0.0;      // its robustified sum: a constant term of every chi2
+  std::vector<int32_t> h_slot_off;
+  // device
+  DevBuf<double> d_pose_cam, d_cub_fixedscale, d_ptcub_pts;
+  DevBuf<int32_t> d_pose_col, d_pose_free_id, d_cub_col, d_mo_off, d_st_off, d_slot_off, d_slot_col, d_slot_lm;
+  DevBuf<uint8_t> d_point_fixed, d_cub_flags;
+  DevBuf<MonoEdge> d_mono;
+  DevBuf<StereoEdge> d_stereo;
+  DevBuf<PlaneEdge> d_pl;
+  DevBuf<CubEdge> d_bbox, d_corner;
+  DevBuf<PtCubEdge> d_ptcub;
+  DevBuf<double> d_chi2_all;  // per-edge chi2 / norms
+  DevBuf<double> d_state[2];  // two copies of all estimates (current / trial)
+  DevBuf<double> d_init;      // pristine estimates for reset()
+  DevBuf<double> d_arena;     // HB | HC | acc | D | bl | W ; a prefix is zeroed before every linearisation
+  DevBuf<double> d_Wpc, d_Dinv, d_yl, d_Y, d_S, d_bs, d_xr, d_cholws;
+  DevBuf<int> d_info;
+  size_t state_doubles = 0;
+  double* h_pinned = nullptr;  // ACC_N doubles then one int
+  Graph g{};
+  State st[2]{};
+  int cur = 0;
+  int lds_bytes = 0;
+  bool use_lds = true;
+  int n_cu = 256;
+  // memset plan for a linearisation: [HB|HC|acc] always, and the plane part of D/bl/W (accumulated with atomics)
+  size_t zero_head = 0;
+  size_t zD_off = 0, zD_n = 0, zbl_off = 0, zbl_n = 0, zW_off = 0, zW_n = 0;
+  // LM state (levenberg.cpp:43-55)
+  double lambda = -1, ni = 2;
+  int nBad = 0;
+  ppo_ba_stats stats{};
+  bool ran = false;
+  int64_t lin_bytes = 0;
+  int solver_kind = PPO_SOLVER_ROCSOLVER;
+  bool have_system = false;  // S/bs/xr hold the last solve attempt
+};
+
+namespace {
+
+bool finite_all(const double* p, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(p[i])) return false;
+  return true;
+}
+bool idx_ok(const int32_t* p, int n, int hi) {
+  for (int i = 0; i < n; ++i)
+    if (p[i] < 0 || p[i] >= hi) return false;
+  return true;
+}
+#define REQ(cond) do { if (!(cond)) return PPO_BA_ERR_ARG; } while (0)
+#define FIN(ptr, n) do { if (!finite_all((ptr), (size_t)(n))) return PPO_BA_ERR_NONFINITE; } while (0)
+
+int validate(const ppo_ba_problem* p) {
+  REQ(p->n_poses >= 0 && p->n_points >= 0 && p->n_planes >= 0 && p->n_cuboids >= 0);
+  REQ(p->n_mono >= 0 && p->n_stereo >= 0 && p->n_plane_edges >= 0 && p->n_bbox >= 0 && p->n_corner >= 0 && p->n_ptcub >= 0 && p->n_cubpl >= 0);
+  if (p->n_poses) { REQ(p->pose_qt && p->pose_fixed && p->pose_cam); FIN(p->pose_qt, 7 * (size_t)p->n_poses); FIN(p->pose_cam, 5 * (size_t)p->n_poses); }
+  if (p->n_points) { REQ(p->point_xyz); FIN(p->point_xyz, 3 * (size_t)p->n_points); }
+  if (p->n_planes) { REQ(p->plane_coef); FIN(p->plane_coef, 4 * (size_t)p->n_planes); }
+  if (p->n_cuboids) { REQ(p->cuboid_qt && p->cuboid_scale); FIN(p->cuboid_qt, 7 * (size_t)p->n_cuboids); FIN(p->cuboid_scale, 3 * (size_t)p->n_cuboids); }
+  if (p->n_mono) {
+    REQ(p->mono_point && p->mono_pose && p->mono_obs && p->mono_info && p->mono_huber);
+    REQ(idx_ok(p->mono_point, p->n_mono, p->n_points) && idx_ok(p->mono_pose, p->n_mono, p->n_poses));
+    FIN(p->mono_obs, 2 * (size_t)p->n_mono); FIN(p->mono_info, p->n_mono); FIN(p->mono_huber, p->n_mono);
+  }
+  if (p->n_stereo) {
+    REQ(p->stereo_point && p->stereo_pose && p->stereo_obs && p->stereo_info && p->stereo_huber);
+    REQ(idx_ok(p->stereo_point, p->n_stereo, p->n_points) && idx_ok(p->stereo_pose, p->n_stereo, p->n_poses));
+    FIN(p->stereo_obs, 3 * (size_t)p->n_stereo); FIN(p->stereo_info, p->n_stereo); FIN(p->stereo_huber, p->n_stereo);
+  }
+  if (p->n_plane_edges) {
+    REQ(p->pl_plane && p->pl_pose && p->pl_meas && p->pl_info && p->pl_huber);
+    REQ(idx_ok(p->pl_plane, p->n_plane_edges, p->n_planes) && idx_ok(p->pl_pose, p->n_plane_edges, p->n_poses));
+    FIN(p->pl_meas, 4 * (size_t)p->n_plane_edges); FIN(p->pl_info, 3 * (size_t)p->n_plane_edges); FIN(p->pl_huber, p->n_plane_edges);
+    if (p->pl_kind) for (int i = 0; i < p->n_plane_edges; ++i) REQ(p->pl_kind[i] <= 2);
+  }
+  if (p->n_bbox) {
+    REQ(p->bbox_pose && p->bbox_cuboid && p->bbox_meas && p->bbox_info && p->bbox_huber && p->bbox_K);
+    REQ(idx_ok(p->bbox_pose, p->n_bbox, p->n_poses) && idx_ok(p->bbox_cuboid, p->n_bbox, p->n_cuboids));
+    FIN(p->bbox_meas, 4 * (size_t)p->n_bbox); FIN(p->bbox_info, 4 * (size_t)p->n_bbox); FIN(p->bbox_K, 9 * (size_t)p->n_bbox); FIN(p->bbox_huber, p->n_bbox);
+  }
+  if (p->n_corner) {
+    REQ(p->corner_pose && p->corner_cuboid && p->corner_meas && p->corner_info && p->corner_huber && p->corner_K);
+    REQ(idx_ok(p->corner_pose, p->n_corner, p->n_poses) && idx_ok(p->corner_cuboid, p->n_corner, p->n_cuboids));
+    FIN(p->corner_meas, 16 * (size_t)p->n_corner); FIN(p->corner_info, 16 * (size_t)p->n_corner); FIN(p->corner_K, 9 * (size_t)p->n_corner); FIN(p->corner_huber, p->n_corner);
+  }
+  if (p->n_ptcub) {
+    REQ(p->ptcub_cuboid && p->ptcub_offsets && p->ptcub_margin_ratio && p->ptcub_info);
+    REQ(idx_ok(p->ptcub_cuboid, p->n_ptcub, p->n_cuboids));
+    REQ(p->ptcub_offsets[0] >= 0);
+    for (int i = 0; i < p->n_ptcub; ++i) REQ(p->ptcub_offsets[i] <= p->ptcub_offsets[i + 1]);
+    if (p->ptcub_offsets[p->n_ptcub] > 0) { REQ(p->ptcub_points); FIN(p->ptcub_points, 3 * (size_t)p->ptcub_offsets[p->n_ptcub]); }
+    FIN(p->ptcub_info, 3 * (size_t)p->n_ptcub); FIN(p->ptcub_margin_ratio, p->n_ptcub);
+  }
+  if (p->n_cubpl) {
+    REQ(p->cubpl_cuboid && p->cubpl_plane && p->cubpl_meas && p->cubpl_info && p->cubpl_huber);
+    REQ(idx_ok(p->cubpl_cuboid, p->n_cubpl, p->n_cuboids) && idx_ok(p->cubpl_plane, p->n_cubpl, p->n_planes));
+    FIN(p->cubpl_meas, 3 * (size_t)p->n_cubpl); FIN(p->cubpl_info, 3 * (size_t)p->n_cubpl); FIN(p->cubpl_huber, p->n_cubpl);
+  }
+  return PPO_BA_OK;
+}
+
+void canon_quat(double* q) {  // SE3Quat ctor: w >= 0, unit norm (se3quat.h:331-336)
+  if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+void canon_plane_cv(const double* in, double* out) {  // Converter::toPlane3D (Converter.cc:172-181) + Plane3D::fromVector
+  double t[4] = {in[0], in[1], in[2], in[3]};
+  if (t[3] < 0.0) for (int i = 0; i < 4; ++i) t[i] = -t[i];
+  const PlaneC c = plane_canon(t[0], t[1], t[2], t[3]);
+  out[0] = c.nx; out[1] = c.ny; out[2] = c.nz; out[3] = c.d;
+}
+
+void free_all(ppo_ba_solver* s) {
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  s->d_pose_cam.release(); s->d_cub_fixedscale.release(); s->d_ptcub_pts.release();
+  s->d_pose_col.release(); s->d_pose_free_id.release(); s->d_cub_col.release(); s->d_mo_off.release(); s->d_st_off.release();
+  s->d_slot_off.release(); s->d_slot_col.release(); s->d_slot_lm.release(); s->d_point_fixed.release(); s->d_cub_flags.release();
+  s->d_mono.release(); s->d_stereo.release(); s->d_pl.release(); s->d_bbox.release(); s->d_corner.release(); s->d_ptcub.release();
+  s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
+  s->d_Wpc.release(); s->d_Dinv.release(); s->d_yl.release(); s->d_Y.release();
+  s->d_S.release(); s->d_bs.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
+  if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+  if (s->blas) rocblas_destroy_handle(s->blas);
+  s->comm.destroy();
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+}
+
+State make_state(double* base, int np, int npt, int npl, int nc) {
+  State st;
+  st.pose_qt = base; base += (size_t)np * 7;
+  st.pose_rt = base; base += (size_t)np * 12;
+  st.point = base; base += (size_t)npt * 3;
+  st.plane = base; base += (size_t)npl * 4;
+  st.cub = base;
+  (void)nc;
+  return st;
+}
+
+inline int nblk(long n, int b) { return (int)std::max<long>(1, (n + b - 1) / b); }
+
+int reset_device(ppo_ba_solver* s) {
+  // edge flags back to "level 0, kernel on", estimates back to the inputs
+  auto up = [&](void* dst, const void* src, size_t bytes) {
+    return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream) == hipSuccess;
+  };
+  if (!up(s->d_mono.p, s->h_mono.data(), s->h_mono.size() * sizeof(MonoEdge)) ||
+      !up(s->d_stereo.p, s->h_stereo.data(), s->h_stereo.size() * sizeof(StereoEdge)) ||
+      !up(s->d_pl.p, s->h_pl.data(), s->h_pl.size() * sizeof(PlaneEdge)) ||
+      !up(s->d_bbox.p, s->h_bbox.data(), s->h_bbox.size() * sizeof(CubEdge)) ||
+      !up(s->d_corner.p, s->h_corner.data(), s->h_corner.size() * sizeof(CubEdge)))
+    return PPO_BA_ERR_HIP;
+  if (s->state_doubles) {
+    HIP_TRY(hipMemcpyAsync(s->d_state[0].p, s->d_init.p, s->state_doubles * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_state[1].p, s->d_init.p, s->state_doubles * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  }
+  if (s->d_chi2_all.n) HIP_TRY(hipMemsetAsync(s->d_chi2_all.p, 0, s->d_chi2_all.n * sizeof(double), s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_arena.p, 0, s->d_arena.n * sizeof(double), s->stream));
+  s->cur = 0;
+  s->ran = false;
+  s->have_system = false;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return PPO_BA_OK;
+}
+
+// ---- one linearisation of the current state: fills HB/HC/D/bl/W, per-edge chi2, acc[ACC_CHI2] ------------
+int launch_linearize(ppo_ba_solver* s) {
+  const Graph& g = s->g;
+  const State& st = s->st[s->cur];
+  double* A = s->d_arena.p;
+  HIP_TRY(hipMemsetAsync(A, 0, s->zero_head * sizeof(double), s->stream));
+  if (s->zD_n) HIP_TRY(hipMemsetAsync(A + s->zD_off, 0, s->zD_n * sizeof(double), s->stream));
+  if (s->zbl_n) HIP_TRY(hipMemsetAsync(A + s->zbl_off, 0, s->zbl_n * sizeof(double), s->stream));
+  if (s->zW_n) HIP_TRY(hipMemsetAsync(A + s->zW_off, 0, s->zW_n * sizeof(double), s->stream));
+  const int npts = g.pt_last - g.pt_first;
+  if (npts > 0) {
+    const int grid = std::min(nblk(npts, 256), 2 * s->n_cu);
+    if (s->use_lds) hipLaunchKernelGGL(k_lin_points<true>, dim3(grid), dim3(256), s->lds_bytes, s->stream, g, st);
+    else hipLaunchKernelGGL(k_lin_points<false>, dim3(grid), dim3(256), 0, s->stream, g, st);
+  }
+  const double delta = s->opt.numeric_delta;
+  if (g.plane_last > g.plane_first && g.n_pl > 0)
+    hipLaunchKernelGGL(k_lin_numeric<PlaneModel>, dim3(nblk(g.n_pl, 16)), dim3(256), 0, s->stream, g, st, g.n_pl, false, delta);
+  if (g.owns_reduced) {
+    if (g.n_bbox) hipLaunchKernelGGL(k_lin_numeric<CubProjModel>, dim3(nblk(g.n_bbox, 16)), dim3(256), 0, s->stream, g, st, g.n_bbox, false, delta);
+    if (g.n_corner) hipLaunchKernelGGL(k_lin_numeric<CubProjModel>, dim3(nblk(g.n_corner, 16)), dim3(256), 0, s->stream, g, st, g.n_corner, true, delta);
+    if (g.n_ptcub) hipLaunchKernelGGL(k_lin_numeric<PtCubModel>, dim3(nblk(g.n_ptcub, 16)), dim3(256), 0, s->stream, g, st, g.n_ptcub, false, delta);
+  }
+  HIP_TRY(hipGetLastError());
+  return PPO_BA_OK;
+}
+
+int launch_chi2(ppo_ba_solver* s, const State& st) {
+  const Graph& g = s->g;
+  const int npts = g.pt_last - g.pt_first;
+  if (npts > 0) hipLaunchKernelGGL(k_chi2_points, dim3(std::min(nblk(npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
+  if (g.plane_last > g.plane_first && g.n_pl > 0)
+    hipLaunchKernelGGL(k_chi2_numeric<PlaneModel>, dim3(nblk(g.n_pl, 256)), dim3(256), 0, s->stream, g, st, g.n_pl, false);
+  if (g.owns_reduced) {
+    if (g.n_bbox) hipLaunchKernelGGL(k_chi2_numeric<CubProjModel>, dim3(nblk(g.n_bbox, 256)), dim3(256), 0, s->stream, g, st, g.n_bbox, false);
+    if (g.n_corner) hipLaunchKernelGGL(k_chi2_numeric<CubProjModel>, dim3(nblk(g.n_corner, 256)), dim3(256), 0, s->stream, g, st, g.n_corner, true);
+    if (g.n_ptcub) hipLaunchKernelGGL(k_chi2_numeric<PtCubModel>, dim3(nblk(g.n_ptcub, 256)), dim3(256), 0, s->stream, g, st, g.n_ptcub, false);
+  }
+  HIP_TRY(hipGetLastError());
+  return PPO_BA_OK;
+}
+
+// reduced system for `lambda` into S (lower triangle) / bs      (block_solver.hpp:354-439)
+int launch_reduce(ppo_ba_solver* s, double lambda) {
+  const Graph& g = s->g;
+  const size_t n = g.n_red;
+  HIP_TRY(hipMemsetAsync(s->d_S.p, 0, n * n * sizeof(double), s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_bs.p, 0, n * sizeof(double), s->stream));
+  const long work = (long)g.n_pose_free * 27 + (long)g.n_cuboids * 54 + (long)(g.n_bbox + g.n_corner) * 54;
+  hipLaunchKernelGGL(k_assemble, dim3(nblk(work, 256)), dim3(256), 0, s->stream, g, lambda);
+  const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
+  if (nl > 0) {
+    hipLaunchKernelGGL(k_schur_prep, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, lambda);
+    const int ranges[2][2] = {{g.pt_first, g.pt_last}, {g.n_points + g.plane_first, g.n_points + g.plane_last}};
+    for (auto& r : ranges) {
+      if (r[1] <= r[0]) continue;
+      const int s0 = s->h_slot_off[r[0]], s1 = s->h_slot_off[r[1]];
+      if (s1 > s0) hipLaunchKernelGGL(k_schur_accum, dim3(nblk((long)(s1 - s0) * 8, 256)), dim3(256), 0, s->stream, g, s0, s1);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  if (s->comm.active()) {
+    if (s->comm.sum(s->d_S.p, n * n, s->stream) || s->comm.sum(s->d_bs.p, n, s->stream)) return PPO_BA_ERR_COMM;
+  }
+  return PPO_BA_OK;
+}
+
+// dense SPD solve of S x = bs (LinearSolverDense::solve, linear_solver_dense.h:65-113).  info != 0 <=> not positive.
+int launch_solve(ppo_ba_solver* s) {
+  const Graph& g = s->g;
+  const int n = g.n_red;
+  HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  if (s->solver_kind == PPO_SOLVER_NATIVE) {
+    RC_TRY(chol_factor_solve(s->d_S.p, n, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
+  } else {
+    if (rocsolver_dpotrf(s->blas, rocblas_fill_lower, n, s->d_S.p, n, s->d_info.p) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
+    if (rocsolver_dpotrs(s->blas, rocblas_fill_lower, n, 1, s->d_S.p, n, s->d_xr.p, n) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
+  }
+  return PPO_BA_OK;
+}
+
+int launch_update(ppo_ba_solver* s, double lambda) {
+  const Graph& g = s->g;
+  const State& cur = s->st[s->cur];
+  const State& tr = s->st[s->cur ^ 1];
+  hipLaunchKernelGGL(k_update_reduced, dim3(nblk(g.n_poses + g.n_cuboids, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
+  const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
+  if (nl > 0) hipLaunchKernelGGL(k_backsub, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
+  HIP_TRY(hipGetLastError());
+  return PPO_BA_OK;
+}
+
+// bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first
+int fetch_acc(ppo_ba_solver* s, bool with_info) {
+  if (s->comm.active()) {
+    // chi2 and scale are sums, maxdiag is a max: two tiny collectives on the accumulator block
+    if (s->comm.sum(s->g.acc, 2, s->stream) || s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
+  }
+  HIP_TRY(hipMemcpyAsync(s->h_pinned, s->g.acc, ACC_N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (with_info) HIP_TRY(hipMemcpyAsync(s->h_pinned + ACC_N, s->d_info.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return PPO_BA_OK;
+}
+
+bool stop_requested(const volatile uint8_t* f) { return f && *f; }
+
+// OptimizationAlgorithmLevenberg::solve, levenberg.cpp:61-164.  Returns <0 error, 0 OK, 1 Terminate.
+int lm_iteration(ppo_ba_solver* s, int iteration, const volatile uint8_t* stop, ppo_ba_iter_stat& it) {
+  Graph& g = s->g;
+  RC_TRY(launch_linearize(s));
+  if (s->comm.active()) {  // every rank needs the summed pose blocks (lambda init, scale term, rank 0 assembles them)
+    if (s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
+  }
+  if (iteration == 0) {
+    const long nd = std::max<long>({(long)g.n_pose_free * 6, (long)g.n_cuboids * 9, 3L * ((g.pt_last - g.pt_first) + (g.plane_last - g.plane_first)), 1L});
+    hipLaunchKernelGGL(k_maxdiag, dim3(nblk(nd, 256)), dim3(256), 0, s->stream, g);
+  }
+  RC_TRY(fetch_acc(s, false));
+  double currentChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+  const double iniChi = currentChi;
+  it.chi2_before = currentChi;
+  if (iteration == 0) {  // computeLambdaInit, levenberg.cpp:166-180
+    s->lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
+    s->ni = 2;
+    s->nBad = 0;
+  }
+  double rho = 0;
+  int qmax = 0;
+  do {
+    const double lambda = s->lambda;
+    RC_TRY(launch_reduce(s, lambda));
+    RC_TRY(launch_solve(s));
+    s->have_system = true;
+    // acc: chi2 <- 0, scale <- 0 for the trial
+    HIP_TRY(hipMemsetAsync(g.acc, 0, 2 * sizeof(double), s->stream));
+    RC_TRY(launch_update(s, lambda));
+    RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
+    RC_TRY(fetch_acc(s, true));
+    int info = 0;
+    std::memcpy(&info, s->h_pinned + ACC_N, sizeof(int));
+    double tempChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+    if (info != 0 || !std::isfinite(s->h_pinned[ACC_SCALE])) tempChi = std::numeric_limits<double>::max();  // solver not ok (:126-127)
+    rho = currentChi - tempChi;
+    double scale = s->h_pinned[ACC_SCALE];
+    if (info != 0) scale = 0;
+    scale += 1e-3;
+    rho /= scale;
+    it.lambda = lambda;
+    if (rho > 0 && std::isfinite(tempChi) && info == 0) {
+      double alpha = 1. - std::pow((2 * rho - 1), 3);
+      alpha = std::min(alpha, s->opt.lm_upper);
+      const double scaleFactor = std::max(s->opt.lm_lower, alpha);
+      s->lambda *= scaleFactor;
+      s->ni = 2;
+      currentChi = tempChi;
+      s->cur ^= 1;  // discardTop(): the trial state becomes the estimate
+      it.accepted = 1;
+    } else {
+      s->lambda *= s->ni;
+      s->ni *= 2;
+      it.accepted = 0;  // pop(): keep the current state
+      if (!(rho < 0)) rho = (info != 0) ? -1.0 : rho;
+    }
+    qmax++;
+    s->stats.n_trials++;
+  } while (rho < 0 && qmax < s->opt.lm_max_trials && !stop_requested(stop));
+  it.trials = qmax;
+  it.chi2_after = currentChi;
+  if (qmax == s->opt.lm_max_trials || rho == 0) return 1;
+  if ((iniChi - currentChi) * 1e3 < iniChi) s->nBad++;
+  else s->nBad = 0;
+  if (s->nBad >= 3) return 1;
+  return 0;
+}
+
+// SparseOptimizer::optimize, sparse_optimizer.cpp:354-419
+int optimize(ppo_ba_solver* s, int pass, int iterations, const volatile uint8_t* stop) {
+  if (s->g.n_red == 0) return 0;
+  bool ok = true;
+  for (int i = 0; i < iterations && !stop_requested(stop) && ok; ++i) {
+    ppo_ba_iter_stat it{};
+    it.pass = pass;
+    it.iteration = i;
+    const int res = lm_iteration(s, i, stop, it);
+    if (res < 0) return res;
+    it.result = res;
+    ok = (res == 0);
+    if (s->stats.n_iters < PPO_BA_MAX_ITER_STATS) s->stats.iters[s->stats.n_iters] = it;
+    s->stats.n_iters++;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int ppo_ba_version(void) { return PPO_BA_ABI_VERSION; }
+
+int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handle* out) {
+  if (!p || !o || !out) return PPO_BA_ERR_ARG;
+  *out = nullptr;
+  if (o->abi_version != PPO_BA_ABI_VERSION) return PPO_BA_ERR_ARG;
+  RC_TRY(validate(p));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    std::fprintf(stderr, "[ppo_ba] no HIP device: libppo_ba has no CPU path\n");
+    return PPO_BA_ERR_HIP;
+  }
+  if (o->device_id < 0 || o->device_id >= ndev) return PPO_BA_ERR_ARG;
+  ppo_ba_solver* s = new (std::nothrow) ppo_ba_solver();
+  if (!s) return PPO_BA_ERR_NOMEM;
+  s->opt = *o;
+  s->device = o->device_id;
+  auto fail = [&](int code) { free_all(s); delete s; return code; };
+  if (hipSetDevice(s->device) != hipSuccess) return fail(PPO_BA_ERR_HIP);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return fail(PPO_BA_ERR_HIP);
+  if (rocblas_create_handle(&s->blas) != rocblas_status_success) return fail(PPO_BA_ERR_SOLVER);
+  rocblas_set_stream(s->blas, s->stream);
+  if (s->comm.init(o->comm_id, o->rank, o->world_size)) return fail(PPO_BA_ERR_COMM);
+  s->solver_kind = (o->solver == PPO_SOLVER_NATIVE) ? PPO_SOLVER_NATIVE : (o->solver == PPO_SOLVER_ROCSOLVER ? PPO_SOLVER_ROCSOLVER : chol_default_backend());
+
+  Graph& g = s->g;
+  g.n_poses = p->n_poses; g.n_points = p->n_points; g.n_planes = p->n_planes; g.n_cuboids = p->n_cuboids;
+  g.n_mono = p->n_mono; g.n_stereo = p->n_stereo; g.n_pl = p->n_plane_edges; g.n_bbox = p->n_bbox; g.n_corner = p->n_corner; g.n_ptcub = p->n_ptcub;
+  s->n_cubpl = p->n_cubpl;
+  const int Np = p->n_poses, Npt = p->n_points, Npl = p->n_planes, Nc = p->n_cuboids;
+
+  // ---- which vertices enter the reduced system: non-fixed and touched by at least one edge -----------
+  std::vector<uint8_t> pose_used(Np, 0), cub_used(Nc, 0), point_fixed(Npt, 0);
+  if (p->point_fixed) std::copy(p->point_fixed, p->point_fixed + Npt, point_fixed.begin());
+  for (int e = 0; e < p->n_mono; ++e) pose_used[p->mono_pose[e]] = 1;
+  for (int e = 0; e < p->n_stereo; ++e) pose_used[p->stereo_pose[e]] = 1;
+  for (int e = 0; e < p->n_plane_edges; ++e) pose_used[p->pl_pose[e]] = 1;
+  for (int e = 0; e < p->n_bbox; ++e) { pose_used[p->bbox_pose[e]] = 1; cub_used[p->bbox_cuboid[e]] = 1; }
+  for (int e = 0; e < p->n_corner; ++e) { pose_used[p->corner_pose[e]] = 1; cub_used[p->corner_cuboid[e]] = 1; }
+  for (int e = 0; e < p->n_ptcub; ++e) cub_used[p->ptcub_cuboid[e]] = 1;
+  std::vector<int32_t> pose_col(Np, -1), pose_free_id(Np, -1), cub_col(Nc, -1);
+  int nfree = 0;
+  for (int i = 0; i < Np; ++i)
+    if (!p->pose_fixed[i] && pose_used[i]) { pose_free_id[i] = nfree; pose_col[i] = 6 * nfree; ++nfree; }
+  int ncol = 6 * nfree;
+  for (int i = 0; i < Nc; ++i)
+    if (cub_used[i]) { cub_col[i] = ncol; ncol += 9; }
+  g.n_pose_free = nfree;
+  g.n_red = ncol;
+  g.n_lm = Npt + Npl;
+  s->stats.n_reduced = ncol;
+
+  // ---- reprojection edges sorted by point (stable counting sort), CSR offsets -------------------------
+  auto csr_sort = [&](int n, const int32_t* key, std::vector<int32_t>& off, std::vector<int32_t>& perm) {
+    off.assign(Npt + 1, 0);
+    for (int e = 0; e < n; ++e) off[key[e] + 1]++;
+    for (int i = 0; i < Npt; ++i) off[i + 1] += off[i];
+    perm.resize(n);
+    std::vector<int32_t> cursor(off.begin(), off.end() - 1);
+    for (int e = 0; e < n; ++e) perm[cursor[key[e]]++] = e;
+  };
+  std::vector<int32_t> mo_off, st_off;
+  csr_sort(p->n_mono, p->mono_point, mo_off, s->mono_perm);
+  csr_sort(p->n_stereo, p->stereo_point, st_off, s->stereo_perm);
+
+  // ---- (landmark, pose) slots: unique free poses seen by each free landmark, ascending column ----------
+  std::vector<std::vector<int32_t>> lm_cols(g.n_lm);
+  for (int k = 0; k < p->n_mono; ++k) {
+    const int e = s->mono_perm[k], pt = p->mono_point[e], pc = pose_col[p->mono_pose[e]];
+    if (!point_fixed[pt] && pc >= 0) lm_cols[pt].push_back(pc);
+  }
+  for (int k = 0; k < p->n_stereo; ++k) {
+    const int e = s->stereo_perm[k], pt = p->stereo_point[e], pc = pose_col[p->stereo_pose[e]];
+    if (!point_fixed[pt] && pc >= 0) lm_cols[pt].push_back(pc);
+  }
+  for (int e = 0; e < p->n_plane_edges; ++e) {
+    const int pc = pose_col[p->pl_pose[e]];
+    if (pc >= 0) lm_cols[Npt + p->pl_plane[e]].push_back(pc);
+  }
+  std::vector<int32_t>& slot_off = s->h_slot_off;
+  slot_off.assign(g.n_lm + 1, 0);
+  std::vector<int32_t> slot_col, slot_lm;
+  for (int l = 0; l < g.n_lm; ++l) {
+    auto& v = lm_cols[l];
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    slot_off[l] = (int32_t)slot_col.size();
+    for (int c : v) { slot_col.push_back(c); slot_lm.push_back(l); }
+  }
+  slot_off[g.n_lm] = (int32_t)slot_col.size();
+  g.n_slots = (int)slot_col.size();
+  auto find_slot = [&](int l, int pc) -> int32_t {
+    if (pc < 0) return -1;
+    const int32_t* b = slot_col.data() + slot_off[l];
+    const int32_t* e = slot_col.data() + slot_off[l + 1];
+    const int32_t* it = std::lower_bound(b, e, pc);
+    return (it != e && *it == pc) ? (int32_t)(it - slot_col.data()) : -1;
+  };
+
+  // ---- edge records -----------------------------------------------------------------------------------------
+  s->h_mono.resize(p->n_mono);
+  for (int k = 0; k < p->n_mono; ++k) {
+    const int e = s->mono_perm[k];
+    MonoEdge& m = s->h_mono[k];
+    m.u = p->mono_obs[2 * e]; m.v = p->mono_obs[2 * e + 1]; m.info = p->mono_info[e]; m.huber = p->mono_huber[e];
+    m.pose = p->mono_pose[e];
+    m.slot = point_fixed[p->mono_point[e]] ? -1 : find_slot(p->mono_point[e], pose_col[m.pose]);
+    const bool all_fixed = point_fixed[p->mono_point[e]] && pose_col[m.pose] < 0;
+    m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
+    m.pad = 0;
+  }
+  s->h_stereo.resize(p->n_stereo);
+  for (int k = 0; k < p->n_stereo; ++k) {
+    const int e = s->stereo_perm[k];
+    StereoEdge& m = s->h_stereo[k];
+    std::memset(&m, 0, sizeof(m));
+    m.u = p->stereo_obs[3 * e]; m.v = p->stereo_obs[3 * e + 1]; m.ur = p->stereo_obs[3 * e + 2];
+    m.info = p->stereo_info[e]; m.huber = p->stereo_huber[e];
+    m.pose = p->stereo_pose[e];
+    m.slot = point_fixed[p->stereo_point[e]] ? -1 : find_slot(p->stereo_point[e], pose_col[m.pose]);
+    const bool all_fixed = point_fixed[p->stereo_point[e]] && pose_col[m.pose] < 0;
+    m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
+  }
+  s->h_pl.resize(p->n_plane_edges);
+  for (int e = 0; e < p->n_plane_edges; ++e) {
+    PlaneEdge& m = s->h_pl[e];
+    std::memset(&m, 0, sizeof(m));
+    canon_plane_cv(&p->pl_meas[4 * e], m.meas);
+    for (int i = 0; i < 3; ++i) m.info[i] = p->pl_info[3 * e + i];
+    m.huber = p->pl_huber[e];
+    m.plane = p->pl_plane[e]; m.pose = p->pl_pose[e];
+    m.slot = find_slot(Npt + m.plane, pose_col[m.pose]);
+    m.flags = F_ACTIVE | F_ROBUST | ((uint32_t)(p->pl_kind ? p->pl_kind[e] : 0) << 8);
+  }
+  auto fill_cub = [&](std::vector<CubEdge>& v, int n, const int32_t* pose, const int32_t* cub, const double* meas, const double* info,
+                      const double* hub, const double* K, int dim) {
+    v.resize(n);
+    for (int e = 0; e < n; ++e) {
+      CubEdge& m = v[e];
+      std::memset(&m, 0, sizeof(m));
+      for (int i = 0; i < dim; ++i) { m.meas[i] = meas[dim * e + i]; m.info[i] = info[dim * e + i]; }
+      m.huber = hub[e];
+      for (int i = 0; i < 9; ++i) m.K[i] = K[9 * e + i];
+      m.pose = pose[e]; m.cuboid = cub[e]; m.dim = dim;
+      m.flags = F_ACTIVE | F_ROBUST;
+    }
+  };
+  fill_cub(s->h_bbox, p->n_bbox, p->bbox_pose, p->bbox_cuboid, p->bbox_meas, p->bbox_info, p->bbox_huber, p->bbox_K, 4);
+  fill_cub(s->h_corner, p->n_corner, p->corner_pose, p->corner_cuboid, p->corner_meas, p->corner_info, p->corner_huber, p->corner_K, 16);
+  s->h_ptcub.resize(p->n_ptcub);
+  for (int e = 0; e < p->n_ptcub; ++e) {
+    PtCubEdge& m = s->h_ptcub[e];
+    std::memset(&m, 0, sizeof(m));
+    m.margin = p->ptcub_margin_ratio[e];
+    for (int i = 0; i < 3; ++i) { m.prior[i] = p->ptcub_prior_half ? p->ptcub_prior_half[3 * e + i] : 0.0; m.info[i] = p->ptcub_info[3 * e + i]; }
+    m.huber = p->ptcub_huber ? p->ptcub_huber[e] : 0.0;
+    m.cuboid = p->ptcub_cuboid[e]; m.p0 = p->ptcub_offsets[e]; m.p1 = p->ptcub_offsets[e + 1];
+    m.flags = F_ACTIVE | (m.huber > 0 ? F_ROBUST : 0u);
+  }
+  // EdgeCuboidPlane: constant error (G2O_Plane3D.h:470-473).  Its chi2 and robustified value never change and its
+  // numeric Jacobians are identically zero, so it only shifts every chi2 by a constant.
+  s->cubpl_chi2.resize(p->n_cubpl);
+  s->cubpl_rho_sum = 0;
+  for (int e = 0; e < p->n_cubpl; ++e) {
+    double c = 0;
+    for (int i = 0; i < 3; ++i) c += p->cubpl_meas[3 * e + i] * (p->cubpl_info[3 * e + i] * p->cubpl_meas[3 * e + i]);
+    s->cubpl_chi2[e] = c;
+    double r0, r1;
+    huber(c, p->cubpl_huber[e], r0, r1);
+    s->cubpl_rho_sum += r0;
+  }
+
+  // ---- landmark ownership (multi-GPU): contiguous edge-balanced ranges; rank 0 owns the reduced-only terms ----
+  g.pt_first = 0; g.pt_last = Npt; g.plane_first = 0; g.plane_last = Npl; g.owns_reduced = 1;
+  if (o->world_size > 1) {
+    std::vector<int32_t> fp(o->world_size + 1), fl(o->world_size + 1);
+    if (ppo_ba_partition(p, o->world_size, fp.data(), fl.data()) != PPO_BA_OK) return fail(PPO_BA_ERR_ARG);
+    g.pt_first = fp[o->rank]; g.pt_last = fp[o->rank + 1];
+    g.plane_first = fl[o->rank]; g.plane_last = fl[o->rank + 1];
+    g.owns_reduced = (o->rank == 0);
+    if (!g.owns_reduced) s->cubpl_rho_sum = 0;
+  }
+
+  // ---- initial estimates, canonicalised like the reference's converters ------------------------------------------
+  s->state_doubles = (size_t)Np * 19 + (size_t)Npt * 3 + (size_t)Npl * 4 + (size_t)Nc * 10;
+  std::vector<double> h_state(s->state_doubles, 0.0);
+  {
+    State hs = make_state(h_state.data(), Np, Npt, Npl, Nc);
+    for (int i = 0; i < Np; ++i) {
+      double* q = &hs.pose_qt[7 * i];
+      std::memcpy(q, &p->pose_qt[7 * i], 7 * sizeof(double));
+      canon_quat(q);
+    }
+    if (Npt) std::memcpy(hs.point, p->point_xyz, (size_t)Npt * 3 * sizeof(double));
+    for (int i = 0; i < Npl; ++i) canon_plane_cv(&p->plane_coef[4 * i], &hs.plane[4 * i]);
+    for (int i = 0; i < Nc; ++i) {
+      double* c = &hs.cub[10 * i];
+      std::memcpy(c, &p->cuboid_qt[7 * i], 7 * sizeof(double));
+      canon_quat(c);
+      std::memcpy(c + 7, &p->cuboid_scale[3 * i], 3 * sizeof(double));
+    }
+  }
+
+  // ---- uploads ----------------------------------------------------------------------------------------------------------
+  bool ok = true;
+  std::vector<double> v_cam(p->pose_cam, p->pose_cam + (size_t)5 * Np);
+  std::vector<double> v_fs((size_t)3 * Nc, 0.0);
+  if (p->cuboid_fixedscale) std::copy(p->cuboid_fixedscale, p->cuboid_fixedscale + (size_t)3 * Nc, v_fs.begin());
+  std::vector<uint8_t> v_cf(Nc, (uint8_t)(PPO_CUBOID_FIX_ROLLPITCH | PPO_CUBOID_FIX_HEIGHT));
+  if (p->cuboid_flags) std::copy(p->cuboid_flags, p->cuboid_flags + Nc, v_cf.begin());
+  std::vector<double> v_pts;
+  if (p->n_ptcub && p->ptcub_offsets[p->n_ptcub] > 0) v_pts.assign(p->ptcub_points, p->ptcub_points + (size_t)3 * p->ptcub_offsets[p->n_ptcub]);
+  ok = ok && s->d_pose_cam.upload(v_cam, s->stream) && s->d_cub_fixedscale.upload(v_fs, s->stream) && s->d_ptcub_pts.upload(v_pts, s->stream);
+  ok = ok && s->d_pose_col.upload(pose_col, s->stream) && s->d_pose_free_id.upload(pose_free_id, s->stream) && s->d_cub_col.upload(cub_col, s->stream);
+  ok = ok && s->d_mo_off.upload(mo_off, s->stream) && s->d_st_off.upload(st_off, s->stream);
+  ok = ok && s->d_slot_off.upload(slot_off, s->stream) && s->d_slot_col.upload(slot_col, s->stream) && s->d_slot_lm.upload(slot_lm, s->stream);
+  ok = ok && s->d_point_fixed.upload(point_fixed, s->stream) && s->d_cub_flags.upload(v_cf, s->stream);
+  ok = ok && s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream) && s->d_pl.upload(s->h_pl, s->stream);
+  ok = ok && s->d_bbox.upload(s->h_bbox, s->stream) && s->d_corner.upload(s->h_corner, s->stream) && s->d_ptcub.upload(s->h_ptcub, s->stream);
+  ok = ok && s->d_init.upload(h_state, s->stream) && s->d_state[0].alloc(s->state_doubles) && s->d_state[1].alloc(s->state_doubles);
+  const size_t n_chi = (size_t)p->n_mono + p->n_stereo + p->n_plane_edges + 2 * (size_t)p->n_bbox + 2 * (size_t)p->n_corner + p->n_ptcub;
+  ok = ok && s->d_chi2_all.alloc(n_chi);
+  // arena: HB | HC | acc | D | bl | W
+  const size_t nHB = (size_t)nfree * 27, nHC = (size_t)Nc * 54, nD = (size_t)g.n_lm * 6, nbl = (size_t)g.n_lm * 3, nW = (size_t)g.n_slots * 18;
+  ok = ok && s->d_arena.alloc(nHB + nHC + ACC_N + nD + nbl + nW);
+  ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_yl.alloc(nbl) && s->d_Y.alloc(nW);
+  ok = ok && s->d_S.alloc((size_t)ncol * ncol) && s->d_bs.alloc(ncol) && s->d_xr.alloc(ncol) && s->d_info.alloc(1);
+  ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
+  if (!ok) return fail(PPO_BA_ERR_NOMEM);
+  if (hipHostMalloc((void**)&s->h_pinned, (ACC_N + 2) * sizeof(double)) != hipSuccess) return fail(PPO_BA_ERR_NOMEM);
+  (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
+
+  g.pose_cam = s->d_pose_cam.p; g.pose_col = s->d_pose_col.p; g.pose_free_id = s->d_pose_free_id.p; g.cub_col = s->d_cub_col.p;
+  g.point_fixed = s->d_point_fixed.p; g.cub_flags = s->d_cub_flags.p; g.cub_fixedscale = s->d_cub_fixedscale.p;
+  g.mo_off = s->d_mo_off.p; g.st_off = s->d_st_off.p;
+  g.mono = s->d_mono.p; g.stereo = s->d_stereo.p; g.pl = s->d_pl.p; g.bbox = s->d_bbox.p; g.corner = s->d_corner.p; g.ptcub = s->d_ptcub.p;
+  g.ptcub_pts = s->d_ptcub_pts.p;
+  g.slot_off = s->d_slot_off.p; g.slot_col = s->d_slot_col.p; g.slot_lm = s->d_slot_lm.p;
+  {
+    double* c = s->d_chi2_all.p;
+    g.mono_chi2 = c; c += p->n_mono;
+    g.stereo_chi2 = c; c += p->n_stereo;
+    g.pl_chi2 = c; c += p->n_plane_edges;
+    g.bbox_chi2 = c; c += p->n_bbox;
+    g.bbox_norm = c; c += p->n_bbox;
+    g.corner_chi2 = c; c += p->n_corner;
+    g.corner_norm = c; c += p->n_corner;
+    g.ptcub_chi2 = c;
+  }
+  {
+    double* a = s->d_arena.p;
+    g.HB = a; a += nHB;
+    g.HC = a; a += nHC;
+    g.acc = a; a += ACC_N;
+    s->zero_head = nHB + nHC + ACC_N;
+    g.D = a; s->zD_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 6; s->zD_n = (size_t)Npl * 6; a += nD;
+    g.bl = a; s->zbl_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 3; s->zbl_n = (size_t)Npl * 3; a += nbl;
+    g.W = a; s->zW_off = (size_t)(a - s->d_arena.p) + (size_t)slot_off[Npt] * 18; s->zW_n = (size_t)(g.n_slots - slot_off[Npt]) * 18;
+  }
+  g.Wpc_bbox = s->d_Wpc.p; g.Wpc_corner = s->d_Wpc.p + (size_t)p->n_bbox * 54;
+  g.Dinv = s->d_Dinv.p; g.yl = s->d_yl.p; g.Y = s->d_Y.p; g.S = s->d_S.p; g.bs = s->d_bs.p; g.xr = s->d_xr.p;
+  s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
+  s->st[1] = make_state(s->d_state[1].p, Np, Npt, Npl, Nc);
+
+  // LDS plan for k_lin_points: camera table + pose-block accumulators
+  s->lds_bytes = (int)(((size_t)Np * 16 + (size_t)nfree * 27) * sizeof(double));
+  s->use_lds = s->lds_bytes <= 150 * 1024;
+  if (s->use_lds && s->lds_bytes > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_lin_points<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
+  }
+  // derive the rotation matrices of the pristine state once
+  {
+    State is = make_state(s->d_init.p, Np, Npt, Npl, Nc);
+    if (Np) hipLaunchKernelGGL(k_pose_rt, dim3(nblk(Np, 256)), dim3(256), 0, s->stream, is, Np);
+  }
+  if (reset_device(s) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
+
+  // algorithmic bytes of one linearisation, SURVEY.md 8(d)
+  {
+    long n_vp = 0;
+    for (int e = 0; e < p->n_plane_edges; ++e) n_vp += (p->pl_kind && p->pl_kind[e]) ? 1 : 0;
+    int n_fixed = 0;
+    for (int i = 0; i < Np; ++i) n_fixed += (pose_col[i] < 0);
+    s->lin_bytes = 176L * p->n_mono + 184L * p->n_stereo + 208L * (p->n_plane_edges - n_vp) + 200L * n_vp + 576L * p->n_bbox + 768L * p->n_corner +
+                   96L * Npt + 104L * Npl + 512L * Nc + 272L * nfree + 56L * n_fixed;
+  }
+  *out = s;
+  return PPO_BA_OK;
+}
+
+int ppo_ba_reset(ppo_ba_handle s) {
+  if (!s) return PPO_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  return reset_device(s);
+}
+
+// Optimizer.cc:2723-2838
+int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stats) {
+  if (!s) return PPO_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  const int n_red = s->stats.n_reduced;
+  std::memset(&s->stats, 0, sizeof(s->stats));
+  s->stats.n_reduced = n_red;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  if (stop_requested(stop)) return PPO_BA_ABORTED;
+  int rc = PPO_BA_OK;
+  s->stats.n_active_edges_pass1 = s->g.n_mono + s->g.n_stereo + s->g.n_pl + s->g.n_bbox + s->g.n_corner + s->g.n_ptcub + s->n_cubpl;
+  RC_TRY(optimize(s, 0, s->opt.iters_pass1, stop));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  const auto t1 = std::chrono::steady_clock::now();
+  auto t2 = t1;
+  if (stop_requested(stop)) rc = PPO_BA_ABORTED;
+  if (rc == PPO_BA_OK && s->opt.iters_pass2 > 0) {
+    const Graph& g = s->g;
+    const State& st = s->st[s->cur];
+    if (g.pt_last > g.pt_first)
+      hipLaunchKernelGGL(k_classify_points, dim3(std::min(nblk(g.pt_last - g.pt_first, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st,
+                         s->opt.chi2_mono, s->opt.chi2_stereo);
+    const int nsm = std::max({g.n_pl, g.n_bbox, g.n_corner});
+    if (nsm > 0)
+      hipLaunchKernelGGL(k_classify_small, dim3(nblk(nsm, 256)), dim3(256), 0, s->stream, g, s->opt.chi2_plane, s->opt.chi2_plane_vp,
+                         s->opt.th_bbox_norm, s->opt.th_corner_norm);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    t2 = std::chrono::steady_clock::now();
+    RC_TRY(optimize(s, 1, s->opt.iters_pass2, stop));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (stop_requested(stop)) rc = PPO_BA_ABORTED;
+  }
+  const auto t3 = std::chrono::steady_clock::now();
+  s->stats.wall_ms_total = ms(t0, t3);
+  s->stats.wall_ms_pass1 = ms(t0, t1);
+  s->stats.wall_ms_classify = ms(t1, t2);
+  s->stats.wall_ms_pass2 = ms(t2, t3);
+  s->ran = true;
+  if (stats) *stats = s->stats;
+  return rc;
+}
+
+int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
+  if (!s || !r) return PPO_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  const Graph& g = s->g;
+  const int Np = g.n_poses, Npt = g.n_points, Npl = g.n_planes, Nc = g.n_cuboids;
+  std::vector<double> hs(s->state_doubles);
+  if (s->state_doubles) HIP_TRY(hipMemcpy(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double), hipMemcpyDeviceToHost));
+  State h = make_state(hs.data(), Np, Npt, Npl, Nc);
+  if (s->comm.active()) {
+    // landmarks live on their owner: sum the (disjoint) owned ranges over ranks through a zero-padded device buffer
+    std::vector<double> tmp((size_t)Npt * 3 + (size_t)Npl * 4, 0.0);
+    for (int i = g.pt_first; i < g.pt_last; ++i) for (int a = 0; a < 3; ++a) tmp[(size_t)3 * i + a] = h.point[3 * i + a];
+    for (int i = g.plane_first; i < g.plane_last; ++i) for (int a = 0; a < 4; ++a) tmp[(size_t)3 * Npt + 4 * i + a] = h.plane[4 * i + a];
+    DevBuf<double> d;
+    if (!d.alloc(tmp.size())) return PPO_BA_ERR_NOMEM;
+    HIP_TRY(hipMemcpyAsync(d.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if (s->comm.sum(d.p, tmp.size(), s->stream)) return PPO_BA_ERR_COMM;
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    d.release();
+    std::copy(tmp.begin(), tmp.begin() + (size_t)3 * Npt, h.point);
+    std::copy(tmp.begin() + (size_t)3 * Npt, tmp.end(), h.plane);
+  }
+  if (r->pose_qt) for (int i = 0; i < Np; ++i) std::memcpy(&r->pose_qt[7 * i], &h.pose_qt[7 * i], 7 * sizeof(double));
+  if (r->point_xyz && Npt) std::memcpy(r->point_xyz, h.point, (size_t)Npt * 3 * sizeof(double));
+  if (r->plane_coef && Npl) std::memcpy(r->plane_coef, h.plane, (size_t)Npl * 4 * sizeof(double));
+  for (int i = 0; i < Nc; ++i) {
+    if (r->cuboid_qt) std::memcpy(&r->cuboid_qt[7 * i], &h.cub[10 * i], 7 * sizeof(double));
+    if (r->cuboid_scale) std::memcpy(&r->cuboid_scale[3 * i], &h.cub[10 * i + 7], 3 * sizeof(double));
+  }
+  // per-edge outputs
+  std::vector<double> chi(s->d_chi2_all.n);
+  if (chi.size()) HIP_TRY(hipMemcpy(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<MonoEdge> hm(g.n_mono);
+  std::vector<StereoEdge> hst(g.n_stereo);
+  std::vector<PlaneEdge> hp(g.n_pl);
+  std::vector<CubEdge> hb(g.n_bbox), hc(g.n_corner);
+  if (g.n_mono) HIP_TRY(hipMemcpy(hm.data(), s->d_mono.p, hm.size() * sizeof(MonoEdge), hipMemcpyDeviceToHost));
+  if (g.n_stereo) HIP_TRY(hipMemcpy(hst.data(), s->d_stereo.p, hst.size() * sizeof(StereoEdge), hipMemcpyDeviceToHost));
+  if (g.n_pl) HIP_TRY(hipMemcpy(hp.data(), s->d_pl.p, hp.size() * sizeof(PlaneEdge), hipMemcpyDeviceToHost));
+  if (g.n_bbox) HIP_TRY(hipMemcpy(hb.data(), s->d_bbox.p, hb.size() * sizeof(CubEdge), hipMemcpyDeviceToHost));
+  if (g.n_corner) HIP_TRY(hipMemcpy(hc.data(), s->d_corner.p, hc.size() * sizeof(CubEdge), hipMemcpyDeviceToHost));
+  const double* c = chi.data();
+  const double* c_mono = c; c += g.n_mono;
+  const double* c_st = c; c += g.n_stereo;
+  const double* c_pl = c; c += g.n_pl;
+  const double* c_bb = c; c += g.n_bbox;
+  const double* n_bb = c; c += g.n_bbox;
+  const double* c_co = c; c += g.n_corner;
+  const double* n_co = c; c += g.n_corner;
+  const double* c_pc = c;
+  // isDepthPositive from the final estimates (types_six_dof_expmap.h:181-185)
+  auto depth = [&](int pose, int pt) {
+    const double* q = &h.pose_qt[7 * pose];
+    const Pose T{Quat{q[0], q[1], q[2], q[3]}, Vec3{q[4], q[5], q[6]}};
+    return apply(T, v3(h.point[3 * pt], h.point[3 * pt + 1], h.point[3 * pt + 2])).z > 0.0;
+  };
+  // sorted position -> point id for the reprojection edges
+  std::vector<int32_t> mo_pt(g.n_mono), st_pt(g.n_stereo);
+  {
+    std::vector<int32_t> off(Npt + 1);
+    if (Npt + 1 > 0 && g.n_mono) {
+      HIP_TRY(hipMemcpy(off.data(), s->d_mo_off.p, off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (int pnt = 0; pnt < Npt; ++pnt) for (int k = off[pnt]; k < off[pnt + 1]; ++k) mo_pt[k] = pnt;
+    }
+    if (Npt + 1 > 0 && g.n_stereo) {
+      HIP_TRY(hipMemcpy(off.data(), s->d_st_off.p, off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (int pnt = 0; pnt < Npt; ++pnt) for (int k = off[pnt]; k < off[pnt + 1]; ++k) st_pt[k] = pnt;
+    }
+  }
+  for (int k = 0; k < g.n_mono; ++k) {
+    const int e = s->mono_perm[k];
+    if (r->mono_chi2) r->mono_chi2[e] = c_mono[k];
+    if (r->mono_level) r->mono_level[e] = (hm[k].flags & F_ACTIVE) ? 0 : 1;
+    if (r->mono_depth_positive) r->mono_depth_positive[e] = depth(hm[k].pose, mo_pt[k]);
+  }
+  for (int k = 0; k < g.n_stereo; ++k) {
+    const int e = s->stereo_perm[k];
+    if (r->stereo_chi2) r->stereo_chi2[e] = c_st[k];
+    if (r->stereo_level) r->stereo_level[e] = (hst[k].flags & F_ACTIVE) ? 0 : 1;
+    if (r->stereo_depth_positive) r->stereo_depth_positive[e] = depth(hst[k].pose, st_pt[k]);
+  }
+  for (int e = 0; e < g.n_pl; ++e) {
+    if (r->pl_chi2) r->pl_chi2[e] = c_pl[e];
+    if (r->pl_level) r->pl_level[e] = (hp[e].flags & F_ACTIVE) ? 0 : 1;
+  }
+  for (int e = 0; e < g.n_bbox; ++e) {
+    if (r->bbox_chi2) r->bbox_chi2[e] = c_bb[e];
+    if (r->bbox_errnorm) r->bbox_errnorm[e] = n_bb[e];
+    if (r->bbox_level) r->bbox_level[e] = (hb[e].flags & F_ACTIVE) ? 0 : 1;
+  }
+  for (int e = 0; e < g.n_corner; ++e) {
+    if (r->corner_chi2) r->corner_chi2[e] = c_co[e];
+    if (r->corner_errnorm) r->corner_errnorm[e] = n_co[e];
+    if (r->corner_level) r->corner_level[e] = (hc[e].flags & F_ACTIVE) ? 0 : 1;
+  }
+  if (r->ptcub_chi2) for (int e = 0; e < g.n_ptcub; ++e) r->ptcub_chi2[e] = c_pc[e];
+  if (r->cubpl_chi2) for (int e = 0; e < s->n_cubpl; ++e) r->cubpl_chi2[e] = s->cubpl_chi2[e];
+  return PPO_BA_OK;
+}
+
+void ppo_ba_destroy(ppo_ba_handle s) {
+  if (!s) return;
+  free_all(s);
+  delete s;
+}
+
+// ---- measurement / test hooks -------------------------------------------------------------------------------------------
+int ppo_ba_linearize(ppo_ba_handle s, double* robust_chi2) {
+  if (!s) return PPO_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  RC_TRY(launch_linearize(s));
+  if (s->comm.active() && s->comm.sum(s->g.HB, (size_t)s->g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
+  RC_TRY(fetch_acc(s, false));
+  if (robust_chi2) *robust_chi2 = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+  return PPO_BA_OK;
+}
+
+int ppo_ba_time_linearize(ppo_ba_handle s, int reps, double* ms_out) {
+  if (!s || reps <= 0 || !ms_out) return PPO_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  RC_TRY(launch_linearize(s));  // warm
+  HIP_TRY(hipEventRecord(e0, s->stream));
+  for (int i = 0; i < reps; ++i) RC_TRY(launch_linearize(s));
+  HIP_TRY(hipEventRecord(e1, s->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = (double)ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return PPO_BA_OK;
+}
+
+int ppo_ba_time_factor(ppo_ba_handle s, int reps, double* ms_out) {
+  if (!s || reps <= 0 || !ms_out) return PPO_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->lambda <= 0) {  // no run yet: linearise and take lambda_0
+    RC_TRY(launch_linearize(s));
+    const Graph& g = s->g;
+    const long nd = std::max<long>({(long)g.n_pose_free * 6, (long)g.n_cuboids * 9, 3L * g.n_lm, 1L});
+    hipLaunchKernelGGL(k_maxdiag, dim3(nblk(nd, 256)), dim3(256), 0, s->stream, g);
+    RC_TRY(fetch_acc(s, false));
+    s->lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float total = 0;
+  for (int i = 0; i < reps + 1; ++i) {
+    RC_TRY(launch_reduce(s, s->lambda));  // the factorisation overwrites S: rebuild it outside the timed span
+    HIP_TRY(hipEventRecord(e0, s->stream));
+    RC_TRY(launch_solve(s));
+    HIP_TRY(hipEventRecord(e1, s->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (i > 0) total += ms;
+  }
+  *ms_out = (double)total / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return PPO_BA_OK;
+}
+
+// reduced system of the given lambda at the CURRENT state (re-linearises); S is returned as a full symmetric matrix
+int ppo_ba_debug_reduced(ppo_ba_handle s, double* S, double* b, double* x, int32_t* n_out) {
+  if (!s) return PPO_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  const int n = s->g.n_red;
+  if (n_out) *n_out = n;
+  if (!S && !b && !x) return PPO_BA_OK;
+  const double lambda = s->lambda > 0 ? s->lambda : 0.0;
+  RC_TRY(launch_linearize(s));
+  if (s->comm.active() && s->comm.sum(s->g.HB, (size_t)s->g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
+  RC_TRY(launch_reduce(s, lambda));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (S) {
+    HIP_TRY(hipMemcpy(S, s->d_S.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int c = 0; c < n; ++c) for (int r = c + 1; r < n; ++r) S[(size_t)r * n + c] = S[(size_t)c * n + r];
+  }
+  if (b) HIP_TRY(hipMemcpy(b, s->d_bs.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  if (x) {
+    RC_TRY(launch_solve(s));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(x, s->d_xr.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return PPO_BA_OK;
+}
+
+int ppo_ba_debug_set_lambda(ppo_ba_handle s, double lambda) {
+  if (!s) return PPO_BA_ERR_ARG;
+  s->lambda = lambda;
+  return PPO_BA_OK;
+}
+
+int64_t ppo_ba_linearize_bytes(ppo_ba_handle s) { return s ? s->lin_bytes : -1; }
+
+int ppo_ba_comm_unique_id(uint8_t id[128]) {
+  Comm c;
+  return c.unique_id(id) == 0 ? PPO_BA_OK : PPO_BA_ERR_COMM;
+}
+
+}  // extern "C"

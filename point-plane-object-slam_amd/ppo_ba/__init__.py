@@ -1,0 +1,2 @@
+"""Host-side Python plumbing for libppo_ba.so (tests and bench.py only; the product is the HIP library)."""
+from . import binding, synth  # noqa: F401

@@ -1,0 +1,111 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol include/ppo_ba.h declares,
+the host-only entry points work, and the product path fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ppo_ba import binding as B
+from ppo_ba import synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(REPO, "include", "ppo_ba.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ppo_ba_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    lib = B.load_library()
+    names = declared_functions()
+    assert "ppo_ba_create" in names and "ppo_ba_run" in names and "ppo_ba_read" in names and len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libppo_ba.so does not export " + n
+
+
+def test_version_and_strerror():
+    lib = B.load_library()
+    assert lib.ppo_ba_version() == 1
+    assert lib.ppo_ba_strerror(0) == b"ok"
+    assert b"HIP" in lib.ppo_ba_strerror(-4)
+
+
+def test_default_options_match_reference_constants():
+    lib = B.load_library()
+    o = B.COptions()
+    lib.ppo_ba_default_options(C.byref(o))
+    assert (o.iters_pass1, o.iters_pass2, o.lm_max_trials) == (5, 10, 10)  # Optimizer.cc:2728,2837; levenberg.cpp:51
+    assert o.lm_tau == 1e-5 and o.numeric_delta == 1e-9
+    assert (o.chi2_mono, o.chi2_stereo, o.chi2_plane, o.chi2_plane_vp) == (5.991, 7.815, 500.0, 200.0)
+    assert (o.th_bbox_norm, o.th_corner_norm) == (80.0, 10.0)
+    p = B.default_options()
+    for k, _ in B.COptions._fields_:
+        if k not in ("comm_id",):
+            assert getattr(o, k) == getattr(p, k), k
+
+
+def test_struct_sizes_match_header():
+    # sizes derived from the C declarations: guards against silent layout drift between header and ctypes mirror
+    assert C.sizeof(B.CIterStat) == 4 * 4 + 3 * 8 + 2 * 4
+    assert C.sizeof(B.CStats) == 8 + 64 * C.sizeof(B.CIterStat) + 4 * 4 + 9 * 8
+    assert C.sizeof(B.CResult) == 21 * 8
+
+
+def test_partition_is_contiguous_and_balanced():
+    lib = B.load_library()
+    P = synth.make_problem("small", seed=3)
+    ps = P.as_struct()
+    for world in (1, 2, 3, 8):
+        fp = np.zeros(world + 1, np.int32)
+        fl = np.zeros(world + 1, np.int32)
+        rc = lib.ppo_ba_partition(C.byref(ps), world, fp.ctypes.data_as(B.c_ip), fl.ctypes.data_as(B.c_ip))
+        assert rc == 0
+        assert fp[0] == 0 and fp[-1] == ps.n_points and np.all(np.diff(fp) >= 0)
+        assert fl[0] == 0 and fl[-1] == ps.n_planes and np.all(np.diff(fl) >= 0)
+        counts = np.bincount(P["mono_point"], minlength=ps.n_points)
+        per_rank = [counts[fp[r]:fp[r + 1]].sum() for r in range(world)]
+        assert max(per_rank) - min(per_rank) <= 0.2 * counts.sum() / world + 16
+
+
+def test_bad_arguments_are_rejected_before_touching_the_device():
+    lib = B.load_library()
+    P = synth.make_problem("tiny")
+    ps = P.as_struct()
+    h = C.c_void_p()
+    o = B.default_options()
+    assert lib.ppo_ba_create(None, C.byref(o), C.byref(h)) == -1
+    bad = B.default_options(abi_version=99)
+    assert lib.ppo_ba_create(C.byref(ps), C.byref(bad), C.byref(h)) == -1
+    P2 = synth.make_problem("tiny")
+    a = P2["mono_pose"].copy()
+    a[0] = 10_000
+    P2.set("mono_pose", a)
+    ps2 = P2.as_struct()
+    assert lib.ppo_ba_create(C.byref(ps2), C.byref(o), C.byref(h)) == -1
+    P3 = synth.make_problem("tiny")
+    x = P3["point_xyz"].copy()
+    x[5] = np.nan
+    P3.set("point_xyz", x)
+    ps3 = P3.as_struct()
+    assert lib.ppo_ba_create(C.byref(ps3), C.byref(o), C.byref(h)) == -2
+    lib.ppo_ba_destroy(None)  # NULL-safe
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must refuse to run (PPO_BA_ERR_HIP); with one it must succeed."""
+    import torch
+    lib = B.load_library()
+    P = synth.make_problem("tiny")
+    ps = P.as_struct()
+    h = C.c_void_p()
+    o = B.default_options()
+    rc = lib.ppo_ba_create(C.byref(ps), C.byref(o), C.byref(h))
+    if torch.cuda.is_available():
+        assert rc == 0
+        lib.ppo_ba_destroy(h)
+    else:
+        assert rc == -4 and not h.value
