@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/sec of the local-BA hot path on the BASELINE.json graph.
+
+A *step* is one complete Optimizer::LocalBACameraPlaneCuboids-style call on the resident graph: reset of the
+device estimates (device-to-device), 5 LM iterations, on-device outlier classification, 10 more LM iterations
+(src/Optimizer.cc:2727-2838).  `value` = LM iterations executed / wall time, `ms_per_step` = wall ms per call;
+the per-iteration time is in config.ms_per_lm_iter.  The graph is uploaded once before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4] [--no-cpu-baseline]
+For N > 1 launch under torch.distributed.run (one rank per GPU); the landmark range is sharded over the ranks
+and the reduced pose system is all-reduced with RCCL once per solve attempt (strong scaling of ONE graph).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "point-plane-object-slam_amd"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(P, B, seconds_budget=25.0):
+    """The oracle (a port of the reference algorithm, 1 thread) on the same graph, bounded to a few LM iterations."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_py  # test infrastructure: only this leg touches it
+    be = oracle_py.backend()
+    # calibrate with one LM iteration, then run as many as fit the budget (<= 5 so that pass 1 semantics hold)
+    s = be.create(P, B.default_options(iters_pass1=1, iters_pass2=0))
+    t0 = time.perf_counter()
+    st = s.run()
+    t1 = time.perf_counter() - t0
+    n = int(max(1, min(5, seconds_budget // max(t1, 1e-3))))
+    s.close()
+    s = be.create(P, B.default_options(iters_pass1=n, iters_pass2=0))
+    t0 = time.perf_counter()
+    st = s.run()
+    dt = time.perf_counter() - t0
+    s.close()
+    it = max(1, st["n_iters"])
+    return dict(value=it / dt, unit="LM iters/s", cores=1, kind="port",
+                sample="oracle/libppo_oracle.so, %d LM iterations (%d solve attempts) of pass 1 on the same graph, %.1f s" % (it, st["n_trials"], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg4")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--solver", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lin-reps", type=int, default=200)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from ppo_ba import binding as B
+    from ppo_ba import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: libppo_ba has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lib = B.load_library()
+    P = synth.make_problem(a.config, seed=a.seed)
+    sizes = P.sizes()
+    opt = B.default_options(device_id=local_rank, rank=rank, world_size=world, solver=a.solver)
+    if world > 1:
+        ident = np.zeros(128, np.uint8)
+        if rank == 0:
+            assert lib.ppo_ba_comm_unique_id(ident.ctypes.data_as(B.c_bp)) == 0
+        t = torch.from_numpy(ident).cuda()
+        dist.broadcast(t, 0)
+        ident = t.cpu().numpy()
+        for i in range(128):
+            opt.comm_id[i] = int(ident[i])
+    solver = B.hip_backend().create(P, opt)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        solver.reset()
+        return solver.run()
+
+    for _ in range(a.warmup):
+        st = step()
+    barrier()
+    t0 = time.perf_counter()
+    iters = trials = 0
+    for _ in range(a.steps):
+        st = step()
+        iters += st["n_iters"]
+        trials += st["n_trials"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # dominant-kernel roofline: the Jacobian/assembly kernel group, timed with HIP events on the library's stream
+    lin_ms = C.c_double()
+    solver.reset()
+    assert lib.ppo_ba_time_linearize(solver.h, a.lin_reps, C.byref(lin_ms)) == 0
+    lin_bytes = int(lib.ppo_ba_linearize_bytes(solver.h))
+    fac_ms = C.c_double()
+    assert lib.ppo_ba_time_factor(solver.h, 10, C.byref(fac_ms)) == 0
+    achieved = lin_bytes / (lin_ms.value * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "LM iters/sec on 200KF/50k-pt/200-plane/50-cuboid local BA",
+            "value": iters / dt, "unit": "LM iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "%s seed %d: %d KF / %d points / %d planes / %d cuboids; %d mono + %d plane + %d bbox + %d point-cuboid + %d cuboid-plane edges; "
+                            "reduced system %d; step = one 5+10 LM call (reset + run)" % (
+                                a.config, a.seed, sizes["n_poses"], sizes["n_points"], sizes["n_planes"], sizes["n_cuboids"], sizes["n_mono"],
+                                sizes["n_plane_edges"], sizes["n_bbox"], sizes["n_ptcub"], sizes["n_cubpl"], st["n_reduced"]),
+                "lm_iters_per_step": iters / a.steps, "solve_attempts_per_step": trials / a.steps,
+                "ms_per_lm_iter": 1e3 * dt / max(iters, 1), "solver_backend": int(a.solver),
+                "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
+            },
+            "roofline": {"bound": "hbm", "kernel": "k_lin_points (+ plane/cuboid linearise group)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": lin_bytes, "launch_ms": lin_ms.value},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(P, B)
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

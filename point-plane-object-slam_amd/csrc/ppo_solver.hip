@@ -91,6 +91,10 @@ struct ppo_ba_solver {
   DevBuf<PlaneEdge> d_pl;
   DevBuf<CubEdge> d_bbox, d_corner;
   DevBuf<PtCubEdge> d_ptcub;
+  DevBuf<MonoEdge> d_mono0;      // pristine copies (flags at level 0, kernels on) for reset()
+  DevBuf<StereoEdge> d_stereo0;
+  DevBuf<PlaneEdge> d_pl0;
+  DevBuf<CubEdge> d_bbox0, d_corner0;
   DevBuf<double> d_chi2_all;  // per-edge chi2 / norms
   DevBuf<double> d_state[2];  // two copies of all estimates (current / trial)
   DevBuf<double> d_init;      // pristine estimates for reset()
@@ -201,6 +205,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_pose_col.release(); s->d_pose_free_id.release(); s->d_cub_col.release(); s->d_mo_off.release(); s->d_st_off.release();
   s->d_slot_off.release(); s->d_slot_col.release(); s->d_slot_lm.release(); s->d_point_fixed.release(); s->d_cub_flags.release();
   s->d_mono.release(); s->d_stereo.release(); s->d_pl.release(); s->d_bbox.release(); s->d_corner.release(); s->d_ptcub.release();
+  s->d_mono0.release(); s->d_stereo0.release(); s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
   s->d_Wpc.release(); s->d_Dinv.release(); s->d_yl.release(); s->d_Y.release();
   s->d_S.release(); s->d_bs.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
@@ -225,14 +230,15 @@ inline int nblk(long n, int b) { return (int)std::max<long>(1, (n + b - 1) / b);
 
 int reset_device(ppo_ba_solver* s) {
   // edge flags back to "level 0, kernel on", estimates back to the inputs
+  // (device-to-device from the pristine copies made at create: a reset never crosses PCIe)
   auto up = [&](void* dst, const void* src, size_t bytes) {
-    return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream) == hipSuccess;
+    return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
   };
-  if (!up(s->d_mono.p, s->h_mono.data(), s->h_mono.size() * sizeof(MonoEdge)) ||
-      !up(s->d_stereo.p, s->h_stereo.data(), s->h_stereo.size() * sizeof(StereoEdge)) ||
-      !up(s->d_pl.p, s->h_pl.data(), s->h_pl.size() * sizeof(PlaneEdge)) ||
-      !up(s->d_bbox.p, s->h_bbox.data(), s->h_bbox.size() * sizeof(CubEdge)) ||
-      !up(s->d_corner.p, s->h_corner.data(), s->h_corner.size() * sizeof(CubEdge)))
+  if (!up(s->d_mono.p, s->d_mono0.p, s->d_mono.n * sizeof(MonoEdge)) ||
+      !up(s->d_stereo.p, s->d_stereo0.p, s->d_stereo.n * sizeof(StereoEdge)) ||
+      !up(s->d_pl.p, s->d_pl0.p, s->d_pl.n * sizeof(PlaneEdge)) ||
+      !up(s->d_bbox.p, s->d_bbox0.p, s->d_bbox.n * sizeof(CubEdge)) ||
+      !up(s->d_corner.p, s->d_corner0.p, s->d_corner.n * sizeof(CubEdge)))
     return PPO_BA_ERR_HIP;
   if (s->state_doubles) {
     HIP_TRY(hipMemcpyAsync(s->d_state[0].p, s->d_init.p, s->state_doubles * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -666,6 +672,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_point_fixed.upload(point_fixed, s->stream) && s->d_cub_flags.upload(v_cf, s->stream);
   ok = ok && s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream) && s->d_pl.upload(s->h_pl, s->stream);
   ok = ok && s->d_bbox.upload(s->h_bbox, s->stream) && s->d_corner.upload(s->h_corner, s->stream) && s->d_ptcub.upload(s->h_ptcub, s->stream);
+  ok = ok && s->d_mono0.upload(s->h_mono, s->stream) && s->d_stereo0.upload(s->h_stereo, s->stream) && s->d_pl0.upload(s->h_pl, s->stream);
+  ok = ok && s->d_bbox0.upload(s->h_bbox, s->stream) && s->d_corner0.upload(s->h_corner, s->stream);
   ok = ok && s->d_init.upload(h_state, s->stream) && s->d_state[0].alloc(s->state_doubles) && s->d_state[1].alloc(s->state_doubles);
   const size_t n_chi = (size_t)p->n_mono + p->n_stereo + p->n_plane_edges + 2 * (size_t)p->n_bbox + 2 * (size_t)p->n_corner + p->n_ptcub;
   ok = ok && s->d_chi2_all.alloc(n_chi);
