@@ -7,7 +7,7 @@
 //   k_lin_numeric<M>  16-lane group per plane / bbox / corner / point-cuboid edge, one lane per Jacobian column,
 //                     central differences through the vertex box-plus exactly like g2o (delta = 1e-9).
 //   k_assemble        reduced system S (lower) <- Hpp + lambda I, Hcc + lambda I, pose-cuboid blocks; bs <- b.
-//   k_schur_prep      thread per landmark: (D + lambda I)^-1, y = Dinv b_l, Y = W Dinv, bs -= W y.
+//   k_schur_prep      thread per landmark: 3x3 Cholesky of D + lambda I -> Linv, Dinv, u = Linv b_l.   k_schur_z: Z = W Linv'.
 //   k_schur_accum     8-lane group per (landmark, pose) slot: S(pj, pi) -= W_j Y_i' with row-contiguous atomics.
 //   [dense Cholesky of S: rocSOLVER or ppo_chol.hpp]
 //   k_update_reduced  poses / cuboids: trial = cur [+] x.      k_backsub: x_l = Dinv (b_l - W' x_p), trial landmarks.
@@ -25,12 +25,22 @@ struct MonoEdge {  // 48 B
   double u, v, info, huber;
   int32_t pose, slot;
   uint32_t flags;  // bit0 active (level 0), bit1 robust kernel on
-  int32_t pad;
+  int32_t point;
 };
 struct StereoEdge {  // 64 B
   double u, v, ur, info, huber;
   int32_t pose, slot;
   uint32_t flags;
+  int32_t point;
+  int32_t pad[2];
+};
+struct MonoEdgeP {  // 48 B, pose-major copy of the static part (k_lin_poses streams it)
+  double u, v, info, huber;
+  int32_t point, eid, slot, pad;  // eid = position in the landmark-major arrays (flags, chi2)
+};
+struct StereoEdgeP {  // 64 B
+  double u, v, ur, info, huber;
+  int32_t point, eid, slot;
   int32_t pad[3];
 };
 struct PlaneEdge {  // 88 B
@@ -64,6 +74,7 @@ struct State {       // one copy of all estimates
 
 struct Graph {
   int n_poses, n_points, n_planes, n_cuboids, n_pose_free, n_red, n_lm, n_slots;
+  int ld;  // leading dimension of S (n_red rounded up to the Cholesky panel width; pad rows/cols are identity)
   int n_mono, n_stereo, n_pl, n_bbox, n_corner, n_ptcub;
   const double* pose_cam;      // [Np][5]
   const int32_t* pose_col;     // [Np] column of the pose block in the reduced system, -1 fixed / unused
@@ -81,9 +92,15 @@ struct Graph {
   CubEdge* corner;
   PtCubEdge* ptcub;
   const double* ptcub_pts;
-  const int32_t* slot_off;     // [n_lm+1] slots of a landmark (landmark = point id, or n_points + plane id)
+  // (landmark, pose) slots, numbered POSE-MAJOR: point slots sorted by (pose, point), then plane slots by (pose, plane)
   const int32_t* slot_col;     // [n_slots] reduced column of the slot's pose
-  const int32_t* slot_lm;      // [n_slots]
+  const int32_t* slot_lm;      // [n_slots] landmark (point id, or n_points + plane id)
+  const int32_t* pl_slot_off;  // [n_planes+1] slots of a plane ...
+  const int32_t* pl_slots;     // ... listed here
+  uint32_t* mono_flags;        // [n_mono]   bit0 active (level 0), bit1 robust kernel on -- the single source of truth
+  uint32_t* stereo_flags;      // [n_stereo]
+  const MonoEdgeP* monoP;      // pose-major static copies
+  const StereoEdgeP* stereoP;
   // per-edge outputs (stored-_error semantics)
   double* mono_chi2;  double* stereo_chi2;  double* pl_chi2;
   double* bbox_chi2;  double* bbox_norm;    double* corner_chi2;  double* corner_norm;  double* ptcub_chi2;
@@ -95,9 +112,10 @@ struct Graph {
   double* W;     // [n_slots][18] pose rows x landmark cols, row-major
   double* Wpc_bbox;    // [n_bbox][54] pose rows x cuboid cols
   double* Wpc_corner;  // [n_corner][54]
-  double* Dinv;  // [n_lm][6]
-  double* yl;    // [n_lm][3]
-  double* Y;     // [n_slots][18]
+  double* Dinv;  // [n_lm][6] (D + lambda I)^-1, packed upper
+  double* C;     // [n_lm][6] inverse Cholesky factor of D + lambda I (i00 i10 i11 i20 i21 i22): Dinv = Linv' Linv
+  double* ul;    // [n_lm][3] Linv b_l
+  double* Z;     // [n_slots][18] W Linv'  (so that W Dinv W' = Z Z')
   double* S;     // [n_red][n_red] column-major, lower triangle
   double* bs;    // [n_red]
   double* xr;    // [n_red]
@@ -142,24 +160,71 @@ __device__ __forceinline__ Cub load_cub(const double* c) {
 }
 __device__ __forceinline__ PlaneC load_plane(const double* p) { return PlaneC{p[0], p[1], p[2], p[3]}; }
 
+// Quadratic-form pieces of one reprojection edge with a compile-time residual dimension.
+//   landmark side: D += Jl' w Jl (packed upper), bl += Jl' g          (g = -rho1 Omega e)
+//   coupling:      W = Jp' w Jl (6x3)
+//   pose side:     A += Jp' w Jp (packed lower, 21), bp += Jp' g (6)
+template <int DIM>
+__device__ __forceinline__ void acc_landmark(const double* Jl, double w, const double* gr, double* D, double* bl) {
+#pragma unroll
+  for (int r = 0; r < DIM; ++r) {
+    const double* j = &Jl[3 * r];
+    D[0] += j[0] * w * j[0]; D[1] += j[0] * w * j[1]; D[2] += j[0] * w * j[2];
+    D[3] += j[1] * w * j[1]; D[4] += j[1] * w * j[2]; D[5] += j[2] * w * j[2];
+    bl[0] += j[0] * gr[r]; bl[1] += j[1] * gr[r]; bl[2] += j[2] * gr[r];
+  }
+}
+template <int DIM>
+__device__ __forceinline__ void store_W(const double* Jp, const double* Jl, double w, double* Wd) {
+  double o[18];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double h = 0;
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) h += Jp[6 * r + a] * w * Jl[3 * r + c];
+      o[a * 3 + c] = h;
+    }
+  double2* d2 = reinterpret_cast<double2*>(Wd);  // W records are 144 B = 9 x 16 B, 16-byte aligned
+#pragma unroll
+  for (int q = 0; q < 9; ++q) d2[q] = make_double2(o[2 * q], o[2 * q + 1]);
+}
+template <int DIM>
+__device__ __forceinline__ void acc_pose(const double* Jp, double w, const double* gr, double* A) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) A[21 + a] += Jp[6 * r + a] * gr[r];
+#pragma unroll
+    for (int c = 0; c <= a; ++c) {
+      double h = 0;
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) h += Jp[6 * r + a] * w * Jp[6 * r + c];
+      A[a * (a + 1) / 2 + c] += h;
+    }
+  }
+}
+__device__ __forceinline__ void zero_W(double* Wd) {
+  double2* d2 = reinterpret_cast<double2*>(Wd);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) d2[q] = make_double2(0.0, 0.0);
+}
+
 // ======================================================================================================
-// k_lin_points: reprojection edges.  LDS layout: [n_poses][16] camera table (R, t, fx fy cx cy) followed by
-// [n_pose_free][27] pose-block accumulators.  USE_LDS=false falls back to global atomics and global camera reads
-// when the window has too many keyframes for 160 KB.
+// k_lin_points: landmark side of the reprojection edges, one thread per point.  The camera table (R, t, intrinsics of
+// every keyframe: 128 B each) is staged in LDS once per workgroup (USE_LDS); D_l / b_l / W are written exactly once,
+// no atomics.  The pose blocks are accumulated by k_lin_poses below.
 // ======================================================================================================
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
   extern __shared__ double smem[];
   __shared__ double s_red[4];
-  double* s_cam = smem;
-  const int acc0 = g.n_poses * 16;
-  double* s_acc = smem + acc0;
   if (USE_LDS) {
     for (int i = threadIdx.x; i < g.n_poses * 16; i += blockDim.x) {
       const int p = i >> 4, k = i & 15;
-      s_cam[i] = k < 12 ? st.pose_rt[p * 12 + k] : g.pose_cam[p * 5 + (k - 12)];
+      smem[i] = k < 12 ? st.pose_rt[p * 12 + k] : g.pose_cam[p * 5 + (k - 12)];
     }
-    for (int i = threadIdx.x; i < g.n_pose_free * 27; i += blockDim.x) s_acc[i] = 0.0;
     __syncthreads();
   }
   double chi_local = 0.0;
@@ -167,91 +232,161 @@ __global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
     const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
     const bool lm_free = !g.point_fixed[p];
     double D[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    const int m0 = g.mo_off[p], m1 = g.mo_off[p + 1], s0 = g.st_off[p], s1 = g.st_off[p + 1];
-    for (int ei = m0; ei < m1 + (s1 - s0); ++ei) {
-      const bool is_st = ei >= m1;
-      const int e = is_st ? s0 + (ei - m1) : ei;
-      double ev[3], Jl[9], Jp[18], info, hub, zc;
-      int pose, slot, dim;
-      uint32_t flags;
-      if (!is_st) {
-        const MonoEdge ed = g.mono[e];
-        pose = ed.pose; slot = ed.slot; flags = ed.flags; info = ed.info; hub = ed.huber; dim = 2;
-        if (!(flags & F_ACTIVE)) {
-          if (slot >= 0) for (int k = 0; k < 18; ++k) g.W[(size_t)slot * 18 + k] = 0.0;
-          continue;
-        }
-        const double* c = USE_LDS ? &s_cam[pose * 16] : nullptr;
-        Mat3 R; Vec3 t; double fx, fy, cx, cy;
-        if (USE_LDS) { for (int k = 0; k < 9; ++k) R.a[k] = c[k]; t = v3(c[9], c[10], c[11]); fx = c[12]; fy = c[13]; cx = c[14]; cy = c[15]; }
-        else { const double* rt = &st.pose_rt[pose * 12]; for (int k = 0; k < 9; ++k) R.a[k] = rt[k]; t = v3(rt[9], rt[10], rt[11]);
-               const double* cm = &g.pose_cam[pose * 5]; fx = cm[0]; fy = cm[1]; cx = cm[2]; cy = cm[3]; }
-        mono_eval(R, t, X, fx, fy, cx, cy, ed.u, ed.v, ev, Jl, Jp, zc);
+    for (int e = g.mo_off[p]; e < g.mo_off[p + 1]; ++e) {
+      const uint32_t fl = g.mono_flags[e];
+      if (!(fl & F_ACTIVE)) continue;
+      const MonoEdge ed = g.mono[e];
+      Mat3 R; Vec3 t; double fx, fy, cx, cy;
+      if (USE_LDS) {
+        const double* c = &smem[ed.pose * 16];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R.a[k] = c[k];
+        t = v3(c[9], c[10], c[11]); fx = c[12]; fy = c[13]; cx = c[14]; cy = c[15];
       } else {
-        const StereoEdge ed = g.stereo[e];
-        pose = ed.pose; slot = ed.slot; flags = ed.flags; info = ed.info; hub = ed.huber; dim = 3;
-        if (!(flags & F_ACTIVE)) {
-          if (slot >= 0) for (int k = 0; k < 18; ++k) g.W[(size_t)slot * 18 + k] = 0.0;
-          continue;
-        }
-        const double* rt = &st.pose_rt[pose * 12];
-        Mat3 R; for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
-        const double* cm = &g.pose_cam[pose * 5];
-        stereo_eval(R, v3(rt[9], rt[10], rt[11]), X, cm[0], cm[1], cm[2], cm[3], cm[4], ed.u, ed.v, ed.ur, ev, Jl, Jp, zc);
+        const double* rt = &st.pose_rt[ed.pose * 12];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
+        t = v3(rt[9], rt[10], rt[11]);
+        const double* cm = &g.pose_cam[ed.pose * 5];
+        fx = cm[0]; fy = cm[1]; cx = cm[2]; cy = cm[3];
       }
-      double chi2 = 0;
-      for (int r = 0; r < dim; ++r) chi2 += ev[r] * (info * ev[r]);
-      if (is_st) g.stereo_chi2[e] = chi2; else g.mono_chi2[e] = chi2;
+      double ev[2], Jl[6], Jp[12], zc;
+      mono_eval(R, t, X, fx, fy, cx, cy, ed.u, ed.v, ev, Jl, Jp, zc);
+      const double chi2 = ev[0] * (ed.info * ev[0]) + ev[1] * (ed.info * ev[1]);
+      g.mono_chi2[e] = chi2;
       double rho0, rho1;
-      huber(chi2, (flags & F_ROBUST) ? hub : 0.0, rho0, rho1);
+      huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
       chi_local += rho0;
-      const double w = rho1 * info;
-      double gr[3];  // -rho1 * Omega * e
-      for (int r = 0; r < dim; ++r) gr[r] = -(info * ev[r]) * rho1;
-      if (lm_free) {
-        for (int r = 0; r < dim; ++r) {
-          const double* j = &Jl[3 * r];
-          D[0] += j[0] * w * j[0]; D[1] += j[0] * w * j[1]; D[2] += j[0] * w * j[2];
-          D[3] += j[1] * w * j[1]; D[4] += j[1] * w * j[2]; D[5] += j[2] * w * j[2];
-          bl[0] += j[0] * gr[r]; bl[1] += j[1] * gr[r]; bl[2] += j[2] * gr[r];
-        }
-      }
-      const int fid = g.pose_free_id[pose];
-      if (fid >= 0) {
-        const int base = fid * 27;
-        for (int a = 0; a < 6; ++a) {
-          double ba = 0;
-          for (int r = 0; r < dim; ++r) ba += Jp[6 * r + a] * gr[r];
-          if constexpr (USE_LDS) atomicAdd(&smem[acc0 + base + 21 + a], ba); else atomicAdd(&g.HB[base + 21 + a], ba);
-          for (int c = 0; c <= a; ++c) {
-            double h = 0;
-            for (int r = 0; r < dim; ++r) h += Jp[6 * r + a] * w * Jp[6 * r + c];
-            if constexpr (USE_LDS) atomicAdd(&smem[acc0 + base + packed_lower(a, c)], h); else atomicAdd(&g.HB[base + packed_lower(a, c)], h);
-          }
-        }
-        if (slot >= 0) {
-          double* Wd = &g.W[(size_t)slot * 18];
-          for (int a = 0; a < 6; ++a)
-            for (int c = 0; c < 3; ++c) {
-              double h = 0;
-              for (int r = 0; r < dim; ++r) h += Jp[6 * r + a] * w * Jl[3 * r + c];
-              Wd[a * 3 + c] = h;
-            }
-        }
-      }
+      const double gr[2] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1};
+      if (lm_free) acc_landmark<2>(Jl, rho1 * ed.info, gr, D, bl);
+    }
+    for (int e = g.st_off[p]; e < g.st_off[p + 1]; ++e) {
+      const uint32_t fl = g.stereo_flags[e];
+      if (!(fl & F_ACTIVE)) continue;
+      const StereoEdge ed = g.stereo[e];
+      const double* rt = &st.pose_rt[ed.pose * 12];
+      Mat3 R;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
+      const double* cm = &g.pose_cam[ed.pose * 5];
+      double ev[3], Jl[9], Jp[18], zc;
+      stereo_eval(R, v3(rt[9], rt[10], rt[11]), X, cm[0], cm[1], cm[2], cm[3], cm[4], ed.u, ed.v, ed.ur, ev, Jl, Jp, zc);
+      double chi2 = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) chi2 += ev[r] * (ed.info * ev[r]);
+      g.stereo_chi2[e] = chi2;
+      double rho0, rho1;
+      huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      chi_local += rho0;
+      const double gr[3] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1, -(ed.info * ev[2]) * rho1};
+      if (lm_free) acc_landmark<3>(Jl, rho1 * ed.info, gr, D, bl);
     }
     if (lm_free) {
+#pragma unroll
       for (int k = 0; k < 6; ++k) g.D[(size_t)p * 6 + k] = D[k];
+#pragma unroll
       for (int k = 0; k < 3; ++k) g.bl[(size_t)p * 3 + k] = bl[k];
     }
   }
   block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
-  if (USE_LDS) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < g.n_pose_free * 27; i += blockDim.x) {
-      const double v = s_acc[i];
-      if (v != 0.0) atomicAdd(&g.HB[i], v);
+}
+
+// Sum `NV` per-lane values over the 64 lanes of a wave through LDS: lane t < NV returns the total of value t.
+// buf is this wave's [NV][65] scratch.  (Cheaper than 6 ds_bpermute rounds per value, and it leaves value t in lane t,
+// which is exactly the lane-contiguous layout the atomics that follow want.)
+template <int NV>
+__device__ __forceinline__ double wave_transpose_sum(const double* vals, double (*buf)[65]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) buf[v][lane] = vals[v];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double t = 0.0;
+  if (lane < NV) {
+#pragma unroll 16
+    for (int i = 0; i < 64; ++i) t += buf[lane][i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  return t;
+}
+
+// ======================================================================================================
+// k_lin_poses: pose side + coupling blocks of the reprojection edges, streamed POSE-MAJOR.  The edges of every free
+// keyframe are stored contiguously (static copies monoP / stereoP) and cut into chunks; one thread re-evaluates the
+// edges of one chunk against its keyframe (held in registers), writes W = Jp' w Jl to consecutive slots and
+// accumulates Jp' w Jp / Jp' g in 27 registers: 27 atomics per CHUNK.  Points are gathered from the L2-resident array.
+// ======================================================================================================
+struct PoseChunks {
+  const int32_t* start;  // [n_chunks] range [start, end) in monoP (type 0) or stereoP (type 1)
+  const int32_t* end;    // [n_chunks]
+  const int32_t* pose;   // [n_chunks] (keyframe index << 1) | type
+  int n_chunks;
+};
+__global__ __launch_bounds__(256) void k_lin_poses(Graph g, State st, PoseChunks pc) {
+  __shared__ double s_buf[4][14][65];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;  // one wave per chunk: lanes stride the chunk, records are read fully coalesced
+  if (t >= pc.n_chunks) return;
+  const int code = pc.pose[t], pose = code >> 1;
+  const double* rt = &st.pose_rt[pose * 12];
+  Mat3 R;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
+  const Vec3 tr = v3(rt[9], rt[10], rt[11]);
+  const double* cm = &g.pose_cam[pose * 5];
+  const double fx = cm[0], fy = cm[1], cx = cm[2], cy = cm[3], bf = cm[4];
+  double A[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) A[k] = 0.0;
+  const int q1 = pc.end[t];
+  if (!(code & 1)) {
+    for (int q = pc.start[t] + lane; q < q1; q += 64) {
+      const MonoEdgeP ed = g.monoP[q];
+      const uint32_t fl = g.mono_flags[ed.eid];
+      if (!(fl & F_ACTIVE)) {
+        if (ed.slot >= 0) zero_W(&g.W[(size_t)ed.slot * 18]);
+        continue;
+      }
+      const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
+      double ev[2], Jl[6], Jp[12], zc;
+      mono_eval(R, tr, X, fx, fy, cx, cy, ed.u, ed.v, ev, Jl, Jp, zc);
+      const double chi2 = ev[0] * (ed.info * ev[0]) + ev[1] * (ed.info * ev[1]);
+      double rho0, rho1;
+      huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      const double w = rho1 * ed.info;
+      const double gr[2] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1};
+      acc_pose<2>(Jp, w, gr, A);
+      if (ed.slot >= 0) store_W<2>(Jp, Jl, w, &g.W[(size_t)ed.slot * 18]);
     }
+  } else {
+    for (int q = pc.start[t] + lane; q < q1; q += 64) {
+      const StereoEdgeP ed = g.stereoP[q];
+      const uint32_t fl = g.stereo_flags[ed.eid];
+      if (!(fl & F_ACTIVE)) {
+        if (ed.slot >= 0) zero_W(&g.W[(size_t)ed.slot * 18]);
+        continue;
+      }
+      const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
+      double ev[3], Jl[9], Jp[18], zc;
+      stereo_eval(R, tr, X, fx, fy, cx, cy, bf, ed.u, ed.v, ed.ur, ev, Jl, Jp, zc);
+      double chi2 = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) chi2 += ev[r] * (ed.info * ev[r]);
+      double rho0, rho1;
+      huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      const double w = rho1 * ed.info;
+      const double gr[3] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1, -(ed.info * ev[2]) * rho1};
+      acc_pose<3>(Jp, w, gr, A);
+      if (ed.slot >= 0) store_W<3>(Jp, Jl, w, &g.W[(size_t)ed.slot * 18]);
+    }
+  }
+  double* hb = &g.HB[(size_t)g.pose_free_id[pose] * 27];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {  // 27 values in two rounds of 14: lane v ends up with value 14 half + v
+    const double tot = wave_transpose_sum<14>(&A[14 * half], s_buf[wave]);
+    const int v = 14 * half + lane;
+    if (lane < 14 && v < 27 && tot != 0.0) atomicAdd(&hb[v], tot);
   }
 }
 
@@ -262,8 +397,9 @@ __global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
   for (int p = g.pt_first + blockIdx.x * blockDim.x + threadIdx.x; p < g.pt_last; p += gridDim.x * blockDim.x) {
     const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
     for (int e = g.mo_off[p]; e < g.mo_off[p + 1]; ++e) {
+      const uint32_t fl = g.mono_flags[e];
+      if (!(fl & F_ACTIVE)) continue;
       const MonoEdge ed = g.mono[e];
-      if (!(ed.flags & F_ACTIVE)) continue;
       const double* rt = &st.pose_rt[ed.pose * 12];
       const double* cm = &g.pose_cam[ed.pose * 5];
       Mat3 R; for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
@@ -272,12 +408,13 @@ __global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
       const double chi2 = ev[0] * (ed.info * ev[0]) + ev[1] * (ed.info * ev[1]);
       g.mono_chi2[e] = chi2;
       double rho0, rho1;
-      huber(chi2, (ed.flags & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
       chi_local += rho0;
     }
     for (int e = g.st_off[p]; e < g.st_off[p + 1]; ++e) {
+      const uint32_t fl = g.stereo_flags[e];
+      if (!(fl & F_ACTIVE)) continue;
       const StereoEdge ed = g.stereo[e];
-      if (!(ed.flags & F_ACTIVE)) continue;
       const double* rt = &st.pose_rt[ed.pose * 12];
       const double* cm = &g.pose_cam[ed.pose * 5];
       Mat3 R; for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
@@ -287,7 +424,7 @@ __global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
       for (int r = 0; r < 3; ++r) chi2 += ev[r] * (ed.info * ev[r]);
       g.stereo_chi2[e] = chi2;
       double rho0, rho1;
-      huber(chi2, (ed.flags & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
       chi_local += rho0;
     }
   }
@@ -302,19 +439,19 @@ __global__ void k_classify_points(Graph g, State st, double th_mono, double th_s
       const int pose = g.mono[e].pose;
       const double* rt = &st.pose_rt[pose * 12];
       const double z = rt[6] * X.x + rt[7] * X.y + rt[8] * X.z + rt[11];
-      uint32_t f = g.mono[e].flags;
+      uint32_t f = g.mono_flags[e];
       if (g.mono_chi2[e] > th_mono || !(z > 0.0)) f &= ~F_ACTIVE;
       f &= ~F_ROBUST;
-      g.mono[e].flags = f;
+      g.mono_flags[e] = f;
     }
     for (int e = g.st_off[p]; e < g.st_off[p + 1]; ++e) {
       const int pose = g.stereo[e].pose;
       const double* rt = &st.pose_rt[pose * 12];
       const double z = rt[6] * X.x + rt[7] * X.y + rt[8] * X.z + rt[11];
-      uint32_t f = g.stereo[e].flags;
+      uint32_t f = g.stereo_flags[e];
       if (g.stereo_chi2[e] > th_stereo || !(z > 0.0)) f &= ~F_ACTIVE;
       f &= ~F_ROBUST;
-      g.stereo[e].flags = f;
+      g.stereo_flags[e] = f;
     }
   }
 }
@@ -543,9 +680,14 @@ __global__ void k_maxdiag(Graph g) {
 // S(lower) += Hpp (+ lambda), Hcc (+ lambda), pose-cuboid blocks; bs = b.   S was zeroed beforehand.
 __global__ void k_assemble(Graph g, double lambda) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = g.n_red;
+  const int n = g.ld;
   const int nP = g.n_pose_free * 27, nC = g.n_cuboids * 54, nB = g.n_bbox * 54, nK = g.n_corner * 54;
   if (!g.owns_reduced) return;  // multi-GPU: HB is already summed over ranks, one rank contributes it
+  if (i >= nP + nC + nB + nK) {  // identity on the padding so that the padded matrix stays positive definite
+    const int k = g.n_red + (i - (nP + nC + nB + nK));
+    if (k < g.ld) g.S[(size_t)k * n + k] = 1.0;
+    return;
+  }
   if (i < nP) {
     const int f = i / 27, k = i % 27;
     const int col0 = f * 6;  // free poses occupy the leading 6*n_pose_free columns in free-id order
@@ -599,49 +741,109 @@ __global__ void k_schur_prep(Graph g, double lambda) {
   if (k >= nl_pts + (g.plane_last - g.plane_first)) return;
   const int l = k < nl_pts ? g.pt_first + k : g.n_points + g.plane_first + (k - nl_pts);
   if (l < g.n_points && g.point_fixed[l]) return;
-  double D[6], I[6];
-  for (int q = 0; q < 6; ++q) D[q] = g.D[(size_t)l * 6 + q];
-  D[0] += lambda; D[3] += lambda; D[5] += lambda;
-  sym3_inverse(D, I);
-  for (int q = 0; q < 6; ++q) g.Dinv[(size_t)l * 6 + q] = I[q];
+  const double d00 = g.D[(size_t)l * 6] + lambda, d01 = g.D[(size_t)l * 6 + 1], d02 = g.D[(size_t)l * 6 + 2];
+  const double d11 = g.D[(size_t)l * 6 + 3] + lambda, d12 = g.D[(size_t)l * 6 + 4], d22 = g.D[(size_t)l * 6 + 5] + lambda;
+  // D + lambda I = L L' (3x3), Linv = L^-1 (lower), Dinv = Linv' Linv
+  const double l00 = sqrt(d00), i00 = 1.0 / l00;
+  const double l10 = d01 * i00, l20 = d02 * i00;
+  const double l11 = sqrt(d11 - l10 * l10), i11 = 1.0 / l11;
+  const double l21 = (d12 - l20 * l10) * i11;
+  const double l22 = sqrt(d22 - l20 * l20 - l21 * l21), i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  double* C = &g.C[(size_t)l * 6];
+  C[0] = i00; C[1] = i10; C[2] = i11; C[3] = i20; C[4] = i21; C[5] = i22;
+  double* I = &g.Dinv[(size_t)l * 6];
+  I[0] = i00 * i00 + i10 * i10 + i20 * i20; I[1] = i10 * i11 + i20 * i21; I[2] = i20 * i22;
+  I[3] = i11 * i11 + i21 * i21;             I[4] = i21 * i22;             I[5] = i22 * i22;
   const double b0 = g.bl[(size_t)l * 3], b1 = g.bl[(size_t)l * 3 + 1], b2 = g.bl[(size_t)l * 3 + 2];
-  const double y0 = I[0] * b0 + I[1] * b1 + I[2] * b2;
-  const double y1 = I[1] * b0 + I[3] * b1 + I[4] * b2;
-  const double y2 = I[2] * b0 + I[4] * b1 + I[5] * b2;
-  g.yl[(size_t)l * 3] = y0; g.yl[(size_t)l * 3 + 1] = y1; g.yl[(size_t)l * 3 + 2] = y2;
-  for (int s = g.slot_off[l]; s < g.slot_off[l + 1]; ++s) {
-    const double* w = &g.W[(size_t)s * 18];
-    double* y = &g.Y[(size_t)s * 18];
-    const int col = g.slot_col[s];
-    for (int a = 0; a < 6; ++a) {
-      const double w0 = w[a * 3], w1 = w[a * 3 + 1], w2 = w[a * 3 + 2];
-      y[a * 3] = w0 * I[0] + w1 * I[1] + w2 * I[2];
-      y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
-      y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
-      const double d = w0 * y0 + w1 * y1 + w2 * y2;
-      if (d != 0.0) atomicAdd(&g.bs[col + a], -d);
-    }
-  }
+  g.ul[(size_t)l * 3] = i00 * b0;
+  g.ul[(size_t)l * 3 + 1] = i10 * b0 + i11 * b1;
+  g.ul[(size_t)l * 3 + 2] = i20 * b0 + i21 * b1 + i22 * b2;
 }
 
-// One 8-lane group per slot j (lanes 0..5 active = rows of the pose block).  For every slot i <= j of the same
-// landmark: S(col_j + c, col_i + r) -= W_j[c,:] . Y_i[r,:]; six consecutive rows per column => one 48-byte segment
-// per atomic instruction group.
-__global__ __launch_bounds__(256) void k_schur_accum(Graph g, int slot_first, int slot_last) {
-  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, c = threadIdx.x & 7;
-  const int sj = slot_first + grp;
-  if (sj >= slot_last || c >= 6) return;
-  const int l = g.slot_lm[sj];
-  const int colj = g.slot_col[sj];
-  const double w0 = g.W[(size_t)sj * 18 + c * 3], w1 = g.W[(size_t)sj * 18 + c * 3 + 1], w2 = g.W[(size_t)sj * 18 + c * 3 + 2];
-  const int n = g.n_red;
-  for (int si = g.slot_off[l]; si <= sj; ++si) {
-    const int coli = g.slot_col[si];
-    const double* y = &g.Y[(size_t)si * 18];
-    const int rmax = (si == sj) ? c : 5;  // diagonal block: lower part only
-    for (int r = 0; r <= rmax; ++r) {
-      const double v = w0 * y[r * 3] + w1 * y[r * 3 + 1] + w2 * y[r * 3 + 2];
-      if (v != 0.0) atomicAdd(&g.S[(size_t)(coli + r) * n + colj + c], -v);
+// Z = W Linv' per slot, streamed in slot (pose-major) order; Linv of the slot's landmark is an L2-resident gather.
+__global__ __launch_bounds__(256) void k_schur_z(Graph g) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= g.n_slots) return;
+  const int l = g.slot_lm[s];
+  const double* C = &g.C[(size_t)l * 6];
+  const double i00 = C[0], i10 = C[1], i11 = C[2], i20 = C[3], i21 = C[4], i22 = C[5];
+  const double2* wp = reinterpret_cast<const double2*>(&g.W[(size_t)s * 18]);
+  double w[18], z[18];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { const double2 a = wp[q]; w[2 * q] = a.x; w[2 * q + 1] = a.y; }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    z[a * 3] = w[a * 3] * i00;
+    z[a * 3 + 1] = __builtin_fma(w[a * 3], i10, w[a * 3 + 1] * i11);
+    z[a * 3 + 2] = __builtin_fma(w[a * 3], i20, __builtin_fma(w[a * 3 + 1], i21, w[a * 3 + 2] * i22));
+  }
+  double2* zp = reinterpret_cast<double2*>(&g.Z[(size_t)s * 18]);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) zp[q] = make_double2(z[2 * q], z[2 * q + 1]);
+}
+
+// Schur accumulation by POSE PAIR.  At create time every (slot_j, slot_i) pair of one landmark (pose_j >= pose_i) is
+// filed under its pose pair and each pair's list is cut into chunks; one thread reduces one chunk into 36 register
+// accumulators, S(pj, pi) -= sum Z_j Z_i', and issues one atomic per entry of the 6x6 block per CHUNK (instead of one
+// per landmark).  Slots are numbered pose-major, so a pair's list walks two contiguous Z segments in order.
+// The self pairs (slot_j == slot_i) also carry the right-hand side: bs(pj) -= Z_j u_l.
+struct PairChunks {
+  const int32_t* start;  // [n_chunks+1] into sj / si
+  const int32_t* colj;   // [n_chunks] reduced column of pose j (row block of S)
+  const int32_t* coli;   // [n_chunks] reduced column of pose i (column block of S)
+  const int32_t* sj;     // [n_entries]
+  const int32_t* si;     // [n_entries]
+  int n_chunks;
+};
+__global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
+  __shared__ double s_buf[4][21][65];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;  // one wave per chunk of one pose pair
+  if (t >= pc.n_chunks) return;
+  const int e1 = pc.start[t + 1];
+  const int colj = pc.colj[t], coli = pc.coli[t];
+  // vals[6 r + c] = element (row c of pose j, column r of pose i) so that consecutive values are consecutive in memory
+  double vals[42];
+#pragma unroll
+  for (int k = 0; k < 42; ++k) vals[k] = 0.0;
+  for (int e = pc.start[t] + lane; e < e1; e += 64) {
+    const int sj = pc.sj[e], si = pc.si[e];
+    double w[18], y[18];
+    const double2* wp = reinterpret_cast<const double2*>(&g.Z[(size_t)sj * 18]);
+    const double2* yp = reinterpret_cast<const double2*>(&g.Z[(size_t)si * 18]);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const double2 a = wp[q], b = yp[q];
+      w[2 * q] = a.x; w[2 * q + 1] = a.y; y[2 * q] = b.x; y[2 * q + 1] = b.y;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        vals[6 * r + c] = __builtin_fma(w[c * 3], y[r * 3], __builtin_fma(w[c * 3 + 1], y[r * 3 + 1], __builtin_fma(w[c * 3 + 2], y[r * 3 + 2], vals[6 * r + c])));
+    if (sj == si) {
+      const int l = g.slot_lm[sj];
+      const double y0 = g.ul[(size_t)l * 3], y1 = g.ul[(size_t)l * 3 + 1], y2 = g.ul[(size_t)l * 3 + 2];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) vals[36 + c] += w[c * 3] * y0 + w[c * 3 + 1] * y1 + w[c * 3 + 2] * y2;
+    }
+  }
+  const int n = g.ld;
+  const bool diag = colj == coli;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const double tot = wave_transpose_sum<21>(&vals[21 * half], s_buf[wave]);
+    const int v = 21 * half + lane;
+    if (lane < 21 && tot != 0.0) {
+      if (v < 36) {
+        const int r = v / 6, c = v - 6 * r;
+        if (!diag || c >= r) atomicAdd(&g.S[(size_t)(coli + r) * n + colj + c], -tot);
+      } else if (diag) {
+        atomicAdd(&g.bs[colj + (v - 36)], -tot);
+      }
     }
   }
 }
@@ -683,8 +885,10 @@ __global__ void k_update_reduced(Graph g, State cur, State trial, double lambda)
   block_atomic_add(sc, &g.acc[ACC_SCALE], s_red);
 }
 
-// landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term
-__global__ void k_backsub(Graph g, State cur, State trial, double lambda) {
+// landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term.
+// Points evaluate W' x_p = Jl' w (Jp x_p) from their own edges (streamed landmark-major) instead of reading W back;
+// the few planes read their W blocks.
+__global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial, double lambda) {
   __shared__ double s_red[4];
   const int nl_pts = g.pt_last - g.pt_first;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -696,11 +900,73 @@ __global__ void k_backsub(Graph g, State cur, State trial, double lambda) {
     if (!fixed) {
       const double b0 = g.bl[(size_t)l * 3], b1 = g.bl[(size_t)l * 3 + 1], b2 = g.bl[(size_t)l * 3 + 2];
       double c0 = b0, c1 = b1, c2 = b2;
-      for (int s = g.slot_off[l]; s < g.slot_off[l + 1]; ++s) {
-        const double* w = &g.W[(size_t)s * 18];
-        const double* x = &g.xr[g.slot_col[s]];
-        for (int a = 0; a < 6; ++a) {
-          c0 -= w[a * 3] * x[a]; c1 -= w[a * 3 + 1] * x[a]; c2 -= w[a * 3 + 2] * x[a];
+      if (l < g.n_points) {
+        const Vec3 X = v3(cur.point[3 * l], cur.point[3 * l + 1], cur.point[3 * l + 2]);
+        for (int e = g.mo_off[l]; e < g.mo_off[l + 1]; ++e) {
+          const uint32_t fl = g.mono_flags[e];
+          if (!(fl & F_ACTIVE)) continue;
+          const MonoEdge ed = g.mono[e];
+          const int col = g.pose_col[ed.pose];
+          if (col < 0) continue;
+          const double* rt = &cur.pose_rt[ed.pose * 12];
+          const double* cm = &g.pose_cam[ed.pose * 5];
+          Mat3 R;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) R.a[q] = rt[q];
+          double ev[2], Jl[6], Jp[12], zc;
+          mono_eval(R, v3(rt[9], rt[10], rt[11]), X, cm[0], cm[1], cm[2], cm[3], ed.u, ed.v, ev, Jl, Jp, zc);
+          const double chi2 = ev[0] * (ed.info * ev[0]) + ev[1] * (ed.info * ev[1]);
+          double rho0, rho1;
+          huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+          const double w = rho1 * ed.info;
+          const double* x = &g.xr[col];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            double tr = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) tr += Jp[6 * r + a] * x[a];
+            tr *= w;
+            c0 -= Jl[3 * r] * tr; c1 -= Jl[3 * r + 1] * tr; c2 -= Jl[3 * r + 2] * tr;
+          }
+        }
+        for (int e = g.st_off[l]; e < g.st_off[l + 1]; ++e) {
+          const uint32_t fl = g.stereo_flags[e];
+          if (!(fl & F_ACTIVE)) continue;
+          const StereoEdge ed = g.stereo[e];
+          const int col = g.pose_col[ed.pose];
+          if (col < 0) continue;
+          const double* rt = &cur.pose_rt[ed.pose * 12];
+          const double* cm = &g.pose_cam[ed.pose * 5];
+          Mat3 R;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) R.a[q] = rt[q];
+          double ev[3], Jl[9], Jp[18], zc;
+          stereo_eval(R, v3(rt[9], rt[10], rt[11]), X, cm[0], cm[1], cm[2], cm[3], cm[4], ed.u, ed.v, ed.ur, ev, Jl, Jp, zc);
+          double chi2 = 0;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) chi2 += ev[r] * (ed.info * ev[r]);
+          double rho0, rho1;
+          huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+          const double w = rho1 * ed.info;
+          const double* x = &g.xr[col];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            double tr = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) tr += Jp[6 * r + a] * x[a];
+            tr *= w;
+            c0 -= Jl[3 * r] * tr; c1 -= Jl[3 * r + 1] * tr; c2 -= Jl[3 * r + 2] * tr;
+          }
+        }
+      } else {
+        const int j = l - g.n_points;
+        for (int q = g.pl_slot_off[j]; q < g.pl_slot_off[j + 1]; ++q) {
+          const int s = g.pl_slots[q];
+          const double* w = &g.W[(size_t)s * 18];
+          const double* x = &g.xr[g.slot_col[s]];
+          for (int a = 0; a < 6; ++a) {
+            c0 -= w[a * 3] * x[a]; c1 -= w[a * 3 + 1] * x[a]; c2 -= w[a * 3 + 2] * x[a];
+          }
         }
       }
       const double* I = &g.Dinv[(size_t)l * 6];

@@ -84,22 +84,29 @@ struct ppo_ba_solver {
   std::vector<int32_t> h_slot_off;
   // device
   DevBuf<double> d_pose_cam, d_cub_fixedscale, d_ptcub_pts;
-  DevBuf<int32_t> d_pose_col, d_pose_free_id, d_cub_col, d_mo_off, d_st_off, d_slot_off, d_slot_col, d_slot_lm;
+  DevBuf<int32_t> d_pose_col, d_pose_free_id, d_cub_col, d_mo_off, d_st_off, d_slot_col, d_slot_lm, d_pl_slot_off, d_pl_slots;
+  DevBuf<uint32_t> d_mono_flags, d_stereo_flags, d_mono_flags0, d_stereo_flags0;
+  DevBuf<MonoEdgeP> d_monoP;
+  DevBuf<StereoEdgeP> d_stereoP;
   DevBuf<uint8_t> d_point_fixed, d_cub_flags;
   DevBuf<MonoEdge> d_mono;
   DevBuf<StereoEdge> d_stereo;
   DevBuf<PlaneEdge> d_pl;
   DevBuf<CubEdge> d_bbox, d_corner;
   DevBuf<PtCubEdge> d_ptcub;
-  DevBuf<MonoEdge> d_mono0;      // pristine copies (flags at level 0, kernels on) for reset()
-  DevBuf<StereoEdge> d_stereo0;
+  // pristine copies (flags at level 0, kernels on) for reset()
   DevBuf<PlaneEdge> d_pl0;
   DevBuf<CubEdge> d_bbox0, d_corner0;
   DevBuf<double> d_chi2_all;  // per-edge chi2 / norms
   DevBuf<double> d_state[2];  // two copies of all estimates (current / trial)
   DevBuf<double> d_init;      // pristine estimates for reset()
   DevBuf<double> d_arena;     // HB | HC | acc | D | bl | W ; a prefix is zeroed before every linearisation
-  DevBuf<double> d_Wpc, d_Dinv, d_yl, d_Y, d_S, d_bs, d_xr, d_cholws;
+  DevBuf<double> d_Wpc, d_Dinv, d_C, d_ul, d_Z, d_S, d_bs, d_xr, d_cholws;
+  DevBuf<int32_t> d_pc_start, d_pc_colj, d_pc_coli, d_pc_sj, d_pc_si;  // pose-pair chunks of the Schur accumulation
+  PairChunks pc{};
+  DevBuf<int32_t> d_po_start, d_po_end, d_po_pose;  // pose-major chunks of the reprojection edges
+  PoseChunks posec{};
+  DevBuf<double> d_W;
   DevBuf<int> d_info;
   size_t state_doubles = 0;
   double* h_pinned = nullptr;  // ACC_N doubles then one int
@@ -201,14 +208,18 @@ void canon_plane_cv(const double* in, double* out) {  // Converter::toPlane3D (C
 void free_all(ppo_ba_solver* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  chol_release(s->d_S.p);
   s->d_pose_cam.release(); s->d_cub_fixedscale.release(); s->d_ptcub_pts.release();
   s->d_pose_col.release(); s->d_pose_free_id.release(); s->d_cub_col.release(); s->d_mo_off.release(); s->d_st_off.release();
-  s->d_slot_off.release(); s->d_slot_col.release(); s->d_slot_lm.release(); s->d_point_fixed.release(); s->d_cub_flags.release();
+  s->d_slot_col.release(); s->d_slot_lm.release(); s->d_pl_slot_off.release(); s->d_pl_slots.release();
+  s->d_mono_flags.release(); s->d_stereo_flags.release(); s->d_mono_flags0.release(); s->d_stereo_flags0.release(); s->d_monoP.release(); s->d_stereoP.release(); s->d_point_fixed.release(); s->d_cub_flags.release();
   s->d_mono.release(); s->d_stereo.release(); s->d_pl.release(); s->d_bbox.release(); s->d_corner.release(); s->d_ptcub.release();
-  s->d_mono0.release(); s->d_stereo0.release(); s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
+  s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
-  s->d_Wpc.release(); s->d_Dinv.release(); s->d_yl.release(); s->d_Y.release();
+  s->d_Wpc.release(); s->d_Dinv.release(); s->d_C.release(); s->d_ul.release(); s->d_Z.release();
   s->d_S.release(); s->d_bs.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
+  s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release();
+  s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
   if (s->blas) rocblas_destroy_handle(s->blas);
   s->comm.destroy();
@@ -234,8 +245,8 @@ int reset_device(ppo_ba_solver* s) {
   auto up = [&](void* dst, const void* src, size_t bytes) {
     return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
   };
-  if (!up(s->d_mono.p, s->d_mono0.p, s->d_mono.n * sizeof(MonoEdge)) ||
-      !up(s->d_stereo.p, s->d_stereo0.p, s->d_stereo.n * sizeof(StereoEdge)) ||
+  if (!up(s->d_mono_flags.p, s->d_mono_flags0.p, s->d_mono_flags.n * sizeof(uint32_t)) ||
+      !up(s->d_stereo_flags.p, s->d_stereo_flags0.p, s->d_stereo_flags.n * sizeof(uint32_t)) ||
       !up(s->d_pl.p, s->d_pl0.p, s->d_pl.n * sizeof(PlaneEdge)) ||
       !up(s->d_bbox.p, s->d_bbox0.p, s->d_bbox.n * sizeof(CubEdge)) ||
       !up(s->d_corner.p, s->d_corner0.p, s->d_corner.n * sizeof(CubEdge)))
@@ -261,12 +272,13 @@ int launch_linearize(ppo_ba_solver* s) {
   HIP_TRY(hipMemsetAsync(A, 0, s->zero_head * sizeof(double), s->stream));
   if (s->zD_n) HIP_TRY(hipMemsetAsync(A + s->zD_off, 0, s->zD_n * sizeof(double), s->stream));
   if (s->zbl_n) HIP_TRY(hipMemsetAsync(A + s->zbl_off, 0, s->zbl_n * sizeof(double), s->stream));
-  if (s->zW_n) HIP_TRY(hipMemsetAsync(A + s->zW_off, 0, s->zW_n * sizeof(double), s->stream));
+  if (s->zW_n) HIP_TRY(hipMemsetAsync(s->d_W.p + s->zW_off, 0, s->zW_n * sizeof(double), s->stream));
   const int npts = g.pt_last - g.pt_first;
   if (npts > 0) {
     const int grid = std::min(nblk(npts, 256), 2 * s->n_cu);
     if (s->use_lds) hipLaunchKernelGGL(k_lin_points<true>, dim3(grid), dim3(256), s->lds_bytes, s->stream, g, st);
     else hipLaunchKernelGGL(k_lin_points<false>, dim3(grid), dim3(256), 0, s->stream, g, st);
+    if (s->posec.n_chunks > 0) hipLaunchKernelGGL(k_lin_poses, dim3(nblk(s->posec.n_chunks, 4)), dim3(256), 0, s->stream, g, st, s->posec);
   }
   const double delta = s->opt.numeric_delta;
   if (g.plane_last > g.plane_first && g.n_pl > 0)
@@ -298,24 +310,21 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
 // reduced system for `lambda` into S (lower triangle) / bs      (block_solver.hpp:354-439)
 int launch_reduce(ppo_ba_solver* s, double lambda) {
   const Graph& g = s->g;
-  const size_t n = g.n_red;
+  const size_t n = g.ld;
   HIP_TRY(hipMemsetAsync(s->d_S.p, 0, n * n * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->d_bs.p, 0, n * sizeof(double), s->stream));
-  const long work = (long)g.n_pose_free * 27 + (long)g.n_cuboids * 54 + (long)(g.n_bbox + g.n_corner) * 54;
+  const long work = (long)g.n_pose_free * 27 + (long)g.n_cuboids * 54 + (long)(g.n_bbox + g.n_corner) * 54 + (g.ld - g.n_red);
   hipLaunchKernelGGL(k_assemble, dim3(nblk(work, 256)), dim3(256), 0, s->stream, g, lambda);
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
   if (nl > 0) {
     hipLaunchKernelGGL(k_schur_prep, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, lambda);
-    const int ranges[2][2] = {{g.pt_first, g.pt_last}, {g.n_points + g.plane_first, g.n_points + g.plane_last}};
-    for (auto& r : ranges) {
-      if (r[1] <= r[0]) continue;
-      const int s0 = s->h_slot_off[r[0]], s1 = s->h_slot_off[r[1]];
-      if (s1 > s0) hipLaunchKernelGGL(k_schur_accum, dim3(nblk((long)(s1 - s0) * 8, 256)), dim3(256), 0, s->stream, g, s0, s1);
-    }
+    if (g.n_slots > 0) hipLaunchKernelGGL(k_schur_z, dim3(nblk(g.n_slots, 256)), dim3(256), 0, s->stream, g);
+    if (s->pc.n_chunks > 0) hipLaunchKernelGGL(k_schur_pairs, dim3(nblk(s->pc.n_chunks, 4)), dim3(256), 0, s->stream, g, s->pc);
   }
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
     if (s->comm.sum(s->d_S.p, n * n, s->stream) || s->comm.sum(s->d_bs.p, n, s->stream)) return PPO_BA_ERR_COMM;
+    // every rank wrote nothing on the padding except the owner: identity there after the sum
   }
   return PPO_BA_OK;
 }
@@ -323,13 +332,13 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
 // dense SPD solve of S x = bs (LinearSolverDense::solve, linear_solver_dense.h:65-113).  info != 0 <=> not positive.
 int launch_solve(ppo_ba_solver* s) {
   const Graph& g = s->g;
-  const int n = g.n_red;
-  HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  const int n = g.n_red, ld = g.ld;
+  HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs.p, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
-    RC_TRY(chol_factor_solve(s->d_S.p, n, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
+    RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
   } else {
-    if (rocsolver_dpotrf(s->blas, rocblas_fill_lower, n, s->d_S.p, n, s->d_info.p) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
-    if (rocsolver_dpotrs(s->blas, rocblas_fill_lower, n, 1, s->d_S.p, n, s->d_xr.p, n) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
+    if (rocsolver_dpotrf(s->blas, rocblas_fill_lower, n, s->d_S.p, ld, s->d_info.p) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
+    if (rocsolver_dpotrs(s->blas, rocblas_fill_lower, n, 1, s->d_S.p, ld, s->d_xr.p, ld) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
   }
   return PPO_BA_OK;
 }
@@ -502,6 +511,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (cub_used[i]) { cub_col[i] = ncol; ncol += 9; }
   g.n_pose_free = nfree;
   g.n_red = ncol;
+  g.ld = chol_padded_ld(ncol);
+  const int ld = g.ld;
   g.n_lm = Npt + Npl;
   s->stats.n_reduced = ncol;
 
@@ -544,12 +555,30 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   slot_off[g.n_lm] = (int32_t)slot_col.size();
   g.n_slots = (int)slot_col.size();
+  // device numbering is POSE-MAJOR: point slots ordered by (pose column, point), then plane slots by (pose column, plane),
+  // so that everything a keyframe touches is contiguous (k_lin_poses, k_schur_z, k_schur_pairs stream it)
+  const int n_point_slots = slot_off[Npt];
+  std::vector<int32_t> new_id(g.n_slots), d_slot_col_v(g.n_slots), d_slot_lm_v(g.n_slots);
+  {
+    auto renumber = [&](int first, int last, int base) {
+      std::vector<int32_t> cntc(ncol / 1 + 2, 0);
+      for (int i = first; i < last; ++i) cntc[slot_col[i] + 1]++;
+      for (size_t c = 1; c < cntc.size(); ++c) cntc[c] += cntc[c - 1];
+      for (int i = first; i < last; ++i) new_id[i] = base + cntc[slot_col[i]]++;
+    };
+    renumber(0, n_point_slots, 0);
+    renumber(n_point_slots, g.n_slots, n_point_slots);
+    for (int i = 0; i < g.n_slots; ++i) { d_slot_col_v[new_id[i]] = slot_col[i]; d_slot_lm_v[new_id[i]] = slot_lm[i]; }
+  }
+  std::vector<int32_t> pl_slot_off(Npl + 1, 0), pl_slots(g.n_slots - n_point_slots);
+  for (int j = 0; j <= Npl; ++j) pl_slot_off[j] = slot_off[Npt + j] - n_point_slots;
+  for (int i = n_point_slots; i < g.n_slots; ++i) pl_slots[i - n_point_slots] = new_id[i];
   auto find_slot = [&](int l, int pc) -> int32_t {
     if (pc < 0) return -1;
     const int32_t* b = slot_col.data() + slot_off[l];
     const int32_t* e = slot_col.data() + slot_off[l + 1];
     const int32_t* it = std::lower_bound(b, e, pc);
-    return (it != e && *it == pc) ? (int32_t)(it - slot_col.data()) : -1;
+    return (it != e && *it == pc) ? new_id[it - slot_col.data()] : -1;
   };
 
   // ---- edge records -----------------------------------------------------------------------------------------
@@ -562,7 +591,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     m.slot = point_fixed[p->mono_point[e]] ? -1 : find_slot(p->mono_point[e], pose_col[m.pose]);
     const bool all_fixed = point_fixed[p->mono_point[e]] && pose_col[m.pose] < 0;
     m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
-    m.pad = 0;
+    m.point = p->mono_point[e];
   }
   s->h_stereo.resize(p->n_stereo);
   for (int k = 0; k < p->n_stereo; ++k) {
@@ -572,6 +601,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     m.u = p->stereo_obs[3 * e]; m.v = p->stereo_obs[3 * e + 1]; m.ur = p->stereo_obs[3 * e + 2];
     m.info = p->stereo_info[e]; m.huber = p->stereo_huber[e];
     m.pose = p->stereo_pose[e];
+    m.point = p->stereo_point[e];
     m.slot = point_fixed[p->stereo_point[e]] ? -1 : find_slot(p->stereo_point[e], pose_col[m.pose]);
     const bool all_fixed = point_fixed[p->stereo_point[e]] && pose_col[m.pose] < 0;
     m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
@@ -636,6 +666,89 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (!g.owns_reduced) s->cubpl_rho_sum = 0;
   }
 
+  // ---- Schur accumulation plan: (slot_j, slot_i) pairs of every owned landmark filed by pose pair, then chunked -----
+  std::vector<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si;
+  {
+    const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    const long nkeys = (long)nfree * (nfree + 1) / 2;
+    std::vector<int32_t> cnt(nkeys + 1, 0);
+    auto key_of = [&](int cj, int ci) { const long pj = cj / 6, pi = ci / 6; return pj * (pj + 1) / 2 + pi; };
+    auto for_owned = [&](auto&& fn) {
+      for (int l = g.pt_first; l < g.pt_last; ++l) fn(l);
+      for (int l = Npt + g.plane_first; l < Npt + g.plane_last; ++l) fn(l);
+    };
+    for_owned([&](int l) {
+      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
+        for (int b = slot_off[l]; b <= a; ++b) cnt[key_of(slot_col[a], slot_col[b]) + 1]++;
+    });
+    for (long k = 0; k < nkeys; ++k) cnt[k + 1] += cnt[k];
+    const long n_entries = cnt[nkeys];
+    pc_sj.resize(n_entries);
+    pc_si.resize(n_entries);
+    std::vector<int32_t> cursor(cnt.begin(), cnt.end() - 1);
+    for_owned([&](int l) {
+      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
+        for (int b = slot_off[l]; b <= a; ++b) {
+          const int32_t pos = cursor[key_of(slot_col[a], slot_col[b])]++;
+          pc_sj[pos] = new_id[a];
+          pc_si[pos] = new_id[b];
+        }
+    });
+    pc_start.push_back(0);
+    for (long pj = 0, k = 0; pj < nfree; ++pj)
+      for (long pi = 0; pi <= pj; ++pi, ++k)
+        for (int32_t e = cnt[k]; e < cnt[k + 1]; e += chunk) {
+          pc_colj.push_back((int32_t)(6 * pj));
+          pc_coli.push_back((int32_t)(6 * pi));
+          pc_start.push_back(std::min<int32_t>(e + chunk, cnt[k + 1]));
+        }
+  }
+
+  // ---- pose-major static copies of the owned reprojection edges + chunks (pose side of the linearisation) -----------
+  std::vector<int32_t> po_start, po_end, po_pose;
+  std::vector<MonoEdgeP> h_monoP;
+  std::vector<StereoEdgeP> h_stereoP;
+  {
+    const int chunk = []() { const char* e = getenv("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    auto build = [&](int type) {
+      std::vector<int32_t> cnt(Np + 1, 0);
+      auto visit = [&](auto&& fn) {
+        for (int pt = g.pt_first; pt < g.pt_last; ++pt) {
+          if (type == 0) for (int k = mo_off[pt]; k < mo_off[pt + 1]; ++k) fn(s->h_mono[k].pose, k);
+          else for (int k = st_off[pt]; k < st_off[pt + 1]; ++k) fn(s->h_stereo[k].pose, k);
+        }
+      };
+      visit([&](int pose, int) { if (pose_free_id[pose] >= 0) cnt[pose + 1]++; });
+      for (int i = 0; i < Np; ++i) cnt[i + 1] += cnt[i];
+      std::vector<int32_t> cursor(cnt.begin(), cnt.end() - 1);
+      if (type == 0) h_monoP.resize(cnt[Np]); else h_stereoP.resize(cnt[Np]);
+      visit([&](int pose, int k) {
+        if (pose_free_id[pose] < 0) return;
+        const int q = cursor[pose]++;
+        if (type == 0) {
+          const MonoEdge& m = s->h_mono[k];
+          h_monoP[q] = MonoEdgeP{m.u, m.v, m.info, m.huber, m.point, k, m.slot, 0};
+        } else {
+          const StereoEdge& m = s->h_stereo[k];
+          StereoEdgeP e{};
+          e.u = m.u; e.v = m.v; e.ur = m.ur; e.info = m.info; e.huber = m.huber; e.point = m.point; e.eid = k; e.slot = m.slot;
+          h_stereoP[q] = e;
+        }
+      });
+      for (int i = 0; i < Np; ++i)
+        for (int32_t e = cnt[i]; e < cnt[i + 1]; e += chunk) {
+          po_pose.push_back((i << 1) | type);
+          po_start.push_back(e);
+          po_end.push_back(std::min<int32_t>(e + chunk, cnt[i + 1]));
+        }
+    };
+    build(0);
+    build(1);
+  }
+  std::vector<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
+  for (int k = 0; k < p->n_mono; ++k) h_mono_flags[k] = s->h_mono[k].flags;
+  for (int k = 0; k < p->n_stereo; ++k) h_stereo_flags[k] = s->h_stereo[k].flags;
+
   // ---- initial estimates, canonicalised like the reference's converters ------------------------------------------
   s->state_doubles = (size_t)Np * 19 + (size_t)Npt * 3 + (size_t)Npl * 4 + (size_t)Nc * 10;
   std::vector<double> h_state(s->state_doubles, 0.0);
@@ -668,21 +781,30 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_pose_cam.upload(v_cam, s->stream) && s->d_cub_fixedscale.upload(v_fs, s->stream) && s->d_ptcub_pts.upload(v_pts, s->stream);
   ok = ok && s->d_pose_col.upload(pose_col, s->stream) && s->d_pose_free_id.upload(pose_free_id, s->stream) && s->d_cub_col.upload(cub_col, s->stream);
   ok = ok && s->d_mo_off.upload(mo_off, s->stream) && s->d_st_off.upload(st_off, s->stream);
-  ok = ok && s->d_slot_off.upload(slot_off, s->stream) && s->d_slot_col.upload(slot_col, s->stream) && s->d_slot_lm.upload(slot_lm, s->stream);
+  ok = ok && s->d_slot_col.upload(d_slot_col_v, s->stream) && s->d_slot_lm.upload(d_slot_lm_v, s->stream);
+  ok = ok && s->d_pl_slot_off.upload(pl_slot_off, s->stream) && s->d_pl_slots.upload(pl_slots, s->stream);
+  ok = ok && s->d_mono_flags.upload(h_mono_flags, s->stream) && s->d_mono_flags0.upload(h_mono_flags, s->stream);
+  ok = ok && s->d_stereo_flags.upload(h_stereo_flags, s->stream) && s->d_stereo_flags0.upload(h_stereo_flags, s->stream);
+  ok = ok && s->d_monoP.upload(h_monoP, s->stream) && s->d_stereoP.upload(h_stereoP, s->stream);
   ok = ok && s->d_point_fixed.upload(point_fixed, s->stream) && s->d_cub_flags.upload(v_cf, s->stream);
   ok = ok && s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream) && s->d_pl.upload(s->h_pl, s->stream);
   ok = ok && s->d_bbox.upload(s->h_bbox, s->stream) && s->d_corner.upload(s->h_corner, s->stream) && s->d_ptcub.upload(s->h_ptcub, s->stream);
-  ok = ok && s->d_mono0.upload(s->h_mono, s->stream) && s->d_stereo0.upload(s->h_stereo, s->stream) && s->d_pl0.upload(s->h_pl, s->stream);
+  ok = ok && s->d_pl0.upload(s->h_pl, s->stream);
   ok = ok && s->d_bbox0.upload(s->h_bbox, s->stream) && s->d_corner0.upload(s->h_corner, s->stream);
   ok = ok && s->d_init.upload(h_state, s->stream) && s->d_state[0].alloc(s->state_doubles) && s->d_state[1].alloc(s->state_doubles);
   const size_t n_chi = (size_t)p->n_mono + p->n_stereo + p->n_plane_edges + 2 * (size_t)p->n_bbox + 2 * (size_t)p->n_corner + p->n_ptcub;
   ok = ok && s->d_chi2_all.alloc(n_chi);
   // arena: HB | HC | acc | D | bl | W
   const size_t nHB = (size_t)nfree * 27, nHC = (size_t)Nc * 54, nD = (size_t)g.n_lm * 6, nbl = (size_t)g.n_lm * 3, nW = (size_t)g.n_slots * 18;
-  ok = ok && s->d_arena.alloc(nHB + nHC + ACC_N + nD + nbl + nW);
-  ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_yl.alloc(nbl) && s->d_Y.alloc(nW);
-  ok = ok && s->d_S.alloc((size_t)ncol * ncol) && s->d_bs.alloc(ncol) && s->d_xr.alloc(ncol) && s->d_info.alloc(1);
+  ok = ok && s->d_arena.alloc(nHB + nHC + ACC_N + nD + nbl) && s->d_W.alloc(nW);
+  ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
+  s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
+  ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_C.alloc(nD) && s->d_ul.alloc(nbl) && s->d_Z.alloc(nW);
+  ok = ok && s->d_S.alloc((size_t)ld * ld) && s->d_bs.alloc(ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
+  ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
+  ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream);
+  s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, (int)pc_colj.size()};
   if (!ok) return fail(PPO_BA_ERR_NOMEM);
   if (hipHostMalloc((void**)&s->h_pinned, (ACC_N + 2) * sizeof(double)) != hipSuccess) return fail(PPO_BA_ERR_NOMEM);
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
@@ -692,7 +814,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   g.mo_off = s->d_mo_off.p; g.st_off = s->d_st_off.p;
   g.mono = s->d_mono.p; g.stereo = s->d_stereo.p; g.pl = s->d_pl.p; g.bbox = s->d_bbox.p; g.corner = s->d_corner.p; g.ptcub = s->d_ptcub.p;
   g.ptcub_pts = s->d_ptcub_pts.p;
-  g.slot_off = s->d_slot_off.p; g.slot_col = s->d_slot_col.p; g.slot_lm = s->d_slot_lm.p;
+  g.slot_col = s->d_slot_col.p; g.slot_lm = s->d_slot_lm.p; g.pl_slot_off = s->d_pl_slot_off.p; g.pl_slots = s->d_pl_slots.p;
+  g.mono_flags = s->d_mono_flags.p; g.stereo_flags = s->d_stereo_flags.p; g.monoP = s->d_monoP.p; g.stereoP = s->d_stereoP.p;
   {
     double* c = s->d_chi2_all.p;
     g.mono_chi2 = c; c += p->n_mono;
@@ -712,15 +835,16 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     s->zero_head = nHB + nHC + ACC_N;
     g.D = a; s->zD_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 6; s->zD_n = (size_t)Npl * 6; a += nD;
     g.bl = a; s->zbl_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 3; s->zbl_n = (size_t)Npl * 3; a += nbl;
-    g.W = a; s->zW_off = (size_t)(a - s->d_arena.p) + (size_t)slot_off[Npt] * 18; s->zW_n = (size_t)(g.n_slots - slot_off[Npt]) * 18;
+    g.W = s->d_W.p; s->zW_off = (size_t)slot_off[Npt] * 18; s->zW_n = (size_t)(g.n_slots - slot_off[Npt]) * 18;
+    if (nW) (void)hipMemsetAsync(s->d_W.p, 0, nW * sizeof(double), s->stream);
   }
   g.Wpc_bbox = s->d_Wpc.p; g.Wpc_corner = s->d_Wpc.p + (size_t)p->n_bbox * 54;
-  g.Dinv = s->d_Dinv.p; g.yl = s->d_yl.p; g.Y = s->d_Y.p; g.S = s->d_S.p; g.bs = s->d_bs.p; g.xr = s->d_xr.p;
+  g.Dinv = s->d_Dinv.p; g.C = s->d_C.p; g.ul = s->d_ul.p; g.Z = s->d_Z.p; g.S = s->d_S.p; g.bs = s->d_bs.p; g.xr = s->d_xr.p;
   s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
   s->st[1] = make_state(s->d_state[1].p, Np, Npt, Npl, Nc);
 
   // LDS plan for k_lin_points: camera table + pose-block accumulators
-  s->lds_bytes = (int)(((size_t)Np * 16 + (size_t)nfree * 27) * sizeof(double));
+  s->lds_bytes = (int)((size_t)Np * 16 * sizeof(double));
   s->use_lds = s->lds_bytes <= 150 * 1024;
   if (s->use_lds && s->lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute((const void*)k_lin_points<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
@@ -832,6 +956,9 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
   if (chi.size()) HIP_TRY(hipMemcpy(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost));
   std::vector<MonoEdge> hm(g.n_mono);
   std::vector<StereoEdge> hst(g.n_stereo);
+  std::vector<uint32_t> hmf(g.n_mono), hsf(g.n_stereo);
+  if (g.n_mono) HIP_TRY(hipMemcpy(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (g.n_stereo) HIP_TRY(hipMemcpy(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   std::vector<PlaneEdge> hp(g.n_pl);
   std::vector<CubEdge> hb(g.n_bbox), hc(g.n_corner);
   if (g.n_mono) HIP_TRY(hipMemcpy(hm.data(), s->d_mono.p, hm.size() * sizeof(MonoEdge), hipMemcpyDeviceToHost));
@@ -870,13 +997,13 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
   for (int k = 0; k < g.n_mono; ++k) {
     const int e = s->mono_perm[k];
     if (r->mono_chi2) r->mono_chi2[e] = c_mono[k];
-    if (r->mono_level) r->mono_level[e] = (hm[k].flags & F_ACTIVE) ? 0 : 1;
+    if (r->mono_level) r->mono_level[e] = (hmf[k] & F_ACTIVE) ? 0 : 1;
     if (r->mono_depth_positive) r->mono_depth_positive[e] = depth(hm[k].pose, mo_pt[k]);
   }
   for (int k = 0; k < g.n_stereo; ++k) {
     const int e = s->stereo_perm[k];
     if (r->stereo_chi2) r->stereo_chi2[e] = c_st[k];
-    if (r->stereo_level) r->stereo_level[e] = (hst[k].flags & F_ACTIVE) ? 0 : 1;
+    if (r->stereo_level) r->stereo_level[e] = (hsf[k] & F_ACTIVE) ? 0 : 1;
     if (r->stereo_depth_positive) r->stereo_depth_positive[e] = depth(hst[k].pose, st_pt[k]);
   }
   for (int e = 0; e < g.n_pl; ++e) {
@@ -978,8 +1105,11 @@ int ppo_ba_debug_reduced(ppo_ba_handle s, double* S, double* b, double* x, int32
   RC_TRY(launch_reduce(s, lambda));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (S) {
-    HIP_TRY(hipMemcpy(S, s->d_S.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
-    for (int c = 0; c < n; ++c) for (int r = c + 1; r < n; ++r) S[(size_t)r * n + c] = S[(size_t)c * n + r];
+    const int ld = s->g.ld;
+    std::vector<double> tmp((size_t)ld * ld);
+    HIP_TRY(hipMemcpy(tmp.data(), s->d_S.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int c = 0; c < n; ++c)
+      for (int r = c; r < n; ++r) S[(size_t)c * n + r] = S[(size_t)r * n + c] = tmp[(size_t)c * ld + r];
   }
   if (b) HIP_TRY(hipMemcpy(b, s->d_bs.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   if (x) {
