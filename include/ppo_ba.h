@@ -167,6 +167,9 @@ typedef struct ppo_ba_options {
   double th_corner_norm;    /* thHuberConer2d Optimizer.cc:2783 */
   int32_t deterministic;    /* 1 = order-stable reductions where the backend has them (debug) */
   int32_t solver;           /* PPO_SOLVER_* */
+  int32_t eliminate_cuboids; /* 1 (default): cuboids are Schur-eliminated too and the dense system is poses only --
+                              * the same linear solve as the reference (which keeps them dense, Optimizer.cc:2172),
+                              * smaller factorisation; 0: cuboids stay in the dense system like the reference */
   /* multi-GPU (one process per GPU).  world_size<=1 = single GPU.  The 128-byte RCCL unique id is
    * created by rank 0 with ppo_ba_comm_unique_id() and broadcast by the caller. */
   int32_t device_id;        /* HIP device ordinal for this process */

@@ -68,56 +68,68 @@ __device__ __forceinline__ void mfma_sub_16(double (*M)[LP], int r0, int c0, con
   for (int reg = 0; reg < 4; ++reg) M[r0 + lk + 4 * reg][c0 + li] -= acc[reg];
 }
 
-// One wave factors the 16x16 block sL[o..o+16)[o..o+16) in place (lower) with the rows held in registers.
-// sInv[o+j] receives 1 / L_jj.  Returns the 1-based local index of the first non-positive pivot, 0 if none.
-__device__ __forceinline__ int potf2_16(double (*sL)[LP], double* sInv, int o) {
+// C[16x16] = X[16x16] * T[16x16] written to rows r0.., cols c0.. of M, where X = rows xr.., columns [xo, xo+16) of MX and
+// T is a 16x16 block stored [k][j] with row length 17.  In-place use (M == MX, same tile) is safe: the wave reads all of X
+// before it writes.  With T = L^-T this is the triangular solve X L^T = B.
+__device__ __forceinline__ void mfma_mul_16(double (*M)[LP], int r0, int c0, const double (*MX)[LP], int xr, int xo, const double (*T)[17]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m0 = 0; m0 < SB; m0 += 4) {
+    const double a = MX[xr + li][xo + m0 + lk];  // A[i = li][k = lk]
+    const double b = T[m0 + lk][li];             // B[k = lk][j = li]
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) M[r0 + lk + 4 * reg][c0 + li] = acc[reg];
+}
+
+// One wave factors the 16x16 block sL[o..o+16)[o..o+16) in place (lower) with the rows held in registers: lane r < 16
+// holds row r.  Lanes 16..31 carry the rows of an identity matrix through the SAME column operations (the Cholesky
+// elimination is a right-multiplication by L^-T), so they end up holding L^-T row by row at no extra instruction:
+// sT[i][c] = (L^-T)[i][c].  Returns the 1-based local index of the first non-positive pivot, 0 if none.
+__device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], double* sInv, int o) {
   const int lane = threadIdx.x & 63, r = lane & 15;
+  const bool ident = (lane & 16) != 0;
   double a[SB];
 #pragma unroll
-  for (int c = 0; c < SB; ++c) a[c] = sL[o + r][o + c];
+  for (int c = 0; c < SB; ++c) a[c] = ident ? (c == r ? 1.0 : 0.0) : sL[o + r][o + c];
   int bad = 0;
+  // Column sweep.  Measured on gfx950 (tools/chol_probe.hip): this wave is ISSUE-bound (~4.5 cycles per instruction,
+  // ~60 instructions per column: 2 v_readlane + 1 v_fma per rank-1 column update), not latency-bound -- interleaving the
+  // pivot chain with the updates by hand did not help, so the loop stays in its plain form; one scheduling barrier per
+  // column keeps the broadcasts from piling up in SGPRs (129 SGPR spills without it).
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
     const double d = bcast(a[j], j);
     if (!(d > 0.0) && bad == 0) bad = j + 1;
-    // 1/sqrt(d): hardware estimate + two Newton steps (quadratic: ~2^-26 -> 2^-52)
+    // 1/sqrt(d): v_rsq_f64 (measured 5e-8 relative) + two Newton steps y <- y (1.5 - (d/2) y^2): 3.8e-15, then 2.2e-16
+    const double h = 0.5 * d;
     double y = __builtin_amdgcn_rsq(d);
-    y = y * __builtin_fma(-0.5 * d * y, y, 1.5);
-    y = y * __builtin_fma(-0.5 * d * y, y, 1.5);
+    y = y * __builtin_fma(-h, y * y, 1.5);
+    y = y * __builtin_fma(-h, y * y, 1.5);
     const double l = a[j] * y;
     a[j] = l;
     if (lane == j) sInv[o + j] = y;
 #pragma unroll
     for (int c = j + 1; c < SB; ++c) a[c] = __builtin_fma(-l, bcast(l, c), a[c]);
-    __builtin_amdgcn_sched_barrier(0);  // keep each column step's broadcasts local: no SGPR spilling across steps
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (lane < SB) {
 #pragma unroll
     for (int c = 0; c < SB; ++c)
       if (c <= r) sL[o + r][o + c] = a[c];
+  } else if (lane < 2 * SB) {
+#pragma unroll
+    for (int c = 0; c < SB; ++c) sT[r][c] = a[c];
   }
   return bad;
 }
 
-// row `row` of M, columns [o, o+16):  x L^T = b with L = sL[o..][o..] (16x16 lower, inverse diagonal in sInv);
-// one lane per row, right-looking so that the updates pipeline.
-__device__ __forceinline__ void trsm_16(double (*M)[LP], int row, const double (*sL)[LP], const double* sInv, int o) {
-  double x[SB];
-#pragma unroll
-  for (int c = 0; c < SB; ++c) x[c] = M[row][o + c];
-#pragma unroll
-  for (int c = 0; c < SB; ++c) {
-    x[c] *= sInv[o + c];
-#pragma unroll
-    for (int c2 = c + 1; c2 < SB; ++c2) x[c2] = __builtin_fma(-x[c], sL[o + c2][o + c], x[c2]);
-  }
-#pragma unroll
-  for (int c = 0; c < SB; ++c) M[row][o + c] = x[c];
-}
-
-// Factor the 64x64 block held in sL (lower part valid) in place.  All 256 threads participate.
-// Returns (in every thread) the 1-based index of the first bad pivot or 0.
-__device__ int factor_64(double (*sL)[LP], double* sInv, int* sBad) {
+// Factor the 64x64 block held in sL (lower part valid) in place; sT[kk] receives L_kk^-T of the four 16x16 diagonal
+// blocks.  All 256 threads participate.  Returns (in every thread) the 1-based index of the first bad pivot or 0.
+__device__ int factor_64(double (*sL)[LP], double (*sT)[SB][17], double* sInv, int* sBad) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) *sBad = 0;
   __syncthreads();
@@ -125,14 +137,14 @@ __device__ int factor_64(double (*sL)[LP], double* sInv, int* sBad) {
   for (int kk = 0; kk < NB / SB; ++kk) {
     const int o = kk * SB;
     if (wave == 0) {
-      const int bad = potf2_16(sL, sInv, o);
+      const int bad = potf2_16(sL, sT[kk], sInv, o);
       if (lane == 0 && bad && *sBad == 0) *sBad = o + bad;
     }
     __syncthreads();
     STAMP(8 + 3 * kk);
-    const int below = NB - o - SB;  // rows under the diagonal sub-block
-    if (below == 0) break;
-    if (tid < below) trsm_16(sL, o + SB + tid, sL, sInv, o);
+    if (kk == NB / SB - 1) break;
+    // sub-diagonal tiles of this block column: X = B L^-T, one 16x16 tile per wave
+    if (kk + 1 + wave < NB / SB) mfma_mul_16(sL, (kk + 1 + wave) * SB, o, sL, (kk + 1 + wave) * SB, o, sT[kk]);
     __syncthreads();
     STAMP(9 + 3 * kk);
     // trailing 16x16 tiles (bi >= bj > kk): A[bi][bj] -= X_bi X_bj^T, tiles dealt round-robin to the 4 waves
@@ -168,15 +180,17 @@ __device__ __forceinline__ double bwd_vec_64(double v, const double (*sL)[LP], c
 __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld, int k0, double* __restrict__ rhs, int* __restrict__ info) {
   __shared__ double sL[NB][LP];
   __shared__ double sB[NB + 1][LP];  // row NB carries r_k^T: the forward substitution is one more row of the block solve
+  __shared__ double sT[NB / SB][SB][17];
   __shared__ double sInv[NB];
   __shared__ int sBad;
-  const int tid = threadIdx.x, b = blockIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, b = blockIdx.x, wave = tid >> 6, lane = tid & 63;
   const int row0 = k0 + b * NB;
   STAMP(0);
   {
     double2 td[8], tb[8];
     load_tile(&A[(size_t)k0 * ld + k0], ld, td);
     if (b > 0) load_tile(&A[(size_t)k0 * ld + row0], ld, tb);
+    const double rv = (tid < NB) ? rhs[k0 + tid] : 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
@@ -184,34 +198,50 @@ __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld
       sL[r + 1][c] = (r + 1 >= c) ? td[i].y : 0.0;
       if (b > 0) { sB[r][c] = tb[i].x; sB[r + 1][c] = tb[i].y; }
     }
+    if (tid < NB) sB[NB][tid] = rv;
   }
-  if (tid < NB) sB[NB][tid] = rhs[k0 + tid];
   __syncthreads();
   STAMP(1);
-  const int bad = factor_64(sL, sInv, &sBad);
+  const int bad = factor_64(sL, sT, sInv, &sBad);
   STAMP(2);
-  // X = B L_kk^-T by 16-wide block substitution: the 64 matrix rows of block b (b > 0) and always the rhs row
+  // X = B L_kk^-T by 16-wide block substitution.  Wave w owns rows 16w..16w+15 of the block for the whole sweep (its
+  // tiles only read the shared L / L^-T), so the four waves run without any workgroup barrier; wave 3 also carries the
+  // right-hand-side row.
 #pragma unroll
   for (int kk = 0; kk < NB / SB; ++kk) {
     const int o = kk * SB;
-    if (b > 0 && tid < NB) trsm_16(sB, tid, sL, sInv, o);
-    if (tid == NB) trsm_16(sB, NB, sL, sInv, o);
-    __syncthreads();
-    if (kk == NB / SB - 1) break;
-    // B[:, o+16:] -= X[:, o:o+16] * L[o+16:, o:o+16]^T     (4 row tiles x (3-kk) column tiles; wave = row tile)
     if (b > 0) {
+      mfma_mul_16(sB, wave * SB, o, sB, wave * SB, o, sT[kk]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int ct = kk + 1; ct < NB / SB; ++ct) mfma_sub_16(sB, wave * SB, ct * SB, sB, wave * SB, sL, ct * SB, o);
     }
-    if (tid >= 192 && tid < 192 + NB - o - SB) {  // the rhs row, one lane per remaining column
-      const int c = o + SB + (tid - 192);
-      double s = 0.0;
+    if (wave == 3) {  // rhs row: x = b T (16 lanes), then b[rest] -= x L[rest]^T (48 lanes at most)
+      double xv = 0.0;
+      if (lane < SB) {
 #pragma unroll
-      for (int m = 0; m < SB; ++m) s = __builtin_fma(sB[NB][o + m], sL[c][o + m], s);
-      sB[NB][c] -= s;
+        for (int m = 0; m < SB; ++m) xv = __builtin_fma(sB[NB][o + m], sT[kk][m][lane], xv);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < SB) sB[NB][o + lane] = xv;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < NB - o - SB) {
+        const int c = o + SB + lane;
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m < SB; ++m) sacc = __builtin_fma(sB[NB][o + m], sL[c][o + m], sacc);
+        sB[NB][c] -= sacc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();
   }
+  __syncthreads();
   STAMP(3);
   if (b == 0) {
     if (bad && tid == 0) atomicCAS(info, 0, k0 + bad);
@@ -223,16 +253,17 @@ __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld
     if (tid < NB) rhs[k0 + tid] = sB[NB][tid];  // y_k
     return;
   }
+  const double rold = (tid < NB) ? rhs[row0 + tid] : 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
     *reinterpret_cast<double2*>(&A[(size_t)(k0 + c) * ld + row0 + r]) = make_double2(sB[r][c], sB[r + 1][c]);
   }
   if (tid < NB) {  // r_b -= L_bk y_k
-    double s = 0.0;
+    double sacc = 0.0;
 #pragma unroll 16
-    for (int m = 0; m < NB; ++m) s = __builtin_fma(sB[tid][m], sB[NB][m], s);
-    rhs[row0 + tid] -= s;
+    for (int m = 0; m < NB; ++m) sacc = __builtin_fma(sB[tid][m], sB[NB][m], sacc);
+    rhs[row0 + tid] = rold - sacc;
   }
   STAMP(4);
 }
@@ -300,14 +331,17 @@ __global__ __launch_bounds__(256) void chol_back(const double* __restrict__ A, i
   __shared__ double sInv[NB], sV[NB];
   const int tid = threadIdx.x, j = blockIdx.x;
   const int nblk_above = k0 / NB;
-  // the block of L this workgroup multiplies by x_k, fetched before the serial part
+  // every global load is issued before the serial part
   const int c = tid >> 2, part = tid & 3;  // 4 threads per column, 16 rows each
   double lcol[16];
+  double vold = 0.0, dia = 1.0, vk = 0.0;
   if (j < nblk_above) {
     const double* col = &A[(size_t)(j * NB + c) * ld + k0 + part * 16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) lcol[r] = col[r];
+    if (part == 0) vold = rhs[j * NB + c];
   }
+  if (tid < NB) { dia = A[(size_t)(k0 + tid) * ld + k0 + tid]; vk = rhs[k0 + tid]; }
   {
     double2 td[8];
     load_tile(&A[(size_t)k0 * ld + k0], ld, td);
@@ -318,18 +352,21 @@ __global__ __launch_bounds__(256) void chol_back(const double* __restrict__ A, i
       sL[r + 1][cc] = (r + 1 >= cc) ? td[i].y : 0.0;
     }
   }
-  if (tid < NB) sInv[tid] = 1.0 / A[(size_t)(k0 + tid) * ld + k0 + tid];
+  if (tid < NB) sInv[tid] = 1.0 / dia;
   __syncthreads();
-  if (tid < 64) sV[tid] = bwd_vec_64(rhs[k0 + tid], sL, sInv);
+  if (tid < 64) {
+    const double xk = bwd_vec_64(vk, sL, sInv);
+    sV[tid] = xk;
+    if (j == 0) rhs[k0 + tid] = xk;
+  }
   __syncthreads();
-  if (j == 0 && tid < NB) rhs[k0 + tid] = sV[tid];
   if (j < nblk_above) {
-    double s = 0.0;
+    double sacc = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s = __builtin_fma(lcol[r], sV[part * 16 + r], s);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (part == 0) rhs[j * NB + c] -= s;
+    for (int r = 0; r < 16; ++r) sacc = __builtin_fma(lcol[r], sV[part * 16 + r], sacc);
+    sacc += __shfl_xor(sacc, 1, 64);
+    sacc += __shfl_xor(sacc, 2, 64);
+    if (part == 0) rhs[j * NB + c] = vold - sacc;
   }
 }
 

@@ -121,6 +121,17 @@ struct Graph {
   double* xr;    // [n_red]
   double* acc;   // [ACC_N]
   // landmark range owned by this rank (multi-GPU) -- single GPU: [0, n_points) and [0, n_planes)
+  // cuboid elimination (second-level Schur complement on the 9x9 cuboid blocks; the dense system is poses only)
+  int elim_cub;
+  const int32_t* cub_edge_off;  // [Nc+1] bbox / corner edges of a cuboid ...
+  const int32_t* cub_edges;     // ... as (edge index << 1) | is_corner
+  const int32_t* cp_cub;        // [n_cub_pairs] cuboid of an (edge a >= edge b) pair
+  const int32_t* cp_a;          // [n_cub_pairs] position of a in cub_edges
+  const int32_t* cp_b;
+  int n_cub_pairs;
+  double* cub_Linv;             // [Nc][81] inverse Cholesky factor of Hcc + lambda I (row-major, lower)
+  double* cub_u;                // [Nc][9]  Linv b_c
+  double* xc;                   // [Nc][9]  cuboid update
   int pt_first, pt_last, plane_first, plane_last;
   int owns_reduced;  // 1 on the rank that adds Hcc / lambda / cuboid terms
 };
@@ -592,14 +603,14 @@ struct PtCubModel {  // unary: cols 0-8 cuboid
 // 16 lanes per edge, 16 edges per 256-thread block; lane c < NCOL differentiates column c, lane 15 evaluates the
 // base residual (base_binary_edge.hpp:217-320, base_unary_edge.hpp:82-123, then :55-120 / :43-72).
 template <class Model>
-__global__ __launch_bounds__(256) void k_lin_numeric(Graph g, State st, int n_edges, bool corner, double delta) {
+__device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st, int n_edges, bool corner, double delta, int vblock) {
   constexpr int DM = Model::DIM_MAX, NC = Model::NCOL;
   __shared__ double sJ[16][DM][16];  // [group][row][col]
   __shared__ double sW[16][DM], sG[16][DM];
   __shared__ double s_red[4];
   const Model m{g, corner};
   const int grp = threadIdx.x >> 4, lane = threadIdx.x & 15;
-  const int i = blockIdx.x * 16 + grp;
+  const int i = vblock * 16 + grp;
   const bool act = i < n_edges && m.active(i);
   const int dim = act ? m.dim(i) : 0;
   double chi_local = 0.0;
@@ -640,11 +651,11 @@ __global__ __launch_bounds__(256) void k_lin_numeric(Graph g, State st, int n_ed
 }
 
 template <class Model>
-__global__ __launch_bounds__(256) void k_chi2_numeric(Graph g, State st, int n_edges, bool corner) {
+__device__ __forceinline__ void chi2_numeric_body(const Graph& g, const State& st, int n_edges, bool corner, int vblock) {
   constexpr int DM = Model::DIM_MAX;
   __shared__ double s_red[4];
   const Model m{g, corner};
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = vblock * blockDim.x + threadIdx.x;
   double chi_local = 0.0;
   if (i < n_edges && m.active(i)) {
     double e0[DM];
@@ -658,6 +669,33 @@ __global__ __launch_bounds__(256) void k_chi2_numeric(Graph g, State st, int n_e
     chi_local = rho0;
   }
   block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+}
+
+// All numerically differentiated edge classes in ONE launch (they are tiny and latency-bound: 4000 plane, 500 bbox,
+// 50 point-cuboid edges at the BASELINE size), block ranges select the model.  Runs on a side stream next to the
+// reprojection kernels.
+struct NumericPlan {
+  int nb_plane, nb_bbox, nb_corner, nb_ptcub;  // workgroups per edge class
+};
+__global__ __launch_bounds__(256) void k_lin_numeric_all(Graph g, State st, NumericPlan np, double delta) {
+  int b = blockIdx.x;
+  if (b < np.nb_plane) { lin_numeric_body<PlaneModel>(g, st, g.n_pl, false, delta, b); return; }
+  b -= np.nb_plane;
+  if (b < np.nb_bbox) { lin_numeric_body<CubProjModel>(g, st, g.n_bbox, false, delta, b); return; }
+  b -= np.nb_bbox;
+  if (b < np.nb_corner) { lin_numeric_body<CubProjModel>(g, st, g.n_corner, true, delta, b); return; }
+  b -= np.nb_corner;
+  lin_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, delta, b);
+}
+__global__ __launch_bounds__(256) void k_chi2_numeric_all(Graph g, State st, NumericPlan np) {
+  int b = blockIdx.x;
+  if (b < np.nb_plane) { chi2_numeric_body<PlaneModel>(g, st, g.n_pl, false, b); return; }
+  b -= np.nb_plane;
+  if (b < np.nb_bbox) { chi2_numeric_body<CubProjModel>(g, st, g.n_bbox, false, b); return; }
+  b -= np.nb_bbox;
+  if (b < np.nb_corner) { chi2_numeric_body<CubProjModel>(g, st, g.n_corner, true, b); return; }
+  b -= np.nb_corner;
+  chi2_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, b);
 }
 
 // max |H_jj| over every active diagonal (computeLambdaInit, levenberg.cpp:166-180)
@@ -704,6 +742,7 @@ __global__ void k_assemble(Graph g, double lambda) {
     return;
   }
   int j = i - nP;
+  if (g.elim_cub) return;  // cuboid blocks enter through k_cub_schur instead
   if (j < nC) {
     if (!g.owns_reduced) return;
     const int cb = j / 54, k = j % 54;
@@ -848,6 +887,127 @@ __global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
   }
 }
 
+// ---- cuboid elimination -------------------------------------------------------------------------------------------
+// The reference keeps the 9-DoF cuboids in the dense system (they are not marginalised, Optimizer.cc:2172).  Here they
+// are eliminated like landmarks: Dc = Hcc + lambda I = Lc Lc', S_pp -= sum_{a,b} (W_a Lc^-T)(W_b Lc^-T)', which is the
+// same linear solve with a smaller dense factorisation (BASELINE.json north_star asks for exactly this).
+__device__ __forceinline__ const CubEdge& cub_edge_of(const Graph& g, int code) { return (code & 1) ? g.corner[code >> 1] : g.bbox[code >> 1]; }
+__device__ __forceinline__ const double* wpc_of(const Graph& g, int code) { return ((code & 1) ? g.Wpc_corner : g.Wpc_bbox) + (size_t)(code >> 1) * 54; }
+
+__global__ void k_cub_prep(Graph g, double lambda) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= g.n_cuboids || g.cub_col[c] < 0) return;
+  double L[9][9];
+  const double* hc = &g.HC[(size_t)c * 54];
+  for (int r = 0; r < 9; ++r)
+    for (int k = 0; k <= r; ++k) L[r][k] = hc[packed_lower(r, k)] + (r == k ? lambda : 0.0);
+  for (int j = 0; j < 9; ++j) {  // in-place Cholesky, lower
+    double d = L[j][j];
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    const double ljj = sqrt(d);  // NaN if not positive: propagates to S and fails the dense factorisation
+    L[j][j] = ljj;
+    for (int i = j + 1; i < 9; ++i) {
+      double v = L[i][j];
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      L[i][j] = v / ljj;
+    }
+  }
+  double* Li = &g.cub_Linv[(size_t)c * 81];
+  for (int j = 0; j < 9; ++j) {  // column j of L^-1 by forward substitution
+    for (int i = 0; i < j; ++i) Li[i * 9 + j] = 0.0;
+    Li[j * 9 + j] = 1.0 / L[j][j];
+    for (int i = j + 1; i < 9; ++i) {
+      double v = 0.0;
+      for (int k = j; k < i; ++k) v -= L[i][k] * Li[k * 9 + j];
+      Li[i * 9 + j] = v / L[i][i];
+    }
+  }
+  for (int n = 0; n < 9; ++n) {
+    double v = 0.0;
+    for (int m = 0; m <= n; ++m) v += Li[n * 9 + m] * hc[45 + m];
+    g.cub_u[(size_t)c * 9 + n] = v;
+  }
+}
+__device__ __forceinline__ void cub_make_Z(const double* W, const double* Li, double (*Z)[9]) {  // Z = W Linv'
+  for (int a = 0; a < 6; ++a)
+    for (int n = 0; n < 9; ++n) {
+      double v = 0.0;
+      for (int m = 0; m <= n; ++m) v += W[a * 9 + m] * Li[n * 9 + m];
+      Z[a][n] = v;
+    }
+}
+// one thread per (edge a >= edge b) pair of one cuboid
+__global__ void k_cub_schur(Graph g) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g.n_cub_pairs) return;
+  const int c = g.cp_cub[t];
+  const int ca = g.cub_edges[g.cp_a[t]], cb = g.cub_edges[g.cp_b[t]];
+  const CubEdge& ea = cub_edge_of(g, ca);
+  const CubEdge& eb = cub_edge_of(g, cb);
+  if (!(ea.flags & F_ACTIVE) || !(eb.flags & F_ACTIVE)) return;
+  const int cola = g.pose_col[ea.pose], colb = g.pose_col[eb.pose];
+  if (cola < 0 || colb < 0) return;
+  const double* Li = &g.cub_Linv[(size_t)c * 81];
+  double Za[6][9], Zb[6][9];
+  cub_make_Z(wpc_of(g, ca), Li, Za);
+  const bool self = ca == cb;
+  if (!self) cub_make_Z(wpc_of(g, cb), Li, Zb);
+  const int n = g.ld;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double m = 0.0;  // M[i][j] = (Za Zb')[i][j]: row index on pose a, column index on pose b
+      for (int q = 0; q < 9; ++q) m += Za[i][q] * (self ? Za[j][q] : Zb[j][q]);
+      if (self) {
+        if (i >= j) atomicAdd(&g.S[(size_t)(cola + j) * n + cola + i], -m);
+      } else if (cola > colb) {
+        atomicAdd(&g.S[(size_t)(colb + j) * n + cola + i], -m);
+      } else if (cola < colb) {
+        atomicAdd(&g.S[(size_t)(cola + i) * n + colb + j], -m);
+      } else {  // two different edges on the same keyframe: M + M' lands in one diagonal block
+        if (i >= j) atomicAdd(&g.S[(size_t)(cola + j) * n + cola + i], -m);
+        if (j >= i) atomicAdd(&g.S[(size_t)(cola + i) * n + cola + j], -m);
+      }
+    }
+  if (self) {
+    const double* u = &g.cub_u[(size_t)c * 9];
+    for (int i = 0; i < 6; ++i) {
+      double v = 0.0;
+      for (int q = 0; q < 9; ++q) v += Za[i][q] * u[q];
+      atomicAdd(&g.bs[cola + i], -v);
+    }
+  }
+}
+// x_c = Dc^-1 (b_c - sum_e W_e' x_p(e))
+__global__ void k_cub_backsub(Graph g) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= g.n_cuboids || g.cub_col[c] < 0) return;
+  double t[9];
+  for (int n = 0; n < 9; ++n) t[n] = g.HC[(size_t)c * 54 + 45 + n];
+  for (int q = g.cub_edge_off[c]; q < g.cub_edge_off[c + 1]; ++q) {
+    const int code = g.cub_edges[q];
+    const CubEdge& e = cub_edge_of(g, code);
+    const int col = g.pose_col[e.pose];
+    if (!(e.flags & F_ACTIVE) || col < 0) continue;
+    const double* W = wpc_of(g, code);
+    for (int a = 0; a < 6; ++a) {
+      const double xa = g.xr[col + a];
+      for (int n = 0; n < 9; ++n) t[n] -= W[a * 9 + n] * xa;
+    }
+  }
+  const double* Li = &g.cub_Linv[(size_t)c * 81];
+  double y[9];
+  for (int n = 0; n < 9; ++n) {
+    double v = 0.0;
+    for (int m = 0; m <= n; ++m) v += Li[n * 9 + m] * t[m];
+    y[n] = v;
+  }
+  for (int m = 0; m < 9; ++m) {
+    double v = 0.0;
+    for (int n = m; n < 9; ++n) v += Li[n * 9 + m] * y[n];
+    g.xc[(size_t)c * 9 + m] = v;
+  }
+}
+
 // poses and cuboids: trial = cur [+] x ; scale += x (lambda x + b)   (computeScale, levenberg.cpp:182-189)
 __global__ void k_update_reduced(Graph g, State cur, State trial, double lambda) {
   __shared__ double s_red[4];
@@ -870,7 +1030,7 @@ __global__ void k_update_reduced(Graph g, State cur, State trial, double lambda)
     const int col = g.cub_col[k];
     Cub c = load_cub(&cur.cub[10 * k]);
     if (col >= 0) {
-      const double* x = &g.xr[col];
+      const double* x = g.elim_cub ? &g.xc[9 * k] : &g.xr[col];
       const double* fs = &g.cub_fixedscale[3 * k];
       c = cuboid_boxplus(c, x, g.cub_flags[k], fs[0], fs[1], fs[2]);
       if (g.owns_reduced) {

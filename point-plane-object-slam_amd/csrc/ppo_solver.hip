@@ -69,6 +69,8 @@ struct ppo_ba_solver {
   ppo_ba_options opt;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;        // the small numerically differentiated edge classes run here, next to the point kernels
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   rocblas_handle blas = nullptr;
   Comm comm;
   int n_cubpl = 0;
@@ -107,6 +109,8 @@ struct ppo_ba_solver {
   DevBuf<int32_t> d_po_start, d_po_end, d_po_pose;  // pose-major chunks of the reprojection edges
   PoseChunks posec{};
   DevBuf<double> d_W;
+  DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cp_cub, d_cp_a, d_cp_b;  // cuboid elimination plan
+  DevBuf<double> d_cub_Linv, d_cub_u, d_xc;
   DevBuf<int> d_info;
   size_t state_doubles = 0;
   double* h_pinned = nullptr;  // ACC_N doubles then one int
@@ -220,9 +224,14 @@ void free_all(ppo_ba_solver* s) {
   s->d_S.release(); s->d_bs.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
+  s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release();
+  s->d_cub_Linv.release(); s->d_cub_u.release(); s->d_xc.release();
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
   if (s->blas) rocblas_destroy_handle(s->blas);
   s->comm.destroy();
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->side) (void)hipStreamDestroy(s->side);
   if (s->stream) (void)hipStreamDestroy(s->stream);
 }
 
@@ -273,6 +282,21 @@ int launch_linearize(ppo_ba_solver* s) {
   if (s->zD_n) HIP_TRY(hipMemsetAsync(A + s->zD_off, 0, s->zD_n * sizeof(double), s->stream));
   if (s->zbl_n) HIP_TRY(hipMemsetAsync(A + s->zbl_off, 0, s->zbl_n * sizeof(double), s->stream));
   if (s->zW_n) HIP_TRY(hipMemsetAsync(s->d_W.p + s->zW_off, 0, s->zW_n * sizeof(double), s->stream));
+  // fork: the numerically differentiated edge classes (one merged launch) run on the side stream
+  NumericPlan np{};
+  np.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, 16) : 0;
+  if (g.owns_reduced) {
+    np.nb_bbox = g.n_bbox ? nblk(g.n_bbox, 16) : 0;
+    np.nb_corner = g.n_corner ? nblk(g.n_corner, 16) : 0;
+    np.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, 16) : 0;
+  }
+  const int nb_num = np.nb_plane + np.nb_bbox + np.nb_corner + np.nb_ptcub;
+  if (nb_num > 0) {
+    HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+    hipLaunchKernelGGL(k_lin_numeric_all, dim3(nb_num), dim3(256), 0, s->side, g, st, np, s->opt.numeric_delta);
+    HIP_TRY(hipEventRecord(s->ev_join, s->side));
+  }
   const int npts = g.pt_last - g.pt_first;
   if (npts > 0) {
     const int grid = std::min(nblk(npts, 256), 2 * s->n_cu);
@@ -280,14 +304,7 @@ int launch_linearize(ppo_ba_solver* s) {
     else hipLaunchKernelGGL(k_lin_points<false>, dim3(grid), dim3(256), 0, s->stream, g, st);
     if (s->posec.n_chunks > 0) hipLaunchKernelGGL(k_lin_poses, dim3(nblk(s->posec.n_chunks, 4)), dim3(256), 0, s->stream, g, st, s->posec);
   }
-  const double delta = s->opt.numeric_delta;
-  if (g.plane_last > g.plane_first && g.n_pl > 0)
-    hipLaunchKernelGGL(k_lin_numeric<PlaneModel>, dim3(nblk(g.n_pl, 16)), dim3(256), 0, s->stream, g, st, g.n_pl, false, delta);
-  if (g.owns_reduced) {
-    if (g.n_bbox) hipLaunchKernelGGL(k_lin_numeric<CubProjModel>, dim3(nblk(g.n_bbox, 16)), dim3(256), 0, s->stream, g, st, g.n_bbox, false, delta);
-    if (g.n_corner) hipLaunchKernelGGL(k_lin_numeric<CubProjModel>, dim3(nblk(g.n_corner, 16)), dim3(256), 0, s->stream, g, st, g.n_corner, true, delta);
-    if (g.n_ptcub) hipLaunchKernelGGL(k_lin_numeric<PtCubModel>, dim3(nblk(g.n_ptcub, 16)), dim3(256), 0, s->stream, g, st, g.n_ptcub, false, delta);
-  }
+  if (nb_num > 0) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -296,13 +313,15 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
   const Graph& g = s->g;
   const int npts = g.pt_last - g.pt_first;
   if (npts > 0) hipLaunchKernelGGL(k_chi2_points, dim3(std::min(nblk(npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
-  if (g.plane_last > g.plane_first && g.n_pl > 0)
-    hipLaunchKernelGGL(k_chi2_numeric<PlaneModel>, dim3(nblk(g.n_pl, 256)), dim3(256), 0, s->stream, g, st, g.n_pl, false);
+  NumericPlan np{};
+  np.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, 256) : 0;
   if (g.owns_reduced) {
-    if (g.n_bbox) hipLaunchKernelGGL(k_chi2_numeric<CubProjModel>, dim3(nblk(g.n_bbox, 256)), dim3(256), 0, s->stream, g, st, g.n_bbox, false);
-    if (g.n_corner) hipLaunchKernelGGL(k_chi2_numeric<CubProjModel>, dim3(nblk(g.n_corner, 256)), dim3(256), 0, s->stream, g, st, g.n_corner, true);
-    if (g.n_ptcub) hipLaunchKernelGGL(k_chi2_numeric<PtCubModel>, dim3(nblk(g.n_ptcub, 256)), dim3(256), 0, s->stream, g, st, g.n_ptcub, false);
+    np.nb_bbox = g.n_bbox ? nblk(g.n_bbox, 256) : 0;
+    np.nb_corner = g.n_corner ? nblk(g.n_corner, 256) : 0;
+    np.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, 256) : 0;
   }
+  const int nb_num = np.nb_plane + np.nb_bbox + np.nb_corner + np.nb_ptcub;
+  if (nb_num > 0) hipLaunchKernelGGL(k_chi2_numeric_all, dim3(nb_num), dim3(256), 0, s->stream, g, st, np);
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -320,6 +339,10 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
     hipLaunchKernelGGL(k_schur_prep, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, lambda);
     if (g.n_slots > 0) hipLaunchKernelGGL(k_schur_z, dim3(nblk(g.n_slots, 256)), dim3(256), 0, s->stream, g);
     if (s->pc.n_chunks > 0) hipLaunchKernelGGL(k_schur_pairs, dim3(nblk(s->pc.n_chunks, 4)), dim3(256), 0, s->stream, g, s->pc);
+  }
+  if (g.elim_cub && g.owns_reduced && g.n_cuboids > 0) {
+    hipLaunchKernelGGL(k_cub_prep, dim3(nblk(g.n_cuboids, 64)), dim3(64), 0, s->stream, g, lambda);
+    if (g.n_cub_pairs > 0) hipLaunchKernelGGL(k_cub_schur, dim3(nblk(g.n_cub_pairs, 64)), dim3(64), 0, s->stream, g);
   }
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
@@ -347,6 +370,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   const Graph& g = s->g;
   const State& cur = s->st[s->cur];
   const State& tr = s->st[s->cur ^ 1];
+  if (g.elim_cub && g.n_cuboids > 0) hipLaunchKernelGGL(k_cub_backsub, dim3(nblk(g.n_cuboids, 64)), dim3(64), 0, s->stream, g);
   hipLaunchKernelGGL(k_update_reduced, dim3(nblk(g.n_poses + g.n_cuboids, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
   if (nl > 0) hipLaunchKernelGGL(k_backsub, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
@@ -482,6 +506,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return fail(PPO_BA_ERR_HIP);
+  if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess) return fail(PPO_BA_ERR_HIP);
+  if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail(PPO_BA_ERR_HIP);
   if (rocblas_create_handle(&s->blas) != rocblas_status_success) return fail(PPO_BA_ERR_SOLVER);
   rocblas_set_stream(s->blas, s->stream);
   if (s->comm.init(o->comm_id, o->rank, o->world_size)) return fail(PPO_BA_ERR_COMM);
@@ -506,15 +532,20 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   int nfree = 0;
   for (int i = 0; i < Np; ++i)
     if (!p->pose_fixed[i] && pose_used[i]) { pose_free_id[i] = nfree; pose_col[i] = 6 * nfree; ++nfree; }
-  int ncol = 6 * nfree;
+  int ncol = 6 * nfree, n_cub_used = 0;
+  g.elim_cub = o->eliminate_cuboids ? 1 : 0;
   for (int i = 0; i < Nc; ++i)
-    if (cub_used[i]) { cub_col[i] = ncol; ncol += 9; }
+    if (cub_used[i]) {
+      ++n_cub_used;
+      if (g.elim_cub) cub_col[i] = 0;  // marker only: eliminated cuboids have no column in the dense system
+      else { cub_col[i] = ncol; ncol += 9; }
+    }
   g.n_pose_free = nfree;
   g.n_red = ncol;
   g.ld = chol_padded_ld(ncol);
   const int ld = g.ld;
   g.n_lm = Npt + Npl;
-  s->stats.n_reduced = ncol;
+  s->stats.n_reduced = 6 * nfree + 9 * n_cub_used;  // the reference's reduced dimension (cuboids are not marginalised there)
 
   // ---- reprojection edges sorted by point (stable counting sort), CSR offsets -------------------------
   auto csr_sort = [&](int n, const int32_t* key, std::vector<int32_t>& off, std::vector<int32_t>& perm) {
@@ -749,6 +780,23 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   for (int k = 0; k < p->n_mono; ++k) h_mono_flags[k] = s->h_mono[k].flags;
   for (int k = 0; k < p->n_stereo; ++k) h_stereo_flags[k] = s->h_stereo[k].flags;
 
+  // ---- cuboid elimination plan: edges per cuboid and all (a >= b) pairs of them -----------------------------------------
+  std::vector<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cp_cub, cp_a, cp_b;
+  {
+    std::vector<std::vector<int32_t>> per(Nc);
+    for (int e = 0; e < p->n_bbox; ++e) per[p->bbox_cuboid[e]].push_back(e << 1);
+    for (int e = 0; e < p->n_corner; ++e) per[p->corner_cuboid[e]].push_back((e << 1) | 1);
+    for (int c = 0; c < Nc; ++c) {
+      cub_edge_off[c] = (int32_t)cub_edges.size();
+      cub_edges.insert(cub_edges.end(), per[c].begin(), per[c].end());
+    }
+    cub_edge_off[Nc] = (int32_t)cub_edges.size();
+    if (g.elim_cub)
+      for (int c = 0; c < Nc; ++c)
+        for (int a = cub_edge_off[c]; a < cub_edge_off[c + 1]; ++a)
+          for (int b = cub_edge_off[c]; b <= a; ++b) { cp_cub.push_back(c); cp_a.push_back(a); cp_b.push_back(b); }
+  }
+
   // ---- initial estimates, canonicalised like the reference's converters ------------------------------------------
   s->state_doubles = (size_t)Np * 19 + (size_t)Npt * 3 + (size_t)Npl * 4 + (size_t)Nc * 10;
   std::vector<double> h_state(s->state_doubles, 0.0);
@@ -802,6 +850,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_C.alloc(nD) && s->d_ul.alloc(nbl) && s->d_Z.alloc(nW);
   ok = ok && s->d_S.alloc((size_t)ld * ld) && s->d_bs.alloc(ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
+  ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream);
+  ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
+  ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_u.alloc((size_t)Nc * 9) && s->d_xc.alloc((size_t)Nc * 9);
   ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
   ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream);
   s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, (int)pc_colj.size()};
@@ -839,6 +890,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (nW) (void)hipMemsetAsync(s->d_W.p, 0, nW * sizeof(double), s->stream);
   }
   g.Wpc_bbox = s->d_Wpc.p; g.Wpc_corner = s->d_Wpc.p + (size_t)p->n_bbox * 54;
+  g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p;
+  g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_u = s->d_cub_u.p; g.xc = s->d_xc.p;
   g.Dinv = s->d_Dinv.p; g.C = s->d_C.p; g.ul = s->d_ul.p; g.Z = s->d_Z.p; g.S = s->d_S.p; g.bs = s->d_bs.p; g.xr = s->d_xr.p;
   s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
   s->st[1] = make_state(s->d_state[1].p, Np, Npt, Npl, Nc);

@@ -46,7 +46,7 @@ class COptions(C.Structure):
         ("numeric_delta", C.c_double), ("jacobian_mode", C.c_int32),
         ("chi2_mono", C.c_double), ("chi2_stereo", C.c_double), ("chi2_plane", C.c_double), ("chi2_plane_vp", C.c_double),
         ("th_bbox_norm", C.c_double), ("th_corner_norm", C.c_double),
-        ("deterministic", C.c_int32), ("solver", C.c_int32),
+        ("deterministic", C.c_int32), ("solver", C.c_int32), ("eliminate_cuboids", C.c_int32),
         ("device_id", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
         ("comm_id", C.c_uint8 * 128), ("verbose", C.c_int32),
     ]
@@ -285,7 +285,7 @@ def default_options(**over):
     o.numeric_delta, o.jacobian_mode = 1e-9, 0
     o.chi2_mono, o.chi2_stereo, o.chi2_plane, o.chi2_plane_vp = 5.991, 7.815, 500.0, 200.0
     o.th_bbox_norm, o.th_corner_norm = 80.0, 10.0
-    o.deterministic, o.solver = 0, 0
+    o.deterministic, o.solver, o.eliminate_cuboids = 0, 0, 1
     o.device_id, o.rank, o.world_size, o.verbose = 0, 0, 1, 0
     for k, v in over.items():
         setattr(o, k, v)

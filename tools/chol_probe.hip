@@ -10,7 +10,22 @@ __device__ long long g_stamps[32];
 #define STAMP(i) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
 #include "../point-plane-object-slam_amd/csrc/ppo_chol.hip"
 
+__global__ void rsq_acc(double* out) {
+  const double d = 1.0 + 1e-3 * (threadIdx.x + 256.0 * blockIdx.x) * (1.0 + 0.37 * threadIdx.x);
+  const double h = 0.5 * d;
+  double y = __builtin_amdgcn_rsq(d);
+  const double e0 = fabs(y * sqrt(d) - 1.0);
+  y = y * __builtin_fma(-h, y * y, 1.5);
+  const double e1 = fabs(y * sqrt(d) - 1.0);
+  y = y * __builtin_fma(-h, y * y, 1.5);
+  const double e2 = fabs(y * sqrt(d) - 1.0);
+  atomicMax((unsigned long long*)&out[0], (unsigned long long)__double_as_longlong(e0));
+  atomicMax((unsigned long long*)&out[1], (unsigned long long)__double_as_longlong(e1));
+  atomicMax((unsigned long long*)&out[2], (unsigned long long)__double_as_longlong(e2));
+}
 int main() {
+  { double* o; hipMalloc((void**)&o, 32); hipMemset(o, 0, 32); hipLaunchKernelGGL(rsq_acc, dim3(64), dim3(256), 0, 0, o); double h[3]; hipMemcpy(h, o, 24, hipMemcpyDeviceToHost);
+    printf("v_rsq_f64 max rel err: raw %.3e, 1 Newton %.3e, 2 Newton %.3e\n", h[0], h[1], h[2]); }
   const int n = 1664;
   std::vector<double> A((size_t)n * n, 0.0), b(n, 1.0);
   srand(1);
