@@ -115,7 +115,7 @@ struct Graph {
   double* Dinv;  // [n_lm][6] (D + lambda I)^-1, packed upper
   double* C;     // [n_lm][6] inverse Cholesky factor of D + lambda I (i00 i10 i11 i20 i21 i22): Dinv = Linv' Linv
   double* ul;    // [n_lm][3] Linv b_l
-  double* Z;     // [n_slots][18] W Linv'  (so that W Dinv W' = Z Z')
+  double* Z;     // [n_slots][18] W Linv'  (so that W Dinv W' = Z Z'); measured: a plane-by-plane (SoA) layout is slower here
   double* S;     // [n_red][n_red] column-major, lower triangle
   double* bs;    // [n_red]
   double* xr;    // [n_red]
@@ -131,6 +131,7 @@ struct Graph {
   int n_cub_pairs;
   double* cub_Linv;             // [Nc][81] inverse Cholesky factor of Hcc + lambda I (row-major, lower)
   double* cub_u;                // [Nc][9]  Linv b_c
+  double* cub_Z;                // [n cuboid edges][54] W Linv' per bbox / corner edge
   double* xc;                   // [Nc][9]  cuboid update
   int pt_first, pt_last, plane_first, plane_last;
   int owns_reduced;  // 1 on the rank that adds Hcc / lambda / cuboid terms
@@ -698,6 +699,27 @@ __global__ __launch_bounds__(256) void k_chi2_numeric_all(Graph g, State st, Num
   chi2_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, b);
 }
 
+// One launch zeroes every accumulator range of a phase (instead of one memset node per range).
+struct ZeroPlan {
+  double* p[6];
+  unsigned long long n[6];  // doubles
+};
+__global__ __launch_bounds__(256) void k_zero_ranges(ZeroPlan zp) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double* p = zp.p[r];
+    const size_t n = zp.n[r];
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      double2* p2 = reinterpret_cast<double2*>(p);
+      for (size_t i = t0; i < n / 2; i += stride) p2[i] = make_double2(0.0, 0.0);
+      if (t0 == 0 && (n & 1)) p[n - 1] = 0.0;
+    } else {
+      for (size_t i = t0; i < n; i += stride) p[i] = 0.0;
+    }
+  }
+}
+
 // max |H_jj| over every active diagonal (computeLambdaInit, levenberg.cpp:166-180)
 __global__ void k_maxdiag(Graph g) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -840,7 +862,13 @@ struct PairChunks {
 __global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
   __shared__ double s_buf[4][21][65];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + wave;  // one wave per chunk of one pose pair
+  // One wave per chunk of one pose pair.  Chunks are ordered by (pose j, pose i) and every Z record is needed by ~7
+  // pairs, so the launch is made XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only),
+  // and each XCD is given a CONTIGUOUS range of chunks -- the Z segments of "its" keyframes then stay in its 4 MB L2
+  // instead of being streamed from HBM once per pair (264 MB -> ~36 MB at the BASELINE size).
+  const int per_xcd = (gridDim.x + 7) >> 3;
+  const int vb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int t = vb * 4 + wave;
   if (t >= pc.n_chunks) return;
   const int e1 = pc.start[t + 1];
   const int colj = pc.colj[t], coli = pc.coli[t];
@@ -936,76 +964,100 @@ __device__ __forceinline__ void cub_make_Z(const double* W, const double* Li, do
       Z[a][n] = v;
     }
 }
-// one thread per (edge a >= edge b) pair of one cuboid
+// Z = W Linv' of one cuboid edge: one thread per (edge, row)
+__global__ void k_cub_z(Graph g) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = t / 6, a = t - 6 * q;
+  if (q >= g.cub_edge_off[g.n_cuboids]) return;
+  const int code = g.cub_edges[q];
+  const CubEdge& e = cub_edge_of(g, code);
+  const double* W = wpc_of(g, code) + a * 9;
+  const double* Li = &g.cub_Linv[(size_t)e.cuboid * 81];
+  double* Z = &g.cub_Z[(size_t)q * 54 + a * 9];
+  for (int n = 0; n < 9; ++n) {
+    double v = 0.0;
+    for (int m = 0; m <= n; ++m) v += W[m] * Li[n * 9 + m];
+    Z[n] = v;
+  }
+}
+// S -= Z_a Z_b' for every (edge a >= edge b) pair of one cuboid: 8 lanes per pair, lane i < 6 owns row i of the block,
+// so the six lanes of a pair hit six consecutive addresses per column (one atomic line-op)
 __global__ void k_cub_schur(Graph g) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= g.n_cub_pairs) return;
-  const int c = g.cp_cub[t];
-  const int ca = g.cub_edges[g.cp_a[t]], cb = g.cub_edges[g.cp_b[t]];
+  const int pr = t >> 3, i = t & 7;
+  if (pr >= g.n_cub_pairs || i >= 6) return;
+  const int c = g.cp_cub[pr];
+  const int qa = g.cp_a[pr], qb = g.cp_b[pr];
+  const int ca = g.cub_edges[qa], cb = g.cub_edges[qb];
   const CubEdge& ea = cub_edge_of(g, ca);
   const CubEdge& eb = cub_edge_of(g, cb);
   if (!(ea.flags & F_ACTIVE) || !(eb.flags & F_ACTIVE)) return;
   const int cola = g.pose_col[ea.pose], colb = g.pose_col[eb.pose];
   if (cola < 0 || colb < 0) return;
-  const double* Li = &g.cub_Linv[(size_t)c * 81];
-  double Za[6][9], Zb[6][9];
-  cub_make_Z(wpc_of(g, ca), Li, Za);
-  const bool self = ca == cb;
-  if (!self) cub_make_Z(wpc_of(g, cb), Li, Zb);
+  const double* Za = &g.cub_Z[(size_t)qa * 54 + i * 9];
+  const double* Zb = &g.cub_Z[(size_t)qb * 54];
+  double za[9];
+  for (int q = 0; q < 9; ++q) za[q] = Za[q];
+  const bool self = qa == qb;
   const int n = g.ld;
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j < 6; ++j) {
-      double m = 0.0;  // M[i][j] = (Za Zb')[i][j]: row index on pose a, column index on pose b
-      for (int q = 0; q < 9; ++q) m += Za[i][q] * (self ? Za[j][q] : Zb[j][q]);
-      if (self) {
-        if (i >= j) atomicAdd(&g.S[(size_t)(cola + j) * n + cola + i], -m);
-      } else if (cola > colb) {
-        atomicAdd(&g.S[(size_t)(colb + j) * n + cola + i], -m);
-      } else if (cola < colb) {
-        atomicAdd(&g.S[(size_t)(cola + i) * n + colb + j], -m);
-      } else {  // two different edges on the same keyframe: M + M' lands in one diagonal block
-        if (i >= j) atomicAdd(&g.S[(size_t)(cola + j) * n + cola + i], -m);
-        if (j >= i) atomicAdd(&g.S[(size_t)(cola + i) * n + cola + j], -m);
-      }
+  for (int j = 0; j < 6; ++j) {
+    double m = 0.0;  // M[i][j] = (Za Zb')[i][j]: row index on pose a, column index on pose b
+    for (int q = 0; q < 9; ++q) m += za[q] * Zb[j * 9 + q];
+    if (self) {
+      if (i >= j) atomicAdd(&g.S[(size_t)(cola + j) * n + cola + i], -m);
+    } else if (cola > colb) {
+      atomicAdd(&g.S[(size_t)(colb + j) * n + cola + i], -m);
+    } else if (cola < colb) {
+      atomicAdd(&g.S[(size_t)(cola + i) * n + colb + j], -m);
+    } else {  // two different edges on the same keyframe: M + M' lands in one diagonal block
+      if (i >= j) atomicAdd(&g.S[(size_t)(cola + j) * n + cola + i], -m);
+      if (j >= i) atomicAdd(&g.S[(size_t)(cola + i) * n + cola + j], -m);
     }
+  }
   if (self) {
     const double* u = &g.cub_u[(size_t)c * 9];
-    for (int i = 0; i < 6; ++i) {
-      double v = 0.0;
-      for (int q = 0; q < 9; ++q) v += Za[i][q] * u[q];
-      atomicAdd(&g.bs[cola + i], -v);
-    }
+    double v = 0.0;
+    for (int q = 0; q < 9; ++q) v += za[q] * u[q];
+    atomicAdd(&g.bs[cola + i], -v);
   }
 }
-// x_c = Dc^-1 (b_c - sum_e W_e' x_p(e))
-__global__ void k_cub_backsub(Graph g) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= g.n_cuboids || g.cub_col[c] < 0) return;
-  double t[9];
-  for (int n = 0; n < 9; ++n) t[n] = g.HC[(size_t)c * 54 + 45 + n];
-  for (int q = g.cub_edge_off[c]; q < g.cub_edge_off[c + 1]; ++q) {
-    const int code = g.cub_edges[q];
-    const CubEdge& e = cub_edge_of(g, code);
-    const int col = g.pose_col[e.pose];
-    if (!(e.flags & F_ACTIVE) || col < 0) continue;
-    const double* W = wpc_of(g, code);
-    for (int a = 0; a < 6; ++a) {
-      const double xa = g.xr[col + a];
-      for (int n = 0; n < 9; ++n) t[n] -= W[a * 9 + n] * xa;
+// x_c = Dc^-1 (b_c - sum_e W_e' x_p(e)): one 64-lane workgroup per cuboid, lane (a, n) accumulates W_e[a][n] x_p[a]
+__global__ __launch_bounds__(64) void k_cub_backsub(Graph g) {
+  __shared__ double sp[54], st[9], sy[9];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (g.cub_col[c] < 0) return;
+  const int a = lane / 9, n = lane - 9 * a;
+  double part = 0.0;
+  if (lane < 54) {
+    for (int q = g.cub_edge_off[c]; q < g.cub_edge_off[c + 1]; ++q) {
+      const int code = g.cub_edges[q];
+      const CubEdge& e = cub_edge_of(g, code);
+      const int col = g.pose_col[e.pose];
+      if (!(e.flags & F_ACTIVE) || col < 0) continue;
+      part += wpc_of(g, code)[lane] * g.xr[col + a];
     }
+    sp[lane] = part;
   }
+  __syncthreads();
+  if (lane < 9) {
+    double t = g.HC[(size_t)c * 54 + 45 + lane];
+    for (int k = 0; k < 6; ++k) t -= sp[k * 9 + lane];
+    st[lane] = t;
+  }
+  __syncthreads();
   const double* Li = &g.cub_Linv[(size_t)c * 81];
-  double y[9];
-  for (int n = 0; n < 9; ++n) {
+  if (lane < 9) {
     double v = 0.0;
-    for (int m = 0; m <= n; ++m) v += Li[n * 9 + m] * t[m];
-    y[n] = v;
+    for (int m = 0; m <= lane; ++m) v += Li[lane * 9 + m] * st[m];
+    sy[lane] = v;
   }
-  for (int m = 0; m < 9; ++m) {
+  __syncthreads();
+  if (lane < 9) {
     double v = 0.0;
-    for (int n = m; n < 9; ++n) v += Li[n * 9 + m] * y[n];
-    g.xc[(size_t)c * 9 + m] = v;
+    for (int k = lane; k < 9; ++k) v += Li[k * 9 + lane] * sy[k];
+    g.xc[(size_t)c * 9 + lane] = v;
   }
+  (void)n;
 }
 
 // poses and cuboids: trial = cur [+] x ; scale += x (lambda x + b)   (computeScale, levenberg.cpp:182-189)
@@ -1048,8 +1100,17 @@ __global__ void k_update_reduced(Graph g, State cur, State trial, double lambda)
 // landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term.
 // Points evaluate W' x_p = Jl' w (Jp x_p) from their own edges (streamed landmark-major) instead of reading W back;
 // the few planes read their W blocks.
+template <bool USE_LDS>
 __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial, double lambda) {
+  extern __shared__ double smem[];
   __shared__ double s_red[4];
+  if (USE_LDS) {  // camera table: R, t, intrinsics of every keyframe
+    for (int i = threadIdx.x; i < g.n_poses * 16; i += blockDim.x) {
+      const int p = i >> 4, q = i & 15;
+      smem[i] = q < 12 ? cur.pose_rt[p * 12 + q] : g.pose_cam[p * 5 + (q - 12)];
+    }
+    __syncthreads();
+  }
   const int nl_pts = g.pt_last - g.pt_first;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   double sc = 0.0;
@@ -1068,8 +1129,8 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
           const MonoEdge ed = g.mono[e];
           const int col = g.pose_col[ed.pose];
           if (col < 0) continue;
-          const double* rt = &cur.pose_rt[ed.pose * 12];
-          const double* cm = &g.pose_cam[ed.pose * 5];
+          const double* rt = USE_LDS ? &smem[ed.pose * 16] : &cur.pose_rt[ed.pose * 12];
+          const double* cm = USE_LDS ? &smem[ed.pose * 16 + 12] : &g.pose_cam[ed.pose * 5];
           Mat3 R;
 #pragma unroll
           for (int q = 0; q < 9; ++q) R.a[q] = rt[q];

@@ -74,6 +74,7 @@ struct ppo_ba_solver {
   rocblas_handle blas = nullptr;
   Comm comm;
   int n_cubpl = 0;
+  int n_cub_edges = 0;
   // host copies kept after create
   std::vector<int32_t> mono_perm, stereo_perm;  // sorted position -> caller index
   std::vector<MonoEdge> h_mono;
@@ -110,7 +111,7 @@ struct ppo_ba_solver {
   PoseChunks posec{};
   DevBuf<double> d_W;
   DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cp_cub, d_cp_a, d_cp_b;  // cuboid elimination plan
-  DevBuf<double> d_cub_Linv, d_cub_u, d_xc;
+  DevBuf<double> d_cub_Linv, d_cub_u, d_xc, d_cub_Z;
   DevBuf<int> d_info;
   size_t state_doubles = 0;
   double* h_pinned = nullptr;  // ACC_N doubles then one int
@@ -225,7 +226,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release();
-  s->d_cub_Linv.release(); s->d_cub_u.release(); s->d_xc.release();
+  s->d_cub_Linv.release(); s->d_cub_u.release(); s->d_xc.release(); s->d_cub_Z.release();
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
   if (s->blas) rocblas_destroy_handle(s->blas);
   s->comm.destroy();
@@ -278,10 +279,15 @@ int launch_linearize(ppo_ba_solver* s) {
   const Graph& g = s->g;
   const State& st = s->st[s->cur];
   double* A = s->d_arena.p;
-  HIP_TRY(hipMemsetAsync(A, 0, s->zero_head * sizeof(double), s->stream));
-  if (s->zD_n) HIP_TRY(hipMemsetAsync(A + s->zD_off, 0, s->zD_n * sizeof(double), s->stream));
-  if (s->zbl_n) HIP_TRY(hipMemsetAsync(A + s->zbl_off, 0, s->zbl_n * sizeof(double), s->stream));
-  if (s->zW_n) HIP_TRY(hipMemsetAsync(s->d_W.p + s->zW_off, 0, s->zW_n * sizeof(double), s->stream));
+  {
+    ZeroPlan zp{};
+    zp.p[0] = A; zp.n[0] = s->zero_head;
+    zp.p[1] = A + s->zD_off; zp.n[1] = s->zD_n;
+    zp.p[2] = A + s->zbl_off; zp.n[2] = s->zbl_n;
+    zp.p[3] = s->d_W.p + s->zW_off; zp.n[3] = s->zW_n;
+    const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
+    hipLaunchKernelGGL(k_zero_ranges, dim3(std::min(nblk((long)tot / 2, 256), 2 * s->n_cu)), dim3(256), 0, s->stream, zp);
+  }
   // fork: the numerically differentiated edge classes (one merged launch) run on the side stream
   NumericPlan np{};
   np.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, 16) : 0;
@@ -330,20 +336,31 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
 int launch_reduce(ppo_ba_solver* s, double lambda) {
   const Graph& g = s->g;
   const size_t n = g.ld;
-  HIP_TRY(hipMemsetAsync(s->d_S.p, 0, n * n * sizeof(double), s->stream));
-  HIP_TRY(hipMemsetAsync(s->d_bs.p, 0, n * sizeof(double), s->stream));
+  {
+    ZeroPlan zp{};
+    zp.p[0] = s->d_S.p; zp.n[0] = n * n;
+    zp.p[1] = s->d_bs.p; zp.n[1] = n;
+    hipLaunchKernelGGL(k_zero_ranges, dim3(4 * s->n_cu), dim3(256), 0, s->stream, zp);
+  }
+  const bool cub_stage = g.elim_cub && g.owns_reduced && g.n_cuboids > 0;
+  if (cub_stage) {  // fork: the (small, latency-bound) cuboid elimination runs next to the landmark Schur complement
+    HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+    hipLaunchKernelGGL(k_cub_prep, dim3(nblk(g.n_cuboids, 64)), dim3(64), 0, s->side, g, lambda);
+    const int n_ce = s->n_cub_edges;
+    if (n_ce > 0) hipLaunchKernelGGL(k_cub_z, dim3(nblk((long)n_ce * 6, 64)), dim3(64), 0, s->side, g);
+    if (g.n_cub_pairs > 0) hipLaunchKernelGGL(k_cub_schur, dim3(nblk((long)g.n_cub_pairs * 8, 256)), dim3(256), 0, s->side, g);
+    HIP_TRY(hipEventRecord(s->ev_join, s->side));
+  }
   const long work = (long)g.n_pose_free * 27 + (long)g.n_cuboids * 54 + (long)(g.n_bbox + g.n_corner) * 54 + (g.ld - g.n_red);
   hipLaunchKernelGGL(k_assemble, dim3(nblk(work, 256)), dim3(256), 0, s->stream, g, lambda);
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
   if (nl > 0) {
     hipLaunchKernelGGL(k_schur_prep, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, lambda);
     if (g.n_slots > 0) hipLaunchKernelGGL(k_schur_z, dim3(nblk(g.n_slots, 256)), dim3(256), 0, s->stream, g);
-    if (s->pc.n_chunks > 0) hipLaunchKernelGGL(k_schur_pairs, dim3(nblk(s->pc.n_chunks, 4)), dim3(256), 0, s->stream, g, s->pc);
+    if (s->pc.n_chunks > 0) hipLaunchKernelGGL(k_schur_pairs, dim3((nblk(s->pc.n_chunks, 4) + 7) / 8 * 8), dim3(256), 0, s->stream, g, s->pc);
   }
-  if (g.elim_cub && g.owns_reduced && g.n_cuboids > 0) {
-    hipLaunchKernelGGL(k_cub_prep, dim3(nblk(g.n_cuboids, 64)), dim3(64), 0, s->stream, g, lambda);
-    if (g.n_cub_pairs > 0) hipLaunchKernelGGL(k_cub_schur, dim3(nblk(g.n_cub_pairs, 64)), dim3(64), 0, s->stream, g);
-  }
+  if (cub_stage) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
     if (s->comm.sum(s->d_S.p, n * n, s->stream) || s->comm.sum(s->d_bs.p, n, s->stream)) return PPO_BA_ERR_COMM;
@@ -370,10 +387,13 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   const Graph& g = s->g;
   const State& cur = s->st[s->cur];
   const State& tr = s->st[s->cur ^ 1];
-  if (g.elim_cub && g.n_cuboids > 0) hipLaunchKernelGGL(k_cub_backsub, dim3(nblk(g.n_cuboids, 64)), dim3(64), 0, s->stream, g);
+  if (g.elim_cub && g.n_cuboids > 0) hipLaunchKernelGGL(k_cub_backsub, dim3(g.n_cuboids), dim3(64), 0, s->stream, g);
   hipLaunchKernelGGL(k_update_reduced, dim3(nblk(g.n_poses + g.n_cuboids, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
-  if (nl > 0) hipLaunchKernelGGL(k_backsub, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
+  if (nl > 0) {
+    if (s->use_lds) hipLaunchKernelGGL(k_backsub<true>, dim3(nblk(nl, 256)), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda);
+    else hipLaunchKernelGGL(k_backsub<false>, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
+  }
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -791,6 +811,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       cub_edges.insert(cub_edges.end(), per[c].begin(), per[c].end());
     }
     cub_edge_off[Nc] = (int32_t)cub_edges.size();
+    s->n_cub_edges = (int)cub_edges.size();
     if (g.elim_cub)
       for (int c = 0; c < Nc; ++c)
         for (int a = cub_edge_off[c]; a < cub_edge_off[c + 1]; ++a)
@@ -852,7 +873,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
   ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream);
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
-  ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_u.alloc((size_t)Nc * 9) && s->d_xc.alloc((size_t)Nc * 9);
+  ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_u.alloc((size_t)Nc * 9) && s->d_xc.alloc((size_t)Nc * 9) && s->d_cub_Z.alloc(cub_edges.size() * 54);
   ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
   ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream);
   s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, (int)pc_colj.size()};
@@ -891,7 +912,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   g.Wpc_bbox = s->d_Wpc.p; g.Wpc_corner = s->d_Wpc.p + (size_t)p->n_bbox * 54;
   g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p;
-  g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_u = s->d_cub_u.p; g.xc = s->d_xc.p;
+  g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_u = s->d_cub_u.p; g.xc = s->d_xc.p; g.cub_Z = s->d_cub_Z.p;
   g.Dinv = s->d_Dinv.p; g.C = s->d_C.p; g.ul = s->d_ul.p; g.Z = s->d_Z.p; g.S = s->d_S.p; g.bs = s->d_bs.p; g.xr = s->d_xr.p;
   s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
   s->st[1] = make_state(s->d_state[1].p, Np, Npt, Npl, Nc);
@@ -900,7 +921,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   s->lds_bytes = (int)((size_t)Np * 16 * sizeof(double));
   s->use_lds = s->lds_bytes <= 150 * 1024;
   if (s->use_lds && s->lds_bytes > 48 * 1024) {
-    if (hipFuncSetAttribute((const void*)k_lin_points<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
+    if (hipFuncSetAttribute((const void*)k_lin_points<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_backsub<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
   }
   // derive the rotation matrices of the pristine state once
   {
