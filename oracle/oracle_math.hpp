@@ -385,7 +385,7 @@ inline V3 cuboid_point_boundary_error(const Cuboid& c, const V3& p, double max_o
 
 // ---- RobustKernelHuber::robustify, Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:78-91 ----------
 inline void huber_robustify(double e, double delta, double rho[3]) {
-  const double dsqr = delta * delta;  // setDelta, :65-69
+  const double dsqr = (double)(float)(delta * delta);  // setDelta, :65-69; the member is `float dsqr` (robust_kernel_impl.h:84)
   if (e <= dsqr) {
     rho[0] = e; rho[1] = 1.; rho[2] = 0.;
   } else {

@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: golden vectors from the reference's OWN prebuilt Thirdparty/g2o/lib/libg2o.so.
+
+The reference cannot be compiled here (Eigen3 / OpenCV / PCL / Pangolin are absent) but its prebuilt g2o core library
+loads, and the following entry points can be driven with plain pointers (layouts found as described, nothing is
+assumed from headers that could not be compiled):
+  g2o::SE3Quat::exp(Vector6d)                        returns the 7-double (qx qy qz qw tx ty tz) state by hidden pointer
+  g2o::VertexSE3Expmap::oplusImpl(const double*)     object built by its exported constructor; the estimate is located by
+                                                     scanning the object for the identity pose the constructor stores
+  g2o::VertexSBAPointXYZ::oplusImpl(const double*)   estimate located by a probe update
+  g2o::RobustKernelHuber::setDelta / robustify       on a zeroed object (both fields are written by setDelta)
+  g2o::EdgeSE3ProjectXYZ::cam_project                fx fy cx cy at this+0x128..0x140 (read off the disassembly)
+  g2o::EdgeStereoSE3ProjectXYZ::cam_project          fx fy cx cy at this+0x160..0x178, bf passed as const float&
+The custom plane / cuboid types live in lib/libORB_SLAM2.so, which does not load in this container (OpenCV 3.3, PCL 1.8,
+Pangolin, VTK missing): they stay unpinned.
+
+  python oracle/pin_g2o_prebuilt.py            regenerate tests/golden/g2o_prebuilt.json (needs /root/reference)
+  python oracle/pin_g2o_prebuilt.py --check-only   compare the oracle with the committed file
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+GOLD = os.path.join(REPO, "tests", "golden", "g2o_prebuilt.json")
+G2O = "/root/reference/Thirdparty/g2o/lib/libg2o.so"
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def generate():
+    lib = C.CDLL(G2O)
+    rng = np.random.default_rng(20260929)
+    out = {"source": "Thirdparty/g2o/lib/libg2o.so (prebuilt, gcc 7.5 / Ubuntu 18.04, Eigen as compiled in)", "cases": {}}
+
+    # ---- SE3Quat::exp ---------------------------------------------------------------------------------------------
+    f = lib._ZN3g2o7SE3Quat3expERKN5Eigen6MatrixIdLi6ELi1ELi0ELi6ELi1EEE
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    f.restype = C.c_void_p
+    cases = []
+    ups = [rng.normal(size=6) * s for s in (1.0, 0.3, 0.05, 1e-3, 1e-7, 1e-9) for _ in range(6)]
+    ups += [np.array([1e-9, 0, 0, 0, 0, 0.0]), np.array([0, 0, 3.0, 1.0, 2.0, 3.0]), np.array([2.0, -2.0, 1.0, 0, 0, 0.0])]
+    for u in ups:
+        buf = np.zeros(16)
+        f(buf.ctypes.data, np.ascontiguousarray(u).ctypes.data)
+        cases.append({"update": u.tolist(), "qt": buf[:7].tolist()})  # Quaterniond coeffs x y z w, then translation
+    out["cases"]["se3_exp"] = cases
+
+    # ---- VertexSE3Expmap::oplusImpl -----------------------------------------------------------------------------------
+    ctor = lib._ZN3g2o15VertexSE3ExpmapC1Ev
+    ctor.argtypes = [C.c_void_p]
+    opl = lib._ZN3g2o15VertexSE3Expmap9oplusImplEPKd
+    opl.argtypes = [C.c_void_p, C.c_void_p]
+    obj = np.zeros(1024)  # 8 KB, far larger than the object
+    ctor(obj.ctypes.data)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    off = [i for i in range(0, 400) if np.array_equal(obj[i:i + 7], ident)]
+    assert len(off) >= 1, "estimate not found"
+    eo = off[0]
+    cases = []
+    for k in range(24):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        if q[3] < 0:
+            q = -q
+        t = rng.normal(size=3) * 3
+        u = rng.normal(size=6) * [1.0, 0.1, 1e-3, 1e-9][k % 4]
+        obj[eo:eo + 4] = q
+        obj[eo + 4:eo + 7] = t
+        opl(obj.ctypes.data, np.ascontiguousarray(u).ctypes.data)
+        cases.append({"qt": q.tolist() + t.tolist(), "update": u.tolist(), "out": obj[eo:eo + 7].tolist()})
+    out["cases"]["pose_oplus"] = cases
+
+    # ---- RobustKernelHuber ---------------------------------------------------------------------------------------------
+    sd = lib._ZN3g2o17RobustKernelHuber8setDeltaEd
+    sd.argtypes = [C.c_void_p, C.c_double]
+    rb = lib._ZNK3g2o17RobustKernelHuber9robustifyEdRN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEE
+    rb.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+    cases = []
+    for delta in (float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815))), float(np.float32(np.sqrt(500.0))), 1.0):
+        k = np.zeros(8)
+        sd(k.ctypes.data, delta)
+        for e in (0.0, 0.5 * delta * delta, delta * delta, delta * delta * (1 + 1e-12), 2 * delta * delta, 1e4, 1e7):
+            rho = np.zeros(4)
+            rb(k.ctypes.data, e, rho.ctypes.data)
+            cases.append({"delta": delta, "e": e, "rho": rho[:3].tolist()})
+    out["cases"]["huber"] = cases
+
+    # ---- cam_project (mono / stereo) ----------------------------------------------------------------------------------------
+    cm = lib._ZNK3g2o17EdgeSE3ProjectXYZ11cam_projectERKN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEE
+    cm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    cs = lib._ZNK3g2o23EdgeStereoSE3ProjectXYZ11cam_projectERKN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEERKf
+    cs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    mono, stereo = [], []
+    for _ in range(32):
+        fx, fy, cx, cy = rng.uniform(300, 700), rng.uniform(300, 700), rng.uniform(300, 340), rng.uniform(220, 260)
+        X = np.array([rng.normal() * 2, rng.normal() * 2, rng.uniform(0.3, 9.0)])
+        this = np.zeros(64)
+        this[0x128 // 8:0x128 // 8 + 4] = [fx, fy, cx, cy]
+        res = np.zeros(4)
+        cm(res.ctypes.data, this.ctypes.data, X.ctypes.data)
+        mono.append({"cam": [fx, fy, cx, cy], "X": X.tolist(), "uv": res[:2].tolist()})
+        this = np.zeros(64)
+        this[0x160 // 8:0x160 // 8 + 4] = [fx, fy, cx, cy]
+        bf = np.array([rng.uniform(20, 60)], dtype=np.float32)
+        res = np.zeros(4)
+        cs(res.ctypes.data, this.ctypes.data, X.ctypes.data, bf.ctypes.data)
+        stereo.append({"cam": [fx, fy, cx, cy, float(bf[0])], "X": X.tolist(), "uvr": res[:3].tolist()})
+    out["cases"]["mono_project"] = mono
+    out["cases"]["stereo_project"] = stereo
+
+    os.makedirs(os.path.dirname(GOLD), exist_ok=True)
+    with open(GOLD, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote", GOLD, {k: len(v) for k, v in out["cases"].items()})
+
+
+def check():
+    """Oracle vs the committed vectors (the same comparison tests/test_golden.py runs under pytest)."""
+    sys.path.insert(0, HERE)
+    import oracle_py
+    lib = oracle_py.load()
+    gold = json.load(open(GOLD))["cases"]
+    worst = {}
+    for c in gold["se3_exp"]:
+        o = np.zeros(7)
+        lib.oracle_se3_exp(dptr(np.array(c["update"])), dptr(o))
+        worst["se3_exp"] = max(worst.get("se3_exp", 0), float(np.abs(o - c["qt"]).max()))
+    for c in gold["pose_oplus"]:
+        o = np.zeros(7)
+        lib.oracle_pose_oplus(dptr(np.array(c["qt"])), dptr(np.array(c["update"])), dptr(o))
+        worst["pose_oplus"] = max(worst.get("pose_oplus", 0), float(np.abs(o - c["out"]).max()))
+    for c in gold["huber"]:
+        r = np.zeros(3)
+        lib.oracle_huber(c["e"], c["delta"], dptr(r))
+        worst["huber"] = max(worst.get("huber", 0), float(np.abs(r - c["rho"]).max() / max(1.0, np.abs(c["rho"]).max())))
+    # reprojection through the oracle's edge evaluation: a 1-keyframe / 1-point graph with identity pose, e = obs - proj
+    B = oracle_py.B
+    be = oracle_py.backend()
+    for kind, key in (("mono", "mono_project"), ("stereo", "stereo_project")):
+        for c in gold[key]:
+            P = B.Problem()
+            cam = c["cam"] + ([0.0] if kind == "mono" else [])
+            P.set("pose_qt", [[0, 0, 0, 1, 0, 0, 0]]); P.set("pose_fixed", [0]); P.set("pose_cam", [cam])
+            P.set("point_xyz", [c["X"]])
+            names = ["mono_point", "mono_pose", "mono_obs", "mono_info", "mono_huber", "stereo_point", "stereo_pose", "stereo_obs", "stereo_info", "stereo_huber"]
+            for n_ in names:
+                P.set(n_, np.zeros(0))
+            P.set(kind + "_point", [0]); P.set(kind + "_pose", [0]); P.set(kind + "_obs", [[0.0] * (2 if kind == "mono" else 3)])
+            P.set(kind + "_info", [1.0]); P.set(kind + "_huber", [0.0])
+            for n_ in ("plane_coef", "cuboid_qt", "cuboid_scale", "pl_plane", "pl_pose", "pl_meas", "pl_info", "pl_huber", "bbox_pose", "bbox_cuboid",
+                       "bbox_meas", "bbox_info", "bbox_huber", "bbox_K", "corner_pose", "corner_cuboid", "corner_meas", "corner_info", "corner_huber",
+                       "corner_K", "ptcub_cuboid", "ptcub_margin_ratio", "ptcub_info", "cubpl_cuboid", "cubpl_plane", "cubpl_meas", "cubpl_info", "cubpl_huber"):
+                P.set(n_, np.zeros(0))
+            s_ = be.create(P, B.default_options())
+            e = np.zeros(3)
+            lib.oracle_edge_eval(s_.h, 1 if kind == "mono" else 2, 0, dptr(e), None, None)
+            ref = np.array(c["uv"] if kind == "mono" else c["uvr"])
+            worst[key] = max(worst.get(key, 0), float(np.abs(-e[:len(ref)] - ref).max()))
+            s_.close()
+    print("max abs deviation oracle vs prebuilt g2o:", worst)
+    return worst
+
+
+if __name__ == "__main__":
+    if "--check-only" in sys.argv:
+        if os.path.exists(GOLD):
+            check()
+    else:
+        generate()
+        check()

@@ -161,7 +161,7 @@ void compute_error(const Oracle& o, int type, int idx, const void* a, const void
       const double* obs = &o.e_meas[type][3 * idx];
       const V3 pc = se3_map(T, X);
       const float bf = (float)cam[4];
-      const float invz = 1.0f / (float)pc[2];
+      const float invz = (float)(1.0 / pc[2]);  // 1.0f / double: a double division rounded to float (divsd + cvtsd2ss in the prebuilt libg2o.so)
       const double r0 = pc[0] * invz * cam[0] + cam[2];
       const double r1 = pc[1] * invz * cam[1] + cam[3];
       const double r2 = r0 - (double)(bf * invz);

@@ -1,0 +1,58 @@
+// hostcheck.cpp -- TEST AID: the formulas of ppo_math.hpp (the header the HIP kernels use) compiled for the host so that
+// the CPU test-suite can check them against the golden vectors of the reference's prebuilt libg2o.so and against the
+// oracle.  Not linked into libppo_ba.so and never used by the product path.
+#include "ppo_math.hpp"
+
+using namespace ppo;
+
+extern "C" {
+void hc_se3_exp(const double* u, double* qt) {
+  const Pose P = exp_se3(u);
+  qt[0] = P.q.x; qt[1] = P.q.y; qt[2] = P.q.z; qt[3] = P.q.w; qt[4] = P.t.x; qt[5] = P.t.y; qt[6] = P.t.z;
+}
+void hc_pose_oplus(const double* qt, const double* u, double* out) {
+  const Pose T{Quat{qt[0], qt[1], qt[2], qt[3]}, Vec3{qt[4], qt[5], qt[6]}};
+  const Pose P = pose_boxplus(T, u);
+  out[0] = P.q.x; out[1] = P.q.y; out[2] = P.q.z; out[3] = P.q.w; out[4] = P.t.x; out[5] = P.t.y; out[6] = P.t.z;
+}
+void hc_huber(double e, double delta, double* rho01) { huber(e, delta, rho01[0], rho01[1]); }
+void hc_mono(const double* qt, const double* X, const double* cam, const double* obs, double* e, double* Jl, double* Jp) {
+  const Mat3 R = rotmat(Quat{qt[0], qt[1], qt[2], qt[3]});
+  double z;
+  mono_eval(R, Vec3{qt[4], qt[5], qt[6]}, Vec3{X[0], X[1], X[2]}, cam[0], cam[1], cam[2], cam[3], obs[0], obs[1], e, Jl, Jp, z);
+}
+void hc_stereo(const double* qt, const double* X, const double* cam, const double* obs, double* e, double* Jl, double* Jp) {
+  const Mat3 R = rotmat(Quat{qt[0], qt[1], qt[2], qt[3]});
+  double z;
+  stereo_eval(R, Vec3{qt[4], qt[5], qt[6]}, Vec3{X[0], X[1], X[2]}, cam[0], cam[1], cam[2], cam[3], cam[4], obs[0], obs[1], obs[2], e, Jl, Jp, z);
+}
+void hc_plane_oplus(const double* c, const double* u, double* out) {
+  const PlaneC p = plane_boxplus(plane_canon(c[0], c[1], c[2], c[3]), u);
+  out[0] = p.nx; out[1] = p.ny; out[2] = p.nz; out[3] = p.d;
+}
+void hc_plane_residual(const double* qt, const double* plane, const double* meas, int kind, double* e) {
+  const Pose T{Quat{qt[0], qt[1], qt[2], qt[3]}, Vec3{qt[4], qt[5], qt[6]}};
+  const PlaneC local = plane_into_camera(T, plane_canon(plane[0], plane[1], plane[2], plane[3]));
+  plane_residual(local, plane_canon(meas[0], meas[1], meas[2], meas[3]), kind, e);
+}
+void hc_cuboid_oplus(const double* c10, const double* u, unsigned flags, const double* fs, double* out10) {
+  const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};
+  const Cub n = cuboid_boxplus(c, u, flags, fs ? fs[0] : 0.0, fs ? fs[1] : 0.0, fs ? fs[2] : 0.0);
+  out10[0] = n.T.q.x; out10[1] = n.T.q.y; out10[2] = n.T.q.z; out10[3] = n.T.q.w; out10[4] = n.T.t.x; out10[5] = n.T.t.y; out10[6] = n.T.t.z;
+  out10[7] = n.s.x; out10[8] = n.s.y; out10[9] = n.s.z;
+}
+void hc_bbox(const double* pose_qt, const double* c10, const double* K, const double* meas, double* e) {
+  const Pose T{Quat{pose_qt[0], pose_qt[1], pose_qt[2], pose_qt[3]}, Vec3{pose_qt[4], pose_qt[5], pose_qt[6]}};
+  const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};
+  bbox_residual(T, c, K, meas, e);
+}
+void hc_corner(const double* pose_qt, const double* c10, const double* K, const double* meas, double* e) {
+  const Pose T{Quat{pose_qt[0], pose_qt[1], pose_qt[2], pose_qt[3]}, Vec3{pose_qt[4], pose_qt[5], pose_qt[6]}};
+  const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};
+  corner_residual(T, c, K, meas, e);
+}
+void hc_ptcub(const double* c10, const double* pts, int npts, double margin, const double* prior, double* e) {
+  const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};
+  ptcub_residual(c, pts, npts, margin, prior, e);
+}
+}

@@ -357,7 +357,7 @@ PPO_HD void stereo_residual(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy,
   const Vec3 pc = matvec(R, X) + t;
   zc = pc.z;
   const float bf = (float)bfd;
-  const float invz = 1.0f / (float)pc.z;
+  const float invz = (float)(1.0 / pc.z);  // 1.0f / double = double division, then rounded to float
   const double r0 = pc.x * invz * fx + cx;
   const double r1 = pc.y * invz * fy + cy;
   const double r2 = r0 - (double)(bf * invz);
@@ -386,7 +386,7 @@ PPO_HD void huber(double chi2, double delta, double& rho0, double& rho1) {
   rho0 = chi2;
   rho1 = 1.0;
   if (delta > 0) {
-    const double dsqr = delta * delta;
+    const double dsqr = (double)(float)(delta * delta);  // g2o keeps delta^2 in a float member (robust_kernel_impl.h:84)
     if (!(chi2 <= dsqr)) {
       const double sq = sqrt(chi2);
       rho0 = 2 * sq * delta - dsqr;

@@ -301,7 +301,7 @@ def load_library(path=LIB_PATH):
     if _lib is None:
         if not os.path.exists(path):
             raise RuntimeError("libppo_ba.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
-        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(path)  # RTLD_LOCAL: the HIP runtime it pulls in must not shadow the one bundled with torch
         lib.ppo_ba_strerror.restype = C.c_char_p
         lib.ppo_ba_strerror.argtypes = [C.c_int]
         lib.ppo_ba_version.restype = C.c_int

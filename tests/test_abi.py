@@ -97,14 +97,13 @@ def test_bad_arguments_are_rejected_before_touching_the_device():
 
 def test_no_cpu_fallback():
     """Without a GPU the product must refuse to run (PPO_BA_ERR_HIP); with one it must succeed."""
-    import torch
     lib = B.load_library()
     P = synth.make_problem("tiny")
     ps = P.as_struct()
     h = C.c_void_p()
     o = B.default_options()
     rc = lib.ppo_ba_create(C.byref(ps), C.byref(o), C.byref(h))
-    if torch.cuda.is_available():
+    if os.path.exists("/dev/kfd"):  # a ROCm device node: the GPU box
         assert rc == 0
         lib.ppo_ba_destroy(h)
     else:

@@ -1,0 +1,114 @@
+"""The multi-GPU path on CPU: two processes, torch.distributed with the gloo backend.
+
+What the N > 1 path of libppo_ba.so does per solve attempt (csrc/ppo_solver.hip: launch_reduce / fetch_acc):
+  * landmarks are range-partitioned with ppo_ba_partition() (host code of the product library, runs without a GPU);
+  * every rank forms the Schur contributions of ITS landmarks, rank 0 additionally adds Hpp + lambda I and the cuboid terms;
+  * ONE sum all-reduce of (S, b_schur) gives every rank the full reduced system, which each rank then factors redundantly;
+  * the robust chi2 is a sum all-reduce of per-rank partial sums.
+Here the per-rank arithmetic is done by the CPU oracle (test infrastructure) and the collective by gloo, so the test
+checks the decomposition itself: partial systems of disjoint landmark ranges must sum to the unsharded system, identical
+on both ranks (=> identical accept/reject decisions), for graphs with points, planes and cuboids.
+"""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cfg, seed, out_q):
+    sys.path.insert(0, os.path.join(REPO, "point-plane-object-slam_amd"))
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import torch
+    import torch.distributed as dist
+    from ppo_ba import binding as B
+    from ppo_ba import synth
+    import oracle_py
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dptr = lambda a: a.ctypes.data_as(B.c_dp)
+    P = synth.make_problem(cfg, seed=seed)
+    sizes = P.sizes()
+    lib = B.load_library()  # host-only entry point of the product library
+    ps = P.as_struct()
+    fp = np.zeros(world + 1, np.int32)
+    fl = np.zeros(world + 1, np.int32)
+    assert lib.ppo_ba_partition(C.byref(ps), world, fp.ctypes.data_as(B.c_ip), fl.ctypes.data_as(B.c_ip)) == 0
+    olib = oracle_py.load()
+    s = oracle_py.backend().create(P, B.default_options())
+    chi_full = s.linearize()
+    lam = 3.25
+    n = C.c_int32()
+    olib.oracle_ba_reduced(s.h, lam, 0, -1, 1, None, None, C.byref(n))
+    n = n.value
+    S_full, b_full = np.zeros((n, n)), np.zeros(n)
+    olib.oracle_ba_reduced(s.h, lam, 0, -1, 1, dptr(S_full), dptr(b_full), None)
+    # this rank's share: its planes, its points (the oracle numbers landmarks planes first, then points)
+    npl = sizes["n_planes"]
+    S_part, b_part = np.zeros((n, n)), np.zeros(n)
+    tmpS, tmpb = np.zeros((n, n)), np.zeros(n)
+    olib.oracle_ba_reduced(s.h, lam, int(fl[rank]), int(fl[rank + 1]), 1 if rank == 0 else 0, dptr(tmpS), dptr(tmpb), None)
+    S_part += tmpS; b_part += tmpb
+    olib.oracle_ba_reduced(s.h, lam, int(npl + fp[rank]), int(npl + fp[rank + 1]), 0, dptr(tmpS), dptr(tmpb), None)
+    S_part += tmpS; b_part += tmpb
+    tS, tb = torch.from_numpy(S_part.copy()), torch.from_numpy(b_part.copy())
+    dist.all_reduce(tS, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+    S_sum, b_sum = tS.numpy(), tb.numpy()
+    # partial robust chi2: the point edges of the owned points (+ everything else on rank 0), summed over ranks
+    r = s.read()  # chi2 of the linearisation point
+    own = (P["mono_point"] >= fp[rank]) & (P["mono_point"] < fp[rank + 1])
+    hub = P["mono_huber"][own]
+    c = r.mono_chi2[own]
+    dsq = np.float32(hub * hub).astype(np.float64)
+    rho = np.where(c <= dsq, c, 2 * np.sqrt(c) * hub - dsq)
+    tchi = torch.tensor([rho.sum()], dtype=torch.float64)
+    dist.all_reduce(tchi, op=dist.ReduceOp.SUM)
+    x = np.linalg.solve(S_sum, b_sum)
+    # every rank must hold bit-identical inputs to the (redundant) factorisation
+    gathered = [torch.zeros_like(tb) for _ in range(world)]
+    dist.all_gather(gathered, tb)
+    out_q.put(dict(rank=rank, err_S=float(np.abs(S_sum - S_full).max() / np.abs(S_full).max()),
+                   err_b=float(np.abs(b_sum - b_full).max() / np.abs(b_full).max()),
+                   same_b=bool(all(torch.equal(g, tb) for g in gathered)),
+                   x=x, share=int(own.sum()), n_mono=int(P["mono_point"].size), mono_chi=float(tchi.item()),
+                   ranges=(fp.tolist(), fl.tolist())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg,seed", [("small", 1), (dict(n_kf=14, n_points=500, n_planes=6, n_cuboids=3), 2)])
+def test_partial_reduced_systems_sum_to_the_full_one_over_gloo(cfg, seed):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda d: d["rank"])
+    for d in res:
+        assert d["err_S"] < 1e-12 and d["err_b"] < 1e-12, d
+        assert d["same_b"]
+    np.testing.assert_array_equal(res[0]["x"], res[1]["x"])  # identical decisions on every rank
+    assert res[0]["share"] + res[1]["share"] == res[0]["n_mono"]  # every edge is owned exactly once
+    assert abs(res[0]["share"] - res[1]["share"]) < 0.25 * res[0]["n_mono"]  # edge-balanced ranges
+    assert res[0]["mono_chi"] == res[1]["mono_chi"]
