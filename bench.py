@@ -23,26 +23,40 @@ sys.path.insert(0, os.path.join(REPO, "point-plane-object-slam_amd"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(P, B, seconds_budget=25.0):
-    """The oracle (a port of the reference algorithm, 1 thread) on the same graph, bounded to a few LM iterations."""
+def cpu_baseline(P, B, seconds_budget=12.0):
+    """The oracle (a port of the reference algorithm, 1 thread) on the same graph: the full 5+10 protocol, repeated
+    until about `seconds_budget` seconds of CPU work have been timed (at least one complete call)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle_py  # test infrastructure: only this leg touches it
     be = oracle_py.backend()
-    # calibrate with one LM iteration, then run as many as fit the budget (<= 5 so that pass 1 semantics hold)
-    s = be.create(P, B.default_options(iters_pass1=1, iters_pass2=0))
-    t0 = time.perf_counter()
-    st = s.run()
-    t1 = time.perf_counter() - t0
-    n = int(max(1, min(5, seconds_budget // max(t1, 1e-3))))
+    s = be.create(P, B.default_options())
+    iters = trials = calls = 0
+    dt = 0.0
+    while calls == 0 or (dt < seconds_budget and dt / calls * (calls + 1) < 2.5 * seconds_budget):
+        s.reset()
+        t0 = time.perf_counter()
+        st = s.run()
+        dt += time.perf_counter() - t0
+        iters += st["n_iters"]
+        trials += st["n_trials"]
+        calls += 1
     s.close()
-    s = be.create(P, B.default_options(iters_pass1=n, iters_pass2=0))
-    t0 = time.perf_counter()
-    st = s.run()
-    dt = time.perf_counter() - t0
-    s.close()
-    it = max(1, st["n_iters"])
-    return dict(value=it / dt, unit="LM iters/s", cores=1, kind="port",
-                sample="oracle/libppo_oracle.so, %d LM iterations (%d solve attempts) of pass 1 on the same graph, %.1f s" % (it, st["n_trials"], dt))
+    return dict(value=iters / dt, unit="LM iters/s", cores=1, kind="port", ms_per_call=1e3 * dt / calls,
+                sample="oracle/libppo_oracle.so (g2o algorithm restated, fixed-size blocks, -O3 -march=native, 1 thread): %d complete 5+10 calls "
+                       "on the same graph = %d LM iterations (%d solve attempts) in %.1f s; host has %d logical CPUs" % (
+                           calls, iters, trials, dt, os.cpu_count() or 0))
+
+
+def committed_traffic(k_bytes):
+    """HBM bytes per launch of the roofline kernel from the committed PMC pass (profiles/r01_lin_traffic.json, made by
+    tools/pmc_probe.sh on this exact workload); None when absent or made for a different graph."""
+    try:
+        j = json.load(open(os.path.join(REPO, "profiles", "r01_lin_traffic.json")))
+        if int(j.get("algorithmic_bytes", -1)) == int(k_bytes):
+            return float(j["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -88,7 +102,9 @@ def main():
         ident = t.cpu().numpy()
         for i in range(128):
             opt.comm_id[i] = int(ident[i])
+    t_c = time.perf_counter()
     solver = B.hip_backend().create(P, opt)
+    create_ms = 1e3 * (time.perf_counter() - t_c)
 
     def barrier():
         torch.cuda.synchronize()
@@ -116,14 +132,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # dominant-kernel roofline: the Jacobian/assembly kernel group, timed with HIP events on the library's stream
+    # roofline of the dominant streaming kernel -- the reprojection Jacobian kernel k_lin_poses (residual + Jacobians of
+    # every mono/stereo edge, W blocks out) -- timed alone with HIP events on the library's stream; the whole
+    # linearise group (k_zero_ranges + k_lin_points + k_lin_poses || k_lin_numeric_all) is reported next to it.
     lin_ms = C.c_double()
     solver.reset()
     assert lib.ppo_ba_time_linearize(solver.h, a.lin_reps, C.byref(lin_ms)) == 0
     lin_bytes = int(lib.ppo_ba_linearize_bytes(solver.h))
+    k_ms, k_bytes = C.c_double(), C.c_int64()
+    assert lib.ppo_ba_time_kernel(solver.h, 0, a.lin_reps, C.byref(k_ms), C.byref(k_bytes)) == 0
+    kernels = {}
+    n_red = C.c_int32()
+    lib.ppo_ba_debug_reduced(solver.h, None, None, None, C.byref(n_red))
+    b_red = np.zeros(max(1, n_red.value))
+    assert lib.ppo_ba_debug_reduced(solver.h, None, b_red.ctypes.data_as(B.c_dp), None, None) == 0  # builds W, Z, C for the Schur kernels
+    for name, which in (("k_lin_poses", 0), ("k_lin_points", 1), ("k_schur_z", 2), ("k_schur_pairs", 3), ("k_backsub", 4), ("k_chi2_points", 5)):
+        ms_, by_ = C.c_double(), C.c_int64()
+        if lib.ppo_ba_time_kernel(solver.h, which, 50, C.byref(ms_), C.byref(by_)) == 0 and ms_.value > 0:
+            kernels[name] = {"us": 1e3 * ms_.value, "algorithmic_bytes": int(by_.value), "GBps": by_.value / (ms_.value * 1e-3) / 1e9}
     fac_ms = C.c_double()
     assert lib.ppo_ba_time_factor(solver.h, 10, C.byref(fac_ms)) == 0
-    achieved = lin_bytes / (lin_ms.value * 1e-3) / 1e9
+    achieved = k_bytes.value / (k_ms.value * 1e-3) / 1e9 if k_ms.value > 0 else 0.0
 
     if rank == 0:
         out = {
@@ -139,10 +168,14 @@ def main():
                 "lm_iters_per_step": iters / a.steps, "solve_attempts_per_step": trials / a.steps,
                 "ms_per_lm_iter": 1e3 * dt / max(iters, 1), "solver_backend": int(a.solver),
                 "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
+                "create_ms_host_flatten_plus_pcie_upload": create_ms, "kernels": kernels,
             },
-            "roofline": {"bound": "hbm", "kernel": "k_lin_points (+ plane/cuboid linearise group)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes": lin_bytes, "launch_ms": lin_ms.value},
+            "roofline": {"bound": "hbm", "kernel": "k_lin_poses", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(int(k_bytes.value)),
+                         "algorithmic_bytes": int(k_bytes.value), "launch_ms": k_ms.value,
+                         "linearise_group": {"kernels": "k_zero_ranges + k_lin_points + k_lin_poses || k_lin_numeric_all",
+                                             "algorithmic_bytes": lin_bytes, "launch_ms": lin_ms.value,
+                                             "achieved": lin_bytes / (lin_ms.value * 1e-3) / 1e9}},
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P, B)

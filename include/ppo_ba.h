@@ -256,6 +256,20 @@ int ppo_ba_linearize(ppo_ba_handle h, double* robust_chi2);
  * library's own stream; returns average milliseconds per linearisation in *ms. */
 int ppo_ba_time_linearize(ppo_ba_handle h, int reps, double* ms);
 
+/* Time ONE kernel of the path alone: `reps` back-to-back launches between two HIP events on the library's own
+ * stream; *ms = average per launch (agrees with rocprofv3's average duration up to the inter-launch gap),
+ * *bytes = the algorithmic bytes that kernel must move per launch.  State is not advanced;
+ * call after ppo_ba_linearize() / ppo_ba_debug_reduced() so that the kernel's inputs exist. */
+enum {
+  PPO_BA_KERNEL_LIN_POSES = 0,   /* reprojection residual + Jacobians, pose side: W blocks, Hpp, b_p */
+  PPO_BA_KERNEL_LIN_POINTS = 1,  /* reprojection residual + Jacobians, landmark side: D, b_l, chi2 */
+  PPO_BA_KERNEL_SCHUR_Z = 2,
+  PPO_BA_KERNEL_SCHUR_PAIRS = 3,
+  PPO_BA_KERNEL_BACKSUB = 4,
+  PPO_BA_KERNEL_CHI2_POINTS = 5
+};
+int ppo_ba_time_kernel(ppo_ba_handle h, int which, int reps, double* ms, int64_t* bytes);
+
 /* Time `reps` factorisations of the current reduced system (HIP events); average ms in *ms. */
 int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
 

@@ -1136,6 +1136,82 @@ int ppo_ba_time_linearize(ppo_ba_handle s, int reps, double* ms_out) {
   return PPO_BA_OK;
 }
 
+// One kernel of the hot path alone, `reps` back-to-back launches between two HIP events on the library's stream.
+int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int64_t* bytes_out) {
+  if (!s || reps <= 0 || !ms_out) return PPO_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  const Graph& g = s->g;
+  const State& st = s->st[s->cur];
+  const State& tr = s->st[s->cur ^ 1];
+  const int npts = g.pt_last - g.pt_first;
+  const int nl = npts + (g.plane_last - g.plane_first);
+  const long n_edges = (long)g.n_mono + g.n_stereo;
+  int64_t bytes = 0;
+  auto launch = [&]() -> bool {
+    switch (which) {
+      case PPO_BA_KERNEL_LIN_POSES:
+        if (s->posec.n_chunks <= 0) return false;
+        hipLaunchKernelGGL(k_lin_poses, dim3(nblk(s->posec.n_chunks, 4)), dim3(256), 0, s->stream, g, st, s->posec);
+        return true;
+      case PPO_BA_KERNEL_LIN_POINTS:
+        if (npts <= 0) return false;
+        if (s->use_lds) hipLaunchKernelGGL(k_lin_points<true>, dim3(std::min(nblk(npts, 256), 2 * s->n_cu)), dim3(256), s->lds_bytes, s->stream, g, st);
+        else hipLaunchKernelGGL(k_lin_points<false>, dim3(std::min(nblk(npts, 256), 2 * s->n_cu)), dim3(256), 0, s->stream, g, st);
+        return true;
+      case PPO_BA_KERNEL_SCHUR_Z:
+        if (g.n_slots <= 0) return false;
+        hipLaunchKernelGGL(k_schur_z, dim3(nblk(g.n_slots, 256)), dim3(256), 0, s->stream, g);
+        return true;
+      case PPO_BA_KERNEL_SCHUR_PAIRS:
+        if (s->pc.n_chunks <= 0) return false;
+        hipLaunchKernelGGL(k_schur_pairs, dim3((nblk(s->pc.n_chunks, 4) + 7) / 8 * 8), dim3(256), 0, s->stream, g, s->pc);
+        return true;
+      case PPO_BA_KERNEL_BACKSUB:
+        if (nl <= 0) return false;
+        if (s->use_lds) hipLaunchKernelGGL(k_backsub<true>, dim3(nblk(nl, 256)), dim3(256), s->lds_bytes, s->stream, g, st, tr, s->lambda);
+        else hipLaunchKernelGGL(k_backsub<false>, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, st, tr, s->lambda);
+        return true;
+      case PPO_BA_KERNEL_CHI2_POINTS:
+        if (npts <= 0) return false;
+        hipLaunchKernelGGL(k_chi2_points, dim3(std::min(nblk(npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
+        return true;
+      default: return false;
+    }
+  };
+  // algorithmic bytes: what the kernel must read and write once (records, flags, vertex estimates, output blocks)
+  const long nP = (long)s->d_monoP.n, nSP = (long)s->d_stereoP.n;
+  switch (which) {
+    case PPO_BA_KERNEL_LIN_POSES:  // pose-major record + flag + W block per edge; point per landmark; pose R|t + cam + packed Hpp|b per keyframe
+      bytes = nP * (long)(sizeof(MonoEdgeP) + 4 + 144) + nSP * (long)(sizeof(StereoEdgeP) + 4 + 144) + 24L * npts + (96L + 40 + 216) * g.n_pose_free;
+      break;
+    case PPO_BA_KERNEL_LIN_POINTS:  // landmark-major record + flag + chi2 per edge; point in, D + b_l out
+      bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4 + 8) + (long)g.n_stereo * (sizeof(StereoEdge) + 4 + 8) + 96L * npts + 136L * g.n_poses;
+      break;
+    case PPO_BA_KERNEL_SCHUR_Z: bytes = 288L * g.n_slots + 48L * nl; break;
+    case PPO_BA_KERNEL_SCHUR_PAIRS: bytes = 144L * g.n_slots + 24L * nl + 8L * ((long)g.n_red * (g.n_red + 1) / 2 + g.n_red); break;
+    case PPO_BA_KERNEL_BACKSUB: bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4) + (long)g.n_stereo * (sizeof(StereoEdge) + 4) + 96L * nl + 8L * g.n_red; break;
+    case PPO_BA_KERNEL_CHI2_POINTS: bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4 + 8) + (long)g.n_stereo * (sizeof(StereoEdge) + 4 + 8) + 24L * npts + 136L * g.n_poses; break;
+    default: return PPO_BA_ERR_ARG;
+  }
+  (void)n_edges;
+  if (bytes_out) *bytes_out = bytes;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  if (!launch()) { *ms_out = 0; return PPO_BA_OK; }
+  HIP_TRY(hipEventRecord(e0, s->stream));
+  for (int i = 0; i < reps; ++i) launch();
+  HIP_TRY(hipEventRecord(e1, s->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipGetLastError());
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = (double)ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return PPO_BA_OK;
+}
+
 int ppo_ba_time_factor(ppo_ba_handle s, int reps, double* ms_out) {
   if (!s || reps <= 0 || !ms_out) return PPO_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));

@@ -309,6 +309,7 @@ def load_library(path=LIB_PATH):
         lib.ppo_ba_linearize_bytes.argtypes = [C.c_void_p]
         lib.ppo_ba_time_linearize.argtypes = [C.c_void_p, C.c_int, c_dp]
         lib.ppo_ba_time_factor.argtypes = [C.c_void_p, C.c_int, c_dp]
+        lib.ppo_ba_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, C.POINTER(C.c_int64)]
         lib.ppo_ba_debug_reduced.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip]
         lib.ppo_ba_partition.argtypes = [C.POINTER(CProblem), C.c_int32, c_ip, c_ip]
         lib.ppo_ba_comm_unique_id.argtypes = [c_bp]
