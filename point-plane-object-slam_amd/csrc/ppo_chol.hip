@@ -4,13 +4,15 @@
 // Why not rocSOLVER: at n ~ 1.6k dpotrf + dpotrs spend 5 ms in latency-bound single-workgroup kernels
 // (profiles/r01_v1_kernel_stats.txt).  This solver is built for that regime:
 //   * right-looking, 64-wide panels, the matrix padded to a multiple of 64 (pad diagonal = 1);
-//   * chol_panel(k): every workgroup factors the 64x64 diagonal block redundantly in LDS -- four 16x16 wave-level
-//     register factorizations (pivot broadcast by v_readlane, no barrier inside), 16-wide substitutions with one row per
-//     lane, and v_mfma_f64_16x16x4 for every 16x16x16 block update -- then workgroup b solves its own 64-row block
-//     against it; the right-hand side rides along as a 65th row, so the forward substitution costs nothing extra;
-//   * chol_update(k): one 64x64 tile of the trailing lower triangle per workgroup, 64 FP64 MFMAs per wave;
+//   * chol_step(k), ONE launch per panel: the "column" workgroups first apply the rank-64 update of panel k-1 to the diagonal
+//     block and to their own block (look-ahead by one), then every one of them factors the 64x64 diagonal block redundantly in
+//     LDS -- four 16x16 wave-level register factorisations whose broadcast-multiply-adds are single f64 DPP instructions
+//     (v_fmac_f64 row_newbcast), the rows below riding along in the other lanes, and v_mfma_f64_16x16x4 for every 16x16x16
+//     block update -- and solves its own 64-row block against it; the right-hand side rides along as a 65th row, so the
+//     forward substitution costs nothing extra.  The remaining workgroups of the launch apply panel k-1's update to one
+//     64x64 tile of the trailing matrix each (64 FP64 MFMAs per wave);
 //   * chol_back(k): blocked backward substitution, the 64-vector held one entry per lane;
-//   * the 3 x n/64 launches are captured once into a hipGraph and replayed per solve.
+//   * the 2 x n/64 launches are captured once into a hipGraph and replayed per solve.
 // FMAs are written explicitly (__builtin_fma): the library is built with -ffp-contract=off for the numeric Jacobians.
 // info follows LAPACK potrf: 0 = positive definite, j > 0 = leading minor j is not (the LM loop treats that as
 // "solver failed", levenberg.cpp:126-127).
@@ -85,68 +87,101 @@ __device__ __forceinline__ void mfma_mul_16(double (*M)[LP], int r0, int c0, con
   for (int reg = 0; reg < 4; ++reg) M[r0 + lk + 4 * reg][c0 + li] = acc[reg];
 }
 
-// One wave factors the 16x16 block sL[o..o+16)[o..o+16) in place (lower) with the rows held in registers: lane r < 16
-// holds row r.  Lanes 16..31 carry the rows of an identity matrix through the SAME column operations (the Cholesky
-// elimination is a right-multiplication by L^-T), so they end up holding L^-T row by row at no extra instruction:
-// sT[i][c] = (L^-T)[i][c].  Returns the 1-based local index of the first non-positive pivot, 0 if none.
-__device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], double* sInv, int o) {
-  const int lane = threadIdx.x & 63, r = lane & 15;
-  const bool ident = (lane & 16) != 0;
-  double a[SB];
-#pragma unroll
-  for (int c = 0; c < SB; ++c) a[c] = ident ? (c == r ? 1.0 : 0.0) : sL[o + r][o + c];
-  int bad = 0;
-  // Column sweep.  Measured on gfx950 (tools/chol_probe.hip): this wave is ISSUE-bound (~4.5 cycles per instruction,
-  // ~60 instructions per column: 2 v_readlane + 1 v_fma per rank-1 column update), not latency-bound -- interleaving the
-  // pivot chain with the updates by hand did not help, so the loop stays in its plain form; one scheduling barrier per
-  // column keeps the broadcasts from piling up in SGPRs (129 SGPR spills without it).
-#pragma unroll
-  for (int j = 0; j < SB; ++j) {
-    const double d = bcast(a[j], j);
-    if (!(d > 0.0) && bad == 0) bad = j + 1;
+// ---- f64 DPP: v_fmac_f64 / v_mov_b64 accept `row_newbcast:N` (source operand taken from lane N of the reader's own row of
+// 16 lanes), which turns "broadcast + multiply-add" into ONE instruction.  The wave that factors a 16x16 block is issue-bound
+// (tools/chol_probe.hip: ~4.5 cycles per instruction whatever the dependencies), so instruction count is what matters: the
+// v_readlane formulation needed 2 broadcasts + 1 FMA per element update.  `s_nop 1` covers the VALU-write -> DPP-read hazard,
+// which the compiler cannot see inside inline assembly.
+template <int C, bool FRESH>
+__device__ __forceinline__ void fmac_bcast(double& acc, double l_src, double mul) {  // acc -= l_src[lane C of my row] * mul
+  if constexpr (FRESH)  // l_src was written by the preceding VALU instruction
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(l_src), "v"(mul), "n"(C));
+  else
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(l_src), "v"(mul), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ double row_bcast(double v) {
+  double d;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "n"(C));
+  return d;
+}
+
+template <int J, int C>
+struct ColUpdate {
+  static __device__ __forceinline__ void run(double (&a)[SB], double (&e)[SB], double l, double le) {
+    fmac_bcast<C, C == J + 1>(a[C], l, l);
+    fmac_bcast<C, false>(e[C], l, le);
+    if constexpr (C + 1 < SB) ColUpdate<J, C + 1>::run(a, e, l, le);
+  }
+};
+
+template <int J>
+struct ColSweep {
+  static __device__ __forceinline__ void run(double (&a)[SB], double (&e)[SB], int& bad) {
+    const double d = row_bcast<J>(a[J]);
+    if (!(d > 0.0) && bad == 0) bad = J + 1;
     // 1/sqrt(d): v_rsq_f64 (measured 5e-8 relative) + two Newton steps y <- y (1.5 - (d/2) y^2): 3.8e-15, then 2.2e-16
     const double h = 0.5 * d;
     double y = __builtin_amdgcn_rsq(d);
     y = y * __builtin_fma(-h, y * y, 1.5);
     y = y * __builtin_fma(-h, y * y, 1.5);
-    const double l = a[j] * y;
-    a[j] = l;
-    if (lane == j) sInv[o + j] = y;
-#pragma unroll
-    for (int c = j + 1; c < SB; ++c) a[c] = __builtin_fma(-l, bcast(l, c), a[c]);
-    __builtin_amdgcn_sched_barrier(0);
+    const double l = a[J] * y, le = e[J] * y;
+    a[J] = l;
+    e[J] = le;
+    if constexpr (J + 1 < SB) {
+      ColUpdate<J, J + 1>::run(a, e, l, le);
+      ColSweep<J + 1>::run(a, e, bad);
+    }
   }
-  if (lane < SB) {
+};
+
+// One wave factors the 16x16 block sL[o..o+16)[o..o+16) in place (lower) AND applies the same column operations to 48 more
+// rows.  Every group of 16 lanes (a DPP row) holds a copy of the 16 block rows, one row per lane, in registers (a[]); next
+// to it each lane carries one extra row (e[]): group 0 the rows of an identity matrix -- the Cholesky elimination is a
+// right-multiplication by L^-T, so they end up as L^-T: sT[i][c] = (L^-T)[i][c] -- and groups 1..3 the rows of the 16x16
+// tiles below the block inside the 64x64 panel block, which come out as X = B L^-T (the triangular solve, for free).
+// Returns the 1-based local index of the first non-positive pivot, 0 if none.
+__device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], int o) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int xrow = o + SB * g + r;  // extra row of groups 1..3
+  const bool has_x = g > 0 && xrow < NB;
+  double a[SB], e[SB];
 #pragma unroll
-    for (int c = 0; c < SB; ++c)
+  for (int c = 0; c < SB; ++c) {
+    a[c] = sL[o + r][o + c];
+    e[c] = g == 0 ? (c == r ? 1.0 : 0.0) : (has_x ? sL[xrow][o + c] : 0.0);
+  }
+  int bad = 0;
+  ColSweep<0>::run(a, e, bad);
+  if (g == 0) {
+#pragma unroll
+    for (int c = 0; c < SB; ++c) {
       if (c <= r) sL[o + r][o + c] = a[c];
-  } else if (lane < 2 * SB) {
+      sT[r][c] = e[c];
+    }
+  } else if (has_x) {
 #pragma unroll
-    for (int c = 0; c < SB; ++c) sT[r][c] = a[c];
+    for (int c = 0; c < SB; ++c) sL[xrow][o + c] = e[c];
   }
   return bad;
 }
 
 // Factor the 64x64 block held in sL (lower part valid) in place; sT[kk] receives L_kk^-T of the four 16x16 diagonal
 // blocks.  All 256 threads participate.  Returns (in every thread) the 1-based index of the first bad pivot or 0.
-__device__ int factor_64(double (*sL)[LP], double (*sT)[SB][17], double* sInv, int* sBad) {
+__device__ int factor_64(double (*sL)[LP], double (*sT)[SB][17], int* sBad) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) *sBad = 0;
   __syncthreads();
 #pragma unroll
   for (int kk = 0; kk < NB / SB; ++kk) {
     const int o = kk * SB;
-    if (wave == 0) {
-      const int bad = potf2_16(sL, sT[kk], sInv, o);
+    if (wave == 0) {  // diagonal 16x16 block + the sub-diagonal tiles of this block column
+      const int bad = potf2_16(sL, sT[kk], o);
       if (lane == 0 && bad && *sBad == 0) *sBad = o + bad;
     }
     __syncthreads();
-    STAMP(8 + 3 * kk);
+    STAMP(8 + 2 * kk);
     if (kk == NB / SB - 1) break;
-    // sub-diagonal tiles of this block column: X = B L^-T, one 16x16 tile per wave
-    if (kk + 1 + wave < NB / SB) mfma_mul_16(sL, (kk + 1 + wave) * SB, o, sL, (kk + 1 + wave) * SB, o, sT[kk]);
-    __syncthreads();
-    STAMP(9 + 3 * kk);
     // trailing 16x16 tiles (bi >= bj > kk): A[bi][bj] -= X_bi X_bj^T, tiles dealt round-robin to the 4 waves
     int t = 0;
 #pragma unroll
@@ -155,7 +190,7 @@ __device__ int factor_64(double (*sL)[LP], double (*sT)[SB][17], double* sInv, i
       for (int bj = kk + 1; bj <= bi; ++bj, ++t)
         if ((t & 3) == wave) mfma_sub_16(sL, bi * SB, bj * SB, sL, bi * SB, sL, bj * SB, o);
     __syncthreads();
-    STAMP(10 + 3 * kk);
+    STAMP(9 + 2 * kk);
   }
   return *sBad;
 }
@@ -174,23 +209,91 @@ __device__ __forceinline__ double bwd_vec_64(double v, const double (*sL)[LP], c
   return v;
 }
 
+constexpr int UP = NB + 4;  // row length of the update operand tiles in LDS
+
+// The wave's 32x32 quadrant of X Y^T for two 64x64 operand tiles held k-major in LDS (sX[m][row]); computed transposed
+// (A operand = Y rows = columns of the result, B operand = X rows) so that in the accumulator 16 lanes hold 16 consecutive
+// rows: acc[jc][ir][reg] = element (row wr + 16 ir + li, column wc + 16 jc + lk + 4 reg).
+__device__ __forceinline__ void quadrant_product(const double (*sX)[UP], const double (*sY)[UP], int wr, int wc, int li, int lk, v4d (&acc)[2][2]) {
+#pragma unroll 4
+  for (int m0 = 0; m0 < NB; m0 += 4) {
+    const double q0 = sY[m0 + lk][wc + li], q1 = sY[m0 + lk][wc + 16 + li];
+    const double p0 = sX[m0 + lk][wr + li], p1 = sX[m0 + lk][wr + 16 + li];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, p0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, p1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, p0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, p1, acc[1][1], 0, 0, 0);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
-// chol_panel: grid = (ld - k0) / 64 workgroups of 256.  Block 0 owns the diagonal block, block b >= 1 the 64 rows below.
+// chol_step(k): ONE launch per 64-wide panel.  With m = (ld - k0) / 64 block rows left, the grid is
+//   * m "column" workgroups (blockIdx < m, block row b): apply the rank-64 update of the PREVIOUS panel (k0 - 64) to the
+//     diagonal block (k,k) and to their own block (k+b, k), factor the diagonal block (every workgroup redundantly, in LDS),
+//     solve their block against it, carry the right-hand side along as a 65th row;
+//   * m (m - 1) / 2 "trailing" workgroups: apply the previous panel's update to one 64x64 tile (i >= j > k) each.
+// Fusing the update of panel k-1 with the factorisation of panel k (look-ahead by one) halves the launches on the critical
+// path: the column workgroups no longer wait for the whole trailing update to finish and be relaunched.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld, int k0, double* __restrict__ rhs, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs,
+                                                 int* __restrict__ info) {
   __shared__ double sL[NB][LP];
   __shared__ double sB[NB + 1][LP];  // row NB carries r_k^T: the forward substitution is one more row of the block solve
   __shared__ double sT[NB / SB][SB][17];
-  __shared__ double sInv[NB];
+  __shared__ __attribute__((aligned(16))) double sP[NB][UP];  // [m][row of block i] of the previous panel
+  __shared__ __attribute__((aligned(16))) double sQ[NB][UP];  // [m][row of block j]
   __shared__ int sBad;
-  const int tid = threadIdx.x, b = blockIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int row0 = k0 + b * NB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int m = (ld - k0) / NB;
+  const int kp = k0 - NB;  // previous panel's column
   STAMP(0);
-  {
+  if ((int)blockIdx.x >= m) {
+    // ---- trailing tile (bi >= bj >= 1 relative to block k) --------------------------------------------------------------
+    int t = blockIdx.x - m, bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
+    double2 tp[8], tq[8];
+    load_tile(&A[(size_t)kp * ld + r0], ld, tp);
+    load_tile(&A[(size_t)kp * ld + c0], ld, tq);
+    double cold[2][2][4];  // old values of the output quadrant, fetched while the panel tiles land
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+      for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) cold[jc][ir][reg] = A[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = tid + 256 * i, mm = p >> 5, r = 2 * (p & 31);
+      *reinterpret_cast<double2*>(&sP[mm][r]) = tp[i];
+      *reinterpret_cast<double2*>(&sQ[mm][r]) = tq[i];
+    }
+    __syncthreads();
+    v4d acc[2][2] = {};
+    quadrant_product(sP, sQ, wr, wc, li, lk, acc);
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+      for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int c = wc + 16 * jc + lk + 4 * reg, r = wr + 16 * ir + li;
+          if (bi != bj || r >= c) A[(size_t)(c0 + c) * ld + r0 + r] = cold[jc][ir][reg] - acc[jc][ir][reg];
+        }
+    return;
+  }
+  // ---- column workgroup ---------------------------------------------------------------------------------------------------
+  const int b = blockIdx.x;
+  const int row0 = k0 + b * NB;
+  // step 0 takes the right-hand side from rhs_in (the caller's b stays intact), later steps continue in rhs
+  const double* rsrc = (k0 == 0) ? rhs_in : rhs;
+  const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
+  if (k0 == 0) {
     double2 td[8], tb[8];
     load_tile(&A[(size_t)k0 * ld + k0], ld, td);
     if (b > 0) load_tile(&A[(size_t)k0 * ld + row0], ld, tb);
-    const double rv = (tid < NB) ? rhs[k0 + tid] : 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
@@ -198,11 +301,47 @@ __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld
       sL[r + 1][c] = (r + 1 >= c) ? td[i].y : 0.0;
       if (b > 0) { sB[r][c] = tb[i].x; sB[r + 1][c] = tb[i].y; }
     }
-    if (tid < NB) sB[NB][tid] = rv;
+  } else {
+    double2 tp[8], tq[8];
+    load_tile(&A[(size_t)kp * ld + k0], ld, tq);  // L[k][k-1]
+    if (b > 0) load_tile(&A[(size_t)kp * ld + row0], ld, tp);  // L[k+b][k-1]
+    double cd[2][2][4], co[2][2][4];
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+      for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const size_t col = (size_t)(k0 + wc + 16 * jc + lk + 4 * reg) * ld;
+          cd[jc][ir][reg] = (wr >= wc) ? A[col + k0 + wr + 16 * ir + li] : 0.0;
+          co[jc][ir][reg] = (b > 0) ? A[col + row0 + wr + 16 * ir + li] : 0.0;
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = tid + 256 * i, mm = p >> 5, r = 2 * (p & 31);
+      *reinterpret_cast<double2*>(&sQ[mm][r]) = tq[i];
+      if (b > 0) *reinterpret_cast<double2*>(&sP[mm][r]) = tp[i];
+    }
+    __syncthreads();
+    STAMP(5);
+    v4d ad[2][2] = {}, ao[2][2] = {};
+    if (wr >= wc) quadrant_product(sQ, sQ, wr, wc, li, lk, ad);  // the strictly upper quadrant of the diagonal block is not needed
+    if (b > 0) quadrant_product(sP, sQ, wr, wc, li, lk, ao);
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+      for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int c = wc + 16 * jc + lk + 4 * reg, r = wr + 16 * ir + li;
+          sL[r][c] = (r >= c) ? cd[jc][ir][reg] - ad[jc][ir][reg] : 0.0;
+          if (b > 0) sB[r][c] = co[jc][ir][reg] - ao[jc][ir][reg];
+        }
   }
+  if (tid < NB) sB[NB][tid] = rv;
   __syncthreads();
   STAMP(1);
-  const int bad = factor_64(sL, sT, sInv, &sBad);
+  const int bad = factor_64(sL, sT, &sBad);
   STAMP(2);
   // X = B L_kk^-T by 16-wide block substitution.  Wave w owns rows 16w..16w+15 of the block for the whole sweep (its
   // tiles only read the shared L / L^-T), so the four waves run without any workgroup barrier; wave 3 also carries the
@@ -222,7 +361,7 @@ __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld
       double xv = 0.0;
       if (lane < SB) {
 #pragma unroll
-        for (int m = 0; m < SB; ++m) xv = __builtin_fma(sB[NB][o + m], sT[kk][m][lane], xv);
+        for (int mm = 0; mm < SB; ++mm) xv = __builtin_fma(sB[NB][o + mm], sT[kk][mm][lane], xv);
       }
       __builtin_amdgcn_wave_barrier();
       if (lane < SB) sB[NB][o + lane] = xv;
@@ -233,7 +372,7 @@ __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld
         const int c = o + SB + lane;
         double sacc = 0.0;
 #pragma unroll
-        for (int m = 0; m < SB; ++m) sacc = __builtin_fma(sB[NB][o + m], sL[c][o + m], sacc);
+        for (int mm = 0; mm < SB; ++mm) sacc = __builtin_fma(sB[NB][o + mm], sL[c][o + mm], sacc);
         sB[NB][c] -= sacc;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -244,7 +383,10 @@ __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld
   __syncthreads();
   STAMP(3);
   if (b == 0) {
-    if (bad && tid == 0) atomicCAS(info, 0, k0 + bad);
+    if (tid == 0) {
+      if (k0 == 0) *info = bad;  // also resets the flag of the previous solve
+      else if (bad) atomicCAS(info, 0, k0 + bad);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
@@ -253,7 +395,7 @@ __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld
     if (tid < NB) rhs[k0 + tid] = sB[NB][tid];  // y_k
     return;
   }
-  const double rold = (tid < NB) ? rhs[row0 + tid] : 0.0;
+  const double rold = (tid < NB) ? rsrc[row0 + tid] : 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
@@ -262,64 +404,10 @@ __global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, int ld
   if (tid < NB) {  // r_b -= L_bk y_k
     double sacc = 0.0;
 #pragma unroll 16
-    for (int m = 0; m < NB; ++m) sacc = __builtin_fma(sB[tid][m], sB[NB][m], sacc);
+    for (int mm = 0; mm < NB; ++mm) sacc = __builtin_fma(sB[tid][mm], sB[NB][mm], sacc);
     rhs[row0 + tid] = rold - sacc;
   }
   STAMP(4);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// chol_update: A[i-block][j-block] -= P_i P_j^T for the panel at column k0; one 64x64 tile per workgroup,
-// blockIdx.x enumerates the lower-triangular tiles of the trailing matrix.  Wave w owns a 32x32 quadrant as 2x2 MFMA
-// tiles computed transposed (A operand = columns, B operand = rows) so that 16 lanes write 16 consecutive rows.
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_update(double* __restrict__ A, int ld, int k0) {
-  __shared__ __attribute__((aligned(16))) double sP[NB][NB + 4];  // [m][row of block i]
-  __shared__ __attribute__((aligned(16))) double sQ[NB][NB + 4];  // [m][row of block j]
-  int t = blockIdx.x, bi = 0;
-  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-  const int bj = t - bi * (bi + 1) / 2;
-  const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  double2 tp[8], tq[8];
-  load_tile(&A[(size_t)k0 * ld + r0], ld, tp);
-  load_tile(&A[(size_t)k0 * ld + c0], ld, tq);
-  // old values of the output quadrant, fetched while the panel tiles land
-  double cold[2][2][4];
-#pragma unroll
-  for (int jc = 0; jc < 2; ++jc)
-#pragma unroll
-    for (int ir = 0; ir < 2; ++ir)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        cold[jc][ir][reg] = A[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = tid + 256 * i, m = p >> 5, r = 2 * (p & 31);
-    *reinterpret_cast<double2*>(&sP[m][r]) = tp[i];
-    *reinterpret_cast<double2*>(&sQ[m][r]) = tq[i];
-  }
-  __syncthreads();
-  v4d acc[2][2] = {};
-#pragma unroll 4
-  for (int m0 = 0; m0 < NB; m0 += 4) {
-    const double q0 = sQ[m0 + lk][wc + li], q1 = sQ[m0 + lk][wc + 16 + li];  // A operand: i = column of C
-    const double p0 = sP[m0 + lk][wr + li], p1 = sP[m0 + lk][wr + 16 + li];  // B operand: j = row of C
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, p0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, p1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, p0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, p1, acc[1][1], 0, 0, 0);
-  }
-#pragma unroll
-  for (int jc = 0; jc < 2; ++jc)
-#pragma unroll
-    for (int ir = 0; ir < 2; ++ir)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int c = wc + 16 * jc + lk + 4 * reg, r = wr + 16 * ir + li;
-        if (bi != bj || r >= c) A[(size_t)(c0 + c) * ld + r0 + r] = cold[jc][ir][reg] - acc[jc][ir][reg];
-      }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -372,11 +460,13 @@ __global__ __launch_bounds__(256) void chol_back(const double* __restrict__ A, i
 
 struct GraphKey {
   double* A;
+  const double* b;
   double* x;
   int* info;
   int n;
   bool operator<(const GraphKey& o) const {
     if (A != o.A) return A < o.A;
+    if (b != o.b) return b < o.b;
     if (x != o.x) return x < o.x;
     if (info != o.info) return info < o.info;
     return n < o.n;
@@ -385,14 +475,12 @@ struct GraphKey {
 std::mutex g_mu;
 std::map<GraphKey, hipGraphExec_t> g_graphs;
 
-int enqueue_all(double* A, int ld, double* x, int* info, hipStream_t s) {
+int enqueue_all(double* A, int ld, const double* b, double* x, int* info, hipStream_t s) {
   const int nb = ld / NB;
-  if (hipMemsetAsync(info, 0, sizeof(int), s) != hipSuccess) return PPO_BA_ERR_HIP;
   for (int k = 0; k < nb; ++k) {
     const int k0 = k * NB;
-    hipLaunchKernelGGL(chol_panel, dim3(nb - k), dim3(256), 0, s, A, ld, k0, x, info);
-    const int m = nb - k - 1;
-    if (m > 0) hipLaunchKernelGGL(chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, A, ld, k0);
+    const int m = nb - k;
+    hipLaunchKernelGGL(chol_step, dim3(m + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(256), 0, s, A, ld, k0, b, x, info);
   }
   for (int k = nb - 1; k >= 0; --k) hipLaunchKernelGGL(chol_back, dim3(k > 0 ? k : 1), dim3(256), 0, s, (const double*)A, ld, k * NB, x);
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
@@ -401,20 +489,20 @@ int enqueue_all(double* A, int ld, double* x, int* info, hipStream_t s) {
 }  // namespace
 
 // A: ld x ld column-major with ld a multiple of 64 (chol_padded_ld), lower triangle valid, pad diagonal = 1.
-int chol_factor_solve(double* A, int ld, double* x, int* info, double* /*workspace*/, hipStream_t stream) {
+int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, double* /*workspace*/, hipStream_t stream) {
   if (ld % NB != 0) return PPO_BA_ERR_ARG;
   if (ld == 0) return PPO_BA_OK;
   static const bool use_graph = []() { const char* e = getenv("PPO_BA_CHOL_NOGRAPH"); return !(e && e[0] == '1'); }();
-  if (!use_graph) return enqueue_all(A, ld, x, info, stream);
+  if (!use_graph) return enqueue_all(A, ld, b, x, info, stream);
   hipGraphExec_t exec = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    const GraphKey key{A, x, info, ld};
+    const GraphKey key{A, b, x, info, ld};
     auto it = g_graphs.find(key);
     if (it == g_graphs.end()) {
       hipGraph_t graph = nullptr;
       if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return PPO_BA_ERR_HIP;
-      const int rc = enqueue_all(A, ld, x, info, stream);
+      const int rc = enqueue_all(A, ld, b, x, info, stream);
       if (hipStreamEndCapture(stream, &graph) != hipSuccess || rc != PPO_BA_OK) return PPO_BA_ERR_HIP;
       if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) return PPO_BA_ERR_HIP;
       (void)hipGraphDestroy(graph);

@@ -70,7 +70,9 @@ struct ppo_ba_solver {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;        // the small numerically differentiated edge classes run here, next to the point kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_acc = nullptr;
+  bool lin_valid = false;   // the linearisation buffers hold the linearisation of state `cur` (speculated by the previous trial)
+  double chi_cur = 0;       // robust chi2 of state `cur` when lin_valid
   rocblas_handle blas = nullptr;
   Comm comm;
   int n_cubpl = 0;
@@ -232,6 +234,7 @@ void free_all(ppo_ba_solver* s) {
   s->comm.destroy();
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->ev_acc) (void)hipEventDestroy(s->ev_acc);
   if (s->side) (void)hipStreamDestroy(s->side);
   if (s->stream) (void)hipStreamDestroy(s->stream);
 }
@@ -275,9 +278,9 @@ int reset_device(ppo_ba_solver* s) {
 }
 
 // ---- one linearisation of the current state: fills HB/HC/D/bl/W, per-edge chi2, acc[ACC_CHI2] ------------
-int launch_linearize(ppo_ba_solver* s) {
+int launch_linearize(ppo_ba_solver* s, int which_state = -1) {
   const Graph& g = s->g;
-  const State& st = s->st[s->cur];
+  const State& st = s->st[which_state < 0 ? s->cur : which_state];
   double* A = s->d_arena.p;
   {
     ZeroPlan zp{};
@@ -340,6 +343,7 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
     ZeroPlan zp{};
     zp.p[0] = s->d_S.p; zp.n[0] = n * n;
     zp.p[1] = s->d_bs.p; zp.n[1] = n;
+    zp.p[2] = s->g.acc; zp.n[2] = 2;  // chi2 and scale of the trial that follows
     hipLaunchKernelGGL(k_zero_ranges, dim3(4 * s->n_cu), dim3(256), 0, s->stream, zp);
   }
   const bool cub_stage = g.elim_cub && g.owns_reduced && g.n_cuboids > 0;
@@ -373,10 +377,11 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
 int launch_solve(ppo_ba_solver* s) {
   const Graph& g = s->g;
   const int n = g.n_red, ld = g.ld;
-  HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs.p, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
-    RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
+    RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs.p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
   } else {
+    HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs.p, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream));
     if (rocsolver_dpotrf(s->blas, rocblas_fill_lower, n, s->d_S.p, ld, s->d_info.p) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
     if (rocsolver_dpotrs(s->blas, rocblas_fill_lower, n, 1, s->d_S.p, ld, s->d_xr.p, ld) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
   }
@@ -398,33 +403,56 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   return PPO_BA_OK;
 }
 
-// bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first
-int fetch_acc(ppo_ba_solver* s, bool with_info) {
+// bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
+// can be queued behind the copy before the host blocks on it.
+int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info) {
   if (s->comm.active()) {
     // chi2 and scale are sums, maxdiag is a max: two tiny collectives on the accumulator block
     if (s->comm.sum(s->g.acc, 2, s->stream) || s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
   }
   HIP_TRY(hipMemcpyAsync(s->h_pinned, s->g.acc, ACC_N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   if (with_info) HIP_TRY(hipMemcpyAsync(s->h_pinned + ACC_N, s->d_info.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
   return PPO_BA_OK;
+}
+int fetch_acc_wait(ppo_ba_solver* s) {
+  HIP_TRY(hipEventSynchronize(s->ev_acc));
+  return PPO_BA_OK;
+}
+int fetch_acc(ppo_ba_solver* s, bool with_info) {
+  RC_TRY(fetch_acc_enqueue(s, with_info));
+  return fetch_acc_wait(s);
 }
 
 bool stop_requested(const volatile uint8_t* f) { return f && *f; }
 
 // OptimizationAlgorithmLevenberg::solve, levenberg.cpp:61-164.  Returns <0 error, 0 OK, 1 Terminate.
-int lm_iteration(ppo_ba_solver* s, int iteration, const volatile uint8_t* stop, ppo_ba_iter_stat& it) {
+//
+// Host/device pipelining: the only value the host must see per trial is (chi2, scale, info) of the trial state.  While
+// that copy is in flight the NEXT iteration's linearisation is already queued on the trial state (an accepted trial is
+// the common case), so the device never idles on the host's decision; a rejected trial re-linearises the kept state.
+// `may_speculate` is false on the last iteration of a pass (the outlier classification or the caller comes next).
+int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const volatile uint8_t* stop, ppo_ba_iter_stat& it) {
   Graph& g = s->g;
-  RC_TRY(launch_linearize(s));
-  if (s->comm.active()) {  // every rank needs the summed pose blocks (lambda init, scale term, rank 0 assembles them)
-    if (s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
+  const bool fresh = !s->lin_valid;
+  if (fresh) {
+    RC_TRY(launch_linearize(s));
+    if (s->comm.active()) {  // every rank needs the summed pose blocks (lambda init, scale term, rank 0 assembles them)
+      if (s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
+    }
   }
   if (iteration == 0) {
     const long nd = std::max<long>({(long)g.n_pose_free * 6, (long)g.n_cuboids * 9, 3L * ((g.pt_last - g.pt_first) + (g.plane_last - g.plane_first)), 1L});
     hipLaunchKernelGGL(k_maxdiag, dim3(nblk(nd, 256)), dim3(256), 0, s->stream, g);
   }
-  RC_TRY(fetch_acc(s, false));
-  double currentChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+  double currentChi;
+  if (fresh || iteration == 0) {
+    RC_TRY(fetch_acc(s, false));
+    currentChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+  } else {
+    currentChi = s->chi_cur;  // computeActiveErrors of the state the previous trial produced (levenberg.cpp:72-75)
+  }
+  s->lin_valid = false;
   const double iniChi = currentChi;
   it.chi2_before = currentChi;
   if (iteration == 0) {  // computeLambdaInit, levenberg.cpp:166-180
@@ -439,11 +467,15 @@ int lm_iteration(ppo_ba_solver* s, int iteration, const volatile uint8_t* stop, 
     RC_TRY(launch_reduce(s, lambda));
     RC_TRY(launch_solve(s));
     s->have_system = true;
-    // acc: chi2 <- 0, scale <- 0 for the trial
-    HIP_TRY(hipMemsetAsync(g.acc, 0, 2 * sizeof(double), s->stream));
     RC_TRY(launch_update(s, lambda));
     RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
-    RC_TRY(fetch_acc(s, true));
+    RC_TRY(fetch_acc_enqueue(s, true));
+    const bool speculated = may_speculate && !stop_requested(stop);
+    if (speculated) {
+      RC_TRY(launch_linearize(s, s->cur ^ 1));
+      if (s->comm.active() && s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
+    }
+    RC_TRY(fetch_acc_wait(s));
     int info = 0;
     std::memcpy(&info, s->h_pinned + ACC_N, sizeof(int));
     double tempChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
@@ -463,11 +495,18 @@ int lm_iteration(ppo_ba_solver* s, int iteration, const volatile uint8_t* stop, 
       currentChi = tempChi;
       s->cur ^= 1;  // discardTop(): the trial state becomes the estimate
       it.accepted = 1;
+      s->lin_valid = speculated;
+      s->chi_cur = tempChi;
     } else {
       s->lambda *= s->ni;
       s->ni *= 2;
       it.accepted = 0;  // pop(): keep the current state
       if (!(rho < 0)) rho = (info != 0) ? -1.0 : rho;
+      if (speculated && rho < 0 && qmax + 1 < s->opt.lm_max_trials && !stop_requested(stop)) {
+        // the buffers hold the rejected state's linearisation: restore the kept state's before the retry
+        RC_TRY(launch_linearize(s));
+        if (s->comm.active() && s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
+      }
     }
     qmax++;
     s->stats.n_trials++;
@@ -485,11 +524,12 @@ int lm_iteration(ppo_ba_solver* s, int iteration, const volatile uint8_t* stop, 
 int optimize(ppo_ba_solver* s, int pass, int iterations, const volatile uint8_t* stop) {
   if (s->g.n_red == 0) return 0;
   bool ok = true;
+  s->lin_valid = false;
   for (int i = 0; i < iterations && !stop_requested(stop) && ok; ++i) {
     ppo_ba_iter_stat it{};
     it.pass = pass;
     it.iteration = i;
-    const int res = lm_iteration(s, i, stop, it);
+    const int res = lm_iteration(s, i, i + 1 < iterations, stop, it);
     if (res < 0) return res;
     it.result = res;
     ok = (res == 0);
@@ -527,7 +567,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return fail(PPO_BA_ERR_HIP);
   if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess) return fail(PPO_BA_ERR_HIP);
-  if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail(PPO_BA_ERR_HIP);
+  if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_acc, hipEventDisableTiming) != hipSuccess) return fail(PPO_BA_ERR_HIP);
   if (rocblas_create_handle(&s->blas) != rocblas_status_success) return fail(PPO_BA_ERR_SOLVER);
   rocblas_set_stream(s->blas, s->stream);
   if (s->comm.init(o->comm_id, o->rank, o->world_size)) return fail(PPO_BA_ERR_COMM);

@@ -7,7 +7,7 @@
 #include <cmath>
 #define PPO_CHOL_STAMPS 1
 __device__ long long g_stamps[32];
-#define STAMP(i) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#define STAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
 #include "../point-plane-object-slam_amd/csrc/ppo_chol.hip"
 
 __global__ void rsq_acc(double* out) {
@@ -23,9 +23,62 @@ __global__ void rsq_acc(double* out) {
   atomicMax((unsigned long long*)&out[1], (unsigned long long)__double_as_longlong(e1));
   atomicMax((unsigned long long*)&out[2], (unsigned long long)__double_as_longlong(e2));
 }
+
+// ---- micro-benchmarks of the 16x16 register factorisation: where do the ~330 cycles per column go? -------------------
+template <int MODE>  // 0 = full potf2_16, 1 = pivot chains only (no trailing updates), 2 = trailing updates only (fixed y)
+__global__ void potf2_bench(double* out, long long* cyc) {
+  __shared__ double sL[ppo::NB][ppo::LP];
+  __shared__ double sT[16][17];
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  for (int i = threadIdx.x; i < 64 * 65; i += 64) (&sL[0][0])[i] = 0.0;
+  __syncthreads();
+  for (int c = 0; c < 64; ++c) sL[lane][c] = (lane == c) ? 70.0 : 0.01 * ((lane * 7 + c * 3) % 11);
+  __syncthreads();
+  double a[16], e[16];
+  for (int c = 0; c < 16; ++c) { a[c] = sL[r][c]; e[c] = sL[16 + lane % 48][c]; }
+  const long long t0 = clock64();
+  if (MODE == 0) {
+    int bad = 0;
+    ppo::ColSweep<0>::run(a, e, bad);
+    e[0] += bad;
+  } else if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double d = ppo::row_bcast<0>(a[j]);
+      const double h = 0.5 * d;
+      double y = __builtin_amdgcn_rsq(d);
+      y = y * __builtin_fma(-h, y * y, 1.5);
+      y = y * __builtin_fma(-h, y * y, 1.5);
+      a[j] = a[j] * y;
+      if (j + 1 < 16) ppo::fmac_bcast<0, true>(a[j + 1], a[j], a[j]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double l = a[j], le = e[j];
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) { ppo::fmac_bcast<0, false>(a[c], l, l); ppo::fmac_bcast<0, false>(e[c], l, le); }
+    }
+  }
+  const long long t1 = clock64();
+  double sum = 0;
+  for (int c = 0; c < 16; ++c) sum += a[c] + e[c];
+  out[threadIdx.x] = sum;
+  if (threadIdx.x == 0) cyc[MODE] = t1 - t0;
+}
 int main() {
   { double* o; hipMalloc((void**)&o, 32); hipMemset(o, 0, 32); hipLaunchKernelGGL(rsq_acc, dim3(64), dim3(256), 0, 0, o); double h[3]; hipMemcpy(h, o, 24, hipMemcpyDeviceToHost);
     printf("v_rsq_f64 max rel err: raw %.3e, 1 Newton %.3e, 2 Newton %.3e\n", h[0], h[1], h[2]); }
+  {
+    double* o; long long* c; hipMalloc((void**)&o, 64 * 8); hipMalloc((void**)&c, 3 * 8);
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(potf2_bench<0>, dim3(1), dim3(64), 0, 0, o, c);
+      hipLaunchKernelGGL(potf2_bench<1>, dim3(1), dim3(64), 0, 0, o, c);
+      hipLaunchKernelGGL(potf2_bench<2>, dim3(1), dim3(64), 0, 0, o, c);
+    }
+    long long h[3]; hipMemcpy(h, c, 24, hipMemcpyDeviceToHost);
+    printf("potf2_16 register sweep (s_memtime ticks): full %lld, pivot chains only %lld, 240 DPP fmacs only %lld\n", h[0], h[1], h[2]);
+  }
   const int n = 1664;
   std::vector<double> A((size_t)n * n, 0.0), b(n, 1.0);
   srand(1);
@@ -45,7 +98,7 @@ int main() {
     hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(dx, b.data(), n * 8, hipMemcpyHostToDevice, s);
     hipEventRecord(e0, s);
-    ppo::chol_factor_solve(dA, n, dx, dinfo, nullptr, s);
+    ppo::chol_factor_solve(dA, n, dx, dx, dinfo, nullptr, s);
     hipEventRecord(e1, s);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -58,14 +111,19 @@ int main() {
   for (int r = 0; r < n; ++r) { double sres = -1.0; for (int c = 0; c < n; ++c) sres += A[(size_t)c * n + r] * x[c]; rmax = fmax(rmax, fabs(sres)); }
   int info; hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
   printf("info %d max residual %.3e\n", info, rmax);
-  // phase stamps of the LAST block of the first panel launch: rerun one panel
+  // phase stamps of column workgroup 1 of the second step (update of panel 0 fused with the factorisation of panel 1)
   hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(ppo::chol_panel, dim3(n / 64), dim3(256), 0, s, dA, n, 0, dx, dinfo);
+  hipLaunchKernelGGL(ppo::chol_step, dim3(n / 64), dim3(256), 0, s, dA, n, 0, dx, dx, dinfo);
+  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(m + m * (m - 1) / 2), dim3(256), 0, s, dA, n, 64, dx, dx, dinfo); }
   hipStreamSynchronize(s);
   long long st[32];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
-  const char* names[] = {"start", "loaded->LDS", "factor_64 done", "R subst done", "stored"};
-  for (int i = 1; i < 5; ++i) printf("  %-16s +%lld ticks (100 MHz wall clock => %.2f us)\n", names[i], st[i] - st[i - 1], (st[i] - st[i - 1]) * 0.01);
-  for (int i = 8; i < 20; ++i) if (st[i]) printf("  factor stamp %d: +%.2f us\n", i, (st[i] - st[i - 1 < 8 ? 1 : i - 1]) * 0.01);
+  printf("  tiles in LDS        +%.2f us\n", (st[5] - st[0]) * 0.01);
+  printf("  update MFMAs -> LDS +%.2f us\n", (st[1] - st[5]) * 0.01);
+  printf("  factor_64           +%.2f us\n", (st[2] - st[1]) * 0.01);
+  printf("  block solve         +%.2f us\n", (st[3] - st[2]) * 0.01);
+  printf("  stored              +%.2f us\n", (st[4] - st[3]) * 0.01);
+  for (int i = 8; i < 15; ++i) printf("  factor stamp %d: +%.2f us\n", i, (st[i] - (i == 8 ? st[1] : st[i - 1])) * 0.01);
+  // per-kernel time of the graph's launches
   return 0;
 }
