@@ -11,8 +11,9 @@
 //     block update -- and solves its own 64-row block against it; the right-hand side rides along as a 65th row, so the
 //     forward substitution costs nothing extra.  The remaining workgroups of the launch apply panel k-1's update to one
 //     64x64 tile of the trailing matrix each (64 FP64 MFMAs per wave);
-//   * chol_back(k): blocked backward substitution, the 64-vector held one entry per lane;
-//   * the 2 x n/64 launches are captured once into a hipGraph and replayed per solve.
+//   * chol_back_all: the backward substitution in one launch, one workgroup per block, pipelined through data-tagged
+//     8-byte granules (no fences, no grid barrier);
+//   * the n/64 + 1 launches are captured once into a hipGraph and replayed per solve.
 // FMAs are written explicitly (__builtin_fma): the library is built with -ffp-contract=off for the numeric Jacobians.
 // info follows LAPACK potrf: 0 = positive definite, j > 0 = leading minor j is not (the LM loop treats that as
 // "solver failed", levenberg.cpp:126-127).
@@ -33,6 +34,8 @@ constexpr int LP = 65;  // padded LDS row length (doubles): column walks are ban
 constexpr int SB = 16;  // sub-block of the diagonal factorization = MFMA tile edge
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr unsigned long long kSentinel = 0xFFF8C0DEC0DE0001ull;  // "not written yet": a NaN payload no arithmetic produces
+constexpr int kSpinCap = 400000;
 
 #ifndef STAMP
 #define STAMP(i)  // tools/chol_probe.hip defines it to record wall-clock stamps
@@ -141,7 +144,7 @@ struct ColSweep {
 // right-multiplication by L^-T, so they end up as L^-T: sT[i][c] = (L^-T)[i][c] -- and groups 1..3 the rows of the 16x16
 // tiles below the block inside the 64x64 panel block, which come out as X = B L^-T (the triangular solve, for free).
 // Returns the 1-based local index of the first non-positive pivot, 0 if none.
-__device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], int o) {
+__device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], int o, bool store) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int xrow = o + SB * g + r;  // extra row of groups 1..3
   const bool has_x = g > 0 && xrow < NB;
@@ -153,6 +156,7 @@ __device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], int 
   }
   int bad = 0;
   ColSweep<0>::run(a, e, bad);
+  if (!store) return bad;
   if (g == 0) {
 #pragma unroll
     for (int c = 0; c < SB; ++c) {
@@ -166,47 +170,21 @@ __device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], int 
   return bad;
 }
 
-// Factor the 64x64 block held in sL (lower part valid) in place; sT[kk] receives L_kk^-T of the four 16x16 diagonal
-// blocks.  All 256 threads participate.  Returns (in every thread) the 1-based index of the first bad pivot or 0.
-__device__ int factor_64(double (*sL)[LP], double (*sT)[SB][17], int* sBad) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid == 0) *sBad = 0;
-  __syncthreads();
-#pragma unroll
-  for (int kk = 0; kk < NB / SB; ++kk) {
-    const int o = kk * SB;
-    if (wave == 0) {  // diagonal 16x16 block + the sub-diagonal tiles of this block column
-      const int bad = potf2_16(sL, sT[kk], o);
-      if (lane == 0 && bad && *sBad == 0) *sBad = o + bad;
-    }
-    __syncthreads();
-    STAMP(8 + 2 * kk);
-    if (kk == NB / SB - 1) break;
-    // trailing 16x16 tiles (bi >= bj > kk): A[bi][bj] -= X_bi X_bj^T, tiles dealt round-robin to the 4 waves
-    int t = 0;
-#pragma unroll
-    for (int bi = kk + 1; bi < NB / SB; ++bi)
-#pragma unroll
-      for (int bj = kk + 1; bj <= bi; ++bj, ++t)
-        if ((t & 3) == wave) mfma_sub_16(sL, bi * SB, bj * SB, sL, bi * SB, sL, bj * SB, o);
-    __syncthreads();
-    STAMP(9 + 2 * kk);
-  }
-  return *sBad;
-}
-
-// x <- L^-T v for the factored 64x64 block in sL, executed by one wave: lane i holds v_i in a register, the solution
-// sweeps from the last unknown to the first, one broadcast + one FMA per step (the L reads do not depend on data).
-__device__ __forceinline__ double bwd_vec_64(double v, const double (*sL)[LP], const double* sInv) {
+// x <- L^-T v for a factored 64x64 block, executed by one wave.  Lane i works on the pre-scaled unknown w_i = v_i / L_ii
+// and holds, in registers, column i of L scaled the same way (lcol[c] = L[c][i] / L_ii for c > i, 0 otherwise -- loaded
+// before the data arrives).  The sweep from the last unknown to the first is then one broadcast + one FMA per step with
+// no memory access, multiply or select inside the dependency chain (with LDS reads inside it the sweep took 3.8 us).
+__device__ __forceinline__ void bwd_load_64(const double (*sL)[LP], double (&lcol)[NB], double& inv) {
   const int lane = threadIdx.x & 63;
-  const double myinv = sInv[lane];
+  inv = 1.0 / sL[lane][lane];
 #pragma unroll
-  for (int c = NB - 1; c >= 0; --c) {
-    const double xc = bcast(v * myinv, c);
-    if (lane == c) v = xc;
-    else if (lane < c) v = __builtin_fma(-sL[c][lane], xc, v);
-  }
-  return v;
+  for (int c = 0; c < NB; ++c) lcol[c] = (c > lane) ? sL[c][lane] * inv : 0.0;
+}
+__device__ __forceinline__ double bwd_vec_64(double v, const double (&lcol)[NB], double inv) {
+  double w = v * inv;
+#pragma unroll
+  for (int c = NB - 1; c > 0; --c) w = __builtin_fma(-lcol[c], bcast(w, c), w);
+  return w;
 }
 
 constexpr int UP = NB + 4;  // row length of the update operand tiles in LDS
@@ -226,17 +204,115 @@ __device__ __forceinline__ void quadrant_product(const double (*sX)[UP], const d
   }
 }
 
+// One wave, two 16x16 tiles at once: M[16 t.., 16 u..] -= X_t Y_u^T over the whole previous panel (K = 64), X / Y k-major
+// in LDS.  A chain of dependent FP64 MFMAs on ONE accumulator runs at roughly the instruction's latency (~90 cycles each
+// measured in situ), two interleaved chains hide most of it.  lo1/lo2: only the lower triangle of that tile is touched.
+__device__ __forceinline__ void tile_update2(double (*M)[LP], int t1, int u1, bool lo1, int t2, int u2, bool lo2, const double (*sX)[UP],
+                                             const double (*sY)[UP]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  v4d acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m0 = 0; m0 < NB; m0 += 4) {
+    const double a1 = sX[m0 + lk][t1 * SB + li], b1 = sY[m0 + lk][u1 * SB + li];
+    const double a2 = sX[m0 + lk][t2 * SB + li], b2 = sY[m0 + lk][u2 * SB + li];
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2, 0, 0, 0);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int r1 = t1 * SB + lk + 4 * reg, c1 = u1 * SB + li, r2 = t2 * SB + lk + 4 * reg, c2 = u2 * SB + li;
+    if (!lo1 || r1 >= c1) M[r1][c1] -= acc1[reg];
+    if (!lo2 || r2 >= c2) M[r2][c2] -= acc2[reg];
+  }
+}
+
+// One tile with the K range split over two accumulators (used where a wave has a single tile to do).
+__device__ __forceinline__ void tile_update1(double (*M)[LP], int t, int u, bool lo, const double (*sX)[UP], const double (*sY)[UP]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  v4d acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m0 = 0; m0 < NB; m0 += 8) {
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[m0 + lk][t * SB + li], sY[m0 + lk][u * SB + li], acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[m0 + 4 + lk][t * SB + li], sY[m0 + 4 + lk][u * SB + li], acc2, 0, 0, 0);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int r = t * SB + lk + 4 * reg, c = u * SB + li;
+    if (!lo || r >= c) M[r][c] -= acc1[reg] + acc2[reg];
+  }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {  // make this wave's LDS writes visible to its own other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Block substitution step KK for the 16 rows rt of B (X = B L^-T): tile (rt, KK) <- tile * L_KK^-T, then the tiles to its
+// right take their update (independent accumulators, interleaved).  One wave.
+template <int KK>
+__device__ __forceinline__ void solve_rows(double (*sB)[LP], int rt, const double (*sL)[LP], const double (*sT)[SB][17]) {
+  constexpr int o = KK * SB, NR = NB / SB - 1 - KK;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  wave_lds_fence();
+  mfma_mul_16(sB, rt * SB, o, sB, rt * SB, o, sT[KK]);
+  wave_lds_fence();
+  if constexpr (NR > 0) {
+    v4d acc[NR] = {};
+#pragma unroll
+    for (int m0 = 0; m0 < SB; m0 += 4) {
+      const double a = sB[rt * SB + li][o + m0 + lk];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sL[(KK + 1 + q) * SB + li][o + m0 + lk], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) sB[rt * SB + lk + 4 * reg][(KK + 1 + q) * SB + li] -= acc[q][reg];
+  }
+}
+
+// The right-hand-side row (row NB of sB) through substitution step kk: x = b T (16 lanes), then b[rest] -= x L[rest]^T.
+__device__ __forceinline__ void solve_rhs_row(double (*sB)[LP], int kk, const double (*sL)[LP], const double (*sT)[SB][17]) {
+  const int lane = threadIdx.x & 63, o = kk * SB;
+  double xv = 0.0;
+  wave_lds_fence();
+  if (lane < SB) {
+#pragma unroll
+    for (int mm = 0; mm < SB; ++mm) xv = __builtin_fma(sB[NB][o + mm], sT[kk][mm][lane], xv);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < SB) sB[NB][o + lane] = xv;
+  wave_lds_fence();
+  if (lane < NB - o - SB) {
+    const int c = o + SB + lane;
+    double sacc = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < SB; ++mm) sacc = __builtin_fma(sB[NB][o + mm], sL[c][o + mm], sacc);
+    sB[NB][c] -= sacc;
+  }
+  wave_lds_fence();
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // chol_step(k): ONE launch per 64-wide panel.  With m = (ld - k0) / 64 block rows left, the grid is
 //   * m "column" workgroups (blockIdx < m, block row b): apply the rank-64 update of the PREVIOUS panel (k0 - 64) to the
 //     diagonal block (k,k) and to their own block (k+b, k), factor the diagonal block (every workgroup redundantly, in LDS),
 //     solve their block against it, carry the right-hand side along as a 65th row;
 //   * m (m - 1) / 2 "trailing" workgroups: apply the previous panel's update to one 64x64 tile (i >= j > k) each.
-// Fusing the update of panel k-1 with the factorisation of panel k (look-ahead by one) halves the launches on the critical
-// path: the column workgroups no longer wait for the whole trailing update to finish and be relaunched.
+// The serial part is the chain of four 16x16 register factorisations on wave 0 (~2 us each).  Everything else a column
+// workgroup has to do -- the rest of the diagonal block's update, the update of its own block and the block substitution
+// -- is MFMA work cut into jobs of <= 32 MFMAs and run by waves 1..3 in the shadow of those factorisations:
+//                 wave 1                           wave 2                           wave 3
+//   potf2(0)  D(1,1) D(2,1)  U(0,0) U(0,1)     D(2,2) D(3,1)  U(0,2) U(0,3)     D(3,2) D(3,3)  U(1,0) U(1,1)
+//   potf2(1)  U(1,2) U(1,3)  S0(row 1)         S0(row 0)  U(2,0) U(2,1)         U(2,2) U(2,3)  R0
+//   potf2(2)  U(3,0) U(3,1)  S1(row 0)         U(3,2) U(3,3)  S0(row 2)         S1(row 1)  R1
+//   potf2(3)  S0(row 3) S1(row 3) S2(row 3)    S1(row 2) S2(row 2)              S2(row 0) S2(row 1)  R2
+//   after     S3(row w) on wave w, R3 on wave 3
+// D = panel update of a diagonal-block tile, U = of an own-block tile, Ss = substitution step s of an own-block row,
+// Rs = step s of the right-hand-side row.  (Before potf2(0) all four waves update block column 0 of the diagonal block.)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs,
-                                                 int* __restrict__ info) {
+__global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info) {
   __shared__ double sL[NB][LP];
   __shared__ double sB[NB + 1][LP];  // row NB carries r_k^T: the forward substitution is one more row of the block solve
   __shared__ double sT[NB / SB][SB][17];
@@ -244,12 +320,13 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
   __shared__ __attribute__((aligned(16))) double sQ[NB][UP];  // [m][row of block j]
   __shared__ int sBad;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
   const int m = (ld - k0) / NB;
   const int kp = k0 - NB;  // previous panel's column
+  const bool upd = k0 > 0;
   STAMP(0);
   if ((int)blockIdx.x >= m) {
     // ---- trailing tile (bi >= bj >= 1 relative to block k) --------------------------------------------------------------
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     int t = blockIdx.x - m, bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     const int bj = t - bi * (bi + 1) / 2;
@@ -287,102 +364,115 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
   // ---- column workgroup ---------------------------------------------------------------------------------------------------
   const int b = blockIdx.x;
   const int row0 = k0 + b * NB;
+  const bool own = b > 0;
+  const bool uo = own && upd;
   // step 0 takes the right-hand side from rhs_in (the caller's b stays intact), later steps continue in rhs
   const double* rsrc = (k0 == 0) ? rhs_in : rhs;
-  const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
-  if (k0 == 0) {
-    double2 td[8], tb[8];
+  {
+    double2 td[8], tb[8], tp[8], tq[8];
     load_tile(&A[(size_t)k0 * ld + k0], ld, td);
-    if (b > 0) load_tile(&A[(size_t)k0 * ld + row0], ld, tb);
+    if (upd) load_tile(&A[(size_t)kp * ld + k0], ld, tq);  // L[k][k-1]
+    if (own) load_tile(&A[(size_t)k0 * ld + row0], ld, tb);
+    if (uo) load_tile(&A[(size_t)kp * ld + row0], ld, tp);  // L[k+b][k-1]
+    const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
+    STAMP(6);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
       sL[r][c] = (r >= c) ? td[i].x : 0.0;
       sL[r + 1][c] = (r + 1 >= c) ? td[i].y : 0.0;
-      if (b > 0) { sB[r][c] = tb[i].x; sB[r + 1][c] = tb[i].y; }
+      if (upd) *reinterpret_cast<double2*>(&sQ[c][r]) = tq[i];
     }
-  } else {
-    double2 tp[8], tq[8];
-    load_tile(&A[(size_t)kp * ld + k0], ld, tq);  // L[k][k-1]
-    if (b > 0) load_tile(&A[(size_t)kp * ld + row0], ld, tp);  // L[k+b][k-1]
-    double cd[2][2][4], co[2][2][4];
+    if (own) {
 #pragma unroll
-    for (int jc = 0; jc < 2; ++jc)
-#pragma unroll
-      for (int ir = 0; ir < 2; ++ir)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const size_t col = (size_t)(k0 + wc + 16 * jc + lk + 4 * reg) * ld;
-          cd[jc][ir][reg] = (wr >= wc) ? A[col + k0 + wr + 16 * ir + li] : 0.0;
-          co[jc][ir][reg] = (b > 0) ? A[col + row0 + wr + 16 * ir + li] : 0.0;
-        }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = tid + 256 * i, mm = p >> 5, r = 2 * (p & 31);
-      *reinterpret_cast<double2*>(&sQ[mm][r]) = tq[i];
-      if (b > 0) *reinterpret_cast<double2*>(&sP[mm][r]) = tp[i];
+      for (int i = 0; i < 8; ++i) {
+        const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
+        sB[r][c] = tb[i].x;
+        sB[r + 1][c] = tb[i].y;
+        if (upd) *reinterpret_cast<double2*>(&sP[c][r]) = tp[i];
+      }
     }
-    __syncthreads();
-    STAMP(5);
-    v4d ad[2][2] = {}, ao[2][2] = {};
-    if (wr >= wc) quadrant_product(sQ, sQ, wr, wc, li, lk, ad);  // the strictly upper quadrant of the diagonal block is not needed
-    if (b > 0) quadrant_product(sP, sQ, wr, wc, li, lk, ao);
-#pragma unroll
-    for (int jc = 0; jc < 2; ++jc)
-#pragma unroll
-      for (int ir = 0; ir < 2; ++ir)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int c = wc + 16 * jc + lk + 4 * reg, r = wr + 16 * ir + li;
-          sL[r][c] = (r >= c) ? cd[jc][ir][reg] - ad[jc][ir][reg] : 0.0;
-          if (b > 0) sB[r][c] = co[jc][ir][reg] - ao[jc][ir][reg];
-        }
+    if (tid < NB) sB[NB][tid] = rv;
+    if (tid == 0) sBad = 0;
   }
-  if (tid < NB) sB[NB][tid] = rv;
   __syncthreads();
+  STAMP(5);
+  if (upd) {
+    tile_update1(sL, wave, 0, wave == 0, sQ, sQ);  // block column 0 of the diagonal block: what potf2(0) needs
+    __syncthreads();
+  }
   STAMP(1);
-  const int bad = factor_64(sL, sT, &sBad);
-  STAMP(2);
-  // X = B L_kk^-T by 16-wide block substitution.  Wave w owns rows 16w..16w+15 of the block for the whole sweep (its
-  // tiles only read the shared L / L^-T), so the four waves run without any workgroup barrier; wave 3 also carries the
-  // right-hand-side row.
 #pragma unroll
   for (int kk = 0; kk < NB / SB; ++kk) {
     const int o = kk * SB;
-    if (b > 0) {
-      mfma_mul_16(sB, wave * SB, o, sB, wave * SB, o, sT[kk]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int ct = kk + 1; ct < NB / SB; ++ct) mfma_sub_16(sB, wave * SB, ct * SB, sB, wave * SB, sL, ct * SB, o);
-    }
-    if (wave == 3) {  // rhs row: x = b T (16 lanes), then b[rest] -= x L[rest]^T (48 lanes at most)
-      double xv = 0.0;
-      if (lane < SB) {
-#pragma unroll
-        for (int mm = 0; mm < SB; ++mm) xv = __builtin_fma(sB[NB][o + mm], sT[kk][mm][lane], xv);
+    if (wave == 0) {  // diagonal 16x16 block + the sub-diagonal tiles of this block column
+      const int bad = potf2_16(sL, sT[kk], o, true);
+      if (lane == 0 && bad && sBad == 0) sBad = o + bad;
+    } else if (kk == 0) {
+      if (upd) {
+        if (wave == 1) tile_update2(sL, 1, 1, true, 2, 1, false, sQ, sQ);
+        if (wave == 2) tile_update2(sL, 2, 2, true, 3, 1, false, sQ, sQ);
+        if (wave == 3) tile_update2(sL, 3, 2, false, 3, 3, true, sQ, sQ);
       }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < SB) sB[NB][o + lane] = xv;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < NB - o - SB) {
-        const int c = o + SB + lane;
-        double sacc = 0.0;
-#pragma unroll
-        for (int mm = 0; mm < SB; ++mm) sacc = __builtin_fma(sB[NB][o + mm], sL[c][o + mm], sacc);
-        sB[NB][c] -= sacc;
+      if (uo) {
+        if (wave == 1) tile_update2(sB, 0, 0, false, 0, 1, false, sP, sQ);
+        if (wave == 2) tile_update2(sB, 0, 2, false, 0, 3, false, sP, sQ);
+        if (wave == 3) tile_update2(sB, 1, 0, false, 1, 1, false, sP, sQ);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else if (kk == 1) {
+      if (wave == 1) {
+        if (uo) tile_update2(sB, 1, 2, false, 1, 3, false, sP, sQ);
+        if (own) solve_rows<0>(sB, 1, sL, sT);
+      } else if (wave == 2) {
+        if (own) solve_rows<0>(sB, 0, sL, sT);
+        if (uo) tile_update2(sB, 2, 0, false, 2, 1, false, sP, sQ);
+      } else {
+        if (uo) tile_update2(sB, 2, 2, false, 2, 3, false, sP, sQ);
+        solve_rhs_row(sB, 0, sL, sT);
+      }
+    } else if (kk == 2) {
+      if (wave == 1) {
+        if (uo) tile_update2(sB, 3, 0, false, 3, 1, false, sP, sQ);
+        if (own) solve_rows<1>(sB, 0, sL, sT);
+      } else if (wave == 2) {
+        if (uo) tile_update2(sB, 3, 2, false, 3, 3, false, sP, sQ);
+        if (own) solve_rows<0>(sB, 2, sL, sT);
+      } else {
+        if (own) solve_rows<1>(sB, 1, sL, sT);
+        solve_rhs_row(sB, 1, sL, sT);
+      }
+    } else {
+      if (wave == 1) {
+        if (own) { solve_rows<0>(sB, 3, sL, sT); solve_rows<1>(sB, 3, sL, sT); solve_rows<2>(sB, 3, sL, sT); }
+      } else if (wave == 2) {
+        if (own) { solve_rows<1>(sB, 2, sL, sT); solve_rows<2>(sB, 2, sL, sT); }
+      } else {
+        if (own) { solve_rows<2>(sB, 0, sL, sT); solve_rows<2>(sB, 1, sL, sT); }
+        solve_rhs_row(sB, 2, sL, sT);
+      }
     }
+    __syncthreads();
+    STAMP(8 + 2 * kk);
+    if (kk == NB / SB - 1) break;
+    // trailing 16x16 tiles of the diagonal block (bi >= bj > kk): A[bi][bj] -= X_bi X_bj^T, dealt round-robin to the 4 waves
+    int t = 0;
+#pragma unroll
+    for (int bi = kk + 1; bi < NB / SB; ++bi)
+#pragma unroll
+      for (int bj = kk + 1; bj <= bi; ++bj, ++t)
+        if ((t & 3) == wave) mfma_sub_16(sL, bi * SB, bj * SB, sL, bi * SB, sL, bj * SB, o);
+    __syncthreads();
+    STAMP(9 + 2 * kk);
   }
+  const int bad = sBad;
+  STAMP(2);
+  if (own) solve_rows<3>(sB, wave, sL, sT);
+  if (wave == 3) solve_rhs_row(sB, NB / SB - 1, sL, sT);
   __syncthreads();
   STAMP(3);
   if (b == 0) {
+    if (k0 == 0)  // arm the hand-off granules of the backward substitution (chol_back_all)
+      for (int i = tid; i < ld; i += 256) xout[i] = __longlong_as_double((long long)kSentinel);
     if (tid == 0) {
       if (k0 == 0) *info = bad;  // also resets the flag of the previous solve
       else if (bad) atomicCAS(info, 0, k0 + bad);
@@ -411,51 +501,95 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// chol_back: backward substitution step for block k (k0 = 64 k).  grid = max(k, 1): every workgroup recomputes
-// x_k = L_kk^-T v_k; workgroup j < k applies v_j -= L_kj^T x_k; workgroup 0 also stores x_k.
+// chol_back_all: the whole backward substitution L^T x = y in ONE launch, one workgroup per 64-block, pipelined through
+// memory.  Workgroup j starts from y_j, subtracts L_ij^T x_i for i = nb-1 .. j+1 as the x_i appear, then solves its own
+// diagonal block and publishes x_j.  Hand-off is by data-tagged granules (MI355X_MICROARCH.md, handoff-1to1, ~1 us per
+// hop and no fences): x was pre-filled with a sentinel bit pattern by chol_step(0); the producer writes each value
+// with ONE 8-byte write-through (sc1) store, consumers poll the values they need with sc1 loads until none of them is the
+// sentinel.  Progress: workgroup nb-1 waits for nobody and nb <= 32 workgroups are always co-resident; every spin is
+// bounded (a timeout marks the solve as failed instead of hanging the device).
+// The per-panel launches this replaces cost ~7.5 us each (19 at n = 1216), this pipeline ~2 us per block.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_back(const double* __restrict__ A, int ld, int k0, double* __restrict__ rhs) {
+
+__device__ __forceinline__ double load_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void chol_back_all(const double* __restrict__ A, int ld, const double* __restrict__ y, double* x, int* __restrict__ info) {
   __shared__ double sL[NB][LP];
-  __shared__ double sInv[NB], sV[NB];
-  const int tid = threadIdx.x, j = blockIdx.x;
-  const int nblk_above = k0 / NB;
-  // every global load is issued before the serial part
-  const int c = tid >> 2, part = tid & 3;  // 4 threads per column, 16 rows each
-  double lcol[16];
-  double vold = 0.0, dia = 1.0, vk = 0.0;
-  if (j < nblk_above) {
-    const double* col = &A[(size_t)(j * NB + c) * ld + k0 + part * 16];
+  __shared__ double sV[NB];
+  const int tid = threadIdx.x, j = blockIdx.x, nb = ld / NB, k0 = j * NB;
+  const int c = tid >> 2, part = tid & 3;  // 4 threads per column of block j, 16 rows of block i each
+  // ---- everything that does not depend on other workgroups is fetched first
+  double2 td[8];
+  load_tile(&A[(size_t)k0 * ld + k0], ld, td);
+  double acc = (part == 0) ? y[k0 + c] : 0.0;
+  double2 lnext[8];
+  if (nb - 1 > j) {
+    const double2* col = reinterpret_cast<const double2*>(&A[(size_t)(k0 + c) * ld + (size_t)(nb - 1) * NB + part * 16]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) lcol[r] = col[r];
-    if (part == 0) vold = rhs[j * NB + c];
+    for (int r = 0; r < 8; ++r) lnext[r] = col[r];
   }
-  if (tid < NB) { dia = A[(size_t)(k0 + tid) * ld + k0 + tid]; vk = rhs[k0 + tid]; }
-  {
-    double2 td[8];
-    load_tile(&A[(size_t)k0 * ld + k0], ld, td);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = tid + 256 * i, cc = p >> 5, r = 2 * (p & 31);
-      sL[r][cc] = (r >= cc) ? td[i].x : 0.0;
-      sL[r + 1][cc] = (r + 1 >= cc) ? td[i].y : 0.0;
+  for (int i = 0; i < 8; ++i) {
+    const int p = tid + 256 * i, cc = p >> 5, r = 2 * (p & 31);
+    sL[r][cc] = (r >= cc) ? td[i].x : 0.0;
+    sL[r + 1][cc] = (r + 1 >= cc) ? td[i].y : 0.0;
+  }
+  __shared__ double sX[2][NB];
+  __syncthreads();
+  double lcol[NB], inv = 1.0;
+  if (tid < NB) bwd_load_64(sL, lcol, inv);
+  bool timeout = false;
+#pragma unroll 1
+  for (int i = nb - 1; i > j; --i) {
+    double2 lcur[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) lcur[r] = lnext[r];
+    if (i - 1 > j) {
+      const double2* col = reinterpret_cast<const double2*>(&A[(size_t)(k0 + c) * ld + (size_t)(i - 1) * NB + part * 16]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) lnext[r] = col[r];
+    }
+    if (tid < NB) {
+      // Pollers cost memory-side bandwidth (25 workgroups x 64 lanes spinning made a hop 5 us): ONE lane per workgroup
+      // spins on one granule, backing off with its distance from the pipeline front; then the wave reads all 64 and
+      // re-reads the stragglers (the 64 stores of a block are not ordered among themselves).
+      const double* xi = &x[(size_t)i * NB];
+      int spins = 0;
+      if (tid == 0) {
+        const int nap = min(i - j - 1, 24);
+        while ((unsigned long long)__double_as_longlong(load_sc1(xi)) == kSentinel) {
+          if (++spins > kSpinCap) break;
+          __builtin_amdgcn_s_sleep(1);
+          for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      double v = load_sc1(&xi[tid]);
+      while ((unsigned long long)__double_as_longlong(v) == kSentinel) {
+        if (++spins > kSpinCap) { timeout = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+        v = load_sc1(&xi[tid]);
+      }
+      sX[i & 1][tid] = v;
+    }
+    if (i < 10) STAMP(20 + i);
+    __syncthreads();
+    const double* xs = &sX[i & 1][part * 16];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      acc = __builtin_fma(-lcur[r].x, xs[2 * r], acc);
+      acc = __builtin_fma(-lcur[r].y, xs[2 * r + 1], acc);
     }
   }
-  if (tid < NB) sInv[tid] = 1.0 / dia;
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  if (part == 0) sV[c] = acc;
+  if (timeout) atomicMax(info, 1 << 30);
   __syncthreads();
-  if (tid < 64) {
-    const double xk = bwd_vec_64(vk, sL, sInv);
-    sV[tid] = xk;
-    if (j == 0) rhs[k0 + tid] = xk;
-  }
-  __syncthreads();
-  if (j < nblk_above) {
-    double sacc = 0.0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc = __builtin_fma(lcol[r], sV[part * 16 + r], sacc);
-    sacc += __shfl_xor(sacc, 1, 64);
-    sacc += __shfl_xor(sacc, 2, 64);
-    if (part == 0) rhs[j * NB + c] = vold - sacc;
-  }
+  STAMP(30);
+  if (tid < 64) store_sc1(&x[k0 + tid], bwd_vec_64(sV[tid], lcol, inv));
+  STAMP(31);
 }
 
 struct GraphKey {
@@ -475,25 +609,25 @@ struct GraphKey {
 std::mutex g_mu;
 std::map<GraphKey, hipGraphExec_t> g_graphs;
 
-int enqueue_all(double* A, int ld, const double* b, double* x, int* info, hipStream_t s) {
+int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s) {
   const int nb = ld / NB;
   for (int k = 0; k < nb; ++k) {
     const int k0 = k * NB;
     const int m = nb - k;
-    hipLaunchKernelGGL(chol_step, dim3(m + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(256), 0, s, A, ld, k0, b, x, info);
+    hipLaunchKernelGGL(chol_step, dim3(m + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(256), 0, s, A, ld, k0, b, ws, x, info);
   }
-  for (int k = nb - 1; k >= 0; --k) hipLaunchKernelGGL(chol_back, dim3(k > 0 ? k : 1), dim3(256), 0, s, (const double*)A, ld, k * NB, x);
+  hipLaunchKernelGGL(chol_back_all, dim3(nb), dim3(256), 0, s, (const double*)A, ld, (const double*)ws, x, info);
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
 }
 
 }  // namespace
 
 // A: ld x ld column-major with ld a multiple of 64 (chol_padded_ld), lower triangle valid, pad diagonal = 1.
-int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, double* /*workspace*/, hipStream_t stream) {
+int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t stream) {
   if (ld % NB != 0) return PPO_BA_ERR_ARG;
   if (ld == 0) return PPO_BA_OK;
   static const bool use_graph = []() { const char* e = getenv("PPO_BA_CHOL_NOGRAPH"); return !(e && e[0] == '1'); }();
-  if (!use_graph) return enqueue_all(A, ld, b, x, info, stream);
+  if (!use_graph) return enqueue_all(A, ld, b, x, info, ws, stream);
   hipGraphExec_t exec = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -502,7 +636,7 @@ int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, 
     if (it == g_graphs.end()) {
       hipGraph_t graph = nullptr;
       if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return PPO_BA_ERR_HIP;
-      const int rc = enqueue_all(A, ld, b, x, info, stream);
+      const int rc = enqueue_all(A, ld, b, x, info, ws, stream);
       if (hipStreamEndCapture(stream, &graph) != hipSuccess || rc != PPO_BA_OK) return PPO_BA_ERR_HIP;
       if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) return PPO_BA_ERR_HIP;
       (void)hipGraphDestroy(graph);
@@ -526,8 +660,8 @@ void chol_release(double* A) {
   }
 }
 
+size_t chol_workspace_doubles(int n) { return (size_t)chol_padded_ld(n); }  // y of the forward substitution
 int chol_padded_ld(int n) { return (n + NB - 1) / NB * NB; }
-size_t chol_workspace_doubles(int) { return 0; }
 int chol_default_backend() { return PPO_SOLVER_NATIVE; }
 
 }  // namespace ppo

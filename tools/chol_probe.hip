@@ -6,7 +6,7 @@
 #include <vector>
 #include <cmath>
 #define PPO_CHOL_STAMPS 1
-__device__ long long g_stamps[32];
+__device__ long long g_stamps[40];
 #define STAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
 #include "../point-plane-object-slam_amd/csrc/ppo_chol.hip"
 
@@ -36,8 +36,19 @@ __global__ void potf2_bench(double* out, long long* cyc) {
   __syncthreads();
   double a[16], e[16];
   for (int c = 0; c < 16; ++c) { a[c] = sL[r][c]; e[c] = sL[16 + lane % 48][c]; }
-  const long long t0 = clock64();
-  if (MODE == 0) {
+  long long t0 = clock64();
+  if (MODE == 3) {  // the full sweep three times in a loop: is the first (cold instruction cache) pass slower?
+    for (int rep = 0; rep < 3; ++rep) {
+      t0 = clock64();
+      int bad = 0;
+      ppo::ColSweep<0>::run(a, e, bad);
+      e[0] += bad;
+      const long long t1 = clock64();
+      if (threadIdx.x == 0) cyc[3 + rep] = t1 - t0;
+      for (int c = 0; c < 16; ++c) { a[c] = sL[r][c] + 1e-9 * e[c]; e[c] = sL[16 + lane % 48][c]; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  } else if (MODE == 0) {
     int bad = 0;
     ppo::ColSweep<0>::run(a, e, bad);
     e[0] += bad;
@@ -70,13 +81,15 @@ int main() {
   { double* o; hipMalloc((void**)&o, 32); hipMemset(o, 0, 32); hipLaunchKernelGGL(rsq_acc, dim3(64), dim3(256), 0, 0, o); double h[3]; hipMemcpy(h, o, 24, hipMemcpyDeviceToHost);
     printf("v_rsq_f64 max rel err: raw %.3e, 1 Newton %.3e, 2 Newton %.3e\n", h[0], h[1], h[2]); }
   {
-    double* o; long long* c; hipMalloc((void**)&o, 64 * 8); hipMalloc((void**)&c, 3 * 8);
+    double* o; long long* c; hipMalloc((void**)&o, 64 * 8); hipMalloc((void**)&c, 8 * 8);
     for (int rep = 0; rep < 2; ++rep) {
       hipLaunchKernelGGL(potf2_bench<0>, dim3(1), dim3(64), 0, 0, o, c);
       hipLaunchKernelGGL(potf2_bench<1>, dim3(1), dim3(64), 0, 0, o, c);
       hipLaunchKernelGGL(potf2_bench<2>, dim3(1), dim3(64), 0, 0, o, c);
     }
-    long long h[3]; hipMemcpy(h, c, 24, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL(potf2_bench<3>, dim3(1), dim3(64), 0, 0, o, c);
+    long long h[6]; hipMemcpy(h, c, 48, hipMemcpyDeviceToHost);
+    printf("potf2_16 sweep looped in one kernel: pass 1 %lld, pass 2 %lld, pass 3 %lld ticks\n", h[3], h[4], h[5]);
     printf("potf2_16 register sweep (s_memtime ticks): full %lld, pivot chains only %lld, 240 DPP fmacs only %lld\n", h[0], h[1], h[2]);
   }
   const int n = 1664;
@@ -89,16 +102,16 @@ int main() {
       A[(size_t)c * n + r] = v;
       A[(size_t)r * n + c] = v;
     }
-  double *dA, *dA0, *dx; int* dinfo;
-  hipMalloc((void**)&dA, A.size() * 8); hipMalloc((void**)&dA0, A.size() * 8); hipMalloc((void**)&dx, n * 8); hipMalloc((void**)&dinfo, 4);
+  double *dA, *dA0, *dx, *db, *dws; int* dinfo;
+  hipMalloc((void**)&dA, A.size() * 8); hipMalloc((void**)&dA0, A.size() * 8); hipMalloc((void**)&dx, n * 8); hipMalloc((void**)&db, n * 8); hipMalloc((void**)&dws, n * 8); hipMalloc((void**)&dinfo, 4);
   hipMemcpy(dA0, A.data(), A.size() * 8, hipMemcpyHostToDevice);
   hipStream_t s; hipStreamCreate(&s);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 5; ++rep) {
     hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
-    hipMemcpyAsync(dx, b.data(), n * 8, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync(db, b.data(), n * 8, hipMemcpyHostToDevice, s);
     hipEventRecord(e0, s);
-    ppo::chol_factor_solve(dA, n, dx, dx, dinfo, nullptr, s);
+    ppo::chol_factor_solve(dA, n, db, dx, dinfo, dws, s);
     hipEventRecord(e1, s);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -113,17 +126,24 @@ int main() {
   printf("info %d max residual %.3e\n", info, rmax);
   // phase stamps of column workgroup 1 of the second step (update of panel 0 fused with the factorisation of panel 1)
   hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(ppo::chol_step, dim3(n / 64), dim3(256), 0, s, dA, n, 0, dx, dx, dinfo);
-  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(m + m * (m - 1) / 2), dim3(256), 0, s, dA, n, 64, dx, dx, dinfo); }
+  hipLaunchKernelGGL(ppo::chol_step, dim3(n / 64), dim3(256), 0, s, dA, n, 0, db, dws, dx, dinfo);
+  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(m + m * (m - 1) / 2), dim3(256), 0, s, dA, n, 64, db, dws, dx, dinfo); }
   hipStreamSynchronize(s);
-  long long st[32];
+  long long st[40];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
-  printf("  tiles in LDS        +%.2f us\n", (st[5] - st[0]) * 0.01);
-  printf("  update MFMAs -> LDS +%.2f us\n", (st[1] - st[5]) * 0.01);
-  printf("  factor_64           +%.2f us\n", (st[2] - st[1]) * 0.01);
-  printf("  block solve         +%.2f us\n", (st[3] - st[2]) * 0.01);
+  printf("  loads issued        +%.2f us\n", (st[6] - st[0]) * 0.01);
+  printf("  tiles in LDS        +%.2f us\n", (st[5] - st[6]) * 0.01);
+  printf("  column-0 update     +%.2f us\n", (st[1] - st[5]) * 0.01);
+  printf("  factor + side jobs  +%.2f us\n", (st[2] - st[1]) * 0.01);
+  printf("  last solve step     +%.2f us\n", (st[3] - st[2]) * 0.01);
   printf("  stored              +%.2f us\n", (st[4] - st[3]) * 0.01);
   for (int i = 8; i < 15; ++i) printf("  factor stamp %d: +%.2f us\n", i, (st[i] - (i == 8 ? st[1] : st[i - 1])) * 0.01);
-  // per-kernel time of the graph's launches
+  // backward pipeline: block 1's view (stamps 22..29 = moment x_i was seen, i = 2..9)
+  hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
+  ppo::chol_factor_solve(dA, n, db, dx, dinfo, dws, s);
+  hipStreamSynchronize(s);
+  hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
+  for (int i = 9; i >= 3; --i) printf("  hop: x_%d seen -> x_%d seen  %.2f us\n", i, i - 1, (st[20 + i - 1] - st[20 + i]) * 0.01);
+  printf("  block 1: x_2 seen -> reduced %.2f us -> x_1 stored %.2f us\n", (st[30] - st[22]) * 0.01, (st[31] - st[30]) * 0.01);
   return 0;
 }
