@@ -616,25 +616,28 @@ __device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st
   const int dim = act ? m.dim(i) : 0;
   double chi_local = 0.0;
   if (act) {
-    if (lane < NC) {
-      double ep[DM], em[DM];
-      const bool fr = m.col_free(i, lane);
-      if (fr) {
-        m.residual(i, lane, delta, st, ep);
-        m.residual(i, lane, -delta, st, em);
-      }
+    // Two passes over ONE call site of the residual: pass 0 evaluates e(x [+] delta e_c) in lane c < NC and the base
+    // residual e(x) in lane 15, pass 1 evaluates e(x [-] delta e_c).  (One call site instead of three keeps the code --
+    // the residuals are thousands of FP64 instructions each -- small enough for the instruction cache, and the base
+    // evaluation no longer runs as a serialised divergent branch.)
+    double ep[DM], em[DM];
+    const bool col = lane < NC, base = lane == 15;
+    const bool fr = col && m.col_free(i, lane);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      if ((fr || (base && pass == 0))) m.residual(i, base ? -1 : lane, base ? 0.0 : (pass ? -delta : delta), st, pass ? em : ep);
+    }
+    if (col) {
       const double scalar = 1.0 / (2 * delta);
       for (int r = 0; r < dim; ++r) sJ[grp][r][lane] = fr ? scalar * (ep[r] - em[r]) : 0.0;
-    } else if (lane == 15) {
-      double e0[DM];
-      m.residual(i, -1, 0.0, st, e0);
+    } else if (base) {
       double chi2 = 0, nrm = 0;
-      for (int r = 0; r < dim; ++r) { chi2 += e0[r] * (m.info(i, r) * e0[r]); nrm += e0[r] * e0[r]; }
+      for (int r = 0; r < dim; ++r) { chi2 += ep[r] * (m.info(i, r) * ep[r]); nrm += ep[r] * ep[r]; }
       m.store_chi2(i, chi2, sqrt(nrm));
       double rho0, rho1;
       huber(chi2, m.huber_delta(i), rho0, rho1);
       chi_local = rho0;
-      for (int r = 0; r < dim; ++r) { sW[grp][r] = rho1 * m.info(i, r); sG[grp][r] = -(m.info(i, r) * e0[r]) * rho1; }
+      for (int r = 0; r < dim; ++r) { sW[grp][r] = rho1 * m.info(i, r); sG[grp][r] = -(m.info(i, r) * ep[r]) * rho1; }
     }
   }
   __syncthreads();
