@@ -132,21 +132,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # roofline of the dominant streaming kernel -- the reprojection Jacobian kernel k_lin_poses (residual + Jacobians of
-    # every mono/stereo edge, W blocks out) -- timed alone with HIP events on the library's stream; the whole
-    # linearise group (k_zero_ranges + k_lin_points + k_lin_poses || k_lin_numeric_all) is reported next to it.
+    # roofline of the Jacobian/assembly kernel -- k_linearize_all, the ONE fused launch that evaluates residuals and
+    # Jacobians of every edge class and writes the block-sparse system (SURVEY.md 8(d) "linearise + assemble") -- timed
+    # alone with HIP events on the library's stream; with its zeroing kernel in front it is the "linearise group".
     lin_ms = C.c_double()
     solver.reset()
     assert lib.ppo_ba_time_linearize(solver.h, a.lin_reps, C.byref(lin_ms)) == 0
     lin_bytes = int(lib.ppo_ba_linearize_bytes(solver.h))
     k_ms, k_bytes = C.c_double(), C.c_int64()
-    assert lib.ppo_ba_time_kernel(solver.h, 0, a.lin_reps, C.byref(k_ms), C.byref(k_bytes)) == 0
+    assert lib.ppo_ba_time_kernel(solver.h, 6, a.lin_reps, C.byref(k_ms), C.byref(k_bytes)) == 0
     kernels = {}
     n_red = C.c_int32()
     lib.ppo_ba_debug_reduced(solver.h, None, None, None, C.byref(n_red))
     b_red = np.zeros(max(1, n_red.value))
     assert lib.ppo_ba_debug_reduced(solver.h, None, b_red.ctypes.data_as(B.c_dp), None, None) == 0  # builds W, Z, C for the Schur kernels
-    for name, which in (("k_lin_poses", 0), ("k_lin_points", 1), ("k_schur_z", 2), ("k_schur_pairs", 3), ("k_backsub", 4), ("k_chi2_points", 5)):
+    for name, which in (("k_linearize_all", 6), ("k_lin_poses", 0), ("k_lin_points", 1), ("k_schur_z", 2), ("k_schur_pairs", 3), ("k_backsub", 4), ("k_chi2_points", 5)):
         ms_, by_ = C.c_double(), C.c_int64()
         if lib.ppo_ba_time_kernel(solver.h, which, 50, C.byref(ms_), C.byref(by_)) == 0 and ms_.value > 0:
             kernels[name] = {"us": 1e3 * ms_.value, "algorithmic_bytes": int(by_.value), "GBps": by_.value / (ms_.value * 1e-3) / 1e9}
@@ -170,10 +170,10 @@ def main():
                 "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
                 "create_ms_host_flatten_plus_pcie_upload": create_ms, "kernels": kernels,
             },
-            "roofline": {"bound": "hbm", "kernel": "k_lin_poses", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_linearize_all", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(int(k_bytes.value)),
                          "algorithmic_bytes": int(k_bytes.value), "launch_ms": k_ms.value,
-                         "linearise_group": {"kernels": "k_zero_ranges + k_lin_points + k_lin_poses || k_lin_numeric_all",
+                         "linearise_group": {"kernels": "k_zero_ranges + k_linearize_all",
                                              "algorithmic_bytes": lin_bytes, "launch_ms": lin_ms.value,
                                              "achieved": lin_bytes / (lin_ms.value * 1e-3) / 1e9}},
         }

@@ -266,7 +266,8 @@ enum {
   PPO_BA_KERNEL_SCHUR_Z = 2,
   PPO_BA_KERNEL_SCHUR_PAIRS = 3,
   PPO_BA_KERNEL_BACKSUB = 4,
-  PPO_BA_KERNEL_CHI2_POINTS = 5
+  PPO_BA_KERNEL_CHI2_POINTS = 5,
+  PPO_BA_KERNEL_LINEARIZE_ALL = 6 /* the fused linearisation launch of the product path (no zeroing) */
 };
 int ppo_ba_time_kernel(ppo_ba_handle h, int which, int reps, double* ms, int64_t* bytes);
 

@@ -229,9 +229,7 @@ __device__ __forceinline__ void zero_W(double* Wd) {
 // no atomics.  The pose blocks are accumulated by k_lin_poses below.
 // ======================================================================================================
 template <bool USE_LDS>
-__global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
-  extern __shared__ double smem[];
-  __shared__ double s_red[4];
+__device__ __forceinline__ void lin_points_body(const Graph& g, const State& st, int bid, int nblocks, double* smem, double* s_red) {
   if (USE_LDS) {
     for (int i = threadIdx.x; i < g.n_poses * 16; i += blockDim.x) {
       const int p = i >> 4, k = i & 15;
@@ -240,7 +238,7 @@ __global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
     __syncthreads();
   }
   double chi_local = 0.0;
-  for (int p = g.pt_first + blockIdx.x * blockDim.x + threadIdx.x; p < g.pt_last; p += gridDim.x * blockDim.x) {
+  for (int p = g.pt_first + bid * blockDim.x + threadIdx.x; p < g.pt_last; p += nblocks * blockDim.x) {
     const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
     const bool lm_free = !g.point_fixed[p];
     double D[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
@@ -302,6 +300,12 @@ __global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
   }
   block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
 }
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
+  extern __shared__ double smem[];
+  __shared__ double s_red[4];
+  lin_points_body<USE_LDS>(g, st, blockIdx.x, gridDim.x, smem, s_red);
+}
 
 // Sum `NV` per-lane values over the 64 lanes of a wave through LDS: lane t < NV returns the total of value t.
 // buf is this wave's [NV][65] scratch.  (Cheaper than 6 ds_bpermute rounds per value, and it leaves value t in lane t,
@@ -335,10 +339,9 @@ struct PoseChunks {
   const int32_t* pose;   // [n_chunks] (keyframe index << 1) | type
   int n_chunks;
 };
-__global__ __launch_bounds__(256) void k_lin_poses(Graph g, State st, PoseChunks pc) {
-  __shared__ double s_buf[4][14][65];
+__device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, const PoseChunks& pc, int bid, double (*s_buf)[14][65]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + wave;  // one wave per chunk: lanes stride the chunk, records are read fully coalesced
+  const int t = bid * 4 + wave;  // one wave per chunk: lanes stride the chunk, records are read fully coalesced
   if (t >= pc.n_chunks) return;
   const int code = pc.pose[t], pose = code >> 1;
   const double* rt = &st.pose_rt[pose * 12];
@@ -401,12 +404,15 @@ __global__ __launch_bounds__(256) void k_lin_poses(Graph g, State st, PoseChunks
     if (lane < 14 && v < 27 && tot != 0.0) atomicAdd(&hb[v], tot);
   }
 }
+__global__ __launch_bounds__(256) void k_lin_poses(Graph g, State st, PoseChunks pc) {
+  __shared__ double s_buf[4][14][65];
+  lin_poses_body(g, st, pc, blockIdx.x, s_buf);
+}
 
 // residual-only pass over the reprojection edges (trial state)
-__global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
-  __shared__ double s_red[4];
+__device__ __forceinline__ void chi2_points_body(const Graph& g, const State& st, int bid, int nblocks, double* s_red) {
   double chi_local = 0.0;
-  for (int p = g.pt_first + blockIdx.x * blockDim.x + threadIdx.x; p < g.pt_last; p += gridDim.x * blockDim.x) {
+  for (int p = g.pt_first + bid * blockDim.x + threadIdx.x; p < g.pt_last; p += nblocks * blockDim.x) {
     const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
     for (int e = g.mo_off[p]; e < g.mo_off[p + 1]; ++e) {
       const uint32_t fl = g.mono_flags[e];
@@ -441,6 +447,10 @@ __global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
     }
   }
   block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+}
+__global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
+  __shared__ double s_red[4];
+  chi2_points_body(g, st, blockIdx.x, gridDim.x, s_red);
 }
 
 // Optimizer.cc:2739-2769: level 1 if chi2 > threshold or depth <= 0 (depth from the CURRENT estimates), kernel off
@@ -604,11 +614,12 @@ struct PtCubModel {  // unary: cols 0-8 cuboid
 // 16 lanes per edge, 16 edges per 256-thread block; lane c < NCOL differentiates column c, lane 15 evaluates the
 // base residual (base_binary_edge.hpp:217-320, base_unary_edge.hpp:82-123, then :55-120 / :43-72).
 template <class Model>
-__device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st, int n_edges, bool corner, double delta, int vblock) {
+__device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st, int n_edges, bool corner, double delta, int vblock, double* smem) {
   constexpr int DM = Model::DIM_MAX, NC = Model::NCOL;
-  __shared__ double sJ[16][DM][16];  // [group][row][col]
-  __shared__ double sW[16][DM], sG[16][DM];
-  __shared__ double s_red[4];
+  double (*sJ)[DM][16] = reinterpret_cast<double (*)[DM][16]>(smem);  // [group][row][col]
+  double (*sW)[DM] = reinterpret_cast<double (*)[DM]>(smem + 16 * DM * 16);
+  double (*sG)[DM] = reinterpret_cast<double (*)[DM]>(smem + 16 * DM * 16 + 16 * DM);
+  double* s_red = smem + 16 * DM * 16 + 32 * DM;
   const Model m{g, corner};
   const int grp = threadIdx.x >> 4, lane = threadIdx.x & 15;
   const int i = vblock * 16 + grp;
@@ -659,9 +670,9 @@ __device__ __forceinline__ void chi2_numeric_body(const Graph& g, const State& s
   constexpr int DM = Model::DIM_MAX;
   __shared__ double s_red[4];
   const Model m{g, corner};
-  const int i = vblock * blockDim.x + threadIdx.x;
+  const int i = vblock * 64 + threadIdx.x;  // one active wave per workgroup: these residuals are long, spread them over the CUs
   double chi_local = 0.0;
-  if (i < n_edges && m.active(i)) {
+  if (threadIdx.x < 64 && i < n_edges && m.active(i)) {
     double e0[DM];
     const int dim = m.dim(i);
     m.residual(i, -1, 0.0, st, e0);
@@ -681,18 +692,41 @@ __device__ __forceinline__ void chi2_numeric_body(const Graph& g, const State& s
 struct NumericPlan {
   int nb_plane, nb_bbox, nb_corner, nb_ptcub;  // workgroups per edge class
 };
-__global__ __launch_bounds__(256) void k_lin_numeric_all(Graph g, State st, NumericPlan np, double delta) {
-  int b = blockIdx.x;
-  if (b < np.nb_plane) { lin_numeric_body<PlaneModel>(g, st, g.n_pl, false, delta, b); return; }
+constexpr int kNumericLdsDoubles = 16 * 16 * 16 + 32 * 16 + 8;  // lin_numeric_body at DIM_MAX = 16
+__device__ __forceinline__ void lin_numeric_dispatch(const Graph& g, const State& st, const NumericPlan& np, double delta, int b, double* smem) {
+  if (b < np.nb_plane) { lin_numeric_body<PlaneModel>(g, st, g.n_pl, false, delta, b, smem); return; }
   b -= np.nb_plane;
-  if (b < np.nb_bbox) { lin_numeric_body<CubProjModel>(g, st, g.n_bbox, false, delta, b); return; }
+  if (b < np.nb_bbox) { lin_numeric_body<CubProjModel>(g, st, g.n_bbox, false, delta, b, smem); return; }
   b -= np.nb_bbox;
-  if (b < np.nb_corner) { lin_numeric_body<CubProjModel>(g, st, g.n_corner, true, delta, b); return; }
+  if (b < np.nb_corner) { lin_numeric_body<CubProjModel>(g, st, g.n_corner, true, delta, b, smem); return; }
   b -= np.nb_corner;
-  lin_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, delta, b);
+  lin_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, delta, b, smem);
 }
-__global__ __launch_bounds__(256) void k_chi2_numeric_all(Graph g, State st, NumericPlan np) {
+
+// ONE launch for the whole linearisation (horizontal fusion): the workgroups of the numerically differentiated edge
+// classes come first (longest running, 16 lanes per edge), then one wave per pose-major chunk (pose side, W), then the
+// landmark-major point workgroups.  The three parts are independent (they meet only in atomics on H_pp), so the launch
+// lasts as long as its slowest part instead of their sum; as separate kernels on two streams the fork/join events alone
+// cost ~12 us per linearisation (tools/gap_report.py).  All parts share one dynamic LDS allocation.
+struct LinPlan {
+  NumericPlan num;
+  int nb_num, nb_pose, nb_pts;
+};
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
+  extern __shared__ double smem[];
   int b = blockIdx.x;
+  if (b < lp.nb_num) { lin_numeric_dispatch(g, st, lp.num, delta, b, smem); return; }
+  b -= lp.nb_num;
+  if (b < lp.nb_pose) { lin_poses_body(g, st, pc, b, reinterpret_cast<double (*)[14][65]>(smem)); return; }
+  b -= lp.nb_pose;
+  lin_points_body<USE_LDS>(g, st, b, lp.nb_pts, smem + 8, smem);
+}
+// residual-only pass of a trial state in ONE launch: numeric edge classes (thread per edge) | points (thread per point)
+__global__ __launch_bounds__(256) void k_chi2_all(Graph g, State st, NumericPlan np, int nb_num, int nb_pts) {
+  __shared__ double s_red[4];
+  int b = blockIdx.x;
+  if (b >= nb_num) { chi2_points_body(g, st, b - nb_num, nb_pts, s_red); return; }
   if (b < np.nb_plane) { chi2_numeric_body<PlaneModel>(g, st, g.n_pl, false, b); return; }
   b -= np.nb_plane;
   if (b < np.nb_bbox) { chi2_numeric_body<CubProjModel>(g, st, g.n_bbox, false, b); return; }

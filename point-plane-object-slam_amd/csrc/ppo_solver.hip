@@ -120,7 +120,8 @@ struct ppo_ba_solver {
   Graph g{};
   State st[2]{};
   int cur = 0;
-  int lds_bytes = 0;
+  int lds_bytes = 0, lin_lds_bytes = 0;
+  bool use_lds_lin = false;  // camera table in LDS inside the fused linearisation kernel (kept small: 4 workgroups per CU)
   bool use_lds = true;
   int n_cu = 256;
   // memset plan for a linearisation: [HB|HC|acc] always, and the plane part of D/bl/W (accumulated with atomics)
@@ -278,6 +279,7 @@ int reset_device(ppo_ba_solver* s) {
 }
 
 // ---- one linearisation of the current state: fills HB/HC/D/bl/W, per-edge chi2, acc[ACC_CHI2] ------------
+int launch_linearize_kernel(ppo_ba_solver* s, const State& st);
 int launch_linearize(ppo_ba_solver* s, int which_state = -1) {
   const Graph& g = s->g;
   const State& st = s->st[which_state < 0 ? s->cur : which_state];
@@ -291,29 +293,30 @@ int launch_linearize(ppo_ba_solver* s, int which_state = -1) {
     const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
     hipLaunchKernelGGL(k_zero_ranges, dim3(std::min(nblk((long)tot / 2, 256), 2 * s->n_cu)), dim3(256), 0, s->stream, zp);
   }
-  // fork: the numerically differentiated edge classes (one merged launch) run on the side stream
-  NumericPlan np{};
-  np.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, 16) : 0;
+  RC_TRY(launch_linearize_kernel(s, st));
+  HIP_TRY(hipGetLastError());
+  return PPO_BA_OK;
+}
+
+// the fused linearisation launch alone (no zeroing): numeric edge classes | pose-major chunks | landmark-major points
+int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
+  const Graph& g = s->g;
+  LinPlan lp{};
+  lp.num.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, 16) : 0;
   if (g.owns_reduced) {
-    np.nb_bbox = g.n_bbox ? nblk(g.n_bbox, 16) : 0;
-    np.nb_corner = g.n_corner ? nblk(g.n_corner, 16) : 0;
-    np.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, 16) : 0;
+    lp.num.nb_bbox = g.n_bbox ? nblk(g.n_bbox, 16) : 0;
+    lp.num.nb_corner = g.n_corner ? nblk(g.n_corner, 16) : 0;
+    lp.num.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, 16) : 0;
   }
-  const int nb_num = np.nb_plane + np.nb_bbox + np.nb_corner + np.nb_ptcub;
-  if (nb_num > 0) {
-    HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
-    HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-    hipLaunchKernelGGL(k_lin_numeric_all, dim3(nb_num), dim3(256), 0, s->side, g, st, np, s->opt.numeric_delta);
-    HIP_TRY(hipEventRecord(s->ev_join, s->side));
-  }
+  lp.nb_num = lp.num.nb_plane + lp.num.nb_bbox + lp.num.nb_corner + lp.num.nb_ptcub;
   const int npts = g.pt_last - g.pt_first;
-  if (npts > 0) {
-    const int grid = std::min(nblk(npts, 256), 2 * s->n_cu);
-    if (s->use_lds) hipLaunchKernelGGL(k_lin_points<true>, dim3(grid), dim3(256), s->lds_bytes, s->stream, g, st);
-    else hipLaunchKernelGGL(k_lin_points<false>, dim3(grid), dim3(256), 0, s->stream, g, st);
-    if (s->posec.n_chunks > 0) hipLaunchKernelGGL(k_lin_poses, dim3(nblk(s->posec.n_chunks, 4)), dim3(256), 0, s->stream, g, st, s->posec);
+  lp.nb_pose = (npts > 0 && s->posec.n_chunks > 0) ? nblk(s->posec.n_chunks, 4) : 0;
+  lp.nb_pts = npts > 0 ? std::min(nblk(npts, 256), 2 * s->n_cu) : 0;
+  const int grid = lp.nb_num + lp.nb_pose + lp.nb_pts;
+  if (grid > 0) {
+    if (s->use_lds_lin) hipLaunchKernelGGL(k_linearize_all<true>, dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
+    else hipLaunchKernelGGL(k_linearize_all<false>, dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
   }
-  if (nb_num > 0) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -321,16 +324,16 @@ int launch_linearize(ppo_ba_solver* s, int which_state = -1) {
 int launch_chi2(ppo_ba_solver* s, const State& st) {
   const Graph& g = s->g;
   const int npts = g.pt_last - g.pt_first;
-  if (npts > 0) hipLaunchKernelGGL(k_chi2_points, dim3(std::min(nblk(npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
   NumericPlan np{};
-  np.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, 256) : 0;
+  np.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, 64) : 0;
   if (g.owns_reduced) {
-    np.nb_bbox = g.n_bbox ? nblk(g.n_bbox, 256) : 0;
-    np.nb_corner = g.n_corner ? nblk(g.n_corner, 256) : 0;
-    np.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, 256) : 0;
+    np.nb_bbox = g.n_bbox ? nblk(g.n_bbox, 64) : 0;
+    np.nb_corner = g.n_corner ? nblk(g.n_corner, 64) : 0;
+    np.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, 64) : 0;
   }
   const int nb_num = np.nb_plane + np.nb_bbox + np.nb_corner + np.nb_ptcub;
-  if (nb_num > 0) hipLaunchKernelGGL(k_chi2_numeric_all, dim3(nb_num), dim3(256), 0, s->stream, g, st, np);
+  const int nb_pts = npts > 0 ? std::min(nblk(npts, 256), 4 * s->n_cu) : 0;
+  if (nb_num + nb_pts > 0) hipLaunchKernelGGL(k_chi2_all, dim3(nb_num + nb_pts), dim3(256), 0, s->stream, g, st, np, nb_num, nb_pts);
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -965,6 +968,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (hipFuncSetAttribute((const void*)k_lin_points<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_backsub<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
   }
+  s->use_lds_lin = s->use_lds && s->lds_bytes <= 40 * 1024;
+  s->lin_lds_bytes = std::max({(int)(4 * 14 * 65 * sizeof(double)), (int)(kNumericLdsDoubles * sizeof(double)),
+                               s->use_lds_lin ? s->lds_bytes + 64 : 64});
   // derive the rotation matrices of the pristine state once
   {
     State is = make_state(s->d_init.p, Np, Npt, Npl, Nc);
@@ -1212,6 +1218,11 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
         if (s->use_lds) hipLaunchKernelGGL(k_backsub<true>, dim3(nblk(nl, 256)), dim3(256), s->lds_bytes, s->stream, g, st, tr, s->lambda);
         else hipLaunchKernelGGL(k_backsub<false>, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, st, tr, s->lambda);
         return true;
+      case PPO_BA_KERNEL_LINEARIZE_ALL: {
+        const size_t zh = s->zero_head;
+        (void)zh;
+        return launch_linearize_kernel(s, st) == PPO_BA_OK;
+      }
       case PPO_BA_KERNEL_CHI2_POINTS:
         if (npts <= 0) return false;
         hipLaunchKernelGGL(k_chi2_points, dim3(std::min(nblk(npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
@@ -1231,6 +1242,7 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
     case PPO_BA_KERNEL_SCHUR_Z: bytes = 288L * g.n_slots + 48L * nl; break;
     case PPO_BA_KERNEL_SCHUR_PAIRS: bytes = 144L * g.n_slots + 24L * nl + 8L * ((long)g.n_red * (g.n_red + 1) / 2 + g.n_red); break;
     case PPO_BA_KERNEL_BACKSUB: bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4) + (long)g.n_stereo * (sizeof(StereoEdge) + 4) + 96L * nl + 8L * g.n_red; break;
+    case PPO_BA_KERNEL_LINEARIZE_ALL: bytes = s->lin_bytes; break;
     case PPO_BA_KERNEL_CHI2_POINTS: bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4 + 8) + (long)g.n_stereo * (sizeof(StereoEdge) + 4 + 8) + 24L * npts + 136L * g.n_poses; break;
     default: return PPO_BA_ERR_ARG;
   }
