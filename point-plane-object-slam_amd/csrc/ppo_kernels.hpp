@@ -736,6 +736,17 @@ __global__ __launch_bounds__(256) void k_chi2_all(Graph g, State st, NumericPlan
   chi2_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, b);
 }
 
+// Hands the accumulator block and the factorisation flag to the host through mapped, coherent host memory: payload first,
+// then a sequence number the host spins on (a device-to-host copy engine transfer costs ~10 us of idle device per trial).
+__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ acc, const int* __restrict__ info, double* host, unsigned long long seq) {
+  const int t = threadIdx.x;
+  if (t < ACC_N) host[t] = acc[t];
+  if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + ACC_N + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One launch zeroes every accumulator range of a phase (instead of one memset node per range).
 struct ZeroPlan {
   double* p[6];
@@ -775,8 +786,8 @@ __global__ void k_maxdiag(Graph g) {
 }
 
 // S(lower) += Hpp (+ lambda), Hcc (+ lambda), pose-cuboid blocks; bs = b.   S was zeroed beforehand.
-__global__ void k_assemble(Graph g, double lambda) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void assemble_body(const Graph& g, double lambda, int vb) {
+  const int i = vb * blockDim.x + threadIdx.x;
   const int n = g.ld;
   const int nP = g.n_pose_free * 27, nC = g.n_cuboids * 54, nB = g.n_bbox * 54, nK = g.n_corner * 54;
   if (!g.owns_reduced) return;  // multi-GPU: HB is already summed over ranks, one rank contributes it
@@ -833,9 +844,9 @@ __global__ void k_assemble(Graph g, double lambda) {
   }
 }
 
-__global__ void k_schur_prep(Graph g, double lambda) {
+__device__ __forceinline__ void schur_prep_body(const Graph& g, double lambda, int vb) {
   const int nl_pts = g.pt_last - g.pt_first;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = vb * blockDim.x + threadIdx.x;
   if (k >= nl_pts + (g.plane_last - g.plane_first)) return;
   const int l = k < nl_pts ? g.pt_first + k : g.n_points + g.plane_first + (k - nl_pts);
   if (l < g.n_points && g.point_fixed[l]) return;
@@ -862,8 +873,8 @@ __global__ void k_schur_prep(Graph g, double lambda) {
 }
 
 // Z = W Linv' per slot, streamed in slot (pose-major) order; Linv of the slot's landmark is an L2-resident gather.
-__global__ __launch_bounds__(256) void k_schur_z(Graph g) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void schur_z_body(const Graph& g, int vb) {
+  const int s = vb * blockDim.x + threadIdx.x;
   if (s >= g.n_slots) return;
   const int l = g.slot_lm[s];
   const double* C = &g.C[(size_t)l * 6];
@@ -896,15 +907,14 @@ struct PairChunks {
   const int32_t* si;     // [n_entries]
   int n_chunks;
 };
-__global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
-  __shared__ double s_buf[4][21][65];
+__device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunks& pc, int bid, int nblocks, double (*s_buf)[21][65]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // One wave per chunk of one pose pair.  Chunks are ordered by (pose j, pose i) and every Z record is needed by ~7
   // pairs, so the launch is made XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only),
   // and each XCD is given a CONTIGUOUS range of chunks -- the Z segments of "its" keyframes then stay in its 4 MB L2
   // instead of being streamed from HBM once per pair (264 MB -> ~36 MB at the BASELINE size).
-  const int per_xcd = (gridDim.x + 7) >> 3;
-  const int vb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int per_xcd = (nblocks + 7) >> 3;
+  const int vb = (bid & 7) * per_xcd + (bid >> 3);
   const int t = vb * 4 + wave;
   if (t >= pc.n_chunks) return;
   const int e1 = pc.start[t + 1];
@@ -959,8 +969,8 @@ __global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
 __device__ __forceinline__ const CubEdge& cub_edge_of(const Graph& g, int code) { return (code & 1) ? g.corner[code >> 1] : g.bbox[code >> 1]; }
 __device__ __forceinline__ const double* wpc_of(const Graph& g, int code) { return ((code & 1) ? g.Wpc_corner : g.Wpc_bbox) + (size_t)(code >> 1) * 54; }
 
-__global__ void k_cub_prep(Graph g, double lambda) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cub_prep_body(const Graph& g, double lambda, int vb) {
+  const int c = vb * blockDim.x + threadIdx.x;
   if (c >= g.n_cuboids || g.cub_col[c] < 0) return;
   double L[9][9];
   const double* hc = &g.HC[(size_t)c * 54];
@@ -1002,8 +1012,8 @@ __device__ __forceinline__ void cub_make_Z(const double* W, const double* Li, do
     }
 }
 // Z = W Linv' of one cuboid edge: one thread per (edge, row)
-__global__ void k_cub_z(Graph g) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cub_z_body(const Graph& g, int vb) {
+  const int t = vb * blockDim.x + threadIdx.x;
   const int q = t / 6, a = t - 6 * q;
   if (q >= g.cub_edge_off[g.n_cuboids]) return;
   const int code = g.cub_edges[q];
@@ -1019,8 +1029,8 @@ __global__ void k_cub_z(Graph g) {
 }
 // S -= Z_a Z_b' for every (edge a >= edge b) pair of one cuboid: 8 lanes per pair, lane i < 6 owns row i of the block,
 // so the six lanes of a pair hit six consecutive addresses per column (one atomic line-op)
-__global__ void k_cub_schur(Graph g) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
+  const int t = vb * blockDim.x + threadIdx.x;
   const int pr = t >> 3, i = t & 7;
   if (pr >= g.n_cub_pairs || i >= 6) return;
   const int c = g.cp_cub[pr];
@@ -1132,6 +1142,122 @@ __global__ void k_update_reduced(Graph g, State cur, State trial, double lambda)
     o[7] = c.s.x; o[8] = c.s.y; o[9] = c.s.z;
   }
   block_atomic_add(sc, &g.acc[ACC_SCALE], s_red);
+}
+
+// ---- the reduction to the pose system in three launches (horizontal fusion of independent parts) ---------------------------
+// stage 1: assemble Hpp + lambda I into S | factor the landmark blocks | factor the cuboid blocks
+// stage 2: Z = W L^-T per (landmark, pose) slot | per cuboid edge
+// stage 3: S -= Z Z^T over pose pairs (wave per pair chunk) | over cuboid edge pairs
+// The cuboid parts are tiny; as separate kernels on a side stream their fork/join events cost more than they hid.
+struct ReducePlan {
+  int nb_asm, nb_prep, nb_cubprep;
+  int nb_z, nb_cubz;
+  int nb_pairs, nb_cubschur;
+};
+__global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp) {
+  int b = blockIdx.x;
+  if (b < rp.nb_asm) { assemble_body(g, lambda, b); return; }
+  b -= rp.nb_asm;
+  if (b < rp.nb_prep) { schur_prep_body(g, lambda, b); return; }
+  cub_prep_body(g, lambda, b - rp.nb_prep);
+}
+__global__ __launch_bounds__(256) void k_reduce_stage2(Graph g, ReducePlan rp) {
+  const int b = blockIdx.x;
+  if (b < rp.nb_z) { schur_z_body(g, b); return; }
+  cub_z_body(g, b - rp.nb_z);
+}
+__global__ __launch_bounds__(256) void k_reduce_stage3(Graph g, PairChunks pc, ReducePlan rp) {
+  __shared__ double s_buf[4][21][65];
+  const int b = blockIdx.x;
+  if (b < rp.nb_pairs) { schur_pairs_body(g, pc, b, rp.nb_pairs, s_buf); return; }
+  cub_schur_body(g, b - rp.nb_pairs);
+}
+// single-part wrappers (measurement hooks)
+__global__ __launch_bounds__(256) void k_schur_z(Graph g) { schur_z_body(g, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
+  __shared__ double s_buf[4][21][65];
+  schur_pairs_body(g, pc, blockIdx.x, gridDim.x, s_buf);
+}
+
+// Poses and cuboids in ONE launch of 64-thread workgroups: workgroup c < n_cuboids back-substitutes cuboid c (when the cuboids
+// were eliminated) and applies its update, the remaining workgroups update 64 poses each.
+__global__ __launch_bounds__(64) void k_update_reduced_all(Graph g, State cur, State trial, double lambda) {
+  __shared__ double sp[54], st[9], sy[9], sx[9];
+  const int lane = threadIdx.x;
+  double sc = 0.0;
+  if ((int)blockIdx.x < g.n_cuboids) {
+    const int c = blockIdx.x;
+    const int col = g.cub_col[c];
+    if (col >= 0 && g.elim_cub) {
+      const int a = lane / 9;
+      double part = 0.0;
+      if (lane < 54) {
+        for (int q = g.cub_edge_off[c]; q < g.cub_edge_off[c + 1]; ++q) {
+          const int code = g.cub_edges[q];
+          const CubEdge& e = cub_edge_of(g, code);
+          const int pcol = g.pose_col[e.pose];
+          if (!(e.flags & F_ACTIVE) || pcol < 0) continue;
+          part += wpc_of(g, code)[lane] * g.xr[pcol + a];
+        }
+        sp[lane] = part;
+      }
+      __syncthreads();
+      if (lane < 9) {
+        double t = g.HC[(size_t)c * 54 + 45 + lane];
+        for (int k = 0; k < 6; ++k) t -= sp[k * 9 + lane];
+        st[lane] = t;
+      }
+      __syncthreads();
+      const double* Li = &g.cub_Linv[(size_t)c * 81];
+      if (lane < 9) {
+        double v = 0.0;
+        for (int m = 0; m <= lane; ++m) v += Li[lane * 9 + m] * st[m];
+        sy[lane] = v;
+      }
+      __syncthreads();
+      if (lane < 9) {
+        double v = 0.0;
+        for (int k = lane; k < 9; ++k) v += Li[k * 9 + lane] * sy[k];
+        g.xc[(size_t)c * 9 + lane] = v;
+        sx[lane] = v;
+      }
+      __syncthreads();
+    } else if (col >= 0) {
+      if (lane < 9) sx[lane] = g.xr[col + lane];
+      __syncthreads();
+    }
+    if (lane == 0) {
+      Cub cb = load_cub(&cur.cub[10 * c]);
+      if (col >= 0) {
+        const double* fs = &g.cub_fixedscale[3 * c];
+        cb = cuboid_boxplus(cb, sx, g.cub_flags[c], fs[0], fs[1], fs[2]);
+        if (g.owns_reduced) {
+          const double* b = &g.HC[(size_t)c * 54 + 45];
+          for (int a = 0; a < 9; ++a) sc += sx[a] * (lambda * sx[a] + b[a]);
+        }
+      }
+      double* o = &trial.cub[10 * c];
+      o[0] = cb.T.q.x; o[1] = cb.T.q.y; o[2] = cb.T.q.z; o[3] = cb.T.q.w; o[4] = cb.T.t.x; o[5] = cb.T.t.y; o[6] = cb.T.t.z;
+      o[7] = cb.s.x; o[8] = cb.s.y; o[9] = cb.s.z;
+    }
+  } else {
+    const int i = ((int)blockIdx.x - g.n_cuboids) * 64 + lane;
+    if (i < g.n_poses) {
+      const int col = g.pose_col[i];
+      Pose T = load_pose(&cur.pose_qt[7 * i]);
+      if (col >= 0) {
+        const double* x = &g.xr[col];
+        T = pose_boxplus(T, x);
+        if (g.owns_reduced) {
+          const double* b = &g.HB[(size_t)g.pose_free_id[i] * 27 + 21];
+          for (int a = 0; a < 6; ++a) sc += x[a] * (lambda * x[a] + b[a]);
+        }
+      }
+      store_pose(&trial.pose_qt[7 * i], &trial.pose_rt[12 * i], T);
+    }
+  }
+  sc = wave_sum(sc);
+  if (lane == 0 && sc != 0.0) atomicAdd(&g.acc[ACC_SCALE], sc);
 }
 
 // landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term.

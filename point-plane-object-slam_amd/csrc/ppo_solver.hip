@@ -8,6 +8,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -116,7 +117,9 @@ struct ppo_ba_solver {
   DevBuf<double> d_cub_Linv, d_cub_u, d_xc, d_cub_Z;
   DevBuf<int> d_info;
   size_t state_doubles = 0;
-  double* h_pinned = nullptr;  // ACC_N doubles then one int
+  double* h_pinned = nullptr;  // mapped host memory: ACC_N doubles, the factorisation info (as a double), a sequence number
+  double* h_pinned_dev = nullptr;
+  unsigned long long pub_seq = 0;
   Graph g{};
   State st[2]{};
   int cur = 0;
@@ -350,24 +353,19 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
     hipLaunchKernelGGL(k_zero_ranges, dim3(4 * s->n_cu), dim3(256), 0, s->stream, zp);
   }
   const bool cub_stage = g.elim_cub && g.owns_reduced && g.n_cuboids > 0;
-  if (cub_stage) {  // fork: the (small, latency-bound) cuboid elimination runs next to the landmark Schur complement
-    HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
-    HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-    hipLaunchKernelGGL(k_cub_prep, dim3(nblk(g.n_cuboids, 64)), dim3(64), 0, s->side, g, lambda);
-    const int n_ce = s->n_cub_edges;
-    if (n_ce > 0) hipLaunchKernelGGL(k_cub_z, dim3(nblk((long)n_ce * 6, 64)), dim3(64), 0, s->side, g);
-    if (g.n_cub_pairs > 0) hipLaunchKernelGGL(k_cub_schur, dim3(nblk((long)g.n_cub_pairs * 8, 256)), dim3(256), 0, s->side, g);
-    HIP_TRY(hipEventRecord(s->ev_join, s->side));
-  }
-  const long work = (long)g.n_pose_free * 27 + (long)g.n_cuboids * 54 + (long)(g.n_bbox + g.n_corner) * 54 + (g.ld - g.n_red);
-  hipLaunchKernelGGL(k_assemble, dim3(nblk(work, 256)), dim3(256), 0, s->stream, g, lambda);
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
-  if (nl > 0) {
-    hipLaunchKernelGGL(k_schur_prep, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, lambda);
-    if (g.n_slots > 0) hipLaunchKernelGGL(k_schur_z, dim3(nblk(g.n_slots, 256)), dim3(256), 0, s->stream, g);
-    if (s->pc.n_chunks > 0) hipLaunchKernelGGL(k_schur_pairs, dim3((nblk(s->pc.n_chunks, 4) + 7) / 8 * 8), dim3(256), 0, s->stream, g, s->pc);
-  }
-  if (cub_stage) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+  ReducePlan rp{};
+  const long work = (long)g.n_pose_free * 27 + (long)g.n_cuboids * 54 + (long)(g.n_bbox + g.n_corner) * 54 + (g.ld - g.n_red);
+  rp.nb_asm = nblk(work, 256);
+  rp.nb_prep = nl > 0 ? nblk(nl, 256) : 0;
+  rp.nb_cubprep = cub_stage ? nblk(g.n_cuboids, 256) : 0;
+  rp.nb_z = (nl > 0 && g.n_slots > 0) ? nblk(g.n_slots, 256) : 0;
+  rp.nb_cubz = (cub_stage && s->n_cub_edges > 0) ? nblk((long)s->n_cub_edges * 6, 256) : 0;
+  rp.nb_pairs = (nl > 0 && s->pc.n_chunks > 0) ? (nblk(s->pc.n_chunks, 4) + 7) / 8 * 8 : 0;
+  rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? nblk((long)g.n_cub_pairs * 8, 256) : 0;
+  hipLaunchKernelGGL(k_reduce_stage1, dim3(rp.nb_asm + rp.nb_prep + rp.nb_cubprep), dim3(256), 0, s->stream, g, lambda, rp);
+  if (rp.nb_z + rp.nb_cubz > 0) hipLaunchKernelGGL(k_reduce_stage2, dim3(rp.nb_z + rp.nb_cubz), dim3(256), 0, s->stream, g, rp);
+  if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
     if (s->comm.sum(s->d_S.p, n * n, s->stream) || s->comm.sum(s->d_bs.p, n, s->stream)) return PPO_BA_ERR_COMM;
@@ -395,8 +393,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   const Graph& g = s->g;
   const State& cur = s->st[s->cur];
   const State& tr = s->st[s->cur ^ 1];
-  if (g.elim_cub && g.n_cuboids > 0) hipLaunchKernelGGL(k_cub_backsub, dim3(g.n_cuboids), dim3(64), 0, s->stream, g);
-  hipLaunchKernelGGL(k_update_reduced, dim3(nblk(g.n_poses + g.n_cuboids, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
+  hipLaunchKernelGGL(k_update_reduced_all, dim3(g.n_cuboids + nblk(g.n_poses, 64)), dim3(64), 0, s->stream, g, cur, tr, lambda);
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
   if (nl > 0) {
     if (s->use_lds) hipLaunchKernelGGL(k_backsub<true>, dim3(nblk(nl, 256)), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda);
@@ -413,13 +410,24 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info) {
     // chi2 and scale are sums, maxdiag is a max: two tiny collectives on the accumulator block
     if (s->comm.sum(s->g.acc, 2, s->stream) || s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
   }
-  HIP_TRY(hipMemcpyAsync(s->h_pinned, s->g.acc, ACC_N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  if (with_info) HIP_TRY(hipMemcpyAsync(s->h_pinned + ACC_N, s->d_info.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s->stream, (const double*)s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev,
+                     ++s->pub_seq);
   HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
   return PPO_BA_OK;
 }
 int fetch_acc_wait(ppo_ba_solver* s) {
+  // spin on the sequence number the device writes last; fall back to the event if it does not show up
+  volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(s->h_pinned + ACC_N + 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned it = 0;; ++it) {
+    if (*seq == s->pub_seq) { std::atomic_thread_fence(std::memory_order_acquire); return PPO_BA_OK; }
+    if ((it & 1023) == 1023) {
+      if (hipEventQuery(s->ev_acc) == hipSuccess) break;  // the kernel is done: the value is there (or something failed)
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+    }
+  }
   HIP_TRY(hipEventSynchronize(s->ev_acc));
+  if (*seq != s->pub_seq) return PPO_BA_ERR_HIP;
   return PPO_BA_OK;
 }
 int fetch_acc(ppo_ba_solver* s, bool with_info) {
@@ -480,7 +488,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     }
     RC_TRY(fetch_acc_wait(s));
     int info = 0;
-    std::memcpy(&info, s->h_pinned + ACC_N, sizeof(int));
+    info = (int)s->h_pinned[ACC_N];
     double tempChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
     if (info != 0 || !std::isfinite(s->h_pinned[ACC_SCALE])) tempChi = std::numeric_limits<double>::max();  // solver not ok (:126-127)
     rho = currentChi - tempChi;
@@ -922,7 +930,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream);
   s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, (int)pc_colj.size()};
   if (!ok) return fail(PPO_BA_ERR_NOMEM);
-  if (hipHostMalloc((void**)&s->h_pinned, (ACC_N + 2) * sizeof(double)) != hipSuccess) return fail(PPO_BA_ERR_NOMEM);
+  if (hipHostMalloc((void**)&s->h_pinned, (ACC_N + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail(PPO_BA_ERR_NOMEM);
+  std::memset(s->h_pinned, 0, (ACC_N + 2) * sizeof(double));
+  if (hipHostGetDevicePointer((void**)&s->h_pinned_dev, s->h_pinned, 0) != hipSuccess) return fail(PPO_BA_ERR_HIP);
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
 
   g.pose_cam = s->d_pose_cam.p; g.pose_col = s->d_pose_col.p; g.pose_free_id = s->d_pose_free_id.p; g.cub_col = s->d_cub_col.p;
