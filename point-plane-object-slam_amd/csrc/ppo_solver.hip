@@ -772,7 +772,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // ---- Schur accumulation plan: (slot_j, slot_i) pairs of every owned landmark filed by pose pair, then chunked -----
   std::vector<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si;
   {
-    const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
     const long nkeys = (long)nfree * (nfree + 1) / 2;
     std::vector<int32_t> cnt(nkeys + 1, 0);
     auto key_of = [&](int cj, int ci) { const long pj = cj / 6, pi = ci / 6; return pj * (pj + 1) / 2 + pi; };
@@ -812,7 +812,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   std::vector<MonoEdgeP> h_monoP;
   std::vector<StereoEdgeP> h_stereoP;
   {
-    const int chunk = []() { const char* e = getenv("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    const int chunk = []() { const char* e = getenv("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     auto build = [&](int type) {
       std::vector<int32_t> cnt(Np + 1, 0);
       auto visit = [&](auto&& fn) {

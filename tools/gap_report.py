@@ -15,7 +15,7 @@ def main(path):
     ks = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
     rows = list(cur.execute(f"select d.start,d.end,s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
     names = [r[2] for r in rows]
-    lp = [i for i, n in enumerate(names) if 'k_lin_poses' in n]
+    lp = [i for i, n in enumerate(names) if 'k_linearize_all' in n]
     a, b = lp[60], lp[min(360, len(lp) - 1)]
     nit = min(360, len(lp) - 1) - 60
     t0, t1 = rows[a][0], rows[b][0]
