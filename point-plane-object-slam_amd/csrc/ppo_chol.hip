@@ -369,11 +369,17 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
   // step 0 takes the right-hand side from rhs_in (the caller's b stays intact), later steps continue in rhs
   const double* rsrc = (k0 == 0) ? rhs_in : rhs;
   {
+    // All four tiles are requested unconditionally and back to back (a tile that is not needed aliases the diagonal one):
+    // with the loads under `if`s the compiler drained each group before issuing the next, four memory round trips in a row.
     double2 td[8], tb[8], tp[8], tq[8];
-    load_tile(&A[(size_t)k0 * ld + k0], ld, td);
-    if (upd) load_tile(&A[(size_t)kp * ld + k0], ld, tq);  // L[k][k-1]
-    if (own) load_tile(&A[(size_t)k0 * ld + row0], ld, tb);
-    if (uo) load_tile(&A[(size_t)kp * ld + row0], ld, tp);  // L[k+b][k-1]
+    const double* pC = &A[(size_t)k0 * ld + k0];
+    const double* pQ = upd ? &A[(size_t)kp * ld + k0] : pC;   // L[k][k-1]
+    const double* pB = own ? &A[(size_t)k0 * ld + row0] : pC;
+    const double* pP = uo ? &A[(size_t)kp * ld + row0] : pC;  // L[k+b][k-1]
+    load_tile(pC, ld, td);
+    load_tile(pQ, ld, tq);
+    load_tile(pB, ld, tb);
+    load_tile(pP, ld, tp);
     const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
     STAMP(6);
 #pragma unroll
@@ -381,16 +387,14 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
       const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
       sL[r][c] = (r >= c) ? td[i].x : 0.0;
       sL[r + 1][c] = (r + 1 >= c) ? td[i].y : 0.0;
-      if (upd) *reinterpret_cast<double2*>(&sQ[c][r]) = tq[i];
+      *reinterpret_cast<double2*>(&sQ[c][r]) = tq[i];
     }
-    if (own) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
-        sB[r][c] = tb[i].x;
-        sB[r + 1][c] = tb[i].y;
-        if (upd) *reinterpret_cast<double2*>(&sP[c][r]) = tp[i];
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
+      sB[r][c] = tb[i].x;
+      sB[r + 1][c] = tb[i].y;
+      *reinterpret_cast<double2*>(&sP[c][r]) = tp[i];
     }
     if (tid < NB) sB[NB][tid] = rv;
     if (tid == 0) sBad = 0;
