@@ -280,6 +280,11 @@ int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
 int ppo_ba_debug_set_lambda(ppo_ba_handle h, double lambda);
 int ppo_ba_debug_reduced(ppo_ba_handle h, double* S, double* b, double* x, int32_t* n);
 
+/* ppo_ba_destroy() keeps device blocks, streams and the mapped host block of the solver in a process-wide cache so that
+ * the next ppo_ba_create() -- one per local-BA call in the reference -- does not pay for ~60 allocations again (capped at
+ * 4 GiB).  This call returns everything cached to the driver; live solvers are not affected. */
+int ppo_ba_release_cached(void);
+
 /* Algorithmic bytes of one linearisation (SURVEY.md 8(d) formula) for the problem in h. */
 int64_t ppo_ba_linearize_bytes(ppo_ba_handle h);
 

@@ -600,12 +600,14 @@ struct GraphKey {
   double* A;
   const double* b;
   double* x;
+  double* ws;
   int* info;
   int n;
   bool operator<(const GraphKey& o) const {
     if (A != o.A) return A < o.A;
     if (b != o.b) return b < o.b;
     if (x != o.x) return x < o.x;
+    if (ws != o.ws) return ws < o.ws;
     if (info != o.info) return info < o.info;
     return n < o.n;
   }
@@ -635,7 +637,7 @@ int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, 
   hipGraphExec_t exec = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    const GraphKey key{A, b, x, info, ld};
+    const GraphKey key{A, b, x, ws, info, ld};
     auto it = g_graphs.find(key);
     if (it == g_graphs.end()) {
       hipGraph_t graph = nullptr;

@@ -15,7 +15,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <numeric>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -42,25 +45,147 @@ using namespace ppo;
 
 namespace {
 
+// Device memory comes from a process-wide cache of freed blocks (size-bucketed, per device): a SLAM process creates and
+// destroys one solver per local-BA call, and ~60 hipMalloc + hipFree pairs cost ~9 ms per call against ~10 ms of solve.
+// Blocks keep their addresses while cached, so the captured Cholesky launch graph of a recurring window shape is reused too.
+struct DevPool {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void*>> free_;
+  size_t cached = 0;
+  static constexpr size_t kMaxCached = 4ull << 30;
+  static size_t bucket(size_t bytes) {  // next of {1, 1.25, 1.5, 1.75} x 2^k, at least 4 KiB: <= 25 % slack
+    size_t b = 4096;
+    while (b * 2 <= bytes) b *= 2;
+    if (b >= bytes) return b;
+    for (int q = 5; q <= 8; ++q)
+      if (b / 4 * q >= bytes) return b / 4 * q;
+    return b * 2;
+  }
+  void* get(size_t bytes, int dev, size_t* got) {
+    const size_t b = bucket(bytes);
+    *got = b;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_.find({dev, b});
+      if (it != free_.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        cached -= b;
+        return p;
+      }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, b) != hipSuccess) {
+      trim();  // give cached blocks back and retry once
+      if (hipMalloc(&p, b) != hipSuccess) return nullptr;
+    }
+    return p;
+  }
+  void put(void* p, size_t b, int dev) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (cached + b <= kMaxCached) {
+        free_[{dev, b}].push_back(p);
+        cached += b;
+        return;
+      }
+    }
+    chol_release(static_cast<double*>(p));
+    (void)hipFree(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : free_)
+      for (void* p : kv.second) {
+        chol_release(static_cast<double*>(p));
+        (void)hipFree(p);
+      }
+    free_.clear();
+    cached = 0;
+  }
+};
+DevPool g_pool;
+
+// Streams, events and the mapped host block of a solver are recycled the same way (creating and destroying them costs
+// several ms per solver, mostly the pinned allocation and the stream teardown).
+struct DevCtx {
+  int dev = -1;
+  hipStream_t stream = nullptr, side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_acc = nullptr;
+  double* h_pinned = nullptr;
+  double* h_pinned_dev = nullptr;
+};
+constexpr int kPinnedDoubles = 16;
+struct CtxPool {
+  std::mutex mu;
+  std::vector<DevCtx> free_;
+  bool get(int dev, DevCtx* c) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i].dev == dev) {
+          *c = free_[i];
+          free_.erase(free_.begin() + i);
+          return true;
+        }
+    }
+    DevCtx n;
+    n.dev = dev;
+    bool ok = hipStreamCreateWithFlags(&n.stream, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n.ev_join, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&n.ev_acc, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&n.h_pinned, kPinnedDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void**)&n.h_pinned_dev, n.h_pinned, 0) == hipSuccess;
+    if (!ok) { destroy(n); return false; }
+    *c = n;
+    return true;
+  }
+  void put(const DevCtx& c) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_.size() < 8) { free_.push_back(c); return; }
+    destroy(c);
+  }
+  static void destroy(const DevCtx& c) {
+    if (c.h_pinned) (void)hipHostFree(c.h_pinned);
+    if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
+    if (c.ev_join) (void)hipEventDestroy(c.ev_join);
+    if (c.ev_acc) (void)hipEventDestroy(c.ev_acc);
+    if (c.side) (void)hipStreamDestroy(c.side);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const DevCtx& c : free_) destroy(c);
+    free_.clear();
+  }
+};
+CtxPool g_ctx_pool;
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t cap_bytes = 0;
+  int dev = 0;
   bool alloc(size_t count) {
     n = count;
     p = nullptr;
+    cap_bytes = 0;
     if (count == 0) return true;
-    return hipMalloc((void**)&p, count * sizeof(T)) == hipSuccess;
+    (void)hipGetDevice(&dev);
+    p = static_cast<T*>(g_pool.get(count * sizeof(T), dev, &cap_bytes));
+    return p != nullptr;
   }
   bool upload(const std::vector<T>& h, hipStream_t s) {
     if (!alloc(h.size())) return false;
     if (h.empty()) return true;
     return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess;
   }
-  void release() {
-    if (p) (void)hipFree(p);
+  void release() {  // the owner has synchronised its streams (free_all)
+    if (p) g_pool.put(p, cap_bytes, dev);
     p = nullptr;
     n = 0;
+    cap_bytes = 0;
   }
 };
 
@@ -219,7 +344,8 @@ void canon_plane_cv(const double* in, double* out) {  // Converter::toPlane3D (C
 void free_all(ppo_ba_solver* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  chol_release(s->d_S.p);
+  if (s->side) (void)hipStreamSynchronize(s->side);
+  // (the captured Cholesky graph stays with the cached block of S: DevPool drops it when the block is really freed)
   s->d_pose_cam.release(); s->d_cub_fixedscale.release(); s->d_ptcub_pts.release();
   s->d_pose_col.release(); s->d_pose_free_id.release(); s->d_cub_col.release(); s->d_mo_off.release(); s->d_st_off.release();
   s->d_slot_col.release(); s->d_slot_lm.release(); s->d_pl_slot_off.release(); s->d_pl_slots.release();
@@ -233,14 +359,15 @@ void free_all(ppo_ba_solver* s) {
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release();
   s->d_cub_Linv.release(); s->d_cub_u.release(); s->d_xc.release(); s->d_cub_Z.release();
-  if (s->h_pinned) (void)hipHostFree(s->h_pinned);
   if (s->blas) rocblas_destroy_handle(s->blas);
   s->comm.destroy();
-  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
-  if (s->ev_acc) (void)hipEventDestroy(s->ev_acc);
-  if (s->side) (void)hipStreamDestroy(s->side);
-  if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->stream) {  // hand the (drained) streams, events and mapped host block back
+    DevCtx c;
+    c.dev = s->device; c.stream = s->stream; c.side = s->side; c.ev_fork = s->ev_fork; c.ev_join = s->ev_join; c.ev_acc = s->ev_acc;
+    c.h_pinned = s->h_pinned; c.h_pinned_dev = s->h_pinned_dev;
+    g_ctx_pool.put(c);
+    s->stream = s->side = nullptr;
+  }
 }
 
 State make_state(double* base, int np, int npt, int npl, int nc) {
@@ -561,6 +688,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (!p || !o || !out) return PPO_BA_ERR_ARG;
   *out = nullptr;
   if (o->abi_version != PPO_BA_ABI_VERSION) return PPO_BA_ERR_ARG;
+  const auto t_begin = std::chrono::steady_clock::now();
   RC_TRY(validate(p));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -574,17 +702,33 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   s->device = o->device_id;
   auto fail = [&](int code) { free_all(s); delete s; return code; };
   if (hipSetDevice(s->device) != hipSuccess) return fail(PPO_BA_ERR_HIP);
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return fail(PPO_BA_ERR_HIP);
-  if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess) return fail(PPO_BA_ERR_HIP);
-  if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&s->ev_acc, hipEventDisableTiming) != hipSuccess) return fail(PPO_BA_ERR_HIP);
-  if (rocblas_create_handle(&s->blas) != rocblas_status_success) return fail(PPO_BA_ERR_SOLVER);
-  rocblas_set_stream(s->blas, s->stream);
+  {
+    int ncu = 0;  // (hipGetDeviceProperties fills a large structure and costs more than a millisecond)
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess && ncu > 0) s->n_cu = ncu;
+  }
+  {
+    DevCtx c;
+    if (!g_ctx_pool.get(s->device, &c)) return fail(PPO_BA_ERR_HIP);
+    s->stream = c.stream; s->side = c.side; s->ev_fork = c.ev_fork; s->ev_join = c.ev_join; s->ev_acc = c.ev_acc;
+    s->h_pinned = c.h_pinned; s->h_pinned_dev = c.h_pinned_dev;
+    std::memset(s->h_pinned, 0, kPinnedDoubles * sizeof(double));
+    s->pub_seq = 0;
+  }
   if (s->comm.init(o->comm_id, o->rank, o->world_size)) return fail(PPO_BA_ERR_COMM);
   s->solver_kind = (o->solver == PPO_SOLVER_NATIVE) ? PPO_SOLVER_NATIVE : (o->solver == PPO_SOLVER_ROCSOLVER ? PPO_SOLVER_ROCSOLVER : chol_default_backend());
+  if (s->solver_kind == PPO_SOLVER_ROCSOLVER) {  // the rocBLAS handle costs ~3 ms: only the rocSOLVER backend pays for it
+    if (rocblas_create_handle(&s->blas) != rocblas_status_success) return fail(PPO_BA_ERR_SOLVER);
+    rocblas_set_stream(s->blas, s->stream);
+  }
 
+  auto t_mark = t_begin;
+  auto mark = [&](const char* what) {  // phase timer of create (options.verbose)
+    if (!o->verbose) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[ppo_ba] create: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_mark).count());
+    t_mark = t;
+  };
+  mark("validate, device, streams");
   Graph& g = s->g;
   g.n_poses = p->n_poses; g.n_points = p->n_points; g.n_planes = p->n_planes; g.n_cuboids = p->n_cuboids;
   g.n_mono = p->n_mono; g.n_stereo = p->n_stereo; g.n_pl = p->n_plane_edges; g.n_bbox = p->n_bbox; g.n_corner = p->n_corner; g.n_ptcub = p->n_ptcub;
@@ -632,29 +776,43 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   csr_sort(p->n_mono, p->mono_point, mo_off, s->mono_perm);
   csr_sort(p->n_stereo, p->stereo_point, st_off, s->stereo_perm);
 
+  mark("csr sort");
   // ---- (landmark, pose) slots: unique free poses seen by each free landmark, ascending column ----------
-  std::vector<std::vector<int32_t>> lm_cols(g.n_lm);
-  for (int k = 0; k < p->n_mono; ++k) {
-    const int e = s->mono_perm[k], pt = p->mono_point[e], pc = pose_col[p->mono_pose[e]];
-    if (!point_fixed[pt] && pc >= 0) lm_cols[pt].push_back(pc);
-  }
-  for (int k = 0; k < p->n_stereo; ++k) {
-    const int e = s->stereo_perm[k], pt = p->stereo_point[e], pc = pose_col[p->stereo_pose[e]];
-    if (!point_fixed[pt] && pc >= 0) lm_cols[pt].push_back(pc);
-  }
-  for (int e = 0; e < p->n_plane_edges; ++e) {
-    const int pc = pose_col[p->pl_pose[e]];
-    if (pc >= 0) lm_cols[Npt + p->pl_plane[e]].push_back(pc);
+  // flat two-pass layout (count, fill, sort + unique each landmark's short segment in place): no per-landmark allocations
+  std::vector<int32_t> seg_off(g.n_lm + 1, 0), seg_col;
+  {
+    auto visit = [&](auto&& fn) {
+      for (int e = 0; e < p->n_mono; ++e) {
+        const int pt = p->mono_point[e], pc = pose_col[p->mono_pose[e]];
+        if (!point_fixed[pt] && pc >= 0) fn(pt, pc);
+      }
+      for (int e = 0; e < p->n_stereo; ++e) {
+        const int pt = p->stereo_point[e], pc = pose_col[p->stereo_pose[e]];
+        if (!point_fixed[pt] && pc >= 0) fn(pt, pc);
+      }
+      for (int e = 0; e < p->n_plane_edges; ++e) {
+        const int pc = pose_col[p->pl_pose[e]];
+        if (pc >= 0) fn(Npt + p->pl_plane[e], pc);
+      }
+    };
+    visit([&](int l, int) { seg_off[l + 1]++; });
+    for (int l = 0; l < g.n_lm; ++l) seg_off[l + 1] += seg_off[l];
+    seg_col.resize(seg_off[g.n_lm]);
+    std::vector<int32_t> cursor(seg_off.begin(), seg_off.end() - 1);
+    visit([&](int l, int pc) { seg_col[cursor[l]++] = pc; });
   }
   std::vector<int32_t>& slot_off = s->h_slot_off;
   slot_off.assign(g.n_lm + 1, 0);
   std::vector<int32_t> slot_col, slot_lm;
+  slot_col.reserve(seg_col.size());
+  slot_lm.reserve(seg_col.size());
   for (int l = 0; l < g.n_lm; ++l) {
-    auto& v = lm_cols[l];
-    std::sort(v.begin(), v.end());
-    v.erase(std::unique(v.begin(), v.end()), v.end());
+    int32_t* b0 = seg_col.data() + seg_off[l];
+    int32_t* e0 = seg_col.data() + seg_off[l + 1];
+    std::sort(b0, e0);
+    e0 = std::unique(b0, e0);
     slot_off[l] = (int32_t)slot_col.size();
-    for (int c : v) { slot_col.push_back(c); slot_lm.push_back(l); }
+    for (int32_t* q = b0; q != e0; ++q) { slot_col.push_back(*q); slot_lm.push_back(l); }
   }
   slot_off[g.n_lm] = (int32_t)slot_col.size();
   g.n_slots = (int)slot_col.size();
@@ -683,6 +841,57 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     const int32_t* it = std::lower_bound(b, e, pc);
     return (it != e && *it == pc) ? new_id[it - slot_col.data()] : -1;
   };
+
+  // ---- landmark ownership (multi-GPU): contiguous edge-balanced ranges; rank 0 owns the reduced-only terms ----
+  g.pt_first = 0; g.pt_last = Npt; g.plane_first = 0; g.plane_last = Npl; g.owns_reduced = 1;
+  if (o->world_size > 1) {
+    std::vector<int32_t> fp(o->world_size + 1), fl(o->world_size + 1);
+    if (ppo_ba_partition(p, o->world_size, fp.data(), fl.data()) != PPO_BA_OK) return fail(PPO_BA_ERR_ARG);
+    g.pt_first = fp[o->rank]; g.pt_last = fp[o->rank + 1];
+    g.plane_first = fl[o->rank]; g.plane_last = fl[o->rank + 1];
+    g.owns_reduced = (o->rank == 0);
+  }
+
+  // ---- Schur accumulation plan: (slot_j, slot_i) pairs of every owned landmark filed by pose pair, then chunked -----
+  // (built on a helper thread while this one fills the edge records: both are ~3 ms of host work at the BASELINE size)
+  std::vector<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si;
+  std::thread pair_plan_thread([&]()   {
+    const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    const long nkeys = (long)nfree * (nfree + 1) / 2;
+    std::vector<int32_t> cnt(nkeys + 1, 0);
+    std::vector<int32_t> slot_pose(g.n_slots);
+    for (int i = 0; i < g.n_slots; ++i) slot_pose[i] = slot_col[i] / 6;
+    auto key_of = [&](int a, int b) { const long pj = slot_pose[a], pi = slot_pose[b]; return pj * (pj + 1) / 2 + pi; };
+    auto for_owned = [&](auto&& fn) {
+      for (int l = g.pt_first; l < g.pt_last; ++l) fn(l);
+      for (int l = Npt + g.plane_first; l < Npt + g.plane_last; ++l) fn(l);
+    };
+    for_owned([&](int l) {
+      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
+        for (int b = slot_off[l]; b <= a; ++b) cnt[key_of(a, b) + 1]++;
+    });
+    for (long k = 0; k < nkeys; ++k) cnt[k + 1] += cnt[k];
+    const long n_entries = cnt[nkeys];
+    pc_sj.resize(n_entries);
+    pc_si.resize(n_entries);
+    std::vector<int32_t> cursor(cnt.begin(), cnt.end() - 1);
+    for_owned([&](int l) {
+      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
+        for (int b = slot_off[l]; b <= a; ++b) {
+          const int32_t pos = cursor[key_of(a, b)]++;
+          pc_sj[pos] = new_id[a];
+          pc_si[pos] = new_id[b];
+        }
+    });
+    pc_start.push_back(0);
+    for (long pj = 0, k = 0; pj < nfree; ++pj)
+      for (long pi = 0; pi <= pj; ++pi, ++k)
+        for (int32_t e = cnt[k]; e < cnt[k + 1]; e += chunk) {
+          pc_colj.push_back((int32_t)(6 * pj));
+          pc_coli.push_back((int32_t)(6 * pi));
+          pc_start.push_back(std::min<int32_t>(e + chunk, cnt[k + 1]));
+        }
+  });
 
   // ---- edge records -----------------------------------------------------------------------------------------
   s->h_mono.resize(p->n_mono);
@@ -757,56 +966,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     huber(c, p->cubpl_huber[e], r0, r1);
     s->cubpl_rho_sum += r0;
   }
+  if (!g.owns_reduced) s->cubpl_rho_sum = 0;
 
-  // ---- landmark ownership (multi-GPU): contiguous edge-balanced ranges; rank 0 owns the reduced-only terms ----
-  g.pt_first = 0; g.pt_last = Npt; g.plane_first = 0; g.plane_last = Npl; g.owns_reduced = 1;
-  if (o->world_size > 1) {
-    std::vector<int32_t> fp(o->world_size + 1), fl(o->world_size + 1);
-    if (ppo_ba_partition(p, o->world_size, fp.data(), fl.data()) != PPO_BA_OK) return fail(PPO_BA_ERR_ARG);
-    g.pt_first = fp[o->rank]; g.pt_last = fp[o->rank + 1];
-    g.plane_first = fl[o->rank]; g.plane_last = fl[o->rank + 1];
-    g.owns_reduced = (o->rank == 0);
-    if (!g.owns_reduced) s->cubpl_rho_sum = 0;
-  }
-
-  // ---- Schur accumulation plan: (slot_j, slot_i) pairs of every owned landmark filed by pose pair, then chunked -----
-  std::vector<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si;
-  {
-    const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
-    const long nkeys = (long)nfree * (nfree + 1) / 2;
-    std::vector<int32_t> cnt(nkeys + 1, 0);
-    auto key_of = [&](int cj, int ci) { const long pj = cj / 6, pi = ci / 6; return pj * (pj + 1) / 2 + pi; };
-    auto for_owned = [&](auto&& fn) {
-      for (int l = g.pt_first; l < g.pt_last; ++l) fn(l);
-      for (int l = Npt + g.plane_first; l < Npt + g.plane_last; ++l) fn(l);
-    };
-    for_owned([&](int l) {
-      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
-        for (int b = slot_off[l]; b <= a; ++b) cnt[key_of(slot_col[a], slot_col[b]) + 1]++;
-    });
-    for (long k = 0; k < nkeys; ++k) cnt[k + 1] += cnt[k];
-    const long n_entries = cnt[nkeys];
-    pc_sj.resize(n_entries);
-    pc_si.resize(n_entries);
-    std::vector<int32_t> cursor(cnt.begin(), cnt.end() - 1);
-    for_owned([&](int l) {
-      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
-        for (int b = slot_off[l]; b <= a; ++b) {
-          const int32_t pos = cursor[key_of(slot_col[a], slot_col[b])]++;
-          pc_sj[pos] = new_id[a];
-          pc_si[pos] = new_id[b];
-        }
-    });
-    pc_start.push_back(0);
-    for (long pj = 0, k = 0; pj < nfree; ++pj)
-      for (long pi = 0; pi <= pj; ++pi, ++k)
-        for (int32_t e = cnt[k]; e < cnt[k + 1]; e += chunk) {
-          pc_colj.push_back((int32_t)(6 * pj));
-          pc_coli.push_back((int32_t)(6 * pi));
-          pc_start.push_back(std::min<int32_t>(e + chunk, cnt[k + 1]));
-        }
-  }
-
+  mark("edge records");
   // ---- pose-major static copies of the owned reprojection edges + chunks (pose side of the linearisation) -----------
   std::vector<int32_t> po_start, po_end, po_pose;
   std::vector<MonoEdgeP> h_monoP;
@@ -890,6 +1052,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     }
   }
 
+  pair_plan_thread.join();
+  mark("pose-major copies, cuboid plan, pair plan join");
   // ---- uploads ----------------------------------------------------------------------------------------------------------
   bool ok = true;
   std::vector<double> v_cam(p->pose_cam, p->pose_cam + (size_t)5 * Np);
@@ -929,10 +1093,14 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
   ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream);
   s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, (int)pc_colj.size()};
+  mark("hipMalloc + H2D enqueue");
   if (!ok) return fail(PPO_BA_ERR_NOMEM);
-  if (hipHostMalloc((void**)&s->h_pinned, (ACC_N + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail(PPO_BA_ERR_NOMEM);
-  std::memset(s->h_pinned, 0, (ACC_N + 2) * sizeof(double));
-  if (hipHostGetDevicePointer((void**)&s->h_pinned_dev, s->h_pinned, 0) != hipSuccess) return fail(PPO_BA_ERR_HIP);
+  {  // blocks come from the cache with stale contents: the work arrays that are only partially written start from zero
+    auto zero = [&](auto& b) { if (b.p && b.n) (void)hipMemsetAsync(b.p, 0, b.n * sizeof(*b.p), s->stream); };
+    zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_C); zero(s->d_ul); zero(s->d_Z); zero(s->d_bs); zero(s->d_xr); zero(s->d_cholws);
+    zero(s->d_cub_Linv); zero(s->d_cub_u); zero(s->d_xc); zero(s->d_cub_Z); zero(s->d_S);
+  }
+  static_assert(ACC_N + 2 <= kPinnedDoubles, "mapped host block too small");
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
 
   g.pose_cam = s->d_pose_cam.p; g.pose_col = s->d_pose_col.p; g.pose_free_id = s->d_pose_free_id.p; g.cub_col = s->d_cub_col.p;
@@ -987,6 +1155,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (Np) hipLaunchKernelGGL(k_pose_rt, dim3(nblk(Np, 256)), dim3(256), 0, s->stream, is, Np);
   }
   if (reset_device(s) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
+  mark("reset + sync");
 
   // algorithmic bytes of one linearisation, SURVEY.md 8(d)
   {
@@ -1341,6 +1510,12 @@ int ppo_ba_debug_set_lambda(ppo_ba_handle s, double lambda) {
 }
 
 int64_t ppo_ba_linearize_bytes(ppo_ba_handle s) { return s ? s->lin_bytes : -1; }
+
+int ppo_ba_release_cached(void) {
+  g_pool.trim();
+  g_ctx_pool.trim();
+  return PPO_BA_OK;
+}
 
 int ppo_ba_comm_unique_id(uint8_t id[128]) {
   Comm c;
