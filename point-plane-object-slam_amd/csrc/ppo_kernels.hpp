@@ -237,12 +237,14 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
     }
     __syncthreads();
   }
+  constexpr int LPP = 4;  // = kLanesPerPoint
+  const int sub = threadIdx.x % LPP, ppb = blockDim.x / LPP;
   double chi_local = 0.0;
-  for (int p = g.pt_first + bid * blockDim.x + threadIdx.x; p < g.pt_last; p += nblocks * blockDim.x) {
+  for (int p = g.pt_first + bid * ppb + threadIdx.x / LPP; p < g.pt_last; p += nblocks * ppb) {
     const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
     const bool lm_free = !g.point_fixed[p];
     double D[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    for (int e = g.mo_off[p]; e < g.mo_off[p + 1]; ++e) {
+    for (int e = g.mo_off[p] + sub; e < g.mo_off[p + 1]; e += LPP) {
       const uint32_t fl = g.mono_flags[e];
       if (!(fl & F_ACTIVE)) continue;
       const MonoEdge ed = g.mono[e];
@@ -270,7 +272,7 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
       const double gr[2] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1};
       if (lm_free) acc_landmark<2>(Jl, rho1 * ed.info, gr, D, bl);
     }
-    for (int e = g.st_off[p]; e < g.st_off[p + 1]; ++e) {
+    for (int e = g.st_off[p] + sub; e < g.st_off[p + 1]; e += LPP) {
       const uint32_t fl = g.stereo_flags[e];
       if (!(fl & F_ACTIVE)) continue;
       const StereoEdge ed = g.stereo[e];
@@ -291,7 +293,14 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
       const double gr[3] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1, -(ed.info * ev[2]) * rho1};
       if (lm_free) acc_landmark<3>(Jl, rho1 * ed.info, gr, D, bl);
     }
-    if (lm_free) {
+#pragma unroll
+    for (int off = 1; off < LPP; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) D[k] += __shfl_xor(D[k], off, 64);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bl[k] += __shfl_xor(bl[k], off, 64);
+    }
+    if (lm_free && sub == 0) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) g.D[(size_t)p * 6 + k] = D[k];
 #pragma unroll
@@ -410,11 +419,15 @@ __global__ __launch_bounds__(256) void k_lin_poses(Graph g, State st, PoseChunks
 }
 
 // residual-only pass over the reprojection edges (trial state)
+constexpr int kLanesPerPoint = 1;  // lanes per point in the residual-only pass (4 measured slower here: 16.3 vs 12.9 us; it pays in
+                                   // k_backsub and in the linearisation, whose per-edge work is an order of magnitude heavier)
 __device__ __forceinline__ void chi2_points_body(const Graph& g, const State& st, int bid, int nblocks, double* s_red) {
+  constexpr int LPP = kLanesPerPoint;
+  const int sub = threadIdx.x % LPP, ppb = blockDim.x / LPP;
   double chi_local = 0.0;
-  for (int p = g.pt_first + bid * blockDim.x + threadIdx.x; p < g.pt_last; p += nblocks * blockDim.x) {
+  for (int p = g.pt_first + bid * ppb + threadIdx.x / LPP; p < g.pt_last; p += nblocks * ppb) {
     const Vec3 X = v3(st.point[3 * p], st.point[3 * p + 1], st.point[3 * p + 2]);
-    for (int e = g.mo_off[p]; e < g.mo_off[p + 1]; ++e) {
+    for (int e = g.mo_off[p] + sub; e < g.mo_off[p + 1]; e += LPP) {
       const uint32_t fl = g.mono_flags[e];
       if (!(fl & F_ACTIVE)) continue;
       const MonoEdge ed = g.mono[e];
@@ -429,7 +442,7 @@ __device__ __forceinline__ void chi2_points_body(const Graph& g, const State& st
       huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
       chi_local += rho0;
     }
-    for (int e = g.st_off[p]; e < g.st_off[p + 1]; ++e) {
+    for (int e = g.st_off[p] + sub; e < g.st_off[p + 1]; e += LPP) {
       const uint32_t fl = g.stereo_flags[e];
       if (!(fl & F_ACTIVE)) continue;
       const StereoEdge ed = g.stereo[e];
@@ -1263,7 +1276,9 @@ __global__ __launch_bounds__(64) void k_update_reduced_all(Graph g, State cur, S
 // landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term.
 // Points evaluate W' x_p = Jl' w (Jp x_p) from their own edges (streamed landmark-major) instead of reading W back;
 // the few planes read their W blocks.
-template <bool USE_LDS>
+// LPP lanes share one landmark: they split its edges and meet in two shuffles (a point has ~5 edges and the whole graph only
+// 50k points: one thread per point leaves most of the chip idle and every thread walking its edges one after the other).
+template <bool USE_LDS, int LPP>
 __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial, double lambda) {
   extern __shared__ double smem[];
   __shared__ double s_red[4];
@@ -1275,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
     __syncthreads();
   }
   const int nl_pts = g.pt_last - g.pt_first;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) / LPP, sub = threadIdx.x % LPP;
   double sc = 0.0;
   if (k < nl_pts + (g.plane_last - g.plane_first)) {
     const int l = k < nl_pts ? g.pt_first + k : g.n_points + g.plane_first + (k - nl_pts);
@@ -1283,10 +1298,10 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
     double xl[3] = {0, 0, 0};
     if (!fixed) {
       const double b0 = g.bl[(size_t)l * 3], b1 = g.bl[(size_t)l * 3 + 1], b2 = g.bl[(size_t)l * 3 + 2];
-      double c0 = b0, c1 = b1, c2 = b2;
+      double c0 = 0, c1 = 0, c2 = 0;
       if (l < g.n_points) {
         const Vec3 X = v3(cur.point[3 * l], cur.point[3 * l + 1], cur.point[3 * l + 2]);
-        for (int e = g.mo_off[l]; e < g.mo_off[l + 1]; ++e) {
+        for (int e = g.mo_off[l] + sub; e < g.mo_off[l + 1]; e += LPP) {
           const uint32_t fl = g.mono_flags[e];
           if (!(fl & F_ACTIVE)) continue;
           const MonoEdge ed = g.mono[e];
@@ -1313,7 +1328,7 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
             c0 -= Jl[3 * r] * tr; c1 -= Jl[3 * r + 1] * tr; c2 -= Jl[3 * r + 2] * tr;
           }
         }
-        for (int e = g.st_off[l]; e < g.st_off[l + 1]; ++e) {
+        for (int e = g.st_off[l] + sub; e < g.st_off[l + 1]; e += LPP) {
           const uint32_t fl = g.stereo_flags[e];
           if (!(fl & F_ACTIVE)) continue;
           const StereoEdge ed = g.stereo[e];
@@ -1344,7 +1359,7 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
         }
       } else {
         const int j = l - g.n_points;
-        for (int q = g.pl_slot_off[j]; q < g.pl_slot_off[j + 1]; ++q) {
+        for (int q = g.pl_slot_off[j] + sub; q < g.pl_slot_off[j + 1]; q += LPP) {
           const int s = g.pl_slots[q];
           const double* w = &g.W[(size_t)s * 18];
           const double* x = &g.xr[g.slot_col[s]];
@@ -1353,13 +1368,19 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
           }
         }
       }
+#pragma unroll
+      for (int off = 1; off < LPP; off <<= 1) {
+        c0 += __shfl_xor(c0, off, 64); c1 += __shfl_xor(c1, off, 64); c2 += __shfl_xor(c2, off, 64);
+      }
+      c0 += b0; c1 += b1; c2 += b2;
       const double* I = &g.Dinv[(size_t)l * 6];
       xl[0] = I[0] * c0 + I[1] * c1 + I[2] * c2;
       xl[1] = I[1] * c0 + I[3] * c1 + I[4] * c2;
       xl[2] = I[2] * c0 + I[4] * c1 + I[5] * c2;
-      sc = xl[0] * (lambda * xl[0] + b0) + xl[1] * (lambda * xl[1] + b1) + xl[2] * (lambda * xl[2] + b2);
+      if (sub == 0) sc = xl[0] * (lambda * xl[0] + b0) + xl[1] * (lambda * xl[1] + b1) + xl[2] * (lambda * xl[2] + b2);
     }
-    if (l < g.n_points) {
+    if (sub != 0) {
+    } else if (l < g.n_points) {
       for (int a = 0; a < 3; ++a) trial.point[3 * l + a] = cur.point[3 * l + a] + xl[a];
     } else {
       const int j = l - g.n_points;

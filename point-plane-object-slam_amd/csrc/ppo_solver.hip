@@ -441,7 +441,7 @@ int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
   lp.nb_num = lp.num.nb_plane + lp.num.nb_bbox + lp.num.nb_corner + lp.num.nb_ptcub;
   const int npts = g.pt_last - g.pt_first;
   lp.nb_pose = (npts > 0 && s->posec.n_chunks > 0) ? nblk(s->posec.n_chunks, 4) : 0;
-  lp.nb_pts = npts > 0 ? std::min(nblk(npts, 256), 2 * s->n_cu) : 0;
+  lp.nb_pts = npts > 0 ? std::min(nblk(4L * npts, 256), 4 * s->n_cu) : 0;
   const int grid = lp.nb_num + lp.nb_pose + lp.nb_pts;
   if (grid > 0) {
     if (s->use_lds_lin) hipLaunchKernelGGL(k_linearize_all<true>, dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
@@ -462,7 +462,7 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
     np.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, 64) : 0;
   }
   const int nb_num = np.nb_plane + np.nb_bbox + np.nb_corner + np.nb_ptcub;
-  const int nb_pts = npts > 0 ? std::min(nblk(npts, 256), 4 * s->n_cu) : 0;
+  const int nb_pts = npts > 0 ? std::min(nblk((long)kLanesPerPoint * npts, 256), 4 * s->n_cu) : 0;
   if (nb_num + nb_pts > 0) hipLaunchKernelGGL(k_chi2_all, dim3(nb_num + nb_pts), dim3(256), 0, s->stream, g, st, np, nb_num, nb_pts);
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
@@ -523,8 +523,8 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   hipLaunchKernelGGL(k_update_reduced_all, dim3(g.n_cuboids + nblk(g.n_poses, 64)), dim3(64), 0, s->stream, g, cur, tr, lambda);
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
   if (nl > 0) {
-    if (s->use_lds) hipLaunchKernelGGL(k_backsub<true>, dim3(nblk(nl, 256)), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda);
-    else hipLaunchKernelGGL(k_backsub<false>, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
+    if (s->use_lds) hipLaunchKernelGGL((k_backsub<true, 4>), dim3(nblk(4L * nl, 256)), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda);
+    else hipLaunchKernelGGL((k_backsub<false, 4>), dim3(nblk(4L * nl, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
   }
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
@@ -1144,7 +1144,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   s->use_lds = s->lds_bytes <= 150 * 1024;
   if (s->use_lds && s->lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute((const void*)k_lin_points<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_backsub<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
+        hipFuncSetAttribute((const void*)k_backsub<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
   }
   s->use_lds_lin = s->use_lds && s->lds_bytes <= 40 * 1024;
   s->lin_lds_bytes = std::max({(int)(4 * 14 * 65 * sizeof(double)), (int)(kNumericLdsDoubles * sizeof(double)),
@@ -1381,8 +1381,8 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
         return true;
       case PPO_BA_KERNEL_LIN_POINTS:
         if (npts <= 0) return false;
-        if (s->use_lds) hipLaunchKernelGGL(k_lin_points<true>, dim3(std::min(nblk(npts, 256), 2 * s->n_cu)), dim3(256), s->lds_bytes, s->stream, g, st);
-        else hipLaunchKernelGGL(k_lin_points<false>, dim3(std::min(nblk(npts, 256), 2 * s->n_cu)), dim3(256), 0, s->stream, g, st);
+        if (s->use_lds) hipLaunchKernelGGL(k_lin_points<true>, dim3(std::min(nblk(4L * npts, 256), 4 * s->n_cu)), dim3(256), s->lds_bytes, s->stream, g, st);
+        else hipLaunchKernelGGL(k_lin_points<false>, dim3(std::min(nblk(4L * npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
         return true;
       case PPO_BA_KERNEL_SCHUR_Z:
         if (g.n_slots <= 0) return false;
@@ -1394,8 +1394,8 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
         return true;
       case PPO_BA_KERNEL_BACKSUB:
         if (nl <= 0) return false;
-        if (s->use_lds) hipLaunchKernelGGL(k_backsub<true>, dim3(nblk(nl, 256)), dim3(256), s->lds_bytes, s->stream, g, st, tr, s->lambda);
-        else hipLaunchKernelGGL(k_backsub<false>, dim3(nblk(nl, 256)), dim3(256), 0, s->stream, g, st, tr, s->lambda);
+        if (s->use_lds) hipLaunchKernelGGL((k_backsub<true, 4>), dim3(nblk(4L * nl, 256)), dim3(256), s->lds_bytes, s->stream, g, st, tr, s->lambda);
+        else hipLaunchKernelGGL((k_backsub<false, 4>), dim3(nblk(4L * nl, 256)), dim3(256), 0, s->stream, g, st, tr, s->lambda);
         return true;
       case PPO_BA_KERNEL_LINEARIZE_ALL: {
         const size_t zh = s->zero_head;
@@ -1404,7 +1404,7 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
       }
       case PPO_BA_KERNEL_CHI2_POINTS:
         if (npts <= 0) return false;
-        hipLaunchKernelGGL(k_chi2_points, dim3(std::min(nblk(npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
+        hipLaunchKernelGGL(k_chi2_points, dim3(std::min(nblk((long)kLanesPerPoint * npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
         return true;
       default: return false;
     }
