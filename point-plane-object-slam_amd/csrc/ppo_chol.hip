@@ -304,11 +304,13 @@ __device__ __forceinline__ void solve_rhs_row(double (*sB)[LP], int kk, const do
 // workgroup has to do -- the rest of the diagonal block's update, the update of its own block and the block substitution
 // -- is MFMA work cut into jobs of <= 32 MFMAs and run by waves 1..3 in the shadow of those factorisations:
 //                 wave 1                           wave 2                           wave 3
-//   potf2(0)  D(1,1) D(2,1)  U(0,0) U(0,1)     D(2,2) D(3,1)  U(0,2) U(0,3)     D(3,2) D(3,3)  U(1,0) U(1,1)
-//   potf2(1)  U(1,2) U(1,3)  S0(row 1)         S0(row 0)  U(2,0) U(2,1)         U(2,2) U(2,3)  R0
-//   potf2(2)  U(3,0) U(3,1)  S1(row 0)         U(3,2) U(3,3)  S0(row 2)         S1(row 1)  R1
-//   potf2(3)  S0(row 3) S1(row 3) S2(row 3)    S1(row 2) S2(row 2)              S2(row 0) S2(row 1)  R2
+//   potf2(0)  D(1,1) D(2,1)  U(0,0)            D(2,2) D(3,1)  U(0,1)            D(3,2) D(3,3)  U(0,2)
+//   potf2(1)  U(0,3) S0(row 0) U(1,0)          U(1,1) U(1,2) U(1,3)             U(2,0) U(2,1) U(2,2)  R0
+//   potf2(2)  U(2,3) S0(row 2) S1(row 0)       U(3,0) U(3,1) S0(row 1)          U(3,2) U(3,3)  R1
+//   potf2(3)  S0 S1 S2 (row 3)                 S1 S2 (row 1)  S1 S2 (row 2)     S2(row 0)  R2
 //   after     S3(row w) on wave w, R3 on wave 3
+// (at most 48 MFMAs per wave and phase: v_mfma_f64_16x16x4 issues every 64 cycles whatever the chaining, so 48 of them
+// plus their LDS traffic is what fits behind one ~2.1 us register factorisation)
 // D = panel update of a diagonal-block tile, U = of an own-block tile, Ss = substitution step s of an own-block row,
 // Rs = step s of the right-hand-side row.  (Before potf2(0) all four waves update block column 0 of the diagonal block.)
 // ------------------------------------------------------------------------------------------------------------------
@@ -418,40 +420,36 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
         if (wave == 2) tile_update2(sL, 2, 2, true, 3, 1, false, sQ, sQ);
         if (wave == 3) tile_update2(sL, 3, 2, false, 3, 3, true, sQ, sQ);
       }
-      if (uo) {
-        if (wave == 1) tile_update2(sB, 0, 0, false, 0, 1, false, sP, sQ);
-        if (wave == 2) tile_update2(sB, 0, 2, false, 0, 3, false, sP, sQ);
-        if (wave == 3) tile_update2(sB, 1, 0, false, 1, 1, false, sP, sQ);
-      }
+      if (uo) tile_update1(sB, 0, wave - 1, false, sP, sQ);
     } else if (kk == 1) {
       if (wave == 1) {
-        if (uo) tile_update2(sB, 1, 2, false, 1, 3, false, sP, sQ);
-        if (own) solve_rows<0>(sB, 1, sL, sT);
-      } else if (wave == 2) {
+        if (uo) tile_update1(sB, 0, 3, false, sP, sQ);
         if (own) solve_rows<0>(sB, 0, sL, sT);
-        if (uo) tile_update2(sB, 2, 0, false, 2, 1, false, sP, sQ);
+        if (uo) tile_update1(sB, 1, 0, false, sP, sQ);
+      } else if (wave == 2) {
+        if (uo) { tile_update2(sB, 1, 1, false, 1, 2, false, sP, sQ); tile_update1(sB, 1, 3, false, sP, sQ); }
       } else {
-        if (uo) tile_update2(sB, 2, 2, false, 2, 3, false, sP, sQ);
+        if (uo) { tile_update2(sB, 2, 0, false, 2, 1, false, sP, sQ); tile_update1(sB, 2, 2, false, sP, sQ); }
         solve_rhs_row(sB, 0, sL, sT);
       }
     } else if (kk == 2) {
       if (wave == 1) {
-        if (uo) tile_update2(sB, 3, 0, false, 3, 1, false, sP, sQ);
-        if (own) solve_rows<1>(sB, 0, sL, sT);
+        if (uo) tile_update1(sB, 2, 3, false, sP, sQ);
+        if (own) { solve_rows<0>(sB, 2, sL, sT); solve_rows<1>(sB, 0, sL, sT); }
       } else if (wave == 2) {
-        if (uo) tile_update2(sB, 3, 2, false, 3, 3, false, sP, sQ);
-        if (own) solve_rows<0>(sB, 2, sL, sT);
+        if (uo) tile_update2(sB, 3, 0, false, 3, 1, false, sP, sQ);
+        if (own) solve_rows<0>(sB, 1, sL, sT);
       } else {
-        if (own) solve_rows<1>(sB, 1, sL, sT);
+        if (uo) tile_update2(sB, 3, 2, false, 3, 3, false, sP, sQ);
         solve_rhs_row(sB, 1, sL, sT);
       }
     } else {
       if (wave == 1) {
         if (own) { solve_rows<0>(sB, 3, sL, sT); solve_rows<1>(sB, 3, sL, sT); solve_rows<2>(sB, 3, sL, sT); }
       } else if (wave == 2) {
-        if (own) { solve_rows<1>(sB, 2, sL, sT); solve_rows<2>(sB, 2, sL, sT); }
+        if (own) { solve_rows<1>(sB, 1, sL, sT); solve_rows<2>(sB, 1, sL, sT); solve_rows<1>(sB, 2, sL, sT); solve_rows<2>(sB, 2, sL, sT); }
       } else {
-        if (own) { solve_rows<2>(sB, 0, sL, sT); solve_rows<2>(sB, 1, sL, sT); }
+        if (own) solve_rows<2>(sB, 0, sL, sT);
         solve_rhs_row(sB, 2, sL, sT);
       }
     }

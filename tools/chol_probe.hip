@@ -77,6 +77,28 @@ __global__ void potf2_bench(double* out, long long* cyc) {
   out[threadIdx.x] = sum;
   if (threadIdx.x == 0) cyc[MODE] = t1 - t0;
 }
+
+// ---- FP64 MFMA issue rate: NACC independent accumulator chains, 256 instructions per chain, one wave ----------------------
+template <int NACC>
+__global__ void mfma_rate(double* out, long long* cyc) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  v4d acc[NACC];
+  for (int q = 0; q < NACC; ++q) acc[q] = {0.0, 0.0, 0.0, 0.0};
+  const double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 - threadIdx.x * 1e-3;
+  const long long t0 = clock64();
+#pragma unroll 1
+  for (int it = 0; it < 64; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+  }
+  const long long t1 = clock64();
+  double sum = 0;
+  for (int q = 0; q < NACC; ++q) sum += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+  out[threadIdx.x] = sum;
+  if (threadIdx.x == 0) cyc[NACC] = (t1 - t0) / (256 * NACC);
+}
 int main() {
   { double* o; hipMalloc((void**)&o, 32); hipMemset(o, 0, 32); hipLaunchKernelGGL(rsq_acc, dim3(64), dim3(256), 0, 0, o); double h[3]; hipMemcpy(h, o, 24, hipMemcpyDeviceToHost);
     printf("v_rsq_f64 max rel err: raw %.3e, 1 Newton %.3e, 2 Newton %.3e\n", h[0], h[1], h[2]); }
@@ -91,6 +113,15 @@ int main() {
     long long h[6]; hipMemcpy(h, c, 48, hipMemcpyDeviceToHost);
     printf("potf2_16 sweep looped in one kernel: pass 1 %lld, pass 2 %lld, pass 3 %lld ticks\n", h[3], h[4], h[5]);
     printf("potf2_16 register sweep (s_memtime ticks): full %lld, pivot chains only %lld, 240 DPP fmacs only %lld\n", h[0], h[1], h[2]);
+  }
+  {
+    double* o; long long* c; hipMalloc((void**)&o, 64 * 8); hipMalloc((void**)&c, 16 * 8);
+    hipLaunchKernelGGL(mfma_rate<1>, dim3(1), dim3(64), 0, 0, o, c);
+    hipLaunchKernelGGL(mfma_rate<2>, dim3(1), dim3(64), 0, 0, o, c);
+    hipLaunchKernelGGL(mfma_rate<4>, dim3(1), dim3(64), 0, 0, o, c);
+    hipLaunchKernelGGL(mfma_rate<8>, dim3(1), dim3(64), 0, 0, o, c);
+    long long h[16]; hipMemcpy(h, c, 128, hipMemcpyDeviceToHost);
+    printf("v_mfma_f64_16x16x4 cycles per instruction, one wave: 1 chain %lld, 2 chains %lld, 4 chains %lld, 8 chains %lld\n", h[1], h[2], h[4], h[8]);
   }
   const int n = 1664;
   std::vector<double> A((size_t)n * n, 0.0), b(n, 1.0);
