@@ -37,6 +37,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr unsigned long long kSentinel = 0xFFF8C0DEC0DE0001ull;  // "not written yet": a NaN payload no arithmetic produces
 constexpr int kSpinCap = 400000;
 
+#ifndef STAMP1
+#define STAMP1(i)  // same, taken by wave 1
+#endif
 #ifndef STAMP
 #define STAMP(i)  // tools/chol_probe.hip defines it to record wall-clock stamps
 #endif
@@ -58,19 +61,27 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ base, int l
   }
 }
 
+// All MFMA helpers below fetch EVERY LDS operand of a job (and the old values of the output tile) into registers before
+// the first MFMA: left to itself the compiler emitted ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs per k-step, i.e. one full
+// LDS round trip in front of every pair of matrix instructions, and a read-wait-subtract-write chain per output element.
+// Output tiles are written whole, with a select where only the lower triangle may change (no exec-mask branches).
+
 // C[16x16] (rows r0.., cols c0.. of M) -= X[16x16] * Y[16x16]^T where X = rows xr.. / Y = rows yr.. of columns [o, o+16)
 // in the padded LDS arrays MX / MY.  One wave, 4 MFMAs.  D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg.
 __device__ __forceinline__ void mfma_sub_16(double (*M)[LP], int r0, int c0, const double (*MX)[LP], int xr, const double (*MY)[LP], int yr, int o) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  double a[4], b[4], c[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    a[m] = MX[xr + li][o + 4 * m + lk];  // A[i = li][k = lk]
+    b[m] = MY[yr + li][o + 4 * m + lk];  // B[k = lk][j = li]
+    c[m] = M[r0 + lk + 4 * m][c0 + li];
+  }
   v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int m0 = 0; m0 < SB; m0 += 4) {
-    const double a = MX[xr + li][o + m0 + lk];  // A[i = li][k = lk]
-    const double b = MY[yr + li][o + m0 + lk];  // B[k = lk][j = li]
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
+  for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[m], acc, 0, 0, 0);
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) M[r0 + lk + 4 * reg][c0 + li] -= acc[reg];
+  for (int reg = 0; reg < 4; ++reg) M[r0 + lk + 4 * reg][c0 + li] = c[reg] - acc[reg];
 }
 
 // C[16x16] = X[16x16] * T[16x16] written to rows r0.., cols c0.. of M, where X = rows xr.., columns [xo, xo+16) of MX and
@@ -78,13 +89,15 @@ __device__ __forceinline__ void mfma_sub_16(double (*M)[LP], int r0, int c0, con
 // before it writes.  With T = L^-T this is the triangular solve X L^T = B.
 __device__ __forceinline__ void mfma_mul_16(double (*M)[LP], int r0, int c0, const double (*MX)[LP], int xr, int xo, const double (*T)[17]) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  double a[4], b[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    a[m] = MX[xr + li][xo + 4 * m + lk];  // A[i = li][k = lk]
+    b[m] = T[4 * m + lk][li];             // B[k = lk][j = li]
+  }
   v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int m0 = 0; m0 < SB; m0 += 4) {
-    const double a = MX[xr + li][xo + m0 + lk];  // A[i = li][k = lk]
-    const double b = T[m0 + lk][li];             // B[k = lk][j = li]
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
+  for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[m], acc, 0, 0, 0);
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) M[r0 + lk + 4 * reg][c0 + li] = acc[reg];
@@ -144,28 +157,34 @@ struct ColSweep {
 // right-multiplication by L^-T, so they end up as L^-T: sT[i][c] = (L^-T)[i][c] -- and groups 1..3 the rows of the 16x16
 // tiles below the block inside the 64x64 panel block, which come out as X = B L^-T (the triangular solve, for free).
 // Returns the 1-based local index of the first non-positive pivot, 0 if none.
-__device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], int o, bool store) {
+__device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], const double (*sId)[SB], int o, bool store) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int xrow = o + SB * g + r;  // extra row of groups 1..3
   const bool has_x = g > 0 && xrow < NB;
+  // Every lane reads its two rows through one base address each -- the extra row of group 0 comes from an identity block
+  // kept in LDS, a lane without a row reads a zero row -- and writes them back through one base address each, whole rows,
+  // in two predicated regions.  (Per-element selects and `if (c <= r)` stores made this part, not the sweep, the larger
+  // half of the routine: 1.0 us of loads + stores around a 1.0 us sweep.  The upper triangle of the diagonal block is
+  // written with whatever the sweep left there: nothing reads it.)
+  double* pa = &sL[o + r][o];
+  const double* pe = g == 0 ? &sId[r][0] : (has_x ? &sL[xrow][o] : &sId[SB][0]);
   double a[SB], e[SB];
 #pragma unroll
   for (int c = 0; c < SB; ++c) {
-    a[c] = sL[o + r][o + c];
-    e[c] = g == 0 ? (c == r ? 1.0 : 0.0) : (has_x ? sL[xrow][o + c] : 0.0);
+    a[c] = pa[c];
+    e[c] = pe[c];
   }
   int bad = 0;
   ColSweep<0>::run(a, e, bad);
   if (!store) return bad;
   if (g == 0) {
 #pragma unroll
-    for (int c = 0; c < SB; ++c) {
-      if (c <= r) sL[o + r][o + c] = a[c];
-      sT[r][c] = e[c];
-    }
-  } else if (has_x) {
+    for (int c = 0; c < SB; ++c) pa[c] = a[c];
+  }
+  if (g == 0 || has_x) {
+    double* qe = g == 0 ? &sT[r][0] : &sL[xrow][o];
 #pragma unroll
-    for (int c = 0; c < SB; ++c) sL[xrow][o + c] = e[c];
+    for (int c = 0; c < SB; ++c) qe[c] = e[c];
   }
   return bad;
 }
@@ -205,40 +224,56 @@ __device__ __forceinline__ void quadrant_product(const double (*sX)[UP], const d
 }
 
 // One wave, two 16x16 tiles at once: M[16 t.., 16 u..] -= X_t Y_u^T over the whole previous panel (K = 64), X / Y k-major
-// in LDS.  A chain of dependent FP64 MFMAs on ONE accumulator runs at roughly the instruction's latency (~90 cycles each
-// measured in situ), two interleaved chains hide most of it.  lo1/lo2: only the lower triangle of that tile is touched.
+// in LDS; 32 MFMAs (v_mfma_f64_16x16x4 issues every 64 cycles whatever the chaining).  lo1/lo2: only the lower triangle of
+// that tile may change.
 __device__ __forceinline__ void tile_update2(double (*M)[LP], int t1, int u1, bool lo1, int t2, int u2, bool lo2, const double (*sX)[UP],
                                              const double (*sY)[UP]) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  v4d acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+  double a1[16], b1[16], a2[16], b2[16], c1[4], c2[4];
 #pragma unroll
-  for (int m0 = 0; m0 < NB; m0 += 4) {
-    const double a1 = sX[m0 + lk][t1 * SB + li], b1 = sY[m0 + lk][u1 * SB + li];
-    const double a2 = sX[m0 + lk][t2 * SB + li], b2 = sY[m0 + lk][u2 * SB + li];
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2, 0, 0, 0);
+  for (int m = 0; m < 16; ++m) {
+    a1[m] = sX[4 * m + lk][t1 * SB + li];
+    b1[m] = sY[4 * m + lk][u1 * SB + li];
+    a2[m] = sX[4 * m + lk][t2 * SB + li];
+    b2[m] = sY[4 * m + lk][u2 * SB + li];
   }
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
-    const int r1 = t1 * SB + lk + 4 * reg, c1 = u1 * SB + li, r2 = t2 * SB + lk + 4 * reg, c2 = u2 * SB + li;
-    if (!lo1 || r1 >= c1) M[r1][c1] -= acc1[reg];
-    if (!lo2 || r2 >= c2) M[r2][c2] -= acc2[reg];
+    c1[reg] = M[t1 * SB + lk + 4 * reg][u1 * SB + li];
+    c2[reg] = M[t2 * SB + lk + 4 * reg][u2 * SB + li];
+  }
+  v4d acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[m], b1[m], acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[m], b2[m], acc2, 0, 0, 0);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int r1 = t1 * SB + lk + 4 * reg, q1 = u1 * SB + li, r2 = t2 * SB + lk + 4 * reg, q2 = u2 * SB + li;
+    M[r1][q1] = (!lo1 || r1 >= q1) ? c1[reg] - acc1[reg] : c1[reg];
+    M[r2][q2] = (!lo2 || r2 >= q2) ? c2[reg] - acc2[reg] : c2[reg];
   }
 }
 
-// One tile with the K range split over two accumulators (used where a wave has a single tile to do).
+// One tile (16 MFMAs), used where a wave has a single tile to do.
 __device__ __forceinline__ void tile_update1(double (*M)[LP], int t, int u, bool lo, const double (*sX)[UP], const double (*sY)[UP]) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  v4d acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+  double a[16], b[16], c[4];
 #pragma unroll
-  for (int m0 = 0; m0 < NB; m0 += 8) {
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[m0 + lk][t * SB + li], sY[m0 + lk][u * SB + li], acc1, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[m0 + 4 + lk][t * SB + li], sY[m0 + 4 + lk][u * SB + li], acc2, 0, 0, 0);
+  for (int m = 0; m < 16; ++m) {
+    a[m] = sX[4 * m + lk][t * SB + li];
+    b[m] = sY[4 * m + lk][u * SB + li];
   }
 #pragma unroll
+  for (int reg = 0; reg < 4; ++reg) c[reg] = M[t * SB + lk + 4 * reg][u * SB + li];
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[m], acc, 0, 0, 0);
+#pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
-    const int r = t * SB + lk + 4 * reg, c = u * SB + li;
-    if (!lo || r >= c) M[r][c] -= acc1[reg] + acc2[reg];
+    const int r = t * SB + lk + 4 * reg, q = u * SB + li;
+    M[r][q] = (!lo || r >= q) ? c[reg] - acc[reg] : c[reg];
   }
 }
 
@@ -249,26 +284,36 @@ __device__ __forceinline__ void wave_lds_fence() {  // make this wave's LDS writ
 }
 
 // Block substitution step KK for the 16 rows rt of B (X = B L^-T): tile (rt, KK) <- tile * L_KK^-T, then the tiles to its
-// right take their update (independent accumulators, interleaved).  One wave.
+// right take their update.  One wave; the halves meet through LDS, hence the wave-level fences.
 template <int KK>
 __device__ __forceinline__ void solve_rows(double (*sB)[LP], int rt, const double (*sL)[LP], const double (*sT)[SB][17]) {
   constexpr int o = KK * SB, NR = NB / SB - 1 - KK;
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   wave_lds_fence();
+  // operands that do not depend on the multiplication: L tiles below the diagonal block and the old values of the targets
+  double lb[NR > 0 ? NR : 1][4], cold[NR > 0 ? NR : 1][4];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      lb[q][m] = sL[(KK + 1 + q) * SB + li][o + 4 * m + lk];
+      cold[q][m] = sB[rt * SB + lk + 4 * m][(KK + 1 + q) * SB + li];
+    }
   mfma_mul_16(sB, rt * SB, o, sB, rt * SB, o, sT[KK]);
   wave_lds_fence();
   if constexpr (NR > 0) {
+    double a[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = sB[rt * SB + li][o + 4 * m + lk];
     v4d acc[NR] = {};
 #pragma unroll
-    for (int m0 = 0; m0 < SB; m0 += 4) {
-      const double a = sB[rt * SB + li][o + m0 + lk];
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int q = 0; q < NR; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sL[(KK + 1 + q) * SB + li][o + m0 + lk], acc[q], 0, 0, 0);
-    }
+      for (int q = 0; q < NR; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], lb[q][m], acc[q], 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < NR; ++q)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) sB[rt * SB + lk + 4 * reg][(KK + 1 + q) * SB + li] -= acc[q][reg];
+      for (int reg = 0; reg < 4; ++reg) sB[rt * SB + lk + 4 * reg][(KK + 1 + q) * SB + li] = cold[q][reg] - acc[q][reg];
   }
 }
 
@@ -321,6 +366,7 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
   __shared__ __attribute__((aligned(16))) double sP[NB][UP];  // [m][row of block i] of the previous panel
   __shared__ __attribute__((aligned(16))) double sQ[NB][UP];  // [m][row of block j]
   __shared__ int sBad;
+  __shared__ double sId[SB + 1][SB];  // identity rows + one zero row: the "extra rows" of lanes that carry none
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int m = (ld - k0) / NB;
   const int kp = k0 - NB;  // previous panel's column
@@ -400,6 +446,7 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
     }
     if (tid < NB) sB[NB][tid] = rv;
     if (tid == 0) sBad = 0;
+    for (int i = tid; i < (SB + 1) * SB; i += 256) sId[i / SB][i % SB] = (i / SB == i % SB) ? 1.0 : 0.0;
   }
   __syncthreads();
   STAMP(5);
@@ -411,8 +458,9 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
 #pragma unroll
   for (int kk = 0; kk < NB / SB; ++kk) {
     const int o = kk * SB;
+    STAMP1(24 + kk);
     if (wave == 0) {  // diagonal 16x16 block + the sub-diagonal tiles of this block column
-      const int bad = potf2_16(sL, sT[kk], o, true);
+      const int bad = potf2_16(sL, sT[kk], sId, o, true);
       if (lane == 0 && bad && sBad == 0) sBad = o + bad;
     } else if (kk == 0) {
       if (upd) {
@@ -453,6 +501,7 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
         solve_rhs_row(sB, 2, sL, sT);
       }
     }
+    STAMP1(28 + kk);
     __syncthreads();
     STAMP(8 + 2 * kk);
     if (kk == NB / SB - 1) break;

@@ -6,8 +6,9 @@
 #include <vector>
 #include <cmath>
 #define PPO_CHOL_STAMPS 1
-__device__ long long g_stamps[40];
+__device__ long long g_stamps[48];
 #define STAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#define STAMP1(i) do { if (blockIdx.x == 1 && threadIdx.x == 64) g_stamps[i] = wall_clock64(); } while (0)
 #include "../point-plane-object-slam_amd/csrc/ppo_chol.hip"
 
 __global__ void rsq_acc(double* out) {
@@ -160,7 +161,7 @@ int main() {
   hipLaunchKernelGGL(ppo::chol_step, dim3(n / 64), dim3(256), 0, s, dA, n, 0, db, dws, dx, dinfo);
   { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(m + m * (m - 1) / 2), dim3(256), 0, s, dA, n, 64, db, dws, dx, dinfo); }
   hipStreamSynchronize(s);
-  long long st[40];
+  long long st[48];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
   printf("  loads issued        +%.2f us\n", (st[6] - st[0]) * 0.01);
   printf("  tiles in LDS        +%.2f us\n", (st[5] - st[6]) * 0.01);
@@ -169,6 +170,8 @@ int main() {
   printf("  last solve step     +%.2f us\n", (st[3] - st[2]) * 0.01);
   printf("  stored              +%.2f us\n", (st[4] - st[3]) * 0.01);
   for (int i = 8; i < 15; ++i) printf("  factor stamp %d: +%.2f us\n", i, (st[i] - (i == 8 ? st[1] : st[i - 1])) * 0.01);
+  for (int kk = 0; kk < 4; ++kk) printf("  wave 1 side jobs of phase %d: %.2f us\n", kk, (st[28 + kk] - st[24 + kk]) * 0.01);
+  if (0) printf("  potf2(kk=1): LDS loads %.2f us, sweep %.2f, stores %.2f, then to the barrier stamp %.2f\n", (st[40] - st[9]) * 0.01, (st[41] - st[40]) * 0.01, (st[42] - st[41]) * 0.01, (st[10] - st[42]) * 0.01);
   // backward pipeline: block 1's view (stamps 22..29 = moment x_i was seen, i = 2..9)
   hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
   ppo::chol_factor_solve(dA, n, db, dx, dinfo, dws, s);
