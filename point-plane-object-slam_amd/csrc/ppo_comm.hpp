@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace ppo {
@@ -29,6 +30,7 @@ struct Comm {
   fn_allreduce allreduce = nullptr;
   fn_destroy comm_destroy = nullptr;
   int rank = 0, world = 1;
+  bool forced = false;  // PPO_BA_COMM_SELFTEST: a one-rank communicator, so that the whole N > 1 code path runs on a single GPU
 
   bool load() {
     if (lib) return true;
@@ -54,24 +56,34 @@ struct Comm {
   int init(const uint8_t id_bytes[128], int rank_, int world_) {
     rank = rank_;
     world = world_;
-    if (world <= 1) return 0;
+    forced = false;
+    if (world <= 1) {
+      const char* e = getenv("PPO_BA_COMM_SELFTEST");
+      if (!(e && e[0] == '1')) return 0;
+      if (!load()) return -1;
+      UniqueId self;
+      if (get_id(&self) != 0 || init_rank(&comm, 1, self, 0) != 0) return -1;
+      forced = true;
+      return 0;
+    }
     if (!load()) return -1;
     UniqueId id;
     std::memcpy(id.internal, id_bytes, 128);
     return init_rank(&comm, world, id, rank) == 0 ? 0 : -1;
   }
-  bool active() const { return world > 1; }
+  bool active() const { return world > 1 || forced; }
   int sum(double* buf, size_t n, hipStream_t s) {
-    if (world <= 1 || n == 0) return 0;
+    if (!active() || n == 0) return 0;
     return allreduce(buf, buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, s) == 0 ? 0 : -1;
   }
   int max(double* buf, size_t n, hipStream_t s) {
-    if (world <= 1 || n == 0) return 0;
+    if (!active() || n == 0) return 0;
     return allreduce(buf, buf, n, 8, /*ncclMax*/ 2, comm, s) == 0 ? 0 : -1;
   }
   void destroy() {
     if (comm && comm_destroy) comm_destroy(comm);
     comm = nullptr;
+    forced = false;
   }
 };
 

@@ -302,3 +302,23 @@ def test_kernel_timing_hook_reports_every_kernel(hip):
         assert ms.value > 0 and by.value > 0, which
     assert hip.lib.ppo_ba_time_kernel(s.h, 99, 3, C.byref(ms), C.byref(by)) != 0
     s.close()
+
+
+def test_sharded_code_path_with_a_one_rank_rccl_communicator(hip, monkeypatch):
+    """PPO_BA_COMM_SELFTEST=1 makes the library open librccl.so, build a ONE-rank communicator and take every branch of the
+    N > 1 path (all-reduce of the pose blocks after each linearisation, of (S, b) per solve attempt, of the chi2 / scale /
+    max-diagonal scalars, the landmark gather in read) on a single GPU.  Multi-GPU boxes are not available to these tests;
+    the arithmetic of the sharding itself is covered by tests/test_sharding_gloo.py."""
+    P = synth.make_problem("small", seed=1)
+    s = hip.create(P, B.default_options())
+    ref_stats, ref = s.run(), s.read()
+    s.close()
+    monkeypatch.setenv("PPO_BA_COMM_SELFTEST", "1")
+    s = hip.create(P, B.default_options())
+    st, r = s.run(), s.read()
+    s.close()
+    assert [(i["trials"], i["accepted"]) for i in st["iters"]] == [(i["trials"], i["accepted"]) for i in ref_stats["iters"]]
+    assert abs(st["iters"][-1]["chi2_after"] - ref_stats["iters"][-1]["chi2_after"]) <= 1e-7 * ref_stats["iters"][-1]["chi2_after"]
+    np.testing.assert_allclose(r.pose_qt, ref.pose_qt, atol=2e-6)
+    np.testing.assert_allclose(r.point_xyz, ref.point_xyz, atol=1e-5)
+    np.testing.assert_allclose(r.plane_coef, ref.plane_coef, atol=1e-6)
