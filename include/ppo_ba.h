@@ -280,6 +280,14 @@ int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
 int ppo_ba_debug_set_lambda(ppo_ba_handle h, double lambda);
 int ppo_ba_debug_reduced(ppo_ba_handle h, double* S, double* b, double* x, int32_t* n);
 
+/* Graph dump / replay (host only, no device needed).  ppo_ba_problem_save() writes every array of the
+ * problem to one binary file (layout in csrc/ppo_io.cpp); ppo_ba_problem_load() returns a problem that owns its arrays and
+ * must be released with ppo_ba_problem_free().  A maintainer of the reference calls save() next to ppo_ba_create() to
+ * capture real local-BA windows; tools/replay.py runs a capture through the solver (and, where built, the oracle). */
+int ppo_ba_problem_save(const ppo_ba_problem* problem, const char* path);
+int ppo_ba_problem_load(const char* path, ppo_ba_problem** problem);
+void ppo_ba_problem_free(ppo_ba_problem* problem);
+
 /* ppo_ba_destroy() keeps device blocks, streams and the mapped host block of the solver in a process-wide cache so that
  * the next ppo_ba_create() -- one per local-BA call in the reference -- does not pay for ~60 allocations again (capped at
  * 4 GiB).  This call returns everything cached to the driver; live solvers are not affected. */

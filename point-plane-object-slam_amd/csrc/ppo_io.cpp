@@ -1,0 +1,181 @@
+// ppo_io.cpp -- graph dump / replay: one binary file per local-BA call holding the arrays of
+// ppo_ba_problem, so that windows captured on a machine that runs the reference (one ppo_ba_problem_save() next to the
+// flattening of INTEGRATION.md) can be replayed on a GPU box.  g2o's own .g2o text format cannot carry these graphs: the
+// cuboid vertex read/write are stubs in the reference (include/g2o_cuboid.h:280-281).  Host-only, no device work.
+//
+// File layout (little endian): "PPOBA001", uint32 n_records, then per record
+//   uint32 name_len, name bytes, uint32 dtype (0 = f64, 1 = i32, 2 = u8), uint64 count, count * sizeof(dtype) bytes.
+// Scalars (the n_* counts) are i32 records of count 1.  Optional arrays that are NULL are simply absent.  Unknown record
+// names are skipped by the loader, so fields can be added later.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ppo_ba.h"
+
+namespace {
+
+enum { T_F64 = 0, T_I32 = 1, T_U8 = 2 };
+const size_t kElem[3] = {8, 4, 1};
+
+struct Field {
+  const char* name;
+  int dtype;
+  size_t ptr_off;    // offset of the pointer member
+  size_t count_off;  // offset of the int32 count member
+  int width;         // elements per unit
+  bool special;      // ptcub_offsets (count + 1) / ptcub_points (3 * offsets[n])
+};
+#define PF(name, dtype, count, width) {#name, dtype, offsetof(ppo_ba_problem, name), offsetof(ppo_ba_problem, count), width, false}
+const Field kFields[] = {
+    PF(pose_qt, T_F64, n_poses, 7), PF(pose_fixed, T_U8, n_poses, 1), PF(pose_cam, T_F64, n_poses, 5),
+    PF(point_xyz, T_F64, n_points, 3), PF(point_fixed, T_U8, n_points, 1),
+    PF(plane_coef, T_F64, n_planes, 4),
+    PF(cuboid_qt, T_F64, n_cuboids, 7), PF(cuboid_scale, T_F64, n_cuboids, 3), PF(cuboid_flags, T_U8, n_cuboids, 1), PF(cuboid_fixedscale, T_F64, n_cuboids, 3),
+    PF(mono_point, T_I32, n_mono, 1), PF(mono_pose, T_I32, n_mono, 1), PF(mono_obs, T_F64, n_mono, 2), PF(mono_info, T_F64, n_mono, 1), PF(mono_huber, T_F64, n_mono, 1),
+    PF(stereo_point, T_I32, n_stereo, 1), PF(stereo_pose, T_I32, n_stereo, 1), PF(stereo_obs, T_F64, n_stereo, 3), PF(stereo_info, T_F64, n_stereo, 1),
+    PF(stereo_huber, T_F64, n_stereo, 1),
+    PF(pl_plane, T_I32, n_plane_edges, 1), PF(pl_pose, T_I32, n_plane_edges, 1), PF(pl_kind, T_U8, n_plane_edges, 1), PF(pl_meas, T_F64, n_plane_edges, 4),
+    PF(pl_info, T_F64, n_plane_edges, 3), PF(pl_huber, T_F64, n_plane_edges, 1),
+    PF(bbox_pose, T_I32, n_bbox, 1), PF(bbox_cuboid, T_I32, n_bbox, 1), PF(bbox_meas, T_F64, n_bbox, 4), PF(bbox_info, T_F64, n_bbox, 4), PF(bbox_huber, T_F64, n_bbox, 1),
+    PF(bbox_K, T_F64, n_bbox, 9),
+    PF(corner_pose, T_I32, n_corner, 1), PF(corner_cuboid, T_I32, n_corner, 1), PF(corner_meas, T_F64, n_corner, 16), PF(corner_info, T_F64, n_corner, 16),
+    PF(corner_huber, T_F64, n_corner, 1), PF(corner_K, T_F64, n_corner, 9),
+    PF(ptcub_cuboid, T_I32, n_ptcub, 1),
+    {"ptcub_offsets", T_I32, offsetof(ppo_ba_problem, ptcub_offsets), offsetof(ppo_ba_problem, n_ptcub), 1, true},
+    {"ptcub_points", T_F64, offsetof(ppo_ba_problem, ptcub_points), offsetof(ppo_ba_problem, n_ptcub), 3, true},
+    PF(ptcub_margin_ratio, T_F64, n_ptcub, 1), PF(ptcub_prior_half, T_F64, n_ptcub, 3), PF(ptcub_info, T_F64, n_ptcub, 3), PF(ptcub_huber, T_F64, n_ptcub, 1),
+    PF(cubpl_cuboid, T_I32, n_cubpl, 1), PF(cubpl_plane, T_I32, n_cubpl, 1), PF(cubpl_meas, T_F64, n_cubpl, 3), PF(cubpl_info, T_F64, n_cubpl, 3),
+    PF(cubpl_huber, T_F64, n_cubpl, 1),
+};
+struct Count {
+  const char* name;
+  size_t off;
+};
+#define PC(name) {#name, offsetof(ppo_ba_problem, name)}
+const Count kCounts[] = {PC(n_poses), PC(n_points), PC(n_planes), PC(n_cuboids), PC(n_mono), PC(n_stereo), PC(n_plane_edges),
+                         PC(n_bbox), PC(n_corner), PC(n_ptcub), PC(n_cubpl)};
+
+int32_t count_of(const ppo_ba_problem* p, size_t off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p) + off); }
+const void* ptr_of(const ppo_ba_problem* p, size_t off) { return *reinterpret_cast<const void* const*>(reinterpret_cast<const char*>(p) + off); }
+
+size_t field_count(const ppo_ba_problem* p, const Field& f) {
+  const int32_t n = count_of(p, f.count_off);
+  if (!f.special) return (size_t)n * f.width;
+  if (std::strcmp(f.name, "ptcub_offsets") == 0) return (size_t)n + 1;
+  return (n > 0 && p->ptcub_offsets) ? (size_t)3 * p->ptcub_offsets[n] : 0;  // ptcub_points
+}
+
+bool put(FILE* f, const void* p, size_t n) { return n == 0 || std::fwrite(p, 1, n, f) == n; }
+bool put_record(FILE* f, const char* name, uint32_t dtype, uint64_t count, const void* data) {
+  const uint32_t len = (uint32_t)std::strlen(name);
+  return put(f, &len, 4) && put(f, name, len) && put(f, &dtype, 4) && put(f, &count, 8) && put(f, data, (size_t)count * kElem[dtype]);
+}
+
+// a loaded problem owns its arrays: the struct is followed in memory by the list of blocks to free
+struct Loaded {
+  ppo_ba_problem p;
+  std::vector<void*> blocks;
+};
+
+}  // namespace
+
+extern "C" {
+
+int ppo_ba_problem_save(const ppo_ba_problem* p, const char* path) {
+  if (!p || !path) return PPO_BA_ERR_ARG;
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return PPO_BA_ERR_ARG;
+  uint32_t n_rec = (uint32_t)(sizeof(kCounts) / sizeof(kCounts[0]));
+  for (const Field& fd : kFields)
+    if (ptr_of(p, fd.ptr_off) && field_count(p, fd) > 0) ++n_rec;
+  bool ok = put(f, "PPOBA001", 8) && put(f, &n_rec, 4);
+  for (const Count& c : kCounts) {
+    const int32_t v = count_of(p, c.off);
+    ok = ok && put_record(f, c.name, T_I32, 1, &v);
+  }
+  for (const Field& fd : kFields) {
+    const void* q = ptr_of(p, fd.ptr_off);
+    const size_t n = field_count(p, fd);
+    if (q && n > 0) ok = ok && put_record(f, fd.name, (uint32_t)fd.dtype, n, q);
+  }
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? PPO_BA_OK : PPO_BA_ERR_ARG;
+}
+
+int ppo_ba_problem_load(const char* path, ppo_ba_problem** out) {
+  if (!path || !out) return PPO_BA_ERR_ARG;
+  *out = nullptr;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return PPO_BA_ERR_ARG;
+  Loaded* L = new Loaded();
+  std::memset(&L->p, 0, sizeof(L->p));
+  auto fail = [&](int code) {
+    std::fclose(f);
+    for (void* b : L->blocks) std::free(b);
+    delete L;
+    return code;
+  };
+  std::vector<std::pair<std::string, uint64_t>> loaded_counts;
+  char magic[8];
+  uint32_t n_rec = 0;
+  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "PPOBA001", 8) != 0 || std::fread(&n_rec, 4, 1, f) != 1) return fail(PPO_BA_ERR_ARG);
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    uint32_t len = 0, dtype = 0;
+    uint64_t count = 0;
+    if (std::fread(&len, 4, 1, f) != 1 || len > 256) return fail(PPO_BA_ERR_ARG);
+    std::string name(len, '\0');
+    if (len && std::fread(&name[0], 1, len, f) != len) return fail(PPO_BA_ERR_ARG);
+    if (std::fread(&dtype, 4, 1, f) != 1 || dtype > 2 || std::fread(&count, 8, 1, f) != 1 || count > (1ull << 33)) return fail(PPO_BA_ERR_ARG);
+    const size_t bytes = (size_t)count * kElem[dtype];
+    void* block = std::malloc(bytes ? bytes : 1);
+    if (!block) return fail(PPO_BA_ERR_NOMEM);
+    L->blocks.push_back(block);
+    if (bytes && std::fread(block, 1, bytes, f) != bytes) return fail(PPO_BA_ERR_ARG);
+    bool used = false;
+    loaded_counts.emplace_back(name, count);
+    for (const Count& c : kCounts)
+      if (name == c.name && dtype == T_I32 && count == 1) {
+        *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(&L->p) + c.off) = *static_cast<int32_t*>(block);
+        used = true;
+      }
+    for (const Field& fd : kFields)
+      if (name == fd.name && (int)dtype == fd.dtype) {
+        *reinterpret_cast<const void**>(reinterpret_cast<char*>(&L->p) + fd.ptr_off) = block;
+        used = true;
+      }
+    (void)used;  // unknown records are kept allocated and ignored
+  }
+  std::fclose(f);
+  // consistency: every present array must have exactly the length its count implies (a truncated or foreign file must not
+  // turn into out-of-bounds reads inside ppo_ba_create)
+  for (const Count& c : kCounts)
+    if (count_of(&L->p, c.off) < 0) { f = std::fopen(path, "rb"); return fail(PPO_BA_ERR_ARG); }
+  for (const Field& fd : kFields) {
+    if (!ptr_of(&L->p, fd.ptr_off)) continue;
+    uint64_t have = 0;
+    for (const auto& lc : loaded_counts)
+      if (lc.first == fd.name) have = lc.second;
+    if (have != field_count(&L->p, fd)) { f = std::fopen(path, "rb"); return fail(PPO_BA_ERR_ARG); }
+  }
+  if (L->p.n_ptcub == 0 && !L->p.ptcub_offsets) {  // the ABI wants a valid offsets array even when it is empty
+    int32_t* z = static_cast<int32_t*>(std::calloc(1, sizeof(int32_t)));
+    if (!z) return PPO_BA_ERR_NOMEM;
+    L->blocks.push_back(z);
+    L->p.ptcub_offsets = z;
+  }
+  *out = &L->p;
+  return PPO_BA_OK;
+}
+
+void ppo_ba_problem_free(ppo_ba_problem* p) {
+  if (!p) return;
+  Loaded* L = reinterpret_cast<Loaded*>(p);  // p is the first member
+  for (void* b : L->blocks) std::free(b);
+  delete L;
+}
+
+}  // extern "C"

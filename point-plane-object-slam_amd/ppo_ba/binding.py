@@ -165,6 +165,47 @@ class Problem:
         st = self.as_struct()
         return {n: getattr(st, n) for n, t in _PROBLEM_FIELDS if t is C.c_int32}
 
+    # ---- graph dump / replay (ppo_ba_problem_save / _load of the product library, host only) -----------------------------------
+    def save(self, path):
+        lib = load_library()
+        lib.ppo_ba_problem_save.argtypes = [C.POINTER(CProblem), C.c_char_p]
+        st = self.as_struct()
+        rc = lib.ppo_ba_problem_save(C.byref(st), str(path).encode())
+        if rc != 0:
+            raise IOError("ppo_ba_problem_save(%s) failed: %d" % (path, rc))
+
+    @classmethod
+    def load(cls, path):
+        lib = load_library()
+        lib.ppo_ba_problem_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(CProblem))]
+        lib.ppo_ba_problem_free.argtypes = [C.POINTER(CProblem)]
+        lib.ppo_ba_problem_free.restype = None
+        pp = C.POINTER(CProblem)()
+        rc = lib.ppo_ba_problem_load(str(path).encode(), C.byref(pp))
+        if rc != 0:
+            raise IOError("ppo_ba_problem_load(%s) failed: %d" % (path, rc))
+        try:
+            st = pp.contents
+            counts = {n: getattr(st, n) for n, t in _PROBLEM_FIELDS if t is C.c_int32}
+            P = cls()
+            for name, ftype in _PROBLEM_FIELDS:
+                if ftype is C.c_int32:
+                    continue
+                ptr = getattr(st, name)
+                if not ptr:
+                    continue
+                if name == "ptcub_offsets":
+                    n = counts["n_ptcub"] + 1
+                elif name == "ptcub_points":
+                    n = 3 * st.ptcub_offsets[counts["n_ptcub"]] if counts["n_ptcub"] > 0 else 0
+                else:
+                    cf, w = _WIDTH[name]
+                    n = counts[cf] * w
+                P.set(name, np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n > 0 else np.zeros(0, dtype=_DTYPES[ftype]))
+            return P
+        finally:
+            lib.ppo_ba_problem_free(pp)
+
 
 class Result:
     def __init__(self, sizes):
