@@ -1169,6 +1169,7 @@ struct ReducePlan {
 };
 __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp) {
   int b = blockIdx.x;
+  if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
   if (b < rp.nb_asm) { assemble_body(g, lambda, b); return; }
   b -= rp.nb_asm;
   if (b < rp.nb_prep) { schur_prep_body(g, lambda, b); return; }
@@ -1194,12 +1195,13 @@ __global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
 
 // Poses and cuboids in ONE launch of 64-thread workgroups: workgroup c < n_cuboids back-substitutes cuboid c (when the cuboids
 // were eliminated) and applies its update, the remaining workgroups update 64 poses each.
-__global__ __launch_bounds__(64) void k_update_reduced_all(Graph g, State cur, State trial, double lambda) {
-  __shared__ double sp[54], st[9], sy[9], sx[9];
+// (body: any workgroup size >= 64; workgroup vb < n_cuboids handles cuboid vb with its first 64 threads)
+__device__ __forceinline__ void update_reduced_body(const Graph& g, const State& cur, const State& trial, double lambda, int vb, double* sp, double* st,
+                                                    double* sy, double* sx) {
   const int lane = threadIdx.x;
   double sc = 0.0;
-  if ((int)blockIdx.x < g.n_cuboids) {
-    const int c = blockIdx.x;
+  if (vb < g.n_cuboids) {
+    const int c = vb;
     const int col = g.cub_col[c];
     if (col >= 0 && g.elim_cub) {
       const int a = lane / 9;
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(64) void k_update_reduced_all(Graph g, State cur, S
       o[7] = cb.s.x; o[8] = cb.s.y; o[9] = cb.s.z;
     }
   } else {
-    const int i = ((int)blockIdx.x - g.n_cuboids) * 64 + lane;
+    const int i = (vb - g.n_cuboids) * (int)blockDim.x + lane;
     if (i < g.n_poses) {
       const int col = g.pose_col[i];
       Pose T = load_pose(&cur.pose_qt[7 * i]);
@@ -1270,7 +1272,11 @@ __global__ __launch_bounds__(64) void k_update_reduced_all(Graph g, State cur, S
     }
   }
   sc = wave_sum(sc);
-  if (lane == 0 && sc != 0.0) atomicAdd(&g.acc[ACC_SCALE], sc);
+  if ((lane & 63) == 0 && sc != 0.0) atomicAdd(&g.acc[ACC_SCALE], sc);
+}
+__global__ __launch_bounds__(64) void k_update_reduced_all(Graph g, State cur, State trial, double lambda) {
+  __shared__ double sp[54], st[9], sy[9], sx[9];
+  update_reduced_body(g, cur, trial, lambda, blockIdx.x, sp, st, sy, sx);
 }
 
 // landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term.
@@ -1279,9 +1285,7 @@ __global__ __launch_bounds__(64) void k_update_reduced_all(Graph g, State cur, S
 // LPP lanes share one landmark: they split its edges and meet in two shuffles (a point has ~5 edges and the whole graph only
 // 50k points: one thread per point leaves most of the chip idle and every thread walking its edges one after the other).
 template <bool USE_LDS, int LPP>
-__global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial, double lambda) {
-  extern __shared__ double smem[];
-  __shared__ double s_red[4];
+__device__ __forceinline__ void backsub_body(const Graph& g, const State& cur, const State& trial, double lambda, int vb, double* smem, double* s_red) {
   if (USE_LDS) {  // camera table: R, t, intrinsics of every keyframe
     for (int i = threadIdx.x; i < g.n_poses * 16; i += blockDim.x) {
       const int p = i >> 4, q = i & 15;
@@ -1290,7 +1294,7 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
     __syncthreads();
   }
   const int nl_pts = g.pt_last - g.pt_first;
-  const int k = (blockIdx.x * blockDim.x + threadIdx.x) / LPP, sub = threadIdx.x % LPP;
+  const int k = (vb * blockDim.x + threadIdx.x) / LPP, sub = threadIdx.x % LPP;
   double sc = 0.0;
   if (k < nl_pts + (g.plane_last - g.plane_first)) {
     const int l = k < nl_pts ? g.pt_first + k : g.n_points + g.plane_first + (k - nl_pts);
@@ -1389,6 +1393,46 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
     }
   }
   block_atomic_add(sc, &g.acc[ACC_SCALE], s_red);
+}
+template <bool USE_LDS, int LPP>
+__global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial, double lambda) {
+  extern __shared__ double smem[];
+  __shared__ double s_red[4];
+  backsub_body<USE_LDS, LPP>(g, cur, trial, lambda, blockIdx.x, smem, s_red);
+}
+
+// The whole update of a trial in ONE launch (horizontal fusion; none of the parts reads another's output): cuboid
+// back-substitution + update | pose updates | landmark back-substitution + update | and, since the factor in S is dead once
+// the backward substitution has run, the zeroing of S (lower-triangle 64x64 tiles) and b for the NEXT reduction.
+struct UpdatePlan {
+  int nb_red, nb_lm, nb_zero;  // workgroups of the reduced part (cuboids + poses), landmarks, S tiles
+  double* S;
+  double* bs;
+  int ld;
+};
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_update_all(Graph g, State cur, State trial, double lambda, UpdatePlan up) {
+  extern __shared__ double smem[];
+  __shared__ double s_red[4];
+  __shared__ double sp[54], st[9], sy[9], sx[9];
+  int b = blockIdx.x;
+  if (b < up.nb_red) { update_reduced_body(g, cur, trial, lambda, b, sp, st, sy, sx); return; }
+  b -= up.nb_red;
+  if (b < up.nb_lm) { backsub_body<USE_LDS, 4>(g, cur, trial, lambda, b, smem, s_red); return; }
+  b -= up.nb_lm;
+  // zero one 64x64 tile of the lower triangle of S (tile index b -> (bi >= bj)); the last workgroup also clears b
+  int bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+  const int bj = b - bi * (bi + 1) / 2;
+  if (bi * 64 < up.ld) {
+    double2* base = reinterpret_cast<double2*>(&up.S[(size_t)(bj * 64) * up.ld + bi * 64]);
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+      const int c = i >> 5, r2 = i & 31;
+      base[(size_t)c * (up.ld / 2) + r2] = make_double2(0.0, 0.0);
+    }
+  }
+  if (b == up.nb_zero - 1)
+    for (int i = threadIdx.x; i < up.ld; i += 256) up.bs[i] = 0.0;
 }
 
 __global__ void k_pose_rt(State st, int n_poses) {  // derive rotation matrices after an upload

@@ -197,6 +197,7 @@ struct ppo_ba_solver {
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;        // the small numerically differentiated edge classes run here, next to the point kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_acc = nullptr;
+  bool S_is_zero = false;   // S (lower triangle) and bs are cleared and nothing has been accumulated into them yet
   bool lin_valid = false;   // the linearisation buffers hold the linearisation of state `cur` (speculated by the previous trial)
   double chi_cur = 0;       // robust chi2 of state `cur` when lin_valid
   rocblas_handle blas = nullptr;
@@ -472,13 +473,13 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
 int launch_reduce(ppo_ba_solver* s, double lambda) {
   const Graph& g = s->g;
   const size_t n = g.ld;
-  {
+  if (!s->S_is_zero) {  // (normally k_update_all of the previous trial has cleared S and b already)
     ZeroPlan zp{};
     zp.p[0] = s->d_S.p; zp.n[0] = n * n;
     zp.p[1] = s->d_bs.p; zp.n[1] = n;
-    zp.p[2] = s->g.acc; zp.n[2] = 2;  // chi2 and scale of the trial that follows
     hipLaunchKernelGGL(k_zero_ranges, dim3(4 * s->n_cu), dim3(256), 0, s->stream, zp);
   }
+  s->S_is_zero = false;
   const bool cub_stage = g.elim_cub && g.owns_reduced && g.n_cuboids > 0;
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
   ReducePlan rp{};
@@ -520,12 +521,17 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   const Graph& g = s->g;
   const State& cur = s->st[s->cur];
   const State& tr = s->st[s->cur ^ 1];
-  hipLaunchKernelGGL(k_update_reduced_all, dim3(g.n_cuboids + nblk(g.n_poses, 64)), dim3(64), 0, s->stream, g, cur, tr, lambda);
   const int nl = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
-  if (nl > 0) {
-    if (s->use_lds) hipLaunchKernelGGL((k_backsub<true, 4>), dim3(nblk(4L * nl, 256)), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda);
-    else hipLaunchKernelGGL((k_backsub<false, 4>), dim3(nblk(4L * nl, 256)), dim3(256), 0, s->stream, g, cur, tr, lambda);
-  }
+  const int nb = g.ld / 64;
+  UpdatePlan up{};
+  up.nb_red = g.n_cuboids + nblk(g.n_poses, 256);
+  up.nb_lm = nl > 0 ? nblk(4L * nl, 256) : 0;
+  up.nb_zero = nb * (nb + 1) / 2;
+  up.S = s->d_S.p; up.bs = s->d_bs.p; up.ld = g.ld;
+  const int grid = up.nb_red + up.nb_lm + up.nb_zero;
+  if (s->use_lds) hipLaunchKernelGGL(k_update_all<true>, dim3(grid), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda, up);
+  else hipLaunchKernelGGL(k_update_all<false>, dim3(grid), dim3(256), 0, s->stream, g, cur, tr, lambda, up);
+  s->S_is_zero = true;  // the factor is dead after the backward substitution: the next reduction finds S and b cleared
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -1144,7 +1150,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   s->use_lds = s->lds_bytes <= 150 * 1024;
   if (s->use_lds && s->lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute((const void*)k_lin_points<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_backsub<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
+        hipFuncSetAttribute((const void*)k_backsub<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_update_all<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
   }
   s->use_lds_lin = s->use_lds && s->lds_bytes <= 40 * 1024;
   s->lin_lds_bytes = std::max({(int)(4 * 14 * 65 * sizeof(double)), (int)(kNumericLdsDoubles * sizeof(double)),
