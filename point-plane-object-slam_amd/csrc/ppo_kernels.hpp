@@ -751,22 +751,12 @@ __global__ __launch_bounds__(256) void k_chi2_all(Graph g, State st, NumericPlan
 
 // Hands the accumulator block and the factorisation flag to the host through mapped, coherent host memory: payload first,
 // then a sequence number the host spins on (a device-to-host copy engine transfer costs ~10 us of idle device per trial).
-__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ acc, const int* __restrict__ info, double* host, unsigned long long seq) {
-  const int t = threadIdx.x;
-  if (t < ACC_N) host[t] = acc[t];
-  if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
-  __threadfence_system();
-  __syncthreads();
-  if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + ACC_N + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // One launch zeroes every accumulator range of a phase (instead of one memset node per range).
 struct ZeroPlan {
   double* p[6];
   unsigned long long n[6];  // doubles
 };
-__global__ __launch_bounds__(256) void k_zero_ranges(ZeroPlan zp) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void zero_ranges_body(const ZeroPlan& zp, size_t t0, size_t stride) {
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     double* p = zp.p[r];
@@ -779,6 +769,27 @@ __global__ __launch_bounds__(256) void k_zero_ranges(ZeroPlan zp) {
       for (size_t i = t0; i < n; i += stride) p[i] = 0.0;
     }
   }
+}
+// (k_publish) Workgroup 0 hands the accumulator block and the factorisation flag to the host; when the next linearisation is
+// queued right behind (speculation), the remaining workgroups clear its accumulation ranges in the same launch and
+// workgroup 0 clears the accumulator block after copying it.
+__global__ __launch_bounds__(64) void k_publish(double* __restrict__ acc, const int* __restrict__ info, double* host, unsigned long long seq, ZeroPlan zp) {
+  const int t = threadIdx.x;
+  if (blockIdx.x > 0) {
+    zero_ranges_body(zp, (size_t)(blockIdx.x - 1) * 64 + t, (size_t)(gridDim.x - 1) * 64);
+    return;
+  }
+  double v = 0.0;
+  if (t < ACC_N) { v = acc[t]; host[t] = v; }
+  if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + ACC_N + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (gridDim.x > 1 && t < ACC_N) acc[t] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_zero_ranges(ZeroPlan zp) {
+  zero_ranges_body(zp, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
 // max |H_jj| over every active diagonal (computeLambdaInit, levenberg.cpp:166-180)

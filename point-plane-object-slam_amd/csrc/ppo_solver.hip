@@ -411,19 +411,25 @@ int reset_device(ppo_ba_solver* s) {
 
 // ---- one linearisation of the current state: fills HB/HC/D/bl/W, per-edge chi2, acc[ACC_CHI2] ------------
 int launch_linearize_kernel(ppo_ba_solver* s, const State& st);
-int launch_linearize(ppo_ba_solver* s, int which_state = -1) {
+ZeroPlan linearize_zero_plan(ppo_ba_solver* s, bool with_acc) {
+  double* A = s->d_arena.p;
+  ZeroPlan zp{};
+  zp.p[0] = A; zp.n[0] = with_acc ? s->zero_head : s->zero_head - ACC_N;  // HB | HC | acc
+  zp.p[1] = A + s->zD_off; zp.n[1] = s->zD_n;
+  zp.p[2] = A + s->zbl_off; zp.n[2] = s->zbl_n;
+  zp.p[3] = s->d_W.p + s->zW_off; zp.n[3] = s->zW_n;
+  return zp;
+}
+
+int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool already_zeroed = false) {
   const Graph& g = s->g;
   const State& st = s->st[which_state < 0 ? s->cur : which_state];
-  double* A = s->d_arena.p;
-  {
-    ZeroPlan zp{};
-    zp.p[0] = A; zp.n[0] = s->zero_head;
-    zp.p[1] = A + s->zD_off; zp.n[1] = s->zD_n;
-    zp.p[2] = A + s->zbl_off; zp.n[2] = s->zbl_n;
-    zp.p[3] = s->d_W.p + s->zW_off; zp.n[3] = s->zW_n;
+  if (!already_zeroed) {
+    const ZeroPlan zp = linearize_zero_plan(s, true);
     const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
     hipLaunchKernelGGL(k_zero_ranges, dim3(std::min(nblk((long)tot / 2, 256), 2 * s->n_cu)), dim3(256), 0, s->stream, zp);
   }
+  (void)g;
   RC_TRY(launch_linearize_kernel(s, st));
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
@@ -538,13 +544,19 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 
 // bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
 // can be queued behind the copy before the host blocks on it.
-int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info) {
+int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false) {
   if (s->comm.active()) {
     // chi2 and scale are sums, maxdiag is a max: two tiny collectives on the accumulator block
     if (s->comm.sum(s->g.acc, 2, s->stream) || s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
   }
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s->stream, (const double*)s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev,
-                     ++s->pub_seq);
+  ZeroPlan zp{};
+  int grid = 1;
+  if (zero_for_next_linearize) {
+    zp = linearize_zero_plan(s, false);
+    const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
+    grid = 1 + (int)std::min<size_t>(std::max<size_t>(1, tot / 2 / 64), (size_t)2 * s->n_cu);
+  }
+  hipLaunchKernelGGL(k_publish, dim3(grid), dim3(64), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, zp);
   HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
   return PPO_BA_OK;
 }
@@ -613,10 +625,10 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     s->have_system = true;
     RC_TRY(launch_update(s, lambda));
     RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
-    RC_TRY(fetch_acc_enqueue(s, true));
     const bool speculated = may_speculate && !stop_requested(stop);
+    RC_TRY(fetch_acc_enqueue(s, true, speculated));
     if (speculated) {
-      RC_TRY(launch_linearize(s, s->cur ^ 1));
+      RC_TRY(launch_linearize(s, s->cur ^ 1, true));
       if (s->comm.active() && s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
     }
     RC_TRY(fetch_acc_wait(s));
