@@ -996,34 +996,52 @@ __device__ __forceinline__ const double* wpc_of(const Graph& g, int code) { retu
 __device__ __forceinline__ void cub_prep_body(const Graph& g, double lambda, int vb) {
   const int c = vb * blockDim.x + threadIdx.x;
   if (c >= g.n_cuboids || g.cub_col[c] < 0) return;
-  double L[9][9];
+  // everything stays in registers (all loops unrolled, L and L^-1 as full 9x9 register arrays of which only the lower
+  // halves are live): with L^-1 built in global memory the read-after-write chain made this one thread the 10 us tail of
+  // the whole launch
+  double L[9][9], Li[9][9];
   const double* hc = &g.HC[(size_t)c * 54];
+#pragma unroll
   for (int r = 0; r < 9; ++r)
+#pragma unroll
     for (int k = 0; k <= r; ++k) L[r][k] = hc[packed_lower(r, k)] + (r == k ? lambda : 0.0);
+#pragma unroll
   for (int j = 0; j < 9; ++j) {  // in-place Cholesky, lower
     double d = L[j][j];
+#pragma unroll
     for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
     const double ljj = sqrt(d);  // NaN if not positive: propagates to S and fails the dense factorisation
+    const double inv = 1.0 / ljj;
     L[j][j] = ljj;
+    Li[j][j] = inv;
+#pragma unroll
     for (int i = j + 1; i < 9; ++i) {
       double v = L[i][j];
+#pragma unroll
       for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-      L[i][j] = v / ljj;
+      L[i][j] = v * inv;
     }
   }
-  double* Li = &g.cub_Linv[(size_t)c * 81];
+#pragma unroll
   for (int j = 0; j < 9; ++j) {  // column j of L^-1 by forward substitution
-    for (int i = 0; i < j; ++i) Li[i * 9 + j] = 0.0;
-    Li[j * 9 + j] = 1.0 / L[j][j];
+#pragma unroll
     for (int i = j + 1; i < 9; ++i) {
       double v = 0.0;
-      for (int k = j; k < i; ++k) v -= L[i][k] * Li[k * 9 + j];
-      Li[i * 9 + j] = v / L[i][i];
+#pragma unroll
+      for (int k = j; k < i; ++k) v -= L[i][k] * Li[k][j];
+      Li[i][j] = v * Li[i][i];
     }
   }
+  double* out = &g.cub_Linv[(size_t)c * 81];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) out[i * 9 + j] = (j <= i) ? Li[i][j] : 0.0;
+#pragma unroll
   for (int n = 0; n < 9; ++n) {
     double v = 0.0;
-    for (int m = 0; m <= n; ++m) v += Li[n * 9 + m] * hc[45 + m];
+#pragma unroll
+    for (int m = 0; m <= n; ++m) v += Li[n][m] * hc[45 + m];
     g.cub_u[(size_t)c * 9 + n] = v;
   }
 }
