@@ -721,12 +721,15 @@ __device__ __forceinline__ void lin_numeric_dispatch(const Graph& g, const State
 // landmark-major point workgroups.  The three parts are independent (they meet only in atomics on H_pp), so the launch
 // lasts as long as its slowest part instead of their sum; as separate kernels on two streams the fork/join events alone
 // cost ~12 us per linearisation (tools/gap_report.py).  All parts share one dynamic LDS allocation.
+#ifndef PPO_LIN_WAVES
+#define PPO_LIN_WAVES 2  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this)
+#endif
 struct LinPlan {
   NumericPlan num;
   int nb_num, nb_pose, nb_pts;
 };
 template <bool USE_LDS>
-__global__ __launch_bounds__(256) void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
+__global__ __launch_bounds__(256, PPO_LIN_WAVES) void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
   extern __shared__ double smem[];
   int b = blockIdx.x;
   if (b < lp.nb_num) { lin_numeric_dispatch(g, st, lp.num, delta, b, smem); return; }

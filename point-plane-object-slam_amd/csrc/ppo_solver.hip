@@ -449,6 +449,15 @@ int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
   const int npts = g.pt_last - g.pt_first;
   lp.nb_pose = (npts > 0 && s->posec.n_chunks > 0) ? nblk(s->posec.n_chunks, 4) : 0;
   lp.nb_pts = npts > 0 ? std::min(nblk(4L * npts, 256), 4 * s->n_cu) : 0;
+  if (const char* e = getenv("PPO_BA_LIN_PARTS")) {  // development aid: time the parts of the fused launch separately
+    const int m = atoi(e);
+    if (!(m & 1)) lp.num.nb_plane = 0;
+    if (!(m & 2)) lp.num.nb_bbox = 0;
+    if (!(m & 4)) lp.num.nb_ptcub = 0;
+    lp.nb_num = lp.num.nb_plane + lp.num.nb_bbox + lp.num.nb_corner + lp.num.nb_ptcub;
+    if (!(m & 8)) lp.nb_pose = 0;
+    if (!(m & 16)) lp.nb_pts = 0;
+  }
   const int grid = lp.nb_num + lp.nb_pose + lp.nb_pts;
   if (grid > 0) {
     if (s->use_lds_lin) hipLaunchKernelGGL(k_linearize_all<true>, dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
