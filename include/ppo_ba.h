@@ -157,7 +157,7 @@ typedef struct ppo_ba_options {
   double lm_lower;          /* 1/3 :49 */
   double lm_upper;          /* 2/3 :48 */
   double numeric_delta;     /* 1e-9 base_binary_edge.hpp:232 */
-  int32_t jacobian_mode;    /* PPO_JAC_* */
+  int32_t jacobian_mode;    /* PPO_JAC_NUMERIC (the only mode: what the reference does); anything else -> PPO_BA_ERR_ARG */
   /* outlier thresholds of the between-pass classification, Optimizer.cc:2739-2833 */
   double chi2_mono;         /* 5.991 */
   double chi2_stereo;       /* 7.815 */
@@ -165,7 +165,8 @@ typedef struct ppo_ba_options {
   double chi2_plane_vp;     /* 200 */
   double th_bbox_norm;      /* thHuberBbox2d, compared with |e| (not chi2) Optimizer.cc:2774 */
   double th_corner_norm;    /* thHuberConer2d Optimizer.cc:2783 */
-  int32_t deterministic;    /* 1 = order-stable reductions where the backend has them (debug) */
+  int32_t deterministic;    /* reserved, must be 0: the HIP backend sums with atomics (run-to-run differences ~1e-9 in chi2,
+                             * DESIGN.md section 6); ppo_ba_create() fails with PPO_BA_ERR_ARG for any other value */
   int32_t solver;           /* PPO_SOLVER_* */
   int32_t eliminate_cuboids; /* 1 (default): cuboids are Schur-eliminated too and the dense system is poses only --
                               * the same linear solve as the reference (which keeps them dense, Optimizer.cc:2172),

@@ -715,6 +715,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (!p || !o || !out) return PPO_BA_ERR_ARG;
   *out = nullptr;
   if (o->abi_version != PPO_BA_ABI_VERSION) return PPO_BA_ERR_ARG;
+  if (o->deterministic != 0 || o->jacobian_mode != PPO_JAC_NUMERIC) {
+    std::fprintf(stderr, "[ppo_ba] options.deterministic / jacobian_mode: only 0 / PPO_JAC_NUMERIC are implemented\n");
+    return PPO_BA_ERR_ARG;
+  }
   const auto t_begin = std::chrono::steady_clock::now();
   RC_TRY(validate(p));
   int ndev = 0;
