@@ -15,6 +15,11 @@ __global__ void rsq_acc(double* out) {
   const double d = 1.0 + 1e-3 * (threadIdx.x + 256.0 * blockIdx.x) * (1.0 + 0.37 * threadIdx.x);
   const double h = 0.5 * d;
   double y = __builtin_amdgcn_rsq(d);
+  {
+    const double e1_ = __builtin_fma(-(d * y), y, 1.0);
+    const double y3 = __builtin_fma(y, e1_ * __builtin_fma(0.375, e1_, 0.5), y);
+    atomicMax((unsigned long long*)&out[3], (unsigned long long)__double_as_longlong(fabs(y3 * sqrt(d) - 1.0)));
+  }
   const double e0 = fabs(y * sqrt(d) - 1.0);
   y = y * __builtin_fma(-h, y * y, 1.5);
   const double e1 = fabs(y * sqrt(d) - 1.0);
@@ -101,8 +106,8 @@ __global__ void mfma_rate(double* out, long long* cyc) {
   if (threadIdx.x == 0) cyc[NACC] = (t1 - t0) / (256 * NACC);
 }
 int main() {
-  { double* o; hipMalloc((void**)&o, 32); hipMemset(o, 0, 32); hipLaunchKernelGGL(rsq_acc, dim3(64), dim3(256), 0, 0, o); double h[3]; hipMemcpy(h, o, 24, hipMemcpyDeviceToHost);
-    printf("v_rsq_f64 max rel err: raw %.3e, 1 Newton %.3e, 2 Newton %.3e\n", h[0], h[1], h[2]); }
+  { double* o; hipMalloc((void**)&o, 32); hipMemset(o, 0, 32); hipLaunchKernelGGL(rsq_acc, dim3(64), dim3(256), 0, 0, o); double h[4]; hipMemcpy(h, o, 32, hipMemcpyDeviceToHost);
+    printf("v_rsq_f64 max rel err: raw %.3e, 1 Newton %.3e, 2 Newton %.3e, one third-order step %.3e\n", h[0], h[1], h[2], h[3]); }
   {
     double* o; long long* c; hipMalloc((void**)&o, 64 * 8); hipMalloc((void**)&c, 8 * 8);
     for (int rep = 0; rep < 2; ++rep) {
