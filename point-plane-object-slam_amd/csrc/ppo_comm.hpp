@@ -10,11 +10,47 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
 
 namespace ppo {
+
+// ---- loopback communicator (tests only) ---------------------------------------------------------------------------------------
+// A comm_id that starts with "PPOLOOP0" selects an in-process communicator: `world` solver handles of ONE process, each driven
+// by its own host thread on the SAME device, meet at every collective; the last thread to arrive reduces the buffers with a
+// small kernel and copies the result back.  It exists so that the sharded arithmetic of the N > 1 path (partial systems,
+// landmark ownership, the gather in ppo_ba_read) can be tested for real on a single-GPU box, where RCCL cannot put two
+// ranks on one device.
+__global__ void k_loop_reduce(double* __restrict__ a, const double* __restrict__ b, size_t n, int op) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    a[i] = op == 0 ? a[i] + b[i] : (a[i] > b[i] ? a[i] : b[i]);
+}
+struct LoopGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, arrived = 0;
+  unsigned long long gen = 0;
+  std::vector<double*> bufs;
+  bool failed = false;
+};
+inline std::shared_ptr<LoopGroup> loop_group(unsigned long long key, int world) {
+  static std::mutex mu;
+  static std::map<unsigned long long, std::shared_ptr<LoopGroup>> groups;
+  std::lock_guard<std::mutex> lk(mu);
+  auto& g = groups[key];
+  if (!g) {
+    g = std::make_shared<LoopGroup>();
+    g->world = world;
+    g->bufs.assign(world, nullptr);
+  }
+  return g;
+}
 
 struct Comm {
   // minimal RCCL surface (ABI of rccl.h: ncclUniqueId is 128 opaque bytes; enums ncclFloat64 = 8, ncclSum = 0, ncclMax = 2)
@@ -30,6 +66,7 @@ struct Comm {
   fn_allreduce allreduce = nullptr;
   fn_destroy comm_destroy = nullptr;
   int rank = 0, world = 1;
+  std::shared_ptr<LoopGroup> loop;  // non-null: loopback mode
   bool forced = false;  // PPO_BA_COMM_SELFTEST: a one-rank communicator, so that the whole N > 1 code path runs on a single GPU
 
   bool load() {
@@ -57,6 +94,13 @@ struct Comm {
     rank = rank_;
     world = world_;
     forced = false;
+    loop.reset();
+    if (world > 1 && std::memcmp(id_bytes, "PPOLOOP0", 8) == 0) {
+      unsigned long long key = 0;
+      std::memcpy(&key, id_bytes + 8, 8);
+      loop = loop_group(key, world);
+      return loop->world == world ? 0 : -1;
+    }
     if (world <= 1) {
       const char* e = getenv("PPO_BA_COMM_SELFTEST");
       if (!(e && e[0] == '1')) return 0;
@@ -72,18 +116,41 @@ struct Comm {
     return init_rank(&comm, world, id, rank) == 0 ? 0 : -1;
   }
   bool active() const { return world > 1 || forced; }
+  int loop_reduce(double* buf, size_t n, int op, hipStream_t s) {
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    LoopGroup& g = *loop;
+    std::unique_lock<std::mutex> lk(g.mu);
+    g.bufs[rank] = buf;
+    const unsigned long long my_gen = g.gen;
+    if (++g.arrived == g.world) {
+      bool ok = true;
+      for (int r = 1; r < g.world; ++r) hipLaunchKernelGGL(k_loop_reduce, dim3(256), dim3(256), 0, s, g.bufs[0], (const double*)g.bufs[r], n, op);
+      for (int r = 1; r < g.world; ++r) ok = ok && hipMemcpyAsync(g.bufs[r], g.bufs[0], n * sizeof(double), hipMemcpyDeviceToDevice, s) == hipSuccess;
+      ok = ok && hipStreamSynchronize(s) == hipSuccess;
+      g.failed = g.failed || !ok;
+      g.arrived = 0;
+      ++g.gen;
+      g.cv.notify_all();
+    } else {
+      g.cv.wait(lk, [&] { return g.gen != my_gen; });
+    }
+    return g.failed ? -1 : 0;
+  }
   int sum(double* buf, size_t n, hipStream_t s) {
     if (!active() || n == 0) return 0;
+    if (loop) return loop_reduce(buf, n, 0, s);
     return allreduce(buf, buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, s) == 0 ? 0 : -1;
   }
   int max(double* buf, size_t n, hipStream_t s) {
     if (!active() || n == 0) return 0;
+    if (loop) return loop_reduce(buf, n, 1, s);
     return allreduce(buf, buf, n, 8, /*ncclMax*/ 2, comm, s) == 0 ? 0 : -1;
   }
   void destroy() {
     if (comm && comm_destroy) comm_destroy(comm);
     comm = nullptr;
     forced = false;
+    loop.reset();
   }
 };
 

@@ -514,7 +514,11 @@ struct PlaneModel {
   static constexpr int DIM_MAX = 3, NCOL = 9;  // cols 0-2 plane, 3-8 pose
   const Graph& g;
   bool corner;  // unused
-  __device__ bool active(int i) const { return g.pl[i].flags & F_ACTIVE; }
+  // (sharded runs: a plane edge belongs to the rank that owns its plane landmark)
+  __device__ bool active(int i) const {
+    const PlaneEdge& ed = g.pl[i];
+    return (ed.flags & F_ACTIVE) && ed.plane >= g.plane_first && ed.plane < g.plane_last;
+  }
   __device__ int dim(int i) const { return ((g.pl[i].flags >> 8) & 3) == 0 ? 3 : 2; }
   __device__ bool col_free(int i, int c) const { return c < 3 || g.pose_col[g.pl[i].pose] >= 0; }
   __device__ void residual(int i, int c, double step, const State& st, double* e) const {

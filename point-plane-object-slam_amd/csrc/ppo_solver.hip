@@ -997,7 +997,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     huber(c, p->cubpl_huber[e], r0, r1);
     s->cubpl_rho_sum += r0;
   }
-  if (!g.owns_reduced) s->cubpl_rho_sum = 0;
+  // (the constant chi2 of the cuboid-plane edges is added on the host by EVERY rank: all ranks must see the same totals,
+  //  their termination tests compare absolute chi2 values)
 
   mark("edge records");
   // ---- pose-major static copies of the owned reprojection edges + chunks (pose side of the linearisation) -----------
@@ -1263,10 +1264,13 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
   if (s->state_doubles) HIP_TRY(hipMemcpy(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double), hipMemcpyDeviceToHost));
   State h = make_state(hs.data(), Np, Npt, Npl, Nc);
   if (s->comm.active()) {
-    // landmarks live on their owner: sum the (disjoint) owned ranges over ranks through a zero-padded device buffer
-    std::vector<double> tmp((size_t)Npt * 3 + (size_t)Npl * 4, 0.0);
+    // landmarks live on their owner, and with eliminated cuboids only the rank that owns the reduced terms back-substitutes
+    // them: sum the (disjoint) owned parts over ranks through a zero-padded device buffer
+    const size_t n_pt = (size_t)Npt * 3, n_pl = (size_t)Npl * 4, n_cb = (size_t)Nc * 10;
+    std::vector<double> tmp(n_pt + n_pl + n_cb, 0.0);
     for (int i = g.pt_first; i < g.pt_last; ++i) for (int a = 0; a < 3; ++a) tmp[(size_t)3 * i + a] = h.point[3 * i + a];
-    for (int i = g.plane_first; i < g.plane_last; ++i) for (int a = 0; a < 4; ++a) tmp[(size_t)3 * Npt + 4 * i + a] = h.plane[4 * i + a];
+    for (int i = g.plane_first; i < g.plane_last; ++i) for (int a = 0; a < 4; ++a) tmp[n_pt + 4 * i + a] = h.plane[4 * i + a];
+    if (g.owns_reduced) std::copy(h.cub, h.cub + n_cb, tmp.begin() + n_pt + n_pl);
     DevBuf<double> d;
     if (!d.alloc(tmp.size())) return PPO_BA_ERR_NOMEM;
     HIP_TRY(hipMemcpyAsync(d.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -1274,8 +1278,9 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
     HIP_TRY(hipMemcpyAsync(tmp.data(), d.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     d.release();
-    std::copy(tmp.begin(), tmp.begin() + (size_t)3 * Npt, h.point);
-    std::copy(tmp.begin() + (size_t)3 * Npt, tmp.end(), h.plane);
+    std::copy(tmp.begin(), tmp.begin() + n_pt, h.point);
+    std::copy(tmp.begin() + n_pt, tmp.begin() + n_pt + n_pl, h.plane);
+    std::copy(tmp.begin() + n_pt + n_pl, tmp.end(), h.cub);
   }
   if (r->pose_qt) for (int i = 0; i < Np; ++i) std::memcpy(&r->pose_qt[7 * i], &h.pose_qt[7 * i], 7 * sizeof(double));
   if (r->point_xyz && Npt) std::memcpy(r->point_xyz, h.point, (size_t)Npt * 3 * sizeof(double));
@@ -1355,6 +1360,50 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
   }
   if (r->ptcub_chi2) for (int e = 0; e < g.n_ptcub; ++e) r->ptcub_chi2[e] = c_pc[e];
   if (r->cubpl_chi2) for (int e = 0; e < s->n_cubpl; ++e) r->cubpl_chi2[e] = s->cubpl_chi2[e];
+  if (s->comm.active()) {
+    // per-edge outputs are computed by the rank that owns the edge's landmark (cuboid edges: the rank that owns the reduced
+    // terms): mask the others and sum over ranks, one collective for everything
+    struct Item { double* d; uint8_t* u; size_t n; int kind; };  // kind: 0 mono, 1 stereo, 2 plane, 3 owner-rank
+    std::vector<Item> items = {
+        {r->mono_chi2, nullptr, (size_t)g.n_mono, 0}, {nullptr, r->mono_level, (size_t)g.n_mono, 0}, {nullptr, r->mono_depth_positive, (size_t)g.n_mono, 0},
+        {r->stereo_chi2, nullptr, (size_t)g.n_stereo, 1}, {nullptr, r->stereo_level, (size_t)g.n_stereo, 1}, {nullptr, r->stereo_depth_positive, (size_t)g.n_stereo, 1},
+        {r->pl_chi2, nullptr, (size_t)g.n_pl, 2}, {nullptr, r->pl_level, (size_t)g.n_pl, 2},
+        {r->bbox_chi2, nullptr, (size_t)g.n_bbox, 3}, {r->bbox_errnorm, nullptr, (size_t)g.n_bbox, 3}, {nullptr, r->bbox_level, (size_t)g.n_bbox, 3},
+        {r->corner_chi2, nullptr, (size_t)g.n_corner, 3}, {r->corner_errnorm, nullptr, (size_t)g.n_corner, 3}, {nullptr, r->corner_level, (size_t)g.n_corner, 3},
+        {r->ptcub_chi2, nullptr, (size_t)g.n_ptcub, 3}};
+    std::vector<uint8_t> own_mono(g.n_mono, 0), own_stereo(g.n_stereo, 0), own_pl(g.n_pl, 0);
+    for (int k = 0; k < g.n_mono; ++k) own_mono[s->mono_perm[k]] = mo_pt[k] >= g.pt_first && mo_pt[k] < g.pt_last;
+    for (int k = 0; k < g.n_stereo; ++k) own_stereo[s->stereo_perm[k]] = st_pt[k] >= g.pt_first && st_pt[k] < g.pt_last;
+    for (int e = 0; e < g.n_pl; ++e) own_pl[e] = hp[e].plane >= g.plane_first && hp[e].plane < g.plane_last;
+    size_t total = 0;
+    for (const Item& it : items) total += it.n;
+    std::vector<double> buf(total, 0.0);
+    size_t off = 0;
+    for (const Item& it : items) {
+      for (size_t e = 0; e < it.n; ++e) {
+        const bool mine = it.kind == 0 ? own_mono[e] : it.kind == 1 ? own_stereo[e] : it.kind == 2 ? own_pl[e] : (bool)g.owns_reduced;
+        if (mine) buf[off + e] = it.d ? it.d[e] : (it.u ? (double)it.u[e] : 0.0);
+      }
+      off += it.n;
+    }
+    if (total) {
+      DevBuf<double> d;
+      if (!d.alloc(total)) return PPO_BA_ERR_NOMEM;
+      HIP_TRY(hipMemcpyAsync(d.p, buf.data(), total * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      if (s->comm.sum(d.p, total, s->stream)) return PPO_BA_ERR_COMM;
+      HIP_TRY(hipMemcpyAsync(buf.data(), d.p, total * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      d.release();
+      off = 0;
+      for (const Item& it : items) {
+        for (size_t e = 0; e < it.n; ++e) {
+          if (it.d) it.d[e] = buf[off + e];
+          if (it.u) it.u[e] = (uint8_t)(buf[off + e] + 0.5);
+        }
+        off += it.n;
+      }
+    }
+  }
   return PPO_BA_OK;
 }
 
