@@ -135,6 +135,7 @@ struct Graph {
   double* xc;                   // [Nc][9]  cuboid update
   int pt_first, pt_last, plane_first, plane_last;
   int owns_reduced;  // 1 on the rank that adds Hcc / lambda / cuboid terms
+  const double* hb_diag;  // sharded runs, first iteration: diagonal of Hpp summed over ranks (NULL: read it from HB)
 };
 
 __device__ __forceinline__ int packed_lower(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
@@ -800,10 +801,14 @@ __global__ __launch_bounds__(256) void k_zero_ranges(ZeroPlan zp) {
 }
 
 // max |H_jj| over every active diagonal (computeLambdaInit, levenberg.cpp:166-180)
+__global__ void k_hb_diag(Graph g, double* out) {  // out[6 f + a] = Hpp_f[a][a]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < g.n_pose_free * 6) out[i] = g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)];
+}
 __global__ void k_maxdiag(Graph g) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double m = 0.0;
-  if (i < g.n_pose_free * 6) m = fabs(g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)]);
+  if (i < g.n_pose_free * 6) m = fabs(g.hb_diag ? g.hb_diag[i] : g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)]);
   if (i < g.n_cuboids * 9 && g.owns_reduced) m = fmax(m, fabs(g.HC[(size_t)(i / 9) * 54 + packed_lower(i % 9, i % 9)]));
   const int nl_owned = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
   if (i < nl_owned * 3) {
@@ -821,7 +826,9 @@ __device__ __forceinline__ void assemble_body(const Graph& g, double lambda, int
   const int i = vb * blockDim.x + threadIdx.x;
   const int n = g.ld;
   const int nP = g.n_pose_free * 27, nC = g.n_cuboids * 54, nB = g.n_bbox * 54, nK = g.n_corner * 54;
-  if (!g.owns_reduced) return;  // multi-GPU: HB is already summed over ranks, one rank contributes it
+  // sharded runs: every rank adds ITS partial pose blocks (the all-reduce of S sums them); lambda, the padding identity and
+  // the cuboid terms come from the rank that owns the reduced terms
+  if (!g.owns_reduced && i >= nP) return;
   if (i >= nP + nC + nB + nK) {  // identity on the padding so that the padded matrix stays positive definite
     const int k = g.n_red + (i - (nP + nC + nB + nK));
     if (k < g.ld) g.S[(size_t)k * n + k] = 1.0;
@@ -1299,10 +1306,9 @@ __device__ __forceinline__ void update_reduced_body(const Graph& g, const State&
       if (col >= 0) {
         const double* x = &g.xr[col];
         T = pose_boxplus(T, x);
-        if (g.owns_reduced) {
-          const double* b = &g.HB[(size_t)g.pose_free_id[i] * 27 + 21];
-          for (int a = 0; a < 6; ++a) sc += x[a] * (lambda * x[a] + b[a]);
-        }
+        const double* b = &g.HB[(size_t)g.pose_free_id[i] * 27 + 21];  // (sharded: this rank's part of b)
+        const double lam = g.owns_reduced ? lambda : 0.0;
+        for (int a = 0; a < 6; ++a) sc += x[a] * (lam * x[a] + b[a]);
       }
       store_pose(&trial.pose_qt[7 * i], &trial.pose_rt[12 * i], T);
     }

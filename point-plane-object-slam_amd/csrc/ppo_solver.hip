@@ -233,7 +233,8 @@ struct ppo_ba_solver {
   DevBuf<double> d_state[2];  // two copies of all estimates (current / trial)
   DevBuf<double> d_init;      // pristine estimates for reset()
   DevBuf<double> d_arena;     // HB | HC | acc | D | bl | W ; a prefix is zeroed before every linearisation
-  DevBuf<double> d_Wpc, d_Dinv, d_C, d_ul, d_Z, d_S, d_bs, d_xr, d_cholws;
+  DevBuf<double> d_Wpc, d_Dinv, d_C, d_ul, d_Z, d_S, d_xr, d_cholws;
+  double* d_bs_p = nullptr;  // = d_S.p + ld * ld
   DevBuf<int32_t> d_pc_start, d_pc_colj, d_pc_coli, d_pc_sj, d_pc_si;  // pose-pair chunks of the Schur accumulation
   PairChunks pc{};
   DevBuf<int32_t> d_po_start, d_po_end, d_po_pose;  // pose-major chunks of the reprojection edges
@@ -355,7 +356,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
   s->d_Wpc.release(); s->d_Dinv.release(); s->d_C.release(); s->d_ul.release(); s->d_Z.release();
-  s->d_S.release(); s->d_bs.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
+  s->d_S.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release();
@@ -491,7 +492,7 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
   if (!s->S_is_zero) {  // (normally k_update_all of the previous trial has cleared S and b already)
     ZeroPlan zp{};
     zp.p[0] = s->d_S.p; zp.n[0] = n * n;
-    zp.p[1] = s->d_bs.p; zp.n[1] = n;
+    zp.p[1] = s->d_bs_p; zp.n[1] = n;
     hipLaunchKernelGGL(k_zero_ranges, dim3(4 * s->n_cu), dim3(256), 0, s->stream, zp);
   }
   s->S_is_zero = false;
@@ -511,7 +512,7 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
-    if (s->comm.sum(s->d_S.p, n * n, s->stream) || s->comm.sum(s->d_bs.p, n, s->stream)) return PPO_BA_ERR_COMM;
+    if (s->comm.sum(s->d_S.p, n * n + n, s->stream)) return PPO_BA_ERR_COMM;  // S and b in one collective
     // every rank wrote nothing on the padding except the owner: identity there after the sum
   }
   return PPO_BA_OK;
@@ -522,9 +523,9 @@ int launch_solve(ppo_ba_solver* s) {
   const Graph& g = s->g;
   const int n = g.n_red, ld = g.ld;
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
-    RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs.p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
+    RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs_p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
   } else {
-    HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs.p, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs_p, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream));
     if (rocsolver_dpotrf(s->blas, rocblas_fill_lower, n, s->d_S.p, ld, s->d_info.p) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
     if (rocsolver_dpotrs(s->blas, rocblas_fill_lower, n, 1, s->d_S.p, ld, s->d_xr.p, ld) != rocblas_status_success) return PPO_BA_ERR_SOLVER;
@@ -542,7 +543,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   up.nb_red = g.n_cuboids + nblk(g.n_poses, 256);
   up.nb_lm = nl > 0 ? nblk(4L * nl, 256) : 0;
   up.nb_zero = nb * (nb + 1) / 2;
-  up.S = s->d_S.p; up.bs = s->d_bs.p; up.ld = g.ld;
+  up.S = s->d_S.p; up.bs = s->d_bs_p; up.ld = g.ld;
   const int grid = up.nb_red + up.nb_lm + up.nb_zero;
   if (s->use_lds) hipLaunchKernelGGL(k_update_all<true>, dim3(grid), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda, up);
   else hipLaunchKernelGGL(k_update_all<false>, dim3(grid), dim3(256), 0, s->stream, g, cur, tr, lambda, up);
@@ -553,10 +554,11 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 
 // bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
 // can be queued behind the copy before the host blocks on it.
-int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false) {
+int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false) {
   if (s->comm.active()) {
-    // chi2 and scale are sums, maxdiag is a max: two tiny collectives on the accumulator block
-    if (s->comm.sum(s->g.acc, 2, s->stream) || s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
+    // chi2 and scale are sums over ranks; the max-diagonal (first iteration of a pass only) is a max
+    if (s->comm.sum(s->g.acc, 2, s->stream)) return PPO_BA_ERR_COMM;
+    if (with_maxdiag && s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
   }
   ZeroPlan zp{};
   int grid = 1;
@@ -584,9 +586,25 @@ int fetch_acc_wait(ppo_ba_solver* s) {
   if (*seq != s->pub_seq) return PPO_BA_ERR_HIP;
   return PPO_BA_OK;
 }
-int fetch_acc(ppo_ba_solver* s, bool with_info) {
-  RC_TRY(fetch_acc_enqueue(s, with_info));
+int fetch_acc(ppo_ba_solver* s, bool with_info, bool with_maxdiag = false) {
+  RC_TRY(fetch_acc_enqueue(s, with_info, false, with_maxdiag));
   return fetch_acc_wait(s);
+}
+
+// max |H_jj| over every diagonal into acc[ACC_MAXDIAG] (this rank's part; fetch_acc(..., with_maxdiag) takes the max over
+// ranks).  Sharded runs keep Hpp as per-rank partial sums, so its diagonal is summed over ranks first (d_xr is free here).
+int launch_maxdiag(ppo_ba_solver* s) {
+  Graph g = s->g;
+  const long npd = (long)g.n_pose_free * 6;
+  if (s->comm.active() && npd > 0) {
+    hipLaunchKernelGGL(k_hb_diag, dim3(nblk(npd, 256)), dim3(256), 0, s->stream, g, s->d_xr.p);
+    if (s->comm.sum(s->d_xr.p, (size_t)npd, s->stream)) return PPO_BA_ERR_COMM;
+    g.hb_diag = s->d_xr.p;
+  }
+  const long nd = std::max<long>({npd, (long)g.n_cuboids * 9, 3L * ((g.pt_last - g.pt_first) + (g.plane_last - g.plane_first)), 1L});
+  hipLaunchKernelGGL(k_maxdiag, dim3(nblk(nd, 256)), dim3(256), 0, s->stream, g);
+  HIP_TRY(hipGetLastError());
+  return PPO_BA_OK;
 }
 
 bool stop_requested(const volatile uint8_t* f) { return f && *f; }
@@ -602,17 +620,11 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
   const bool fresh = !s->lin_valid;
   if (fresh) {
     RC_TRY(launch_linearize(s));
-    if (s->comm.active()) {  // every rank needs the summed pose blocks (lambda init, scale term, rank 0 assembles them)
-      if (s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
-    }
   }
-  if (iteration == 0) {
-    const long nd = std::max<long>({(long)g.n_pose_free * 6, (long)g.n_cuboids * 9, 3L * ((g.pt_last - g.pt_first) + (g.plane_last - g.plane_first)), 1L});
-    hipLaunchKernelGGL(k_maxdiag, dim3(nblk(nd, 256)), dim3(256), 0, s->stream, g);
-  }
+  if (iteration == 0) RC_TRY(launch_maxdiag(s));
   double currentChi;
   if (fresh || iteration == 0) {
-    RC_TRY(fetch_acc(s, false));
+    RC_TRY(fetch_acc(s, false, iteration == 0));
     currentChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
   } else {
     currentChi = s->chi_cur;  // computeActiveErrors of the state the previous trial produced (levenberg.cpp:72-75)
@@ -638,7 +650,6 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     RC_TRY(fetch_acc_enqueue(s, true, speculated));
     if (speculated) {
       RC_TRY(launch_linearize(s, s->cur ^ 1, true));
-      if (s->comm.active() && s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
     }
     RC_TRY(fetch_acc_wait(s));
     int info = 0;
@@ -670,8 +681,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
       if (speculated && rho < 0 && qmax + 1 < s->opt.lm_max_trials && !stop_requested(stop)) {
         // the buffers hold the rejected state's linearisation: restore the kept state's before the retry
         RC_TRY(launch_linearize(s));
-        if (s->comm.active() && s->comm.sum(g.HB, (size_t)g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
-      }
+        }
     }
     qmax++;
     s->stats.n_trials++;
@@ -781,6 +791,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (!p->pose_fixed[i] && pose_used[i]) { pose_free_id[i] = nfree; pose_col[i] = 6 * nfree; ++nfree; }
   int ncol = 6 * nfree, n_cub_used = 0;
   g.elim_cub = o->eliminate_cuboids ? 1 : 0;
+  g.hb_diag = nullptr;
   for (int i = 0; i < Nc; ++i)
     if (cub_used[i]) {
       ++n_cub_used;
@@ -1117,7 +1128,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
   ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_C.alloc(nD) && s->d_ul.alloc(nbl) && s->d_Z.alloc(nW);
-  ok = ok && s->d_S.alloc((size_t)ld * ld) && s->d_bs.alloc(ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
+  ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
   ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream);
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
@@ -1129,7 +1140,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (!ok) return fail(PPO_BA_ERR_NOMEM);
   {  // blocks come from the cache with stale contents: the work arrays that are only partially written start from zero
     auto zero = [&](auto& b) { if (b.p && b.n) (void)hipMemsetAsync(b.p, 0, b.n * sizeof(*b.p), s->stream); };
-    zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_C); zero(s->d_ul); zero(s->d_Z); zero(s->d_bs); zero(s->d_xr); zero(s->d_cholws);
+    zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_C); zero(s->d_ul); zero(s->d_Z); zero(s->d_xr); zero(s->d_cholws);
     zero(s->d_cub_Linv); zero(s->d_cub_u); zero(s->d_xc); zero(s->d_cub_Z); zero(s->d_S);
   }
   static_assert(ACC_N + 2 <= kPinnedDoubles, "mapped host block too small");
@@ -1167,7 +1178,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   g.Wpc_bbox = s->d_Wpc.p; g.Wpc_corner = s->d_Wpc.p + (size_t)p->n_bbox * 54;
   g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p;
   g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_u = s->d_cub_u.p; g.xc = s->d_xc.p; g.cub_Z = s->d_cub_Z.p;
-  g.Dinv = s->d_Dinv.p; g.C = s->d_C.p; g.ul = s->d_ul.p; g.Z = s->d_Z.p; g.S = s->d_S.p; g.bs = s->d_bs.p; g.xr = s->d_xr.p;
+  g.Dinv = s->d_Dinv.p; g.C = s->d_C.p; g.ul = s->d_ul.p; g.Z = s->d_Z.p; s->d_bs_p = s->d_S.p + (size_t)ld * ld; g.S = s->d_S.p; g.bs = s->d_bs_p; g.xr = s->d_xr.p;
   s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
   s->st[1] = make_state(s->d_state[1].p, Np, Npt, Npl, Nc);
 
@@ -1418,7 +1429,6 @@ int ppo_ba_linearize(ppo_ba_handle s, double* robust_chi2) {
   if (!s) return PPO_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   RC_TRY(launch_linearize(s));
-  if (s->comm.active() && s->comm.sum(s->g.HB, (size_t)s->g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
   RC_TRY(fetch_acc(s, false));
   if (robust_chi2) *robust_chi2 = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
   return PPO_BA_OK;
@@ -1530,10 +1540,8 @@ int ppo_ba_time_factor(ppo_ba_handle s, int reps, double* ms_out) {
   HIP_TRY(hipSetDevice(s->device));
   if (s->lambda <= 0) {  // no run yet: linearise and take lambda_0
     RC_TRY(launch_linearize(s));
-    const Graph& g = s->g;
-    const long nd = std::max<long>({(long)g.n_pose_free * 6, (long)g.n_cuboids * 9, 3L * g.n_lm, 1L});
-    hipLaunchKernelGGL(k_maxdiag, dim3(nblk(nd, 256)), dim3(256), 0, s->stream, g);
-    RC_TRY(fetch_acc(s, false));
+    RC_TRY(launch_maxdiag(s));
+    RC_TRY(fetch_acc(s, false, true));
     s->lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
   }
   hipEvent_t e0, e1;
@@ -1565,7 +1573,6 @@ int ppo_ba_debug_reduced(ppo_ba_handle s, double* S, double* b, double* x, int32
   if (!S && !b && !x) return PPO_BA_OK;
   const double lambda = s->lambda > 0 ? s->lambda : 0.0;
   RC_TRY(launch_linearize(s));
-  if (s->comm.active() && s->comm.sum(s->g.HB, (size_t)s->g.n_pose_free * 27, s->stream)) return PPO_BA_ERR_COMM;
   RC_TRY(launch_reduce(s, lambda));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (S) {
@@ -1575,7 +1582,7 @@ int ppo_ba_debug_reduced(ppo_ba_handle s, double* S, double* b, double* x, int32
     for (int c = 0; c < n; ++c)
       for (int r = c; r < n; ++r) S[(size_t)c * n + r] = S[(size_t)r * n + c] = tmp[(size_t)c * ld + r];
   }
-  if (b) HIP_TRY(hipMemcpy(b, s->d_bs.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  if (b) HIP_TRY(hipMemcpy(b, s->d_bs_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   if (x) {
     RC_TRY(launch_solve(s));
     HIP_TRY(hipStreamSynchronize(s->stream));
