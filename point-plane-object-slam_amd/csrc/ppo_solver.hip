@@ -802,6 +802,15 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   g.n_red = ncol;
   g.ld = chol_padded_ld(ncol);
   const int ld = g.ld;
+  // chol_back_all needs its ld/64 workgroups co-resident (they hand x over inside one launch): far beyond any local-BA
+  // window, but not unbounded -- past 256 blocks (2730 free poses) the automatic choice is rocSOLVER, an explicit request
+  // for the native solver is refused
+  if (s->solver_kind == PPO_SOLVER_NATIVE && ld / 64 > 256) {
+    if (o->solver == PPO_SOLVER_NATIVE) return fail(PPO_BA_ERR_ARG);
+    s->solver_kind = PPO_SOLVER_ROCSOLVER;
+    if (rocblas_create_handle(&s->blas) != rocblas_status_success) return fail(PPO_BA_ERR_SOLVER);
+    rocblas_set_stream(s->blas, s->stream);
+  }
   g.n_lm = Npt + Npl;
   s->stats.n_reduced = 6 * nfree + 9 * n_cub_used;  // the reference's reduced dimension (cuboids are not marginalised there)
 
