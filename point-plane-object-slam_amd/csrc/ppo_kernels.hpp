@@ -1124,81 +1124,7 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
     atomicAdd(&g.bs[cola + i], -v);
   }
 }
-// x_c = Dc^-1 (b_c - sum_e W_e' x_p(e)): one 64-lane workgroup per cuboid, lane (a, n) accumulates W_e[a][n] x_p[a]
-__global__ __launch_bounds__(64) void k_cub_backsub(Graph g) {
-  __shared__ double sp[54], st[9], sy[9];
-  const int c = blockIdx.x, lane = threadIdx.x;
-  if (g.cub_col[c] < 0) return;
-  const int a = lane / 9, n = lane - 9 * a;
-  double part = 0.0;
-  if (lane < 54) {
-    for (int q = g.cub_edge_off[c]; q < g.cub_edge_off[c + 1]; ++q) {
-      const int code = g.cub_edges[q];
-      const CubEdge& e = cub_edge_of(g, code);
-      const int col = g.pose_col[e.pose];
-      if (!(e.flags & F_ACTIVE) || col < 0) continue;
-      part += wpc_of(g, code)[lane] * g.xr[col + a];
-    }
-    sp[lane] = part;
-  }
-  __syncthreads();
-  if (lane < 9) {
-    double t = g.HC[(size_t)c * 54 + 45 + lane];
-    for (int k = 0; k < 6; ++k) t -= sp[k * 9 + lane];
-    st[lane] = t;
-  }
-  __syncthreads();
-  const double* Li = &g.cub_Linv[(size_t)c * 81];
-  if (lane < 9) {
-    double v = 0.0;
-    for (int m = 0; m <= lane; ++m) v += Li[lane * 9 + m] * st[m];
-    sy[lane] = v;
-  }
-  __syncthreads();
-  if (lane < 9) {
-    double v = 0.0;
-    for (int k = lane; k < 9; ++k) v += Li[k * 9 + lane] * sy[k];
-    g.xc[(size_t)c * 9 + lane] = v;
-  }
-  (void)n;
-}
 
-// poses and cuboids: trial = cur [+] x ; scale += x (lambda x + b)   (computeScale, levenberg.cpp:182-189)
-__global__ void k_update_reduced(Graph g, State cur, State trial, double lambda) {
-  __shared__ double s_red[4];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double sc = 0.0;
-  if (i < g.n_poses) {
-    const int col = g.pose_col[i];
-    Pose T = load_pose(&cur.pose_qt[7 * i]);
-    if (col >= 0) {
-      const double* x = &g.xr[col];
-      T = pose_boxplus(T, x);
-      if (g.owns_reduced) {
-        const double* b = &g.HB[(size_t)g.pose_free_id[i] * 27 + 21];
-        for (int a = 0; a < 6; ++a) sc += x[a] * (lambda * x[a] + b[a]);
-      }
-    }
-    store_pose(&trial.pose_qt[7 * i], &trial.pose_rt[12 * i], T);
-  } else if (i < g.n_poses + g.n_cuboids) {
-    const int k = i - g.n_poses;
-    const int col = g.cub_col[k];
-    Cub c = load_cub(&cur.cub[10 * k]);
-    if (col >= 0) {
-      const double* x = g.elim_cub ? &g.xc[9 * k] : &g.xr[col];
-      const double* fs = &g.cub_fixedscale[3 * k];
-      c = cuboid_boxplus(c, x, g.cub_flags[k], fs[0], fs[1], fs[2]);
-      if (g.owns_reduced) {
-        const double* b = &g.HC[(size_t)k * 54 + 45];
-        for (int a = 0; a < 9; ++a) sc += x[a] * (lambda * x[a] + b[a]);
-      }
-    }
-    double* o = &trial.cub[10 * k];
-    o[0] = c.T.q.x; o[1] = c.T.q.y; o[2] = c.T.q.z; o[3] = c.T.q.w; o[4] = c.T.t.x; o[5] = c.T.t.y; o[6] = c.T.t.z;
-    o[7] = c.s.x; o[8] = c.s.y; o[9] = c.s.z;
-  }
-  block_atomic_add(sc, &g.acc[ACC_SCALE], s_red);
-}
 
 // ---- the reduction to the pose system in three launches (horizontal fusion of independent parts) ---------------------------
 // stage 1: assemble Hpp + lambda I into S | factor the landmark blocks | factor the cuboid blocks
@@ -1315,10 +1241,6 @@ __device__ __forceinline__ void update_reduced_body(const Graph& g, const State&
   }
   sc = wave_sum(sc);
   if ((lane & 63) == 0 && sc != 0.0) atomicAdd(&g.acc[ACC_SCALE], sc);
-}
-__global__ __launch_bounds__(64) void k_update_reduced_all(Graph g, State cur, State trial, double lambda) {
-  __shared__ double sp[54], st[9], sy[9], sx[9];
-  update_reduced_body(g, cur, trial, lambda, blockIdx.x, sp, st, sy, sx);
 }
 
 // landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term.
