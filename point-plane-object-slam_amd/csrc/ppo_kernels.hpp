@@ -354,13 +354,17 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
   const int t = bid * 4 + wave;  // one wave per chunk: lanes stride the chunk, records are read fully coalesced
   if (t >= pc.n_chunks) return;
   const int code = pc.pose[t], pose = code >> 1;
+  // the keyframe is the same for the whole wave: keep R, t and the intrinsics in scalar registers
+  auto uni = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
   const double* rt = &st.pose_rt[pose * 12];
   Mat3 R;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) R.a[k] = rt[k];
-  const Vec3 tr = v3(rt[9], rt[10], rt[11]);
+  for (int k = 0; k < 9; ++k) R.a[k] = uni(rt[k]);
+  const Vec3 tr = v3(uni(rt[9]), uni(rt[10]), uni(rt[11]));
   const double* cm = &g.pose_cam[pose * 5];
-  const double fx = cm[0], fy = cm[1], cx = cm[2], cy = cm[3], bf = cm[4];
+  const double fx = uni(cm[0]), fy = uni(cm[1]), cx = uni(cm[2]), cy = uni(cm[3]), bf = uni(cm[4]);
   double A[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) A[k] = 0.0;

@@ -377,3 +377,37 @@ def test_landmark_sharding_gives_the_single_rank_answer(hip, cfg, kw, world):
     # every rank holds the same poses bit for bit (identical inputs to the redundant factorisation)
     for st, r in res[1:]:
         np.testing.assert_array_equal(r.pose_qt, res[0][1].pose_qt)
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+def test_baseline_configurations_match_the_oracle_at_full_size(oracle, hip, cfg):
+    """BASELINE.json configs 2-4 at their full sizes (50 KF / 10k points; 100 KF / 30k points / 100 planes; 200 KF / 50k points /
+    200 planes / 50 cuboids), the complete 5 + 10 protocol on both sides: same accept/reject schedule, final estimates within
+    the parity bar, same outlier sets.  (The single-threaded oracle needs ~2 s for config 4.)"""
+    P = synth.make_problem(cfg, seed=1)
+    so, sh = both(oracle, hip, P)
+    to, th = so.run(), sh.run()
+    assert [(i["pass_"], i["iteration"], i["trials"], i["accepted"]) for i in to["iters"]] == [(i["pass_"], i["iteration"], i["trials"], i["accepted"]) for i in th["iters"]]
+    for a, b in zip(to["iters"], th["iters"]):
+        assert abs(a["chi2_after"] - b["chi2_after"]) <= 3e-6 * abs(a["chi2_after"])
+    ro, rh = so.read(), sh.read()
+    # poses, points, planes: the parity bar.  Cuboids: the bar for all but (at most) 5 % of them -- at config 4 one cuboid of 50
+    # sits on a flat direction of the cost (bounding-box-only constraints, translation along the viewing rays): the 1e-7 noise of
+    # the delta = 1e-9 Jacobians moves it by ~1e-4 from run to run on the device while chi2 repeats to 1e-8
+    # (tools/cfg4_parity.py: 48-49 of 50 within 1e-5, the worst one 0.8-1.6e-4).
+    n = ro.pose_qt.shape[0]
+    assert np.sqrt(np.mean(np.sum((ro.pose_qt[:, 4:] - rh.pose_qt[:, 4:]) ** 2, axis=1))) < 1e-5
+    assert max(rot_angle(ro.pose_qt[i, :4], rh.pose_qt[i, :4]) for i in range(n)) < 1e-6
+    assert np.sqrt(np.mean(np.sum((ro.point_xyz - rh.point_xyz) ** 2, axis=1))) < 1e-5
+    if ro.plane_coef.size:
+        assert np.abs(ro.plane_coef - rh.plane_coef).max() < 1e-6
+    if ro.cuboid_qt.size:
+        d = np.maximum(np.abs(ro.cuboid_qt - rh.cuboid_qt).max(axis=1), np.abs(ro.cuboid_scale - rh.cuboid_scale).max(axis=1))
+        assert np.mean(d < 1e-5) >= 0.95, np.sort(d)[::-1][:5]
+        assert d.max() < 1e-3
+    assert abs(to["iters"][-1]["chi2_after"] - th["iters"][-1]["chi2_after"]) <= 1e-6 * to["iters"][-1]["chi2_after"]
+    o = B.default_options()
+    compare_levels(ro.mono_level, rh.mono_level, ro.mono_chi2, o.chi2_mono)
+    compare_levels(ro.pl_level, rh.pl_level, ro.pl_chi2, o.chi2_plane)
+    assert np.array_equal(ro.bbox_level, rh.bbox_level)
+    so.close(); sh.close()
