@@ -1369,6 +1369,29 @@ __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial
   backsub_body<USE_LDS, LPP>(g, cur, trial, lambda, blockIdx.x, smem, s_red);
 }
 
+// Sharded runs exchange only what the factorisation reads: the lower-triangle 64x64 tiles of S (and b), packed
+// contiguously for ONE all-reduce (half the bytes of the full column-major matrix).  dir = 0: S -> pack, 1: pack -> S.
+__global__ __launch_bounds__(256) void k_pack_lower_tiles(double* __restrict__ S, double* __restrict__ bs, double* __restrict__ pack, int ld, int dir) {
+  int b = blockIdx.x, bi = 0;
+  const int nb = ld / 64, ntiles = nb * (nb + 1) / 2;
+  if (b == ntiles) {  // the right-hand side rides behind the tiles
+    for (int i = threadIdx.x; i < ld; i += 256) {
+      if (dir == 0) pack[(size_t)ntiles * 4096 + i] = bs[i];
+      else bs[i] = pack[(size_t)ntiles * 4096 + i];
+    }
+    return;
+  }
+  while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+  const int bj = b - bi * (bi + 1) / 2;
+  double2* tile = reinterpret_cast<double2*>(&S[(size_t)(bj * 64) * ld + bi * 64]);
+  double2* dst = reinterpret_cast<double2*>(pack + (size_t)b * 4096);
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int c = i >> 5, r2 = i & 31;
+    if (dir == 0) dst[i] = tile[(size_t)c * (ld / 2) + r2];
+    else tile[(size_t)c * (ld / 2) + r2] = dst[i];
+  }
+}
+
 // The whole update of a trial in ONE launch (horizontal fusion; none of the parts reads another's output): cuboid
 // back-substitution + update | pose updates | landmark back-substitution + update | and, since the factor in S is dead once
 // the backward substitution has run, the zeroing of S (lower-triangle 64x64 tiles) and b for the NEXT reduction.

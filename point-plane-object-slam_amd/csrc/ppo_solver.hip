@@ -235,6 +235,7 @@ struct ppo_ba_solver {
   DevBuf<double> d_arena;     // HB | HC | acc | D | bl | W ; a prefix is zeroed before every linearisation
   DevBuf<double> d_Wpc, d_Dinv, d_C, d_ul, d_Z, d_S, d_xr, d_cholws;
   double* d_bs_p = nullptr;  // = d_S.p + ld * ld
+  DevBuf<double> d_pack;     // sharded runs: lower-triangle tiles of S + b, contiguous, for the all-reduce
   DevBuf<int32_t> d_pc_start, d_pc_colj, d_pc_coli, d_pc_sj, d_pc_si;  // pose-pair chunks of the Schur accumulation
   PairChunks pc{};
   DevBuf<int32_t> d_po_start, d_po_end, d_po_pose;  // pose-major chunks of the reprojection edges
@@ -356,7 +357,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
   s->d_Wpc.release(); s->d_Dinv.release(); s->d_C.release(); s->d_ul.release(); s->d_Z.release();
-  s->d_S.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
+  s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release();
@@ -512,8 +513,12 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
-    if (s->comm.sum(s->d_S.p, n * n + n, s->stream)) return PPO_BA_ERR_COMM;  // S and b in one collective
-    // every rank wrote nothing on the padding except the owner: identity there after the sum
+    // ONE collective per solve attempt: the lower-triangle tiles of S and b, packed (the owner's identity on the padding
+    // and lambda on the diagonal are part of its contribution)
+    const int nb = g.ld / 64, ntiles = nb * (nb + 1) / 2;
+    hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 0);
+    if (s->comm.sum(s->d_pack.p, (size_t)ntiles * 4096 + n, s->stream)) return PPO_BA_ERR_COMM;
+    hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 1);
   }
   return PPO_BA_OK;
 }
@@ -1137,7 +1142,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
   ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_C.alloc(nD) && s->d_ul.alloc(nbl) && s->d_Z.alloc(nW);
-  ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);  // S, then b right behind it: ONE all-reduce when sharded
+  ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
+  if (s->comm.active()) ok = ok && s->d_pack.alloc((size_t)(ld / 64) * (ld / 64 + 1) / 2 * 4096 + ld);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
   ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream);
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
