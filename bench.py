@@ -146,7 +146,7 @@ def main():
     lib.ppo_ba_debug_reduced(solver.h, None, None, None, C.byref(n_red))
     b_red = np.zeros(max(1, n_red.value))
     assert lib.ppo_ba_debug_reduced(solver.h, None, b_red.ctypes.data_as(B.c_dp), None, None) == 0  # builds W, Z, C for the Schur kernels
-    for name, which in (("k_linearize_all", 6), ("k_lin_poses", 0), ("k_lin_points", 1), ("k_schur_z", 2), ("k_schur_pairs", 3), ("k_backsub", 4), ("k_chi2_points", 5)):
+    for name, which in (("k_linearize_all", 6), ("k_lin_poses", 0), ("k_lin_points", 1), ("k_schur_pairs", 3), ("k_backsub", 4), ("k_chi2_points", 5)):
         ms_, by_ = C.c_double(), C.c_int64()
         if lib.ppo_ba_time_kernel(solver.h, which, 50, C.byref(ms_), C.byref(by_)) == 0 and ms_.value > 0:
             kernels[name] = {"us": 1e3 * ms_.value, "algorithmic_bytes": int(by_.value), "GBps": by_.value / (ms_.value * 1e-3) / 1e9}

@@ -264,7 +264,7 @@ int ppo_ba_time_linearize(ppo_ba_handle h, int reps, double* ms);
 enum {
   PPO_BA_KERNEL_LIN_POSES = 0,   /* reprojection residual + Jacobians, pose side: W blocks, Hpp, b_p */
   PPO_BA_KERNEL_LIN_POINTS = 1,  /* reprojection residual + Jacobians, landmark side: D, b_l, chi2 */
-  PPO_BA_KERNEL_SCHUR_Z = 2,
+  PPO_BA_KERNEL_SCHUR_Z = 2,     /* retired (folded into the pair kernel): reports 0 ms */
   PPO_BA_KERNEL_SCHUR_PAIRS = 3,
   PPO_BA_KERNEL_BACKSUB = 4,
   PPO_BA_KERNEL_CHI2_POINTS = 5,

@@ -7,7 +7,7 @@
 //   k_lin_numeric<M>  16-lane group per plane / bbox / corner / point-cuboid edge, one lane per Jacobian column,
 //                     central differences through the vertex box-plus exactly like g2o (delta = 1e-9).
 //   k_assemble        reduced system S (lower) <- Hpp + lambda I, Hcc + lambda I, pose-cuboid blocks; bs <- b.
-//   k_schur_prep      thread per landmark: 3x3 Cholesky of D + lambda I -> Linv, Dinv, u = Linv b_l.   k_schur_z: Z = W Linv'.
+//   k_schur_prep      thread per landmark: 3x3 Cholesky of D + lambda I -> Dinv, Dinv b_l.
 //   k_schur_accum     8-lane group per (landmark, pose) slot: S(pj, pi) -= W_j Y_i' with row-contiguous atomics.
 //   [dense Cholesky of S: rocSOLVER or ppo_chol.hpp]
 //   k_update_reduced  poses / cuboids: trial = cur [+] x.      k_backsub: x_l = Dinv (b_l - W' x_p), trial landmarks.
@@ -113,9 +113,7 @@ struct Graph {
   double* Wpc_bbox;    // [n_bbox][54] pose rows x cuboid cols
   double* Wpc_corner;  // [n_corner][54]
   double* Dinv;  // [n_lm][6] (D + lambda I)^-1, packed upper
-  double* C;     // [n_lm][6] inverse Cholesky factor of D + lambda I (i00 i10 i11 i20 i21 i22): Dinv = Linv' Linv
-  double* ul;    // [n_lm][3] Linv b_l
-  double* Z;     // [n_slots][18] W Linv'  (so that W Dinv W' = Z Z'); measured: a plane-by-plane (SoA) layout is slower here
+  double* ul;    // [n_lm][3] (D + lambda I)^-1 b_l
   double* S;     // [n_red][n_red] column-major, lower triangle
   double* bs;    // [n_red]
   double* xr;    // [n_red]
@@ -130,8 +128,7 @@ struct Graph {
   const int32_t* cp_b;
   int n_cub_pairs;
   double* cub_Linv;             // [Nc][81] inverse Cholesky factor of Hcc + lambda I (row-major, lower)
-  double* cub_u;                // [Nc][9]  Linv b_c
-  double* cub_Z;                // [n cuboid edges][54] W Linv' per bbox / corner edge
+  double* cub_Dinv;             // [Nc][81] (Hcc + lambda I)^-1, full symmetric
   double* xc;                   // [Nc][9]  cuboid update
   int pt_first, pt_last, plane_first, plane_last;
   int owns_reduced;  // 1 on the rank that adds Hcc / lambda / cuboid terms
@@ -903,44 +900,23 @@ __device__ __forceinline__ void schur_prep_body(const Graph& g, double lambda, i
   const double i10 = -l10 * i00 * i11;
   const double i21 = -l21 * i11 * i22;
   const double i20 = -(l20 * i00 + l21 * i10) * i22;
-  double* C = &g.C[(size_t)l * 6];
-  C[0] = i00; C[1] = i10; C[2] = i11; C[3] = i20; C[4] = i21; C[5] = i22;
   double* I = &g.Dinv[(size_t)l * 6];
-  I[0] = i00 * i00 + i10 * i10 + i20 * i20; I[1] = i10 * i11 + i20 * i21; I[2] = i20 * i22;
-  I[3] = i11 * i11 + i21 * i21;             I[4] = i21 * i22;             I[5] = i22 * i22;
+  const double v00 = i00 * i00 + i10 * i10 + i20 * i20, v01 = i10 * i11 + i20 * i21, v02 = i20 * i22;
+  const double v11 = i11 * i11 + i21 * i21, v12 = i21 * i22, v22 = i22 * i22;
+  I[0] = v00; I[1] = v01; I[2] = v02; I[3] = v11; I[4] = v12; I[5] = v22;
   const double b0 = g.bl[(size_t)l * 3], b1 = g.bl[(size_t)l * 3 + 1], b2 = g.bl[(size_t)l * 3 + 2];
-  g.ul[(size_t)l * 3] = i00 * b0;
-  g.ul[(size_t)l * 3 + 1] = i10 * b0 + i11 * b1;
-  g.ul[(size_t)l * 3 + 2] = i20 * b0 + i21 * b1 + i22 * b2;
-}
-
-// Z = W Linv' per slot, streamed in slot (pose-major) order; Linv of the slot's landmark is an L2-resident gather.
-__device__ __forceinline__ void schur_z_body(const Graph& g, int vb) {
-  const int s = vb * blockDim.x + threadIdx.x;
-  if (s >= g.n_slots) return;
-  const int l = g.slot_lm[s];
-  const double* C = &g.C[(size_t)l * 6];
-  const double i00 = C[0], i10 = C[1], i11 = C[2], i20 = C[3], i21 = C[4], i22 = C[5];
-  const double2* wp = reinterpret_cast<const double2*>(&g.W[(size_t)s * 18]);
-  double w[18], z[18];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) { const double2 a = wp[q]; w[2 * q] = a.x; w[2 * q + 1] = a.y; }
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    z[a * 3] = w[a * 3] * i00;
-    z[a * 3 + 1] = __builtin_fma(w[a * 3], i10, w[a * 3 + 1] * i11);
-    z[a * 3 + 2] = __builtin_fma(w[a * 3], i20, __builtin_fma(w[a * 3 + 1], i21, w[a * 3 + 2] * i22));
-  }
-  double2* zp = reinterpret_cast<double2*>(&g.Z[(size_t)s * 18]);
-#pragma unroll
-  for (int q = 0; q < 9; ++q) zp[q] = make_double2(z[2 * q], z[2 * q + 1]);
+  g.ul[(size_t)l * 3] = v00 * b0 + v01 * b1 + v02 * b2;  // (D + lambda I)^-1 b_l
+  g.ul[(size_t)l * 3 + 1] = v01 * b0 + v11 * b1 + v12 * b2;
+  g.ul[(size_t)l * 3 + 2] = v02 * b0 + v12 * b1 + v22 * b2;
 }
 
 // Schur accumulation by POSE PAIR.  At create time every (slot_j, slot_i) pair of one landmark (pose_j >= pose_i) is
-// filed under its pose pair and each pair's list is cut into chunks; one thread reduces one chunk into 36 register
-// accumulators, S(pj, pi) -= sum Z_j Z_i', and issues one atomic per entry of the 6x6 block per CHUNK (instead of one
-// per landmark).  Slots are numbered pose-major, so a pair's list walks two contiguous Z segments in order.
-// The self pairs (slot_j == slot_i) also carry the right-hand side: bs(pj) -= Z_j u_l.
+// filed under its pose pair and each pair's list is cut into chunks; one wave reduces one chunk into 36 register
+// accumulators per lane, S(pj, pi) -= sum W_j (D_l + lambda I)^-1 W_i', and issues one atomic per entry of the 6x6 block
+// per CHUNK (instead of one per landmark).  Slots are numbered pose-major, so a pair's list walks two contiguous W
+// segments in order; the 3x3 inverse of the pair's landmark is an L2-resident gather.  (An earlier version first streamed
+// Z = W L^-T to memory in a launch of its own: 73 MB of traffic and 23 us that forming W D^-1 on the fly does not need.)
+// The self pairs (slot_j == slot_i) also carry the right-hand side: bs(pj) -= W_j (D_l + lambda I)^-1 b_l.
 struct PairChunks {
   const int32_t* start;  // [n_chunks+1] into sj / si
   const int32_t* colj;   // [n_chunks] reduced column of pose j (row block of S)
@@ -967,13 +943,22 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
   for (int k = 0; k < 42; ++k) vals[k] = 0.0;
   for (int e = pc.start[t] + lane; e < e1; e += 64) {
     const int sj = pc.sj[e], si = pc.si[e];
-    double w[18], y[18];
-    const double2* wp = reinterpret_cast<const double2*>(&g.Z[(size_t)sj * 18]);
-    const double2* yp = reinterpret_cast<const double2*>(&g.Z[(size_t)si * 18]);
+    const int l = g.slot_lm[sj];
+    double wj[18], y[18], w[18];
+    const double2* wp = reinterpret_cast<const double2*>(&g.W[(size_t)sj * 18]);
+    const double2* yp = reinterpret_cast<const double2*>(&g.W[(size_t)si * 18]);
+    const double* I = &g.Dinv[(size_t)l * 6];
+    const double v00 = I[0], v01 = I[1], v02 = I[2], v11 = I[3], v12 = I[4], v22 = I[5];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       const double2 a = wp[q], b = yp[q];
-      w[2 * q] = a.x; w[2 * q + 1] = a.y; y[2 * q] = b.x; y[2 * q + 1] = b.y;
+      wj[2 * q] = a.x; wj[2 * q + 1] = a.y; y[2 * q] = b.x; y[2 * q + 1] = b.y;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {  // w = W_j (D + lambda I)^-1
+      w[a * 3] = __builtin_fma(wj[a * 3], v00, __builtin_fma(wj[a * 3 + 1], v01, wj[a * 3 + 2] * v02));
+      w[a * 3 + 1] = __builtin_fma(wj[a * 3], v01, __builtin_fma(wj[a * 3 + 1], v11, wj[a * 3 + 2] * v12));
+      w[a * 3 + 2] = __builtin_fma(wj[a * 3], v02, __builtin_fma(wj[a * 3 + 1], v12, wj[a * 3 + 2] * v22));
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -981,10 +966,9 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
       for (int c = 0; c < 6; ++c)
         vals[6 * r + c] = __builtin_fma(w[c * 3], y[r * 3], __builtin_fma(w[c * 3 + 1], y[r * 3 + 1], __builtin_fma(w[c * 3 + 2], y[r * 3 + 2], vals[6 * r + c])));
     if (sj == si) {
-      const int l = g.slot_lm[sj];
-      const double y0 = g.ul[(size_t)l * 3], y1 = g.ul[(size_t)l * 3 + 1], y2 = g.ul[(size_t)l * 3 + 2];
+      const double y0 = g.ul[(size_t)l * 3], y1 = g.ul[(size_t)l * 3 + 1], y2 = g.ul[(size_t)l * 3 + 2];  // (D + lambda I)^-1 b_l
 #pragma unroll
-      for (int c = 0; c < 6; ++c) vals[36 + c] += w[c * 3] * y0 + w[c * 3 + 1] * y1 + w[c * 3 + 2] * y2;
+      for (int c = 0; c < 6; ++c) vals[36 + c] += wj[c * 3] * y0 + wj[c * 3 + 1] * y1 + wj[c * 3 + 2] * y2;
     }
   }
   const int n = g.ld;
@@ -1055,37 +1039,17 @@ __device__ __forceinline__ void cub_prep_body(const Graph& g, double lambda, int
   for (int i = 0; i < 9; ++i)
 #pragma unroll
     for (int j = 0; j < 9; ++j) out[i * 9 + j] = (j <= i) ? Li[i][j] : 0.0;
+  double* di = &g.cub_Dinv[(size_t)c * 81];  // (Hcc + lambda I)^-1 = L^-T L^-1, full symmetric storage
 #pragma unroll
-  for (int n = 0; n < 9; ++n) {
-    double v = 0.0;
+  for (int a = 0; a < 9; ++a)
 #pragma unroll
-    for (int m = 0; m <= n; ++m) v += Li[n][m] * hc[45 + m];
-    g.cub_u[(size_t)c * 9 + n] = v;
-  }
-}
-__device__ __forceinline__ void cub_make_Z(const double* W, const double* Li, double (*Z)[9]) {  // Z = W Linv'
-  for (int a = 0; a < 6; ++a)
-    for (int n = 0; n < 9; ++n) {
+    for (int b = 0; b <= a; ++b) {
       double v = 0.0;
-      for (int m = 0; m <= n; ++m) v += W[a * 9 + m] * Li[n * 9 + m];
-      Z[a][n] = v;
+#pragma unroll
+      for (int k = a; k < 9; ++k) v += Li[k][a] * Li[k][b];
+      di[a * 9 + b] = v;
+      di[b * 9 + a] = v;
     }
-}
-// Z = W Linv' of one cuboid edge: one thread per (edge, row)
-__device__ __forceinline__ void cub_z_body(const Graph& g, int vb) {
-  const int t = vb * blockDim.x + threadIdx.x;
-  const int q = t / 6, a = t - 6 * q;
-  if (q >= g.cub_edge_off[g.n_cuboids]) return;
-  const int code = g.cub_edges[q];
-  const CubEdge& e = cub_edge_of(g, code);
-  const double* W = wpc_of(g, code) + a * 9;
-  const double* Li = &g.cub_Linv[(size_t)e.cuboid * 81];
-  double* Z = &g.cub_Z[(size_t)q * 54 + a * 9];
-  for (int n = 0; n < 9; ++n) {
-    double v = 0.0;
-    for (int m = 0; m <= n; ++m) v += W[m] * Li[n * 9 + m];
-    Z[n] = v;
-  }
 }
 // S -= Z_a Z_b' for every (edge a >= edge b) pair of one cuboid: 8 lanes per pair, lane i < 6 owns row i of the block,
 // so the six lanes of a pair hit six consecutive addresses per column (one atomic line-op)
@@ -1101,10 +1065,16 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
   if (!(ea.flags & F_ACTIVE) || !(eb.flags & F_ACTIVE)) return;
   const int cola = g.pose_col[ea.pose], colb = g.pose_col[eb.pose];
   if (cola < 0 || colb < 0) return;
-  const double* Za = &g.cub_Z[(size_t)qa * 54 + i * 9];
-  const double* Zb = &g.cub_Z[(size_t)qb * 54];
+  // row i of W_a (Hcc + lambda I)^-1, formed on the fly (the cuboid blocks are tiny and L2-resident)
+  const double* Wa = wpc_of(g, ca) + i * 9;
+  const double* Di = &g.cub_Dinv[(size_t)c * 81];
+  const double* Zb = wpc_of(g, cb);
   double za[9];
-  for (int q = 0; q < 9; ++q) za[q] = Za[q];
+  for (int q = 0; q < 9; ++q) {
+    double v = 0.0;
+    for (int m = 0; m < 9; ++m) v += Wa[m] * Di[m * 9 + q];
+    za[q] = v;
+  }
   const bool self = qa == qb;
   const int n = g.ld;
   for (int j = 0; j < 6; ++j) {
@@ -1122,7 +1092,7 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
     }
   }
   if (self) {
-    const double* u = &g.cub_u[(size_t)c * 9];
+    const double* u = &g.HC[(size_t)c * 54 + 45];  // b_c
     double v = 0.0;
     for (int q = 0; q < 9; ++q) v += za[q] * u[q];
     atomicAdd(&g.bs[cola + i], -v);
@@ -1131,13 +1101,12 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
 
 
 // ---- the reduction to the pose system in three launches (horizontal fusion of independent parts) ---------------------------
-// stage 1: assemble Hpp + lambda I into S | factor the landmark blocks | factor the cuboid blocks
-// stage 2: Z = W L^-T per (landmark, pose) slot | per cuboid edge
-// stage 3: S -= Z Z^T over pose pairs (wave per pair chunk) | over cuboid edge pairs
+// stage 1: assemble Hpp + lambda I into S | invert the landmark blocks | invert the cuboid blocks
+// stage 3: S -= W D^-1 W^T over pose pairs (wave per pair chunk) | over cuboid edge pairs
+// (there is no stage 2 any more: it streamed Z = W L^-T to memory)
 // The cuboid parts are tiny; as separate kernels on a side stream their fork/join events cost more than they hid.
 struct ReducePlan {
   int nb_asm, nb_prep, nb_cubprep;
-  int nb_z, nb_cubz;
   int nb_pairs, nb_cubschur;
 };
 __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp) {
@@ -1148,11 +1117,6 @@ __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, R
   if (b < rp.nb_prep) { schur_prep_body(g, lambda, b); return; }
   cub_prep_body(g, lambda, b - rp.nb_prep);
 }
-__global__ __launch_bounds__(256) void k_reduce_stage2(Graph g, ReducePlan rp) {
-  const int b = blockIdx.x;
-  if (b < rp.nb_z) { schur_z_body(g, b); return; }
-  cub_z_body(g, b - rp.nb_z);
-}
 __global__ __launch_bounds__(256) void k_reduce_stage3(Graph g, PairChunks pc, ReducePlan rp) {
   __shared__ double s_buf[4][21][65];
   const int b = blockIdx.x;
@@ -1160,7 +1124,6 @@ __global__ __launch_bounds__(256) void k_reduce_stage3(Graph g, PairChunks pc, R
   cub_schur_body(g, b - rp.nb_pairs);
 }
 // single-part wrappers (measurement hooks)
-__global__ __launch_bounds__(256) void k_schur_z(Graph g) { schur_z_body(g, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
   __shared__ double s_buf[4][21][65];
   schur_pairs_body(g, pc, blockIdx.x, gridDim.x, s_buf);

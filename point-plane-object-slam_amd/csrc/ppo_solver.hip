@@ -233,7 +233,7 @@ struct ppo_ba_solver {
   DevBuf<double> d_state[2];  // two copies of all estimates (current / trial)
   DevBuf<double> d_init;      // pristine estimates for reset()
   DevBuf<double> d_arena;     // HB | HC | acc | D | bl | W ; a prefix is zeroed before every linearisation
-  DevBuf<double> d_Wpc, d_Dinv, d_C, d_ul, d_Z, d_S, d_xr, d_cholws;
+  DevBuf<double> d_Wpc, d_Dinv, d_ul, d_S, d_xr, d_cholws;
   double* d_bs_p = nullptr;  // = d_S.p + ld * ld
   DevBuf<double> d_pack;     // sharded runs: lower-triangle tiles of S + b, contiguous, for the all-reduce
   DevBuf<int32_t> d_pc_start, d_pc_colj, d_pc_coli, d_pc_sj, d_pc_si;  // pose-pair chunks of the Schur accumulation
@@ -242,7 +242,7 @@ struct ppo_ba_solver {
   PoseChunks posec{};
   DevBuf<double> d_W;
   DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cp_cub, d_cp_a, d_cp_b;  // cuboid elimination plan
-  DevBuf<double> d_cub_Linv, d_cub_u, d_xc, d_cub_Z;
+  DevBuf<double> d_cub_Linv, d_cub_Dinv, d_xc;
   DevBuf<int> d_info;
   size_t state_doubles = 0;
   double* h_pinned = nullptr;  // mapped host memory: ACC_N doubles, the factorisation info (as a double), a sequence number
@@ -356,12 +356,12 @@ void free_all(ppo_ba_solver* s) {
   s->d_mono.release(); s->d_stereo.release(); s->d_pl.release(); s->d_bbox.release(); s->d_corner.release(); s->d_ptcub.release();
   s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
-  s->d_Wpc.release(); s->d_Dinv.release(); s->d_C.release(); s->d_ul.release(); s->d_Z.release();
+  s->d_Wpc.release(); s->d_Dinv.release(); s->d_ul.release();
   s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release();
-  s->d_cub_Linv.release(); s->d_cub_u.release(); s->d_xc.release(); s->d_cub_Z.release();
+  s->d_cub_Linv.release(); s->d_cub_Dinv.release(); s->d_xc.release();
   if (s->blas) rocblas_destroy_handle(s->blas);
   s->comm.destroy();
   if (s->stream) {  // hand the (drained) streams, events and mapped host block back
@@ -504,12 +504,9 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
   rp.nb_asm = nblk(work, 256);
   rp.nb_prep = nl > 0 ? nblk(nl, 256) : 0;
   rp.nb_cubprep = cub_stage ? nblk(g.n_cuboids, 256) : 0;
-  rp.nb_z = (nl > 0 && g.n_slots > 0) ? nblk(g.n_slots, 256) : 0;
-  rp.nb_cubz = (cub_stage && s->n_cub_edges > 0) ? nblk((long)s->n_cub_edges * 6, 256) : 0;
   rp.nb_pairs = (nl > 0 && s->pc.n_chunks > 0) ? (nblk(s->pc.n_chunks, 4) + 7) / 8 * 8 : 0;
   rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? nblk((long)g.n_cub_pairs * 8, 256) : 0;
   hipLaunchKernelGGL(k_reduce_stage1, dim3(rp.nb_asm + rp.nb_prep + rp.nb_cubprep), dim3(256), 0, s->stream, g, lambda, rp);
-  if (rp.nb_z + rp.nb_cubz > 0) hipLaunchKernelGGL(k_reduce_stage2, dim3(rp.nb_z + rp.nb_cubz), dim3(256), 0, s->stream, g, rp);
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
@@ -873,7 +870,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   slot_off[g.n_lm] = (int32_t)slot_col.size();
   g.n_slots = (int)slot_col.size();
   // device numbering is POSE-MAJOR: point slots ordered by (pose column, point), then plane slots by (pose column, plane),
-  // so that everything a keyframe touches is contiguous (k_lin_poses, k_schur_z, k_schur_pairs stream it)
+  // so that everything a keyframe touches is contiguous (the pose side of the linearisation and the Schur pair kernel stream it)
   const int n_point_slots = slot_off[Npt];
   std::vector<int32_t> new_id(g.n_slots), d_slot_col_v(g.n_slots), d_slot_lm_v(g.n_slots);
   {
@@ -1141,13 +1138,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_arena.alloc(nHB + nHC + ACC_N + nD + nbl) && s->d_W.alloc(nW);
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
-  ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_C.alloc(nD) && s->d_ul.alloc(nbl) && s->d_Z.alloc(nW);
+  ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
   ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
   if (s->comm.active()) ok = ok && s->d_pack.alloc((size_t)(ld / 64) * (ld / 64 + 1) / 2 * 4096 + ld);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
   ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream);
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
-  ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_u.alloc((size_t)Nc * 9) && s->d_xc.alloc((size_t)Nc * 9) && s->d_cub_Z.alloc(cub_edges.size() * 54);
+  ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_Dinv.alloc((size_t)Nc * 81) && s->d_xc.alloc((size_t)Nc * 9);
   ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
   ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream);
   s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, (int)pc_colj.size()};
@@ -1155,8 +1152,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (!ok) return fail(PPO_BA_ERR_NOMEM);
   {  // blocks come from the cache with stale contents: the work arrays that are only partially written start from zero
     auto zero = [&](auto& b) { if (b.p && b.n) (void)hipMemsetAsync(b.p, 0, b.n * sizeof(*b.p), s->stream); };
-    zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_C); zero(s->d_ul); zero(s->d_Z); zero(s->d_xr); zero(s->d_cholws);
-    zero(s->d_cub_Linv); zero(s->d_cub_u); zero(s->d_xc); zero(s->d_cub_Z); zero(s->d_S);
+    zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_ul); zero(s->d_xr); zero(s->d_cholws);
+    zero(s->d_cub_Linv); zero(s->d_cub_Dinv); zero(s->d_xc); zero(s->d_S);
   }
   static_assert(ACC_N + 2 <= kPinnedDoubles, "mapped host block too small");
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
@@ -1192,8 +1189,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   g.Wpc_bbox = s->d_Wpc.p; g.Wpc_corner = s->d_Wpc.p + (size_t)p->n_bbox * 54;
   g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p;
-  g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_u = s->d_cub_u.p; g.xc = s->d_xc.p; g.cub_Z = s->d_cub_Z.p;
-  g.Dinv = s->d_Dinv.p; g.C = s->d_C.p; g.ul = s->d_ul.p; g.Z = s->d_Z.p; s->d_bs_p = s->d_S.p + (size_t)ld * ld; g.S = s->d_S.p; g.bs = s->d_bs_p; g.xr = s->d_xr.p;
+  g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_Dinv = s->d_cub_Dinv.p; g.xc = s->d_xc.p;
+  g.Dinv = s->d_Dinv.p; g.ul = s->d_ul.p; s->d_bs_p = s->d_S.p + (size_t)ld * ld; g.S = s->d_S.p; g.bs = s->d_bs_p; g.xr = s->d_xr.p;
   s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
   s->st[1] = make_state(s->d_state[1].p, Np, Npt, Npl, Nc);
 
@@ -1490,10 +1487,7 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
         if (s->use_lds) hipLaunchKernelGGL(k_lin_points<true>, dim3(std::min(nblk(4L * npts, 256), 4 * s->n_cu)), dim3(256), s->lds_bytes, s->stream, g, st);
         else hipLaunchKernelGGL(k_lin_points<false>, dim3(std::min(nblk(4L * npts, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, g, st);
         return true;
-      case PPO_BA_KERNEL_SCHUR_Z:
-        if (g.n_slots <= 0) return false;
-        hipLaunchKernelGGL(k_schur_z, dim3(nblk(g.n_slots, 256)), dim3(256), 0, s->stream, g);
-        return true;
+      case PPO_BA_KERNEL_SCHUR_Z: return false;  // (the Z = W L^-T pass no longer exists: folded into the pair kernel)
       case PPO_BA_KERNEL_SCHUR_PAIRS:
         if (s->pc.n_chunks <= 0) return false;
         hipLaunchKernelGGL(k_schur_pairs, dim3((nblk(s->pc.n_chunks, 4) + 7) / 8 * 8), dim3(256), 0, s->stream, g, s->pc);
@@ -1524,8 +1518,8 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
     case PPO_BA_KERNEL_LIN_POINTS:  // landmark-major record + flag + chi2 per edge; point in, D + b_l out
       bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4 + 8) + (long)g.n_stereo * (sizeof(StereoEdge) + 4 + 8) + 96L * npts + 136L * g.n_poses;
       break;
-    case PPO_BA_KERNEL_SCHUR_Z: bytes = 288L * g.n_slots + 48L * nl; break;
-    case PPO_BA_KERNEL_SCHUR_PAIRS: bytes = 144L * g.n_slots + 24L * nl + 8L * ((long)g.n_red * (g.n_red + 1) / 2 + g.n_red); break;
+    case PPO_BA_KERNEL_SCHUR_Z: bytes = 0; break;
+    case PPO_BA_KERNEL_SCHUR_PAIRS: bytes = 144L * g.n_slots + 72L * nl + 8L * ((long)g.n_red * (g.n_red + 1) / 2 + g.n_red); break;  // W once, Dinv + v per landmark, S + b
     case PPO_BA_KERNEL_BACKSUB: bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4) + (long)g.n_stereo * (sizeof(StereoEdge) + 4) + 96L * nl + 8L * g.n_red; break;
     case PPO_BA_KERNEL_LINEARIZE_ALL: bytes = s->lin_bytes; break;
     case PPO_BA_KERNEL_CHI2_POINTS: bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4 + 8) + (long)g.n_stereo * (sizeof(StereoEdge) + 4 + 8) + 24L * npts + 136L * g.n_poses; break;

@@ -299,6 +299,9 @@ def test_kernel_timing_hook_reports_every_kernel(hip):
     for which in range(7):
         ms, by = C.c_double(), C.c_int64()
         assert hip.lib.ppo_ba_time_kernel(s.h, which, 3, C.byref(ms), C.byref(by)) == 0
+        if which == 2:  # PPO_BA_KERNEL_SCHUR_Z is retired (folded into the pair kernel)
+            assert ms.value == 0
+            continue
         assert ms.value > 0 and by.value > 0, which
     assert hip.lib.ppo_ba_time_kernel(s.h, 99, 3, C.byref(ms), C.byref(by)) != 0
     s.close()
