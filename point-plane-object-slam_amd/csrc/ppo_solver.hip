@@ -947,8 +947,18 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   });
 
   // ---- edge records -----------------------------------------------------------------------------------------
+  // (independent per edge: large blocks are filled by a few host threads; this was the longest phase of create)
+  auto parallel_for = [](int n, auto&& body) {
+    const int nt = n >= 40000 ? 4 : 1;
+    if (nt == 1) { body(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body((int)((long)n * t / nt), (int)((long)n * (t + 1) / nt)); });
+    body(0, (int)((long)n / nt));
+    for (auto& x : th) x.join();
+  };
   s->h_mono.resize(p->n_mono);
-  for (int k = 0; k < p->n_mono; ++k) {
+  parallel_for(p->n_mono, [&](int k0, int k1) {
+  for (int k = k0; k < k1; ++k) {
     const int e = s->mono_perm[k];
     MonoEdge& m = s->h_mono[k];
     m.u = p->mono_obs[2 * e]; m.v = p->mono_obs[2 * e + 1]; m.info = p->mono_info[e]; m.huber = p->mono_huber[e];
@@ -958,8 +968,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
     m.point = p->mono_point[e];
   }
+  });
   s->h_stereo.resize(p->n_stereo);
-  for (int k = 0; k < p->n_stereo; ++k) {
+  parallel_for(p->n_stereo, [&](int k0, int k1) {
+  for (int k = k0; k < k1; ++k) {
     const int e = s->stereo_perm[k];
     StereoEdge& m = s->h_stereo[k];
     std::memset(&m, 0, sizeof(m));
@@ -971,6 +983,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     const bool all_fixed = point_fixed[p->stereo_point[e]] && pose_col[m.pose] < 0;
     m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
   }
+  });
   s->h_pl.resize(p->n_plane_edges);
   for (int e = 0; e < p->n_plane_edges; ++e) {
     PlaneEdge& m = s->h_pl[e];
