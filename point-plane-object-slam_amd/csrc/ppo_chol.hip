@@ -342,23 +342,27 @@ __device__ __forceinline__ void solve_rhs_row(double (*sB)[LP], int kk, const do
 
 // ------------------------------------------------------------------------------------------------------------------
 // chol_step(k): ONE launch per 64-wide panel.  With m = (ld - k0) / 64 block rows left, the grid is
-//   * m "column" workgroups (blockIdx < m, block row b): apply the rank-64 update of the PREVIOUS panel (k0 - 64) to the
-//     diagonal block (k,k) and to their own block (k+b, k), factor the diagonal block (every workgroup redundantly, in LDS),
-//     solve their block against it, carry the right-hand side along as a 65th row;
+//   * 1 + 2 (m - 1) "column" workgroups: workgroup 0 owns the diagonal block (k,k); each block row below is split into two
+//     32-row halves, one workgroup each.  They apply the rank-64 update of the PREVIOUS panel (k0 - 64) to the diagonal block
+//     and to their own half block (look-ahead by one), factor the diagonal block (every workgroup redundantly, in LDS), solve
+//     their half against it, and carry the right-hand side along as a 65th row;
 //   * m (m - 1) / 2 "trailing" workgroups: apply the previous panel's update to one 64x64 tile (i >= j > k) each.
-// The serial part is the chain of four 16x16 register factorisations on wave 0 (~2 us each).  Everything else a column
-// workgroup has to do -- the rest of the diagonal block's update, the update of its own block and the block substitution
-// -- is MFMA work cut into jobs of <= 32 MFMAs and run by waves 1..3 in the shadow of those factorisations:
+// The serial part is the chain of four 16x16 register factorisations on wave 0 (~1.8 us each).  Everything else a column
+// workgroup has to do -- the rest of the diagonal block's update, the update of its own rows and the block substitution
+// -- is MFMA work cut into 16-MFMA jobs and run by waves 1..3 in the shadow of those factorisations (r0, r1 = the two
+// 16-row tiles of the own half):
 //                 wave 1                           wave 2                           wave 3
-//   potf2(0)  D(1,1) D(2,1)  U(0,0)            D(2,2) D(3,1)  U(0,1)            D(3,2) D(3,3)  U(0,2)
-//   potf2(1)  U(0,3) S0(row 0) U(1,0)          U(1,1) U(1,2) U(1,3)             U(2,0) U(2,1) U(2,2)  R0
-//   potf2(2)  U(2,3) S0(row 2) S1(row 0)       U(3,0) U(3,1) S0(row 1)          U(3,2) U(3,3)  R1
-//   potf2(3)  S0 S1 S2 (row 3)                 S1 S2 (row 1)  S1 S2 (row 2)     S2(row 0)  R2
-//   after     S3(row w) on wave w, R3 on wave 3
-// (at most 48 MFMAs per wave and phase: v_mfma_f64_16x16x4 issues every 64 cycles whatever the chaining, so 48 of them
-// plus their LDS traffic is what fits behind one ~2.1 us register factorisation)
-// D = panel update of a diagonal-block tile, U = of an own-block tile, Ss = substitution step s of an own-block row,
-// Rs = step s of the right-hand-side row.  (Before potf2(0) all four waves update block column 0 of the diagonal block.)
+//   before    D(w,0) on wave w (all four): block column 0 of the diagonal block, what potf2(0) needs
+//   potf2(0)  D(1,1)  U(r0,0)                  D(2,1)  U(r0,1)                  D(3,1)  U(r0,2)
+//   potf2(1)  U(r0,3)  S0(r0)                  D(2,2)  U(r1,0)                  D(3,2)  U(r1,1)
+//   potf2(2)  U(r1,2)  S1(r0)                  D(3,3)  U(r1,3)                  R0  R1
+//   potf2(3)  S0(r1) S1(r1) S2(r1)             S2(r0)                           R2
+//   after     S3(r0) on wave 0, S3(r1) on wave 1, R3 on wave 3
+// D = panel update of a diagonal-block tile, U = of an own-block tile, Ss = substitution step s of an own 16-row tile,
+// Rs = step s of the right-hand-side row.  v_mfma_f64_16x16x4 issues every 64 cycles whatever the chaining, and a side
+// wave reaches ~60 % of that with its LDS traffic: with whole 64-row blocks per workgroup (<= 48 MFMAs per wave and phase)
+// the phases were bound by the side waves (2.3 us); with halves (<= 36) they are bound by the factorisation again
+// (1.8 us), and the kernel went from 16 to 13.5 us per panel at n = 1216.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info) {
   __shared__ double sL[NB][LP];
@@ -373,10 +377,11 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
   const int kp = k0 - NB;  // previous panel's column
   const bool upd = k0 > 0;
   STAMP(0);
-  if ((int)blockIdx.x >= m) {
+  const int ncol = 1 + 2 * (m - 1);  // column workgroups of this launch
+  if ((int)blockIdx.x >= ncol) {
     // ---- trailing tile (bi >= bj >= 1 relative to block k) --------------------------------------------------------------
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    int t = blockIdx.x - m, bi = 0;
+    int t = blockIdx.x - ncol, bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     const int bj = t - bi * (bi + 1) / 2;
     const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
@@ -410,25 +415,32 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
         }
     return;
   }
-  // ---- column workgroup ---------------------------------------------------------------------------------------------------
-  const int b = blockIdx.x;
+  // ---- column workgroup: workgroup 0 owns the diagonal block, workgroups 1 + 2 (b - 1) + h the row halves h = 0, 1 of block b ----
+  const int cw = blockIdx.x;
+  const int b = cw == 0 ? 0 : 1 + ((cw - 1) >> 1);
+  const int half = cw == 0 ? 0 : ((cw - 1) & 1);
+  const int r0t = 2 * half, r1t = 2 * half + 1;  // the two 16-row tiles of the own half
   const int row0 = k0 + b * NB;
   const bool own = b > 0;
   const bool uo = own && upd;
   // step 0 takes the right-hand side from rhs_in (the caller's b stays intact), later steps continue in rhs
   const double* rsrc = (k0 == 0) ? rhs_in : rhs;
   {
-    // All four tiles are requested unconditionally and back to back (a tile that is not needed aliases the diagonal one):
-    // with the loads under `if`s the compiler drained each group before issuing the next, four memory round trips in a row.
-    double2 td[8], tb[8], tp[8], tq[8];
+    // Everything is requested unconditionally and back to back (what is not needed aliases the diagonal tile): with the
+    // loads under `if`s the compiler drained each group before issuing the next, four memory round trips in a row.
+    double2 td[8], tq[8], tb[4], tp[4];
     const double* pC = &A[(size_t)k0 * ld + k0];
     const double* pQ = upd ? &A[(size_t)kp * ld + k0] : pC;   // L[k][k-1]
     const double* pB = own ? &A[(size_t)k0 * ld + row0] : pC;
     const double* pP = uo ? &A[(size_t)kp * ld + row0] : pC;  // L[k+b][k-1]
     load_tile(pC, ld, td);
     load_tile(pQ, ld, tq);
-    load_tile(pB, ld, tb);
-    load_tile(pP, ld, tp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // the own half: 32 rows x 64 columns, 16 double2 per column
+      const int p = tid + 256 * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
+      tb[i] = *reinterpret_cast<const double2*>(&pB[(size_t)c * ld + r]);
+      tp[i] = *reinterpret_cast<const double2*>(&pP[(size_t)c * ld + r]);
+    }
     const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
     STAMP(6);
 #pragma unroll
@@ -439,8 +451,8 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
       *reinterpret_cast<double2*>(&sQ[c][r]) = tq[i];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + 256 * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
       sB[r][c] = tb[i].x;
       sB[r + 1][c] = tb[i].y;
       *reinterpret_cast<double2*>(&sP[c][r]) = tp[i];
@@ -464,41 +476,36 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
       const int bad = potf2_16(sL, sT[kk], sId, o, true);
       if (lane == 0 && bad && sBad == 0) sBad = o + bad;
     } else if (kk == 0) {
-      if (upd) {
-        if (wave == 1) tile_update2(sL, 1, 1, true, 2, 1, false, sQ, sQ);
-        if (wave == 2) tile_update2(sL, 2, 2, true, 3, 1, false, sQ, sQ);
-        if (wave == 3) tile_update2(sL, 3, 2, false, 3, 3, true, sQ, sQ);
-      }
-      if (uo) tile_update1(sB, 0, wave - 1, false, sP, sQ);
+      if (upd) tile_update1(sL, wave, 1, wave == 1, sQ, sQ);  // D(1,1) D(2,1) D(3,1): what the next factorisation needs
+      if (uo) tile_update1(sB, r0t, wave - 1, false, sP, sQ);
     } else if (kk == 1) {
       if (wave == 1) {
-        if (uo) tile_update1(sB, 0, 3, false, sP, sQ);
-        if (own) solve_rows<0>(sB, 0, sL, sT);
-        if (uo) tile_update1(sB, 1, 0, false, sP, sQ);
+        if (uo) tile_update1(sB, r0t, 3, false, sP, sQ);
+        if (own) solve_rows<0>(sB, r0t, sL, sT);
       } else if (wave == 2) {
-        if (uo) { tile_update2(sB, 1, 1, false, 1, 2, false, sP, sQ); tile_update1(sB, 1, 3, false, sP, sQ); }
+        if (upd) tile_update1(sL, 2, 2, true, sQ, sQ);
+        if (uo) tile_update1(sB, r1t, 0, false, sP, sQ);
       } else {
-        if (uo) { tile_update2(sB, 2, 0, false, 2, 1, false, sP, sQ); tile_update1(sB, 2, 2, false, sP, sQ); }
-        solve_rhs_row(sB, 0, sL, sT);
+        if (upd) tile_update1(sL, 3, 2, false, sQ, sQ);
+        if (uo) tile_update1(sB, r1t, 1, false, sP, sQ);
       }
     } else if (kk == 2) {
       if (wave == 1) {
-        if (uo) tile_update1(sB, 2, 3, false, sP, sQ);
-        if (own) { solve_rows<0>(sB, 2, sL, sT); solve_rows<1>(sB, 0, sL, sT); }
+        if (uo) tile_update1(sB, r1t, 2, false, sP, sQ);
+        if (own) solve_rows<1>(sB, r0t, sL, sT);
       } else if (wave == 2) {
-        if (uo) tile_update2(sB, 3, 0, false, 3, 1, false, sP, sQ);
-        if (own) solve_rows<0>(sB, 1, sL, sT);
+        if (upd) tile_update1(sL, 3, 3, true, sQ, sQ);
+        if (uo) tile_update1(sB, r1t, 3, false, sP, sQ);
       } else {
-        if (uo) tile_update2(sB, 3, 2, false, 3, 3, false, sP, sQ);
+        solve_rhs_row(sB, 0, sL, sT);
         solve_rhs_row(sB, 1, sL, sT);
       }
     } else {
       if (wave == 1) {
-        if (own) { solve_rows<0>(sB, 3, sL, sT); solve_rows<1>(sB, 3, sL, sT); solve_rows<2>(sB, 3, sL, sT); }
+        if (own) { solve_rows<0>(sB, r1t, sL, sT); solve_rows<1>(sB, r1t, sL, sT); solve_rows<2>(sB, r1t, sL, sT); }
       } else if (wave == 2) {
-        if (own) { solve_rows<1>(sB, 1, sL, sT); solve_rows<2>(sB, 1, sL, sT); solve_rows<1>(sB, 2, sL, sT); solve_rows<2>(sB, 2, sL, sT); }
+        if (own) solve_rows<2>(sB, r0t, sL, sT);
       } else {
-        if (own) solve_rows<2>(sB, 0, sL, sT);
         solve_rhs_row(sB, 2, sL, sT);
       }
     }
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
   }
   const int bad = sBad;
   STAMP(2);
-  if (own) solve_rows<3>(sB, wave, sL, sT);
+  if (own && wave < 2) solve_rows<3>(sB, wave == 0 ? r0t : r1t, sL, sT);
   if (wave == 3) solve_rhs_row(sB, NB / SB - 1, sL, sT);
   __syncthreads();
   STAMP(3);
@@ -537,17 +544,18 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
     if (tid < NB) rhs[k0 + tid] = sB[NB][tid];  // y_k
     return;
   }
-  const double rold = (tid < NB) ? rsrc[row0 + tid] : 0.0;
+  const int myrow = 32 * half + tid;  // (tid < 32) row of the block whose right-hand-side entry this thread updates
+  const double rold = (tid < 32) ? rsrc[row0 + myrow] : 0.0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
+  for (int i = 0; i < 4; ++i) {
+    const int p = tid + 256 * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
     *reinterpret_cast<double2*>(&A[(size_t)(k0 + c) * ld + row0 + r]) = make_double2(sB[r][c], sB[r + 1][c]);
   }
-  if (tid < NB) {  // r_b -= L_bk y_k
+  if (tid < 32) {  // r_b -= L_bk y_k
     double sacc = 0.0;
 #pragma unroll 16
-    for (int mm = 0; mm < NB; ++mm) sacc = __builtin_fma(sB[tid][mm], sB[NB][mm], sacc);
-    rhs[row0 + tid] = rold - sacc;
+    for (int mm = 0; mm < NB; ++mm) sacc = __builtin_fma(sB[myrow][mm], sB[NB][mm], sacc);
+    rhs[row0 + myrow] = rold - sacc;
   }
   STAMP(4);
 }
@@ -667,8 +675,8 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
   const int nb = ld / NB;
   for (int k = 0; k < nb; ++k) {
     const int k0 = k * NB;
-    const int m = nb - k;
-    hipLaunchKernelGGL(chol_step, dim3(m + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(256), 0, s, A, ld, k0, b, ws, x, info);
+    const int m = nb - k;  // column workgroups: 1 (diagonal) + 2 per block row below (row halves); then the trailing tiles
+    hipLaunchKernelGGL(chol_step, dim3(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(256), 0, s, A, ld, k0, b, ws, x, info);
   }
   hipLaunchKernelGGL(chol_back_all, dim3(nb), dim3(256), 0, s, (const double*)A, ld, (const double*)ws, x, info);
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
