@@ -556,7 +556,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 
 // bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
 // can be queued behind the copy before the host blocks on it.
-int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false) {
+int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false, bool record_event = true) {
   if (s->comm.active()) {
     // chi2 and scale are sums over ranks; the max-diagonal (first iteration of a pass only) is a max
     if (s->comm.sum(s->g.acc, 2, s->stream)) return PPO_BA_ERR_COMM;
@@ -570,7 +570,9 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linea
     grid = 1 + (int)std::min<size_t>(std::max<size_t>(1, tot / 2 / 64), (size_t)2 * s->n_cu);
   }
   hipLaunchKernelGGL(k_publish, dim3(grid), dim3(64), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, zp);
-  HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
+  // (the event only backs up the host's spin on the sequence number; an event record costs a ~6 us bubble in the queue, so
+  //  with speculation it is recorded behind the linearisation instead of in front of it)
+  if (record_event) HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
   return PPO_BA_OK;
 }
 int fetch_acc_wait(ppo_ba_solver* s) {
@@ -649,9 +651,10 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     RC_TRY(launch_update(s, lambda));
     RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
     const bool speculated = may_speculate && !stop_requested(stop);
-    RC_TRY(fetch_acc_enqueue(s, true, speculated));
+    RC_TRY(fetch_acc_enqueue(s, true, speculated, false, !speculated));
     if (speculated) {
       RC_TRY(launch_linearize(s, s->cur ^ 1, true));
+      HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
     }
     RC_TRY(fetch_acc_wait(s));
     int info = 0;
