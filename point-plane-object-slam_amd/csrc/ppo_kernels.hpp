@@ -1,17 +1,20 @@
 // ppo_kernels.hpp -- CDNA4 (gfx950, wave64) kernels of one Levenberg-Marquardt iteration.
 //
-// Data flow per LM iteration (DESIGN.md has the byte accounting):
-//   k_lin_points      thread per point, its mono/stereo edges in registers: residual, analytic Jacobians, Huber,
-//                     D_l / b_l written once, W = Jp' w Jl written once per edge, pose blocks accumulated in LDS
-//                     (the camera table is staged in LDS too) and flushed with one global atomic per entry.
-//   k_lin_numeric<M>  16-lane group per plane / bbox / corner / point-cuboid edge, one lane per Jacobian column,
-//                     central differences through the vertex box-plus exactly like g2o (delta = 1e-9).
-//   k_assemble        reduced system S (lower) <- Hpp + lambda I, Hcc + lambda I, pose-cuboid blocks; bs <- b.
-//   k_schur_prep      thread per landmark: 3x3 Cholesky of D + lambda I -> Dinv, Dinv b_l.
-//   k_schur_accum     8-lane group per (landmark, pose) slot: S(pj, pi) -= W_j Y_i' with row-contiguous atomics.
-//   [dense Cholesky of S: rocSOLVER or ppo_chol.hpp]
-//   k_update_reduced  poses / cuboids: trial = cur [+] x.      k_backsub: x_l = Dinv (b_l - W' x_p), trial landmarks.
-//   k_chi2_points / k_chi2_numeric<M>   residual-only pass on the trial state, per-edge chi2 kept (g2o's stored _error).
+// Launches of one LM iteration (DESIGN.md section 4 has the table with bounds, bytes and measured times).  Independent parts
+// are fused HORIZONTALLY: one launch, block ranges select the part, one shared LDS allocation.
+//   k_linearize_all   numerically differentiated edges (16 lanes per plane / bbox / corner / point-cuboid edge, one lane per
+//                     Jacobian column, central differences through the vertex box-plus exactly like g2o, delta = 1e-9)
+//                     | pose side of the reprojection edges (wave per keyframe segment: W = Jp' w Jl, Hpp, b_p)
+//                     | landmark side (4 lanes per point: D_l, b_l, per-edge chi2, robust sum)
+//   k_reduce_stage1   assemble Hpp + lambda I into S | (D_l + lambda I)^-1 per landmark | 9x9 inverse per cuboid
+//   k_reduce_stage3   S -= W_j (D_l + lambda I)^-1 W_i' by pose pair (wave per pair chunk) | cuboid edge pairs
+//   [dense Cholesky of S: ppo_chol.hip (chol_step x ld/64, chol_back_all) or rocSOLVER]
+//   k_update_all      cuboid back-substitution + update | pose updates | landmark back-substitution + update (matrix-free)
+//                     | clearing S for the next reduction
+//   k_chi2_all        residual-only pass on the trial state, per-edge chi2 kept (g2o's stored _error)
+//   k_publish         chi2 / scale / factorisation flag -> mapped host memory (+ clearing for the speculated linearisation)
+// The single-part kernels further down (k_lin_points, k_lin_poses, k_schur_pairs, k_backsub, k_chi2_points) wrap the same
+// bodies for the measurement hook ppo_ba_time_kernel().
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
