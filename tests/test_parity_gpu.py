@@ -8,6 +8,7 @@ delta = 1e-9 on both sides, so their Jacobians carry ~1e-7 relative round-off no
 summation order; system-level comparisons therefore use 1e-5 relative where those edges contribute.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -414,3 +415,24 @@ def test_baseline_configurations_match_the_oracle_at_full_size(oracle, hip, cfg)
     compare_levels(ro.pl_level, rh.pl_level, ro.pl_chi2, o.chi2_plane)
     assert np.array_equal(ro.bbox_level, rh.bbox_level)
     so.close(); sh.close()
+
+
+def test_cpp_caller_through_the_c_abi(hip, tmp_path):
+    """examples/replay.cpp (plain g++, links libppo_ba.so) replays a dumped window: the boundary as a C++ host would use it."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "replay")
+    if not os.path.exists(exe):
+        pytest.skip("examples/replay not built (run __graft_entry__.build())")
+    P = synth.make_problem("small", seed=1)
+    path = tmp_path / "w.ppoba"
+    P.save(path)
+    out = subprocess.run([exe, str(path), "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    s = hip.create(P, B.default_options())
+    st = s.run()
+    s.close()
+    lines = [l for l in out.stdout.splitlines() if l.startswith("  pass")]
+    assert len(lines) == len(st["iters"])
+    last = float(lines[-1].split("->")[1].split()[0])
+    assert abs(last - st["iters"][-1]["chi2_after"]) <= 1e-5 * st["iters"][-1]["chi2_after"]
+    assert "call 1:" in out.stdout
