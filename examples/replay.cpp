@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
               P->n_cuboids, P->n_mono, P->n_stereo, P->n_plane_edges, P->n_bbox);
   ppo_ba_options O;
   ppo_ba_default_options(&O);  // the reference's constants: 5 + 10 iterations, chi2 thresholds, delta = 1e-9
+  if (std::getenv("PPO_BA_VERBOSE")) O.verbose = 1;  // phase times of ppo_ba_create on stderr
   for (int rep = 0; rep < repeats; ++rep) {
     const auto t0 = std::chrono::steady_clock::now();
     ppo_ba_handle h = nullptr;

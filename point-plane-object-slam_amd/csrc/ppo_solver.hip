@@ -161,6 +161,136 @@ struct CtxPool {
 };
 CtxPool g_ctx_pool;
 
+// Host staging memory.  Everything ppo_ba_create builds for the device (edge records, CSR tables, plans) and everything
+// ppo_ba_read brings back lives in page-locked blocks that the process keeps: hipMemcpyAsync from ordinary heap memory has
+// to pin the pages first, and a caller whose malloc trims and regrows the heap between calls (glibc's default, measured
+// from examples/replay.cpp) paid 15-25 ms per create for that against 1.5 ms once the memory was already pinned.
+struct HostPool {
+  std::mutex mu;
+  std::map<size_t, std::vector<void*>> free_;
+  size_t cached = 0;
+  static constexpr size_t kMaxCached = 2ull << 30;
+  void* get(size_t bytes, size_t* got, bool* pinned) {
+    const size_t b = DevPool::bucket(bytes);
+    *got = b;
+    *pinned = true;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_.find(b);
+      if (it != free_.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        cached -= b;
+        return p;
+      }
+    }
+    void* p = nullptr;
+    static const bool heap = getenv("PPO_BA_STAGE_HEAP") != nullptr;  // A/B switch: stage through ordinary heap memory
+    if (!heap && hipHostMalloc(&p, b, hipHostMallocDefault) == hipSuccess) return p;
+    (void)hipGetLastError();
+    *pinned = false;  // page-locked memory exhausted: pageable memory still works, only slower
+    return std::malloc(b);
+  }
+  void put(void* p, size_t b, bool pinned) {
+    if (!pinned) { std::free(p); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (cached + b <= kMaxCached) {
+        free_[b].push_back(p);
+        cached += b;
+        return;
+      }
+    }
+    (void)hipHostFree(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : free_)
+      for (void* p : kv.second) (void)hipHostFree(p);
+    free_.clear();
+    cached = 0;
+  }
+};
+HostPool g_host_pool;
+
+// Bump arena of one solver over HostPool blocks.  Memory is handed out again only after the mark it was taken behind is
+// rewound (ppo_ba_read) or the solver is destroyed, both after the stream has drained, so an asynchronous copy never sees its
+// source reused.  Small requests share 16 MB chunks, large ones get a block of their own.
+struct Stage {
+  struct Block { char* p; size_t cap, used; bool pinned; };
+  struct Mark { size_t n_blocks; int open; size_t open_used; };
+  static constexpr size_t kChunk = 16ull << 20;
+  std::mutex mu;
+  std::vector<Block> blocks;
+  int open = -1;  // chunk the small requests are carved from
+  void* take(size_t bytes) {
+    bytes = std::max<size_t>(256, (bytes + 255) & ~size_t(255));
+    std::lock_guard<std::mutex> lk(mu);
+    if (bytes < kChunk / 2 && open >= 0 && blocks[open].used + bytes <= blocks[open].cap) {
+      void* r = blocks[open].p + blocks[open].used;
+      blocks[open].used += bytes;
+      return r;
+    }
+    Block b;
+    b.p = static_cast<char*>(g_host_pool.get(bytes < kChunk / 2 ? kChunk : bytes, &b.cap, &b.pinned));
+    if (!b.p) return nullptr;
+    b.used = bytes;
+    blocks.push_back(b);
+    if (bytes < kChunk / 2) open = (int)blocks.size() - 1;
+    return b.p;
+  }
+  Mark mark() {
+    std::lock_guard<std::mutex> lk(mu);
+    return Mark{blocks.size(), open, open >= 0 ? blocks[open].used : 0};
+  }
+  void rewind(const Mark& m) {
+    std::lock_guard<std::mutex> lk(mu);
+    while (blocks.size() > m.n_blocks) {
+      g_host_pool.put(blocks.back().p, blocks.back().cap, blocks.back().pinned);
+      blocks.pop_back();
+    }
+    open = m.open;
+    if (open >= 0) blocks[open].used = m.open_used;
+  }
+  void release() { rewind(Mark{0, -1, 0}); }
+};
+thread_local Stage* t_stage = nullptr;  // the arena SVec allocations of this thread go to (set by StageScope)
+
+struct StageScope {  // entry guard of an API call that builds SVecs; rewinds to the entry state when asked to
+  Stage* prev;
+  Stage* st;
+  Stage::Mark m;
+  bool rewind_on_exit;
+  StageScope(Stage* a, bool rewind) : prev(t_stage), st(a), rewind_on_exit(rewind) {
+    t_stage = a;
+    if (rewind) m = a->mark();
+  }
+  ~StageScope() {
+    if (rewind_on_exit) st->rewind(m);
+    t_stage = prev;
+  }
+};
+
+template <class T>
+struct StageAlloc {
+  using value_type = T;
+  StageAlloc() = default;
+  template <class U>
+  StageAlloc(const StageAlloc<U>&) {}
+  T* allocate(size_t n) {
+    void* p = t_stage ? t_stage->take(n * sizeof(T)) : nullptr;
+    if (!p) throw std::bad_alloc();
+    return static_cast<T*>(p);
+  }
+  void deallocate(T*, size_t) {}  // see Stage: a copy enqueued from this memory may still be in flight
+  template <class U>
+  bool operator==(const StageAlloc<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const StageAlloc<U>&) const { return false; }
+};
+template <class T>
+using SVec = std::vector<T, StageAlloc<T>>;
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -176,7 +306,8 @@ struct DevBuf {
     p = static_cast<T*>(g_pool.get(count * sizeof(T), dev, &cap_bytes));
     return p != nullptr;
   }
-  bool upload(const std::vector<T>& h, hipStream_t s) {
+  template <class V>
+  bool upload(const V& h, hipStream_t s) {
     if (!alloc(h.size())) return false;
     if (h.empty()) return true;
     return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess;
@@ -205,15 +336,16 @@ struct ppo_ba_solver {
   int n_cubpl = 0;
   int n_cub_edges = 0;
   // host copies kept after create
-  std::vector<int32_t> mono_perm, stereo_perm;  // sorted position -> caller index
-  std::vector<MonoEdge> h_mono;
-  std::vector<StereoEdge> h_stereo;
-  std::vector<PlaneEdge> h_pl;
-  std::vector<CubEdge> h_bbox, h_corner;
-  std::vector<PtCubEdge> h_ptcub;
-  std::vector<double> cubpl_chi2;  // EdgeCuboidPlane: error == measurement, so chi2 is a constant
+  Stage* stage = nullptr;  // page-locked host arena: every SVec below and in create / read lives here until destroy
+  SVec<int32_t> mono_perm, stereo_perm;  // sorted position -> caller index
+  SVec<MonoEdge> h_mono;
+  SVec<StereoEdge> h_stereo;
+  SVec<PlaneEdge> h_pl;
+  SVec<CubEdge> h_bbox, h_corner;
+  SVec<PtCubEdge> h_ptcub;
+  SVec<double> cubpl_chi2;  // EdgeCuboidPlane: error == measurement, so chi2 is a constant
   double cubpl_rho_sum = 0.0;      // its robustified sum: a constant term of every chi2
-  std::vector<int32_t> h_slot_off;
+  SVec<int32_t> h_slot_off;
   // device
   DevBuf<double> d_pose_cam, d_cub_fixedscale, d_ptcub_pts;
   DevBuf<int32_t> d_pose_col, d_pose_free_id, d_cub_col, d_mo_off, d_st_off, d_slot_col, d_slot_lm, d_pl_slot_off, d_pl_slots;
@@ -370,6 +502,11 @@ void free_all(ppo_ba_solver* s) {
     c.h_pinned = s->h_pinned; c.h_pinned_dev = s->h_pinned_dev;
     g_ctx_pool.put(c);
     s->stream = s->side = nullptr;
+  }
+  if (s->stage) {  // (the SVec members never touch their memory again: their deallocate is a no-op)
+    s->stage->release();
+    delete s->stage;
+    s->stage = nullptr;
   }
 }
 
@@ -620,7 +757,6 @@ bool stop_requested(const volatile uint8_t* f) { return f && *f; }
 // the common case), so the device never idles on the host's decision; a rejected trial re-linearises the kept state.
 // `may_speculate` is false on the last iteration of a pass (the outlier classification or the caller comes next).
 int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const volatile uint8_t* stop, ppo_ba_iter_stat& it) {
-  Graph& g = s->g;
   const bool fresh = !s->lin_valid;
   if (fresh) {
     RC_TRY(launch_linearize(s));
@@ -726,7 +862,7 @@ extern "C" {
 
 int ppo_ba_version(void) { return PPO_BA_ABI_VERSION; }
 
-int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handle* out) {
+int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handle* out) try {
   if (!p || !o || !out) return PPO_BA_ERR_ARG;
   *out = nullptr;
   if (o->abi_version != PPO_BA_ABI_VERSION) return PPO_BA_ERR_ARG;
@@ -746,6 +882,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (!s) return PPO_BA_ERR_NOMEM;
   s->opt = *o;
   s->device = o->device_id;
+  s->stage = new Stage();
+  StageScope stage_scope(s->stage, false);  // what create builds stays until destroy: the uploads below read it asynchronously
   auto fail = [&](int code) { free_all(s); delete s; return code; };
   if (hipSetDevice(s->device) != hipSuccess) return fail(PPO_BA_ERR_HIP);
   {
@@ -782,7 +920,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   const int Np = p->n_poses, Npt = p->n_points, Npl = p->n_planes, Nc = p->n_cuboids;
 
   // ---- which vertices enter the reduced system: non-fixed and touched by at least one edge -----------
-  std::vector<uint8_t> pose_used(Np, 0), cub_used(Nc, 0), point_fixed(Npt, 0);
+  SVec<uint8_t> pose_used(Np, 0), cub_used(Nc, 0), point_fixed(Npt, 0);
   if (p->point_fixed) std::copy(p->point_fixed, p->point_fixed + Npt, point_fixed.begin());
   for (int e = 0; e < p->n_mono; ++e) pose_used[p->mono_pose[e]] = 1;
   for (int e = 0; e < p->n_stereo; ++e) pose_used[p->stereo_pose[e]] = 1;
@@ -790,7 +928,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   for (int e = 0; e < p->n_bbox; ++e) { pose_used[p->bbox_pose[e]] = 1; cub_used[p->bbox_cuboid[e]] = 1; }
   for (int e = 0; e < p->n_corner; ++e) { pose_used[p->corner_pose[e]] = 1; cub_used[p->corner_cuboid[e]] = 1; }
   for (int e = 0; e < p->n_ptcub; ++e) cub_used[p->ptcub_cuboid[e]] = 1;
-  std::vector<int32_t> pose_col(Np, -1), pose_free_id(Np, -1), cub_col(Nc, -1);
+  SVec<int32_t> pose_col(Np, -1), pose_free_id(Np, -1), cub_col(Nc, -1);
   int nfree = 0;
   for (int i = 0; i < Np; ++i)
     if (!p->pose_fixed[i] && pose_used[i]) { pose_free_id[i] = nfree; pose_col[i] = 6 * nfree; ++nfree; }
@@ -820,22 +958,22 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   s->stats.n_reduced = 6 * nfree + 9 * n_cub_used;  // the reference's reduced dimension (cuboids are not marginalised there)
 
   // ---- reprojection edges sorted by point (stable counting sort), CSR offsets -------------------------
-  auto csr_sort = [&](int n, const int32_t* key, std::vector<int32_t>& off, std::vector<int32_t>& perm) {
+  auto csr_sort = [&](int n, const int32_t* key, SVec<int32_t>& off, SVec<int32_t>& perm) {
     off.assign(Npt + 1, 0);
     for (int e = 0; e < n; ++e) off[key[e] + 1]++;
     for (int i = 0; i < Npt; ++i) off[i + 1] += off[i];
     perm.resize(n);
-    std::vector<int32_t> cursor(off.begin(), off.end() - 1);
+    SVec<int32_t> cursor(off.begin(), off.end() - 1);
     for (int e = 0; e < n; ++e) perm[cursor[key[e]]++] = e;
   };
-  std::vector<int32_t> mo_off, st_off;
+  SVec<int32_t> mo_off, st_off;
   csr_sort(p->n_mono, p->mono_point, mo_off, s->mono_perm);
   csr_sort(p->n_stereo, p->stereo_point, st_off, s->stereo_perm);
 
   mark("csr sort");
   // ---- (landmark, pose) slots: unique free poses seen by each free landmark, ascending column ----------
   // flat two-pass layout (count, fill, sort + unique each landmark's short segment in place): no per-landmark allocations
-  std::vector<int32_t> seg_off(g.n_lm + 1, 0), seg_col;
+  SVec<int32_t> seg_off(g.n_lm + 1, 0), seg_col;
   {
     auto visit = [&](auto&& fn) {
       for (int e = 0; e < p->n_mono; ++e) {
@@ -854,12 +992,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     visit([&](int l, int) { seg_off[l + 1]++; });
     for (int l = 0; l < g.n_lm; ++l) seg_off[l + 1] += seg_off[l];
     seg_col.resize(seg_off[g.n_lm]);
-    std::vector<int32_t> cursor(seg_off.begin(), seg_off.end() - 1);
+    SVec<int32_t> cursor(seg_off.begin(), seg_off.end() - 1);
     visit([&](int l, int pc) { seg_col[cursor[l]++] = pc; });
   }
-  std::vector<int32_t>& slot_off = s->h_slot_off;
+  SVec<int32_t>& slot_off = s->h_slot_off;
   slot_off.assign(g.n_lm + 1, 0);
-  std::vector<int32_t> slot_col, slot_lm;
+  SVec<int32_t> slot_col, slot_lm;
   slot_col.reserve(seg_col.size());
   slot_lm.reserve(seg_col.size());
   for (int l = 0; l < g.n_lm; ++l) {
@@ -875,10 +1013,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // device numbering is POSE-MAJOR: point slots ordered by (pose column, point), then plane slots by (pose column, plane),
   // so that everything a keyframe touches is contiguous (the pose side of the linearisation and the Schur pair kernel stream it)
   const int n_point_slots = slot_off[Npt];
-  std::vector<int32_t> new_id(g.n_slots), d_slot_col_v(g.n_slots), d_slot_lm_v(g.n_slots);
+  SVec<int32_t> new_id(g.n_slots), d_slot_col_v(g.n_slots), d_slot_lm_v(g.n_slots);
   {
     auto renumber = [&](int first, int last, int base) {
-      std::vector<int32_t> cntc(ncol / 1 + 2, 0);
+      SVec<int32_t> cntc(ncol / 1 + 2, 0);
       for (int i = first; i < last; ++i) cntc[slot_col[i] + 1]++;
       for (size_t c = 1; c < cntc.size(); ++c) cntc[c] += cntc[c - 1];
       for (int i = first; i < last; ++i) new_id[i] = base + cntc[slot_col[i]]++;
@@ -887,7 +1025,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     renumber(n_point_slots, g.n_slots, n_point_slots);
     for (int i = 0; i < g.n_slots; ++i) { d_slot_col_v[new_id[i]] = slot_col[i]; d_slot_lm_v[new_id[i]] = slot_lm[i]; }
   }
-  std::vector<int32_t> pl_slot_off(Npl + 1, 0), pl_slots(g.n_slots - n_point_slots);
+  SVec<int32_t> pl_slot_off(Npl + 1, 0), pl_slots(g.n_slots - n_point_slots);
   for (int j = 0; j <= Npl; ++j) pl_slot_off[j] = slot_off[Npt + j] - n_point_slots;
   for (int i = n_point_slots; i < g.n_slots; ++i) pl_slots[i - n_point_slots] = new_id[i];
   auto find_slot = [&](int l, int pc) -> int32_t {
@@ -901,7 +1039,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // ---- landmark ownership (multi-GPU): contiguous edge-balanced ranges; rank 0 owns the reduced-only terms ----
   g.pt_first = 0; g.pt_last = Npt; g.plane_first = 0; g.plane_last = Npl; g.owns_reduced = 1;
   if (o->world_size > 1) {
-    std::vector<int32_t> fp(o->world_size + 1), fl(o->world_size + 1);
+    SVec<int32_t> fp(o->world_size + 1), fl(o->world_size + 1);
     if (ppo_ba_partition(p, o->world_size, fp.data(), fl.data()) != PPO_BA_OK) return fail(PPO_BA_ERR_ARG);
     g.pt_first = fp[o->rank]; g.pt_last = fp[o->rank + 1];
     g.plane_first = fl[o->rank]; g.plane_last = fl[o->rank + 1];
@@ -910,12 +1048,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   // ---- Schur accumulation plan: (slot_j, slot_i) pairs of every owned landmark filed by pose pair, then chunked -----
   // (built on a helper thread while this one fills the edge records: both are ~3 ms of host work at the BASELINE size)
-  std::vector<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si;
+  SVec<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si;
   std::thread pair_plan_thread([&]()   {
+    t_stage = s->stage;
     const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
     const long nkeys = (long)nfree * (nfree + 1) / 2;
-    std::vector<int32_t> cnt(nkeys + 1, 0);
-    std::vector<int32_t> slot_pose(g.n_slots);
+    SVec<int32_t> cnt(nkeys + 1, 0);
+    SVec<int32_t> slot_pose(g.n_slots);
     for (int i = 0; i < g.n_slots; ++i) slot_pose[i] = slot_col[i] / 6;
     auto key_of = [&](int a, int b) { const long pj = slot_pose[a], pi = slot_pose[b]; return pj * (pj + 1) / 2 + pi; };
     auto for_owned = [&](auto&& fn) {
@@ -930,7 +1069,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     const long n_entries = cnt[nkeys];
     pc_sj.resize(n_entries);
     pc_si.resize(n_entries);
-    std::vector<int32_t> cursor(cnt.begin(), cnt.end() - 1);
+    SVec<int32_t> cursor(cnt.begin(), cnt.end() - 1);
     for_owned([&](int l) {
       for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
         for (int b = slot_off[l]; b <= a; ++b) {
@@ -998,7 +1137,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     m.slot = find_slot(Npt + m.plane, pose_col[m.pose]);
     m.flags = F_ACTIVE | F_ROBUST | ((uint32_t)(p->pl_kind ? p->pl_kind[e] : 0) << 8);
   }
-  auto fill_cub = [&](std::vector<CubEdge>& v, int n, const int32_t* pose, const int32_t* cub, const double* meas, const double* info,
+  auto fill_cub = [&](SVec<CubEdge>& v, int n, const int32_t* pose, const int32_t* cub, const double* meas, const double* info,
                       const double* hub, const double* K, int dim) {
     v.resize(n);
     for (int e = 0; e < n; ++e) {
@@ -1040,13 +1179,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   mark("edge records");
   // ---- pose-major static copies of the owned reprojection edges + chunks (pose side of the linearisation) -----------
-  std::vector<int32_t> po_start, po_end, po_pose;
-  std::vector<MonoEdgeP> h_monoP;
-  std::vector<StereoEdgeP> h_stereoP;
+  SVec<int32_t> po_start, po_end, po_pose;
+  SVec<MonoEdgeP> h_monoP;
+  SVec<StereoEdgeP> h_stereoP;
   {
     const int chunk = []() { const char* e = getenv("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     auto build = [&](int type) {
-      std::vector<int32_t> cnt(Np + 1, 0);
+      SVec<int32_t> cnt(Np + 1, 0);
       auto visit = [&](auto&& fn) {
         for (int pt = g.pt_first; pt < g.pt_last; ++pt) {
           if (type == 0) for (int k = mo_off[pt]; k < mo_off[pt + 1]; ++k) fn(s->h_mono[k].pose, k);
@@ -1055,7 +1194,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       };
       visit([&](int pose, int) { if (pose_free_id[pose] >= 0) cnt[pose + 1]++; });
       for (int i = 0; i < Np; ++i) cnt[i + 1] += cnt[i];
-      std::vector<int32_t> cursor(cnt.begin(), cnt.end() - 1);
+      SVec<int32_t> cursor(cnt.begin(), cnt.end() - 1);
       if (type == 0) h_monoP.resize(cnt[Np]); else h_stereoP.resize(cnt[Np]);
       visit([&](int pose, int k) {
         if (pose_free_id[pose] < 0) return;
@@ -1080,12 +1219,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     build(0);
     build(1);
   }
-  std::vector<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
+  SVec<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
   for (int k = 0; k < p->n_mono; ++k) h_mono_flags[k] = s->h_mono[k].flags;
   for (int k = 0; k < p->n_stereo; ++k) h_stereo_flags[k] = s->h_stereo[k].flags;
 
   // ---- cuboid elimination plan: edges per cuboid and all (a >= b) pairs of them -----------------------------------------
-  std::vector<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cp_cub, cp_a, cp_b;
+  SVec<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cp_cub, cp_a, cp_b;
   {
     std::vector<std::vector<int32_t>> per(Nc);
     for (int e = 0; e < p->n_bbox; ++e) per[p->bbox_cuboid[e]].push_back(e << 1);
@@ -1104,7 +1243,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   // ---- initial estimates, canonicalised like the reference's converters ------------------------------------------
   s->state_doubles = (size_t)Np * 19 + (size_t)Npt * 3 + (size_t)Npl * 4 + (size_t)Nc * 10;
-  std::vector<double> h_state(s->state_doubles, 0.0);
+  SVec<double> h_state(s->state_doubles, 0.0);
   {
     State hs = make_state(h_state.data(), Np, Npt, Npl, Nc);
     for (int i = 0; i < Np; ++i) {
@@ -1126,12 +1265,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   mark("pose-major copies, cuboid plan, pair plan join");
   // ---- uploads ----------------------------------------------------------------------------------------------------------
   bool ok = true;
-  std::vector<double> v_cam(p->pose_cam, p->pose_cam + (size_t)5 * Np);
-  std::vector<double> v_fs((size_t)3 * Nc, 0.0);
+  SVec<double> v_cam(p->pose_cam, p->pose_cam + (size_t)5 * Np);
+  SVec<double> v_fs((size_t)3 * Nc, 0.0);
   if (p->cuboid_fixedscale) std::copy(p->cuboid_fixedscale, p->cuboid_fixedscale + (size_t)3 * Nc, v_fs.begin());
-  std::vector<uint8_t> v_cf(Nc, (uint8_t)(PPO_CUBOID_FIX_ROLLPITCH | PPO_CUBOID_FIX_HEIGHT));
+  SVec<uint8_t> v_cf(Nc, (uint8_t)(PPO_CUBOID_FIX_ROLLPITCH | PPO_CUBOID_FIX_HEIGHT));
   if (p->cuboid_flags) std::copy(p->cuboid_flags, p->cuboid_flags + Nc, v_cf.begin());
-  std::vector<double> v_pts;
+  SVec<double> v_pts;
   if (p->n_ptcub && p->ptcub_offsets[p->n_ptcub] > 0) v_pts.assign(p->ptcub_points, p->ptcub_points + (size_t)3 * p->ptcub_offsets[p->n_ptcub]);
   ok = ok && s->d_pose_cam.upload(v_cam, s->stream) && s->d_cub_fixedscale.upload(v_fs, s->stream) && s->d_ptcub_pts.upload(v_pts, s->stream);
   ok = ok && s->d_pose_col.upload(pose_col, s->stream) && s->d_pose_free_id.upload(pose_free_id, s->stream) && s->d_cub_col.upload(cub_col, s->stream);
@@ -1240,6 +1379,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   *out = s;
   return PPO_BA_OK;
+} catch (const std::bad_alloc&) {  // (the half-built solver is leaked rather than torn down under an unknown state)
+  std::fprintf(stderr, "[ppo_ba] ppo_ba_create: out of host memory\n");
+  return PPO_BA_ERR_NOMEM;
 }
 
 int ppo_ba_reset(ppo_ba_handle s) {
@@ -1294,19 +1436,20 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
   return rc;
 }
 
-int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
+int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
   if (!s || !r) return PPO_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
+  StageScope stage_scope(s->stage, true);  // the staging vectors below are gone (and their memory reusable) when read returns
   const Graph& g = s->g;
   const int Np = g.n_poses, Npt = g.n_points, Npl = g.n_planes, Nc = g.n_cuboids;
-  std::vector<double> hs(s->state_doubles);
+  SVec<double> hs(s->state_doubles);
   if (s->state_doubles) HIP_TRY(hipMemcpy(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double), hipMemcpyDeviceToHost));
   State h = make_state(hs.data(), Np, Npt, Npl, Nc);
   if (s->comm.active()) {
     // landmarks live on their owner, and with eliminated cuboids only the rank that owns the reduced terms back-substitutes
     // them: sum the (disjoint) owned parts over ranks through a zero-padded device buffer
     const size_t n_pt = (size_t)Npt * 3, n_pl = (size_t)Npl * 4, n_cb = (size_t)Nc * 10;
-    std::vector<double> tmp(n_pt + n_pl + n_cb, 0.0);
+    SVec<double> tmp(n_pt + n_pl + n_cb, 0.0);
     for (int i = g.pt_first; i < g.pt_last; ++i) for (int a = 0; a < 3; ++a) tmp[(size_t)3 * i + a] = h.point[3 * i + a];
     for (int i = g.plane_first; i < g.plane_last; ++i) for (int a = 0; a < 4; ++a) tmp[n_pt + 4 * i + a] = h.plane[4 * i + a];
     if (g.owns_reduced) std::copy(h.cub, h.cub + n_cb, tmp.begin() + n_pt + n_pl);
@@ -1329,15 +1472,15 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
     if (r->cuboid_scale) std::memcpy(&r->cuboid_scale[3 * i], &h.cub[10 * i + 7], 3 * sizeof(double));
   }
   // per-edge outputs
-  std::vector<double> chi(s->d_chi2_all.n);
+  SVec<double> chi(s->d_chi2_all.n);
   if (chi.size()) HIP_TRY(hipMemcpy(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost));
-  std::vector<MonoEdge> hm(g.n_mono);
-  std::vector<StereoEdge> hst(g.n_stereo);
-  std::vector<uint32_t> hmf(g.n_mono), hsf(g.n_stereo);
+  SVec<MonoEdge> hm(g.n_mono);
+  SVec<StereoEdge> hst(g.n_stereo);
+  SVec<uint32_t> hmf(g.n_mono), hsf(g.n_stereo);
   if (g.n_mono) HIP_TRY(hipMemcpy(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (g.n_stereo) HIP_TRY(hipMemcpy(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  std::vector<PlaneEdge> hp(g.n_pl);
-  std::vector<CubEdge> hb(g.n_bbox), hc(g.n_corner);
+  SVec<PlaneEdge> hp(g.n_pl);
+  SVec<CubEdge> hb(g.n_bbox), hc(g.n_corner);
   if (g.n_mono) HIP_TRY(hipMemcpy(hm.data(), s->d_mono.p, hm.size() * sizeof(MonoEdge), hipMemcpyDeviceToHost));
   if (g.n_stereo) HIP_TRY(hipMemcpy(hst.data(), s->d_stereo.p, hst.size() * sizeof(StereoEdge), hipMemcpyDeviceToHost));
   if (g.n_pl) HIP_TRY(hipMemcpy(hp.data(), s->d_pl.p, hp.size() * sizeof(PlaneEdge), hipMemcpyDeviceToHost));
@@ -1359,9 +1502,9 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
     return apply(T, v3(h.point[3 * pt], h.point[3 * pt + 1], h.point[3 * pt + 2])).z > 0.0;
   };
   // sorted position -> point id for the reprojection edges
-  std::vector<int32_t> mo_pt(g.n_mono), st_pt(g.n_stereo);
+  SVec<int32_t> mo_pt(g.n_mono), st_pt(g.n_stereo);
   {
-    std::vector<int32_t> off(Npt + 1);
+    SVec<int32_t> off(Npt + 1);
     if (Npt + 1 > 0 && g.n_mono) {
       HIP_TRY(hipMemcpy(off.data(), s->d_mo_off.p, off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
       for (int pnt = 0; pnt < Npt; ++pnt) for (int k = off[pnt]; k < off[pnt + 1]; ++k) mo_pt[k] = pnt;
@@ -1410,13 +1553,13 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
         {r->bbox_chi2, nullptr, (size_t)g.n_bbox, 3}, {r->bbox_errnorm, nullptr, (size_t)g.n_bbox, 3}, {nullptr, r->bbox_level, (size_t)g.n_bbox, 3},
         {r->corner_chi2, nullptr, (size_t)g.n_corner, 3}, {r->corner_errnorm, nullptr, (size_t)g.n_corner, 3}, {nullptr, r->corner_level, (size_t)g.n_corner, 3},
         {r->ptcub_chi2, nullptr, (size_t)g.n_ptcub, 3}};
-    std::vector<uint8_t> own_mono(g.n_mono, 0), own_stereo(g.n_stereo, 0), own_pl(g.n_pl, 0);
+    SVec<uint8_t> own_mono(g.n_mono, 0), own_stereo(g.n_stereo, 0), own_pl(g.n_pl, 0);
     for (int k = 0; k < g.n_mono; ++k) own_mono[s->mono_perm[k]] = mo_pt[k] >= g.pt_first && mo_pt[k] < g.pt_last;
     for (int k = 0; k < g.n_stereo; ++k) own_stereo[s->stereo_perm[k]] = st_pt[k] >= g.pt_first && st_pt[k] < g.pt_last;
     for (int e = 0; e < g.n_pl; ++e) own_pl[e] = hp[e].plane >= g.plane_first && hp[e].plane < g.plane_last;
     size_t total = 0;
     for (const Item& it : items) total += it.n;
-    std::vector<double> buf(total, 0.0);
+    SVec<double> buf(total, 0.0);
     size_t off = 0;
     for (const Item& it : items) {
       for (size_t e = 0; e < it.n; ++e) {
@@ -1444,6 +1587,9 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) {
     }
   }
   return PPO_BA_OK;
+} catch (const std::bad_alloc&) {
+  std::fprintf(stderr, "[ppo_ba] ppo_ba_read: out of host memory\n");
+  return PPO_BA_ERR_NOMEM;
 }
 
 void ppo_ba_destroy(ppo_ba_handle s) {
@@ -1627,6 +1773,7 @@ int64_t ppo_ba_linearize_bytes(ppo_ba_handle s) { return s ? s->lin_bytes : -1; 
 int ppo_ba_release_cached(void) {
   g_pool.trim();
   g_ctx_pool.trim();
+  g_host_pool.trim();
   return PPO_BA_OK;
 }
 
