@@ -59,6 +59,34 @@ def committed_traffic(k_bytes):
     return None
 
 
+def pose_only_figures(B, with_cpu):
+    """Secondary figures (never part of `value`): pose-only optimisation (include/ppo_pose.h, Optimizer::PoseOptimization) of
+    synthetic frames, whole call with host buffers (pack + PCIe + one kernel + read-back); the oracle timed beside it."""
+    from ppo_ba import pose
+    lib = B.load_library()
+    out = {}
+    for label, fr in (("single_frame_500_obs", pose.make_frames(n_frames=1, n_obs=500, seed=21)),
+                      ("batch_256_frames_500_obs", pose.make_frames(n_frames=256, n_obs=500, seed=22))):
+        pose.optimize(lib, fr)
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pose.optimize(lib, fr)
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        out[label] = {"ms_per_call": ms, "frames_per_s": fr.n_frames / (ms * 1e-3)}
+        if with_cpu:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+            import oracle_py
+            small = fr if fr.n_frames == 1 else pose.make_frames(n_frames=16, n_obs=500, seed=22)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 0.5:
+                pose.optimize(oracle_py.load(), small, prefix="oracle_")
+                n += small.n_frames
+            out[label]["cpu_oracle_frames_per_s"] = n / (time.perf_counter() - t0)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +196,8 @@ def main():
         t_d = time.perf_counter()
         call_ms = {"create": 1e3 * (t_b - t_a), "run": 1e3 * (t_c2 - t_b), "read": 1e3 * (t_d - t_c2), "total": 1e3 * (t_d - t_a)}
 
+    pose_only = pose_only_figures(B, not a.no_cpu_baseline) if world == 1 else {}
+
     if rank == 0:
         out = {
             "metric": "LM iters/sec on 200KF/50k-pt/200-plane/50-cuboid local BA",
@@ -183,6 +213,7 @@ def main():
                 "ms_per_lm_iter": 1e3 * dt / max(iters, 1), "solver_backend": int(a.solver),
                 "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
                 "first_create_ms_incl_module_load": create_ms, "steady_state_call_ms": call_ms, "kernels": kernels,
+                "pose_only": pose_only,
             },
             "roofline": {"bound": "hbm", "kernel": "k_linearize_all", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(int(k_bytes.value)),

@@ -11,6 +11,12 @@ assumed from headers that could not be compiled):
   g2o::RobustKernelHuber::setDelta / robustify       on a zeroed object (both fields are written by setDelta)
   g2o::EdgeSE3ProjectXYZ::cam_project                fx fy cx cy at this+0x128..0x140 (read off the disassembly)
   g2o::EdgeStereoSE3ProjectXYZ::cam_project          fx fy cx cy at this+0x160..0x178, bf passed as const float&
+  g2o::EdgeSE3ProjectXYZOnlyPose::computeError / linearizeOplus        (the unary edges of Optimizer::PoseOptimization)
+  g2o::EdgeStereoSE3ProjectXYZOnlyPose::computeError / linearizeOplus  driven on hand-laid-out objects: _vertices.data() at
+                                                     this+0x8, _measurement at +0xa0, _error at +0xd0 / +0x100, the Jacobian
+                                                     map's data pointer at +0xe0 / +0x118, Xw at +0xf0 / +0x128, fx fy cx cy
+                                                     (bf) at +0x108 / +0x140; the vertex keeps q at +0xb0 and t at +0xd0
+                                                     (all read off the disassembly of the four functions)
 The custom plane / cuboid types live in lib/libORB_SLAM2.so, which does not load in this container (OpenCV 3.3, PCL 1.8,
 Pangolin, VTK missing): they stay unpinned.
 
@@ -115,6 +121,57 @@ def generate():
     out["cases"]["mono_project"] = mono
     out["cases"]["stereo_project"] = stereo
 
+
+    # ---- unary OnlyPose edges: computeError + linearizeOplus --------------------------------------------------------------
+    def aligned(n):
+        a = np.zeros(n + 8)
+        o = (-a.ctypes.data // 8) % 2  # 16-byte alignment: computeError uses movapd / movaps on the object
+        return a[o:o + n]
+    only = {"mono": [], "stereo": []}
+    fn = {
+        "mono": (lib._ZN3g2o25EdgeSE3ProjectXYZOnlyPose12computeErrorEv, lib._ZN3g2o25EdgeSE3ProjectXYZOnlyPose14linearizeOplusEv,
+                 dict(meas=0xa0, err=0xd0, jac=0xe0, xw=0xf0, cam=0x108, dim=2)),
+        "stereo": (lib._ZN3g2o31EdgeStereoSE3ProjectXYZOnlyPose12computeErrorEv, lib._ZN3g2o31EdgeStereoSE3ProjectXYZOnlyPose14linearizeOplusEv,
+                   dict(meas=0xa0, err=0x100, jac=0x118, xw=0x128, cam=0x140, dim=3)),
+    }
+    for kind, (f_err, f_lin, L) in fn.items():
+        f_err.argtypes = [C.c_void_p]; f_lin.argtypes = [C.c_void_p]
+        f_err.restype = None; f_lin.restype = None
+        for k in range(24):
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            if q[3] < 0:
+                q = -q
+            t = rng.normal(size=3)
+            # a point in front of the camera: choose it in the camera frame and move it to the world
+            pc = np.array([rng.normal() * 1.5, rng.normal() * 1.5, rng.uniform(0.3, 9.0)])
+            x, y, z, w = q
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            Xw = R.T @ (pc - t)
+            cam = [rng.uniform(300, 700), rng.uniform(300, 700), rng.uniform(300, 340), rng.uniform(220, 260), rng.uniform(20, 60)]
+            obs = [rng.uniform(0, 640), rng.uniform(0, 480), rng.uniform(0, 640)]
+            vert = aligned(64)
+            vert[0xb0 // 8:0xb0 // 8 + 4] = q
+            vert[0xd0 // 8:0xd0 // 8 + 3] = t
+            vptrs = np.array([vert.ctypes.data], dtype=np.uint64)
+            this = aligned(64)
+            assert this.ctypes.data % 16 == 0
+            J = np.zeros(18)
+            this.view(np.uint64)[0x8 // 8] = vptrs.ctypes.data
+            this.view(np.uint64)[L["jac"] // 8] = J.ctypes.data
+            this[L["meas"] // 8:L["meas"] // 8 + L["dim"]] = obs[:L["dim"]]
+            this[L["xw"] // 8:L["xw"] // 8 + 3] = Xw
+            ncam = 4 if kind == "mono" else 5
+            this[L["cam"] // 8:L["cam"] // 8 + ncam] = cam[:ncam]
+            f_err(this.ctypes.data)
+            f_lin(this.ctypes.data)
+            err = this[L["err"] // 8:L["err"] // 8 + L["dim"]].tolist()
+            Jrow = J[:6 * L["dim"]].reshape(6, L["dim"]).T  # Eigen stores the dim x 6 matrix column-major
+            only[kind].append({"qt": q.tolist() + t.tolist(), "cam": cam, "xw": Xw.tolist(), "obs": obs, "error": err, "J": Jrow.reshape(-1).tolist()})
+    out["cases"]["onlypose_mono"] = only["mono"]
+    out["cases"]["onlypose_stereo"] = only["stereo"]
+
     os.makedirs(os.path.dirname(GOLD), exist_ok=True)
     with open(GOLD, "w") as fh:
         json.dump(out, fh, indent=1)
@@ -164,6 +221,17 @@ def check():
             ref = np.array(c["uv"] if kind == "mono" else c["uvr"])
             worst[key] = max(worst.get(key, 0), float(np.abs(-e[:len(ref)] - ref).max()))
             s_.close()
+    lib.oracle_onlypose_eval.argtypes = [C.POINTER(C.c_double)] * 4 + [C.c_int] + [C.POINTER(C.c_double)] * 2
+    lib.oracle_onlypose_eval.restype = None
+    for kind in ("mono", "stereo"):
+        for c in gold.get("onlypose_" + kind, []):
+            e, J = np.zeros(3), np.zeros(18)
+            lib.oracle_onlypose_eval(dptr(np.array(c["qt"])), dptr(np.array(c["cam"])), dptr(np.array(c["xw"])), dptr(np.array(c["obs"])),
+                                     int(kind == "stereo"), dptr(e), dptr(J))
+            d = len(c["error"])
+            worst["onlypose_" + kind + "_error"] = max(worst.get("onlypose_" + kind + "_error", 0), float(np.abs(e[:d] - c["error"]).max()))
+            ref = np.array(c["J"])
+            worst["onlypose_" + kind + "_J"] = max(worst.get("onlypose_" + kind + "_J", 0), float((np.abs(J[:6 * d] - ref) / np.maximum(1.0, np.abs(ref))).max()))
     print("max abs deviation oracle vs prebuilt g2o:", worst)
     return worst
 

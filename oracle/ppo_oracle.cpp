@@ -21,7 +21,10 @@
 //   Levenberg-Marquardt                G2O/core/optimization_algorithm_levenberg.cpp:61-189
 //   outer loop                         G2O/core/sparse_optimizer.cpp:354-419
 //   two-pass protocol + classification src/Optimizer.cc:2723-2838
+//   pose-only optimisation (row N4)    src/Optimizer.cc:247-459 on the same engine, with the unary OnlyPose edges of
+//                                      types_six_dof_expmap.{h:227-290,cpp:298-398} (pinned against the prebuilt libg2o.so)
 #include "../include/ppo_ba.h"
+#include "../include/ppo_pose.h"
 #include "oracle_math.hpp"
 
 #include <algorithm>
@@ -91,6 +94,7 @@ struct Oracle {
   std::vector<double> S, bs, x, coeff, Dinv;  // Schur workspace; x is n_red + 3 n_lm
   std::vector<double> diag_backup_p, diag_backup_l;
   bool do_schur = false;
+  bool only_pose = false;  // the unary Edge*SE3ProjectXYZOnlyPose flavour of the reprojection edges (pose-only optimisation)
   // ---- LM ----
   double lambda = -1, ni = 2;
   int nBad = 0;
@@ -164,7 +168,8 @@ void compute_error(const Oracle& o, int type, int idx, const void* a, const void
       const float invz = (float)(1.0 / pc[2]);  // 1.0f / double: a double division rounded to float (divsd + cvtsd2ss in the prebuilt libg2o.so)
       const double r0 = pc[0] * invz * cam[0] + cam[2];
       const double r1 = pc[1] * invz * cam[1] + cam[3];
-      const double r2 = r0 - (double)(bf * invz);
+      // EdgeStereoSE3ProjectXYZOnlyPose keeps bf as a double member (types_six_dof_expmap.h:288, .cpp:331-338)
+      const double r2 = o.only_pose ? r0 - cam[4] * invz : r0 - (double)(bf * invz);
       e[0] = obs[0] - r0;
       e[1] = obs[1] - r1;
       e[2] = obs[2] - r2;
@@ -275,6 +280,30 @@ void linearize(const Oracle& o, int type, int idx, double* J0, double* J1) {
         J0[1 * 3 + c] = -fy * R.m[1][c] / z + fy * y * R.m[2][c] / z_2;
         J0[2 * 3 + c] = J0[0 * 3 + c] - bf * R.m[2][c] / z_2;
       }
+    }
+    if (o.only_pose) {  // types_six_dof_expmap.cpp:298-320, 367-398: the same matrix written with 1/z and 1/z^2
+      const double invz = 1.0 / z, invz_2 = invz * invz;
+      J1[0] = x * y * invz_2 * fx;
+      J1[1] = -(1 + (x * x * invz_2)) * fx;
+      J1[2] = y * invz * fx;
+      J1[3] = -invz * fx;
+      J1[4] = 0;
+      J1[5] = x * invz_2 * fx;
+      J1[6] = (1 + y * y * invz_2) * fy;
+      J1[7] = -x * y * invz_2 * fy;
+      J1[8] = -x * invz * fy;
+      J1[9] = 0;
+      J1[10] = -invz * fy;
+      J1[11] = y * invz_2 * fy;
+      if (type == E_STEREO) {
+        J1[12] = J1[0] - bf * y * invz_2;
+        J1[13] = J1[1] + bf * x * invz_2;
+        J1[14] = J1[2];
+        J1[15] = J1[3];
+        J1[16] = 0;
+        J1[17] = J1[5] - bf * invz_2;
+      }
+      return;
     }
     J1[0] = x * y / z_2 * fx;
     J1[1] = -(1 + (x * x / z_2)) * fx;
@@ -1142,5 +1171,121 @@ void oracle_cuboid_project(const double cqt[7], const double scale[3], const dou
   cuboid_project_bbox(c, T, K, bbox);
 }
 void oracle_huber(double e, double delta, double rho[3]) { huber_robustify(e, delta, rho); }
+
+// ---- Optimizer::PoseOptimization, src/Optimizer.cc:247-459 ---------------------------------------------------------------
+// One free pose, fixed map points, unary reprojection edges; four rounds of optimize(10) from the same initial pose with a
+// re-classification of every observation after each round.  Runs on the engine above: a fixed point vertex contributes no
+// block, which is what the unary edges amount to; `only_pose` selects their residual / Jacobian flavour.
+int oracle_pose_optimize(const ppo_pose_problem* p, const ppo_pose_options* po, ppo_pose_result* r) {
+  if (!p || !po || !r || !r->pose_qt) return PPO_BA_ERR_ARG;
+  if (po->rounds < 0 || po->rounds > PPO_POSE_MAX_ROUNDS) return PPO_BA_ERR_ARG;
+  for (int f = 0; f < p->n_frames; ++f) {
+    const int e0 = p->edge_offsets[f], e1 = p->edge_offsets[f + 1], n = e1 - e0;
+    ppo_pose_stats st{};
+    for (int e = e0; e < e1; ++e) {  // OPT:297, 331: pFrame->mvbOutlier[i] = false
+      if (r->outlier) r->outlier[e] = 0;
+      if (r->chi2) r->chi2[e] = 0.0;
+    }
+    std::copy(&p->pose_qt[7 * f], &p->pose_qt[7 * f] + 7, &r->pose_qt[7 * f]);
+    if (r->n_inliers) r->n_inliers[f] = 0;
+    if (n < po->min_correspondences) {  // OPT:372-373
+      if (r->stats) r->stats[f] = st;
+      continue;
+    }
+    std::vector<double> pts((size_t)3 * n), m_obs, s_obs, m_info, s_info, m_hub, s_hub;
+    std::vector<uint8_t> pfix(n, 1);
+    std::vector<int32_t> m_pt, m_pose, s_pt, s_pose, m_edge, s_edge;
+    for (int k = 0; k < n; ++k) {
+      const int e = e0 + k;
+      for (int c = 0; c < 3; ++c) pts[3 * k + c] = p->xw[3 * (size_t)e + c];
+      const double* ob = &p->obs[3 * (size_t)e];
+      if (ob[2] < 0) {  // OPT:294
+        m_pt.push_back(k); m_pose.push_back(0); m_edge.push_back(e);
+        m_obs.push_back(ob[0]); m_obs.push_back(ob[1]);
+        m_info.push_back(p->inv_sigma2[e]); m_hub.push_back((double)po->huber_mono);
+      } else {
+        s_pt.push_back(k); s_pose.push_back(0); s_edge.push_back(e);
+        s_obs.push_back(ob[0]); s_obs.push_back(ob[1]); s_obs.push_back(ob[2]);
+        s_info.push_back(p->inv_sigma2[e]); s_hub.push_back((double)po->huber_stereo);
+      }
+    }
+    ppo_ba_problem P{};
+    const uint8_t free_pose = 0;
+    P.n_poses = 1; P.pose_qt = &p->pose_qt[7 * f]; P.pose_fixed = &free_pose; P.pose_cam = &p->cam[5 * f];
+    P.n_points = n; P.point_xyz = pts.data(); P.point_fixed = pfix.data();
+    P.n_mono = (int32_t)m_pt.size(); P.mono_point = m_pt.data(); P.mono_pose = m_pose.data(); P.mono_obs = m_obs.data();
+    P.mono_info = m_info.data(); P.mono_huber = m_hub.data();
+    P.n_stereo = (int32_t)s_pt.size(); P.stereo_point = s_pt.data(); P.stereo_pose = s_pose.data(); P.stereo_obs = s_obs.data();
+    P.stereo_info = s_info.data(); P.stereo_huber = s_hub.data();
+    ppo_ba_options O{};
+    O.abi_version = PPO_BA_ABI_VERSION;
+    O.lm_tau = po->lm_tau; O.lm_max_trials = po->lm_max_trials; O.lm_lower = po->lm_lower; O.lm_upper = po->lm_upper;
+    O.numeric_delta = 1e-9;
+    oracle_handle o = nullptr;
+    const int rc = oracle_ba_create(&P, &O, &o);
+    if (rc != PPO_BA_OK) return rc;
+    o->only_pose = true;
+    std::memset(&o->stats, 0, sizeof(o->stats));
+    std::vector<uint8_t> out_m(P.n_mono, 0), out_s(P.n_stereo, 0);
+    int nBad = 0;
+    for (int it = 0; it < po->rounds; ++it) {
+      o->pose = o->pose0;              // OPT:385 vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw))
+      // OPT:415, 444 `if(it==2) e->setRobustKernel(0)` at the end of round 2: the first robust_rounds (3) rounds keep the kernel
+      for (int t = 0; t < 2; ++t) std::fill(o->robust[t == 0 ? E_MONO : E_STEREO].begin(), o->robust[t == 0 ? E_MONO : E_STEREO].end(), (uint8_t)(it < po->robust_rounds));
+      initialize_optimization(*o, 0);  // OPT:386
+      const int it0 = o->stats.n_iters;
+      optimize(*o, it, po->iters_per_round, nullptr);  // OPT:387
+      if (it == 0 && o->stats.n_iters > it0) st.chi2_initial = o->stats.iters[0].chi2_before;
+      if (o->stats.n_iters > it0 && o->stats.n_iters <= PPO_BA_MAX_ITER_STATS) st.chi2_final = o->stats.iters[o->stats.n_iters - 1].chi2_after;
+      nBad = 0;
+      for (int t = 0; t < 2; ++t) {  // OPT:390-417 (mono), 419-446 (stereo)
+        const int type = t == 0 ? E_MONO : E_STEREO;
+        std::vector<uint8_t>& out = t == 0 ? out_m : out_s;
+        const float thr = t == 0 ? po->chi2_mono : po->chi2_stereo;
+        for (int i = 0; i < o->n_edges[type]; ++i) {
+          if (out[i]) compute_error(*o, type, i, &o->point[o->e_v0[type][i]], &o->pose[0], &o->err[type][(size_t)kMaxDim * i]);
+          const double c = edge_chi2(*o, type, i);
+          const float chi2 = (float)c;
+          if (chi2 > thr) { out[i] = 1; o->level[type][i] = 1; nBad++; }
+          else { out[i] = 0; o->level[type][i] = 0; }
+          const int e = t == 0 ? m_edge[i] : s_edge[i];
+          if (r->outlier) r->outlier[e] = out[i];
+          if (r->chi2) r->chi2[e] = c;
+        }
+      }
+      st.rounds_run = it + 1;
+      if (n < po->min_edges) break;  // OPT:448-449
+    }
+    st.lm_iterations = o->stats.n_iters;
+    st.lm_trials = o->stats.n_trials;
+    st.n_bad = nBad;
+    st.lambda_final = o->lambda;
+    const SE3& T = o->pose[0];
+    double* q = &r->pose_qt[7 * f];
+    q[0] = T.r.x; q[1] = T.r.y; q[2] = T.r.z; q[3] = T.r.w; q[4] = T.t[0]; q[5] = T.t[1]; q[6] = T.t[2];
+    if (r->n_inliers) r->n_inliers[f] = n - nBad;  // OPT:458
+    if (r->stats) r->stats[f] = st;
+    oracle_ba_destroy(o);
+  }
+  return PPO_BA_OK;
+}
+
+// residual and Jacobian of one unary OnlyPose edge (for the golden vectors of the prebuilt libg2o.so)
+void oracle_onlypose_eval(const double qt[7], const double cam[5], const double xw[3], const double obs[3], int stereo, double* e, double* J) {
+  Oracle o;
+  o.only_pose = true;
+  o.n_poses = 1; o.n_points = 1;
+  o.pose.assign(1, se3_make(Quat{qt[0], qt[1], qt[2], qt[3]}, mk(qt[4], qt[5], qt[6])));
+  o.point.assign(1, mk(xw[0], xw[1], xw[2]));
+  o.pose_cam.assign(cam, cam + 5);
+  o.pose_fixed.assign(1, 0); o.point_fixed.assign(1, 1);
+  const int type = stereo ? E_STEREO : E_MONO;
+  o.n_edges[type] = 1;
+  o.e_v0[type].assign(1, 0); o.e_v1[type].assign(1, 0);
+  o.e_meas[type].assign(obs, obs + (stereo ? 3 : 2));
+  compute_error(o, type, 0, &o.point[0], &o.pose[0], e);
+  double J0[9];
+  linearize(o, type, 0, J0, J);
+}
 
 }  // extern "C"

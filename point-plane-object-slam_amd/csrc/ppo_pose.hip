@@ -1,0 +1,453 @@
+// ppo_pose.hip -- pose-only optimisation (include/ppo_pose.h): Optimizer::PoseOptimization of the reference
+// (src/Optimizer.cc:247-459) as ONE kernel launch.
+//
+// The problem is tiny (one 6-DoF pose, a few hundred to a few thousand unary reprojection edges) and strictly sequential
+// on the outside: 4 rounds x <= 10 Levenberg-Marquardt iterations x >= 1 trial, each needing a reduction over all edges.
+// Driving that from the host would cost a launch and a round trip per trial (~10 us each against ~1 us of arithmetic), so
+// the whole protocol runs on the device: one 256-thread workgroup per frame holds the pose, the 6x6 system and the LM
+// state redundantly in the registers of every thread, edges are dealt round-robin to the threads, and the only shared
+// traffic is the reduction (wave shuffles, then one LDS exchange between the four waves -- a fixed summation order, so the
+// result is bit-reproducible from run to run).  Independent frames go to different workgroups of the same launch.
+//
+// Restated per thread, in the reference's order (G2O = Thirdparty/g2o/g2o):
+//   residuals / Jacobians   G2O/types/types_six_dof_expmap.h:236-240, 267-271, .cpp:298-338, 367-398
+//   quadratic form + Huber  G2O/core/base_unary_edge.hpp:43-72, robust_kernel_impl.cpp:78-91
+//   6x6 solve               G2O/solvers/linear_solver_dense.h:65-113 (Cholesky here; same gate: reject when not positive)
+//   LM                      G2O/core/optimization_algorithm_levenberg.cpp:61-189
+//   outer loop              G2O/core/sparse_optimizer.cpp:354-419
+//   rounds + classification src/Optimizer.cc:375-450
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ppo_pose.h"
+#include "ppo_math.hpp"
+#include "ppo_pool.hpp"
+
+namespace ppo {
+
+struct PoseOnlyArgs {
+  const double* pose_qt;
+  const double* cam;
+  const int32_t* off;
+  const double* xw;
+  const double* obs;
+  const double* invs;
+  double* out_pose;       // [F][7]
+  double* out_chi2;       // [E]
+  double* stored;         // [E] chi2 of the stored _error of an active edge (what e->chi2() returns without a recompute)
+  uint8_t* level;         // [E]
+  int32_t* n_inliers;     // [F]
+  ppo_pose_stats* stats;  // [F]
+  int rounds, iters, robust_rounds, min_corr, min_edges, max_trials;
+  float chi2_mono, chi2_stereo;
+  double hub_mono, hub_stereo, tau, lower, upper;
+};
+
+constexpr int kPoseThreads = 256;
+constexpr int kPoseWaves = kPoseThreads / 64;
+
+// sum over the workgroup, the same value in every thread; order: xor-butterfly inside a wave, then waves 0..3
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sbuf) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double x = v[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    v[i] = x;
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sbuf[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double x = sbuf[i];
+#pragma unroll
+    for (int w = 1; w < kPoseWaves; ++w) x += sbuf[w * NV + i];
+    v[i] = x;
+  }
+  __syncthreads();
+}
+
+struct PoseEdge {
+  Vec3 X;
+  double u, v, ur, invs;
+  bool stereo;
+};
+__device__ __forceinline__ PoseEdge load_pose_edge(const PoseOnlyArgs& a, int e) {
+  PoseEdge E;
+  E.X = v3(a.xw[3 * (size_t)e], a.xw[3 * (size_t)e + 1], a.xw[3 * (size_t)e + 2]);
+  E.u = a.obs[3 * (size_t)e];
+  E.v = a.obs[3 * (size_t)e + 1];
+  E.ur = a.obs[3 * (size_t)e + 2];
+  E.invs = a.invs[e];
+  E.stereo = !(E.ur < 0);  // Optimizer.cc:294 `if(pFrame->mvuRight[i]<0)` is the monocular branch
+  return E;
+}
+// computeError + chi2 (base_edge.h:58-61 with Omega = invSigma2 * I); pc = Tcw * Xw
+__device__ __forceinline__ double pose_edge_chi2(const Pose& T, const double* cam, const PoseEdge& E, double* e, Vec3& pc) {
+  pc = qrot(T.q, E.X) + T.t;
+  if (!E.stereo) {
+    e[0] = E.u - (pc.x / pc.z * cam[0] + cam[2]);
+    e[1] = E.v - (pc.y / pc.z * cam[1] + cam[3]);
+    e[2] = 0.0;
+    return e[0] * (E.invs * e[0]) + e[1] * (E.invs * e[1]);
+  }
+  const float invz = (float)(1.0 / pc.z);  // `const float invz = 1.0f/trans_xyz[2]`: a double division rounded to float
+  const double r0 = pc.x * invz * cam[0] + cam[2];
+  const double r1 = pc.y * invz * cam[1] + cam[3];
+  const double r2 = r0 - cam[4] * invz;    // bf is a double member of the OnlyPose edge
+  e[0] = E.u - r0;
+  e[1] = E.v - r1;
+  e[2] = E.ur - r2;
+  return e[0] * (E.invs * e[0]) + e[1] * (E.invs * e[1]) + e[2] * (E.invs * e[2]);
+}
+
+// (H + lambda I) x = b with H packed lower (row r, column c <= r at r(r+1)/2 + c); false when a pivot is not positive
+__device__ __forceinline__ bool solve6(const double* H, double lambda, const double* b, double* x) {
+  double L[21];
+  bool ok = true;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      double s = H[r * (r + 1) / 2 + c] + (r == c ? lambda : 0.0);
+#pragma unroll
+      for (int k = 0; k < c; ++k) s -= L[r * (r + 1) / 2 + k] * L[c * (c + 1) / 2 + k];
+      if (r == c) {
+        ok = ok && (s > 0.0);
+        L[r * (r + 1) / 2 + c] = sqrt(s);
+      } else {
+        L[r * (r + 1) / 2 + c] = s / L[c * (c + 1) / 2 + c];
+      }
+    }
+  }
+  if (!ok) return false;
+  double y[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double s = b[r];
+#pragma unroll
+    for (int k = 0; k < r; ++k) s -= L[r * (r + 1) / 2 + k] * y[k];
+    y[r] = s / L[r * (r + 1) / 2 + r];
+  }
+#pragma unroll
+  for (int r = 5; r >= 0; --r) {
+    double s = y[r];
+#pragma unroll
+    for (int k = r + 1; k < 6; ++k) s -= L[k * (k + 1) / 2 + r] * x[k];
+    x[r] = s / L[r * (r + 1) / 2 + r];
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
+  __shared__ double sbuf[kPoseWaves * 28];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int e0 = a.off[f], e1 = a.off[f + 1], n = e1 - e0;
+  double cam[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) cam[i] = a.cam[5 * f + i];
+  const double* q0 = &a.pose_qt[7 * f];
+  Pose T0;
+  T0.q = canon(Quat{q0[0], q0[1], q0[2], q0[3]});  // SE3Quat(R, t) normalises (se3quat.h:58-60)
+  T0.t = v3(q0[4], q0[5], q0[6]);
+  for (int e = e0 + tid; e < e1; e += kPoseThreads) {  // Optimizer.cc:297, 331: every correspondence starts as an inlier
+    a.level[e] = 0;
+    a.out_chi2[e] = 0.0;
+    a.stored[e] = 0.0;
+  }
+  ppo_pose_stats st;
+  st.rounds_run = 0; st.lm_iterations = 0; st.lm_trials = 0; st.n_bad = 0;
+  st.chi2_initial = 0; st.chi2_final = 0; st.lambda_final = 0;
+  if (n < a.min_corr) {  // Optimizer.cc:372-373: return 0, the frame keeps its pose
+    if (tid == 0) {
+      for (int i = 0; i < 7; ++i) a.out_pose[7 * f + i] = q0[i];
+      a.n_inliers[f] = 0;
+      a.stats[f] = st;
+    }
+    return;
+  }
+  Pose T = T0;
+  double lambda = 0.0, ni = 2.0;
+  double x[6] = {0, 0, 0, 0, 0, 0};
+  int nBad = 0;
+  for (int it = 0; it < a.rounds; ++it) {
+    T = T0;                                   // :385
+    const bool robust = it < a.robust_rounds;  // `if(it==2) e->setRobustKernel(0)` takes effect from the next round on
+    double cnt[1] = {0.0};
+    for (int e = e0 + tid; e < e1; e += kPoseThreads) cnt[0] += a.level[e] == 0 ? 1.0 : 0.0;
+    block_sum<1>(cnt, sbuf);
+    if (cnt[0] > 0.0) {  // initializeOptimization(0) found active edges; otherwise optimize() returns at once (sparse_optimizer.cpp:356-360)
+      int lm_bad = 0;
+      bool ok = true;
+      for (int i = 0; i < a.iters && ok; ++i) {
+        // ---- computeActiveErrors + activeRobustChi2 + buildSystem at T (optimization_algorithm_levenberg.cpp:76-84) ----
+        double acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+        for (int e = e0 + tid; e < e1; e += kPoseThreads) {
+          if (a.level[e]) continue;
+          const PoseEdge E = load_pose_edge(a, e);
+          double er[3];
+          Vec3 pc;
+          const double chi2 = pose_edge_chi2(T, cam, E, er, pc);
+          a.stored[e] = chi2;
+          double rho0, rho1;
+          huber(chi2, robust ? (E.stereo ? a.hub_stereo : a.hub_mono) : 0.0, rho0, rho1);
+          acc[27] += rho0;
+          // types_six_dof_expmap.cpp:298-320, 367-398
+          const double xx = pc.x, yy = pc.y, invz = 1.0 / pc.z, invz_2 = invz * invz;
+          double J[18];
+          J[0] = xx * yy * invz_2 * cam[0]; J[1] = -(1 + (xx * xx * invz_2)) * cam[0]; J[2] = yy * invz * cam[0];
+          J[3] = -invz * cam[0];            J[4] = 0;                                  J[5] = xx * invz_2 * cam[0];
+          J[6] = (1 + yy * yy * invz_2) * cam[1]; J[7] = -xx * yy * invz_2 * cam[1];   J[8] = -xx * invz * cam[1];
+          J[9] = 0;                         J[10] = -invz * cam[1];                    J[11] = yy * invz_2 * cam[1];
+          J[12] = J[0] - cam[4] * yy * invz_2; J[13] = J[1] + cam[4] * xx * invz_2;    J[14] = J[2];
+          J[15] = J[3];                     J[16] = 0;                                 J[17] = J[5] - cam[4] * invz_2;
+          const int dim = E.stereo ? 3 : 2;
+          const double w = rho1 * E.invs;  // robustInformation(rho) = rho[1] * Omega (base_edge.h:96-102)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            if (r < dim) {
+              const double we = rho1 * (E.invs * er[r]);
+#pragma unroll
+              for (int c = 0; c < 6; ++c) {
+                acc[21 + c] -= J[6 * r + c] * we;
+#pragma unroll
+                for (int c2 = 0; c2 <= c; ++c2) acc[c * (c + 1) / 2 + c2] += J[6 * r + c] * w * J[6 * r + c2];
+              }
+            }
+          }
+        }
+        block_sum<28>(acc, sbuf);
+        double currentChi = acc[27];
+        const double iniChi = currentChi;
+        double tempChi = currentChi;
+        if (it == 0 && i == 0) st.chi2_initial = currentChi;
+        if (i == 0) {  // computeLambdaInit, :166-180
+          double maxDiagonal = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) maxDiagonal = fmax(fabs(acc[c * (c + 1) / 2 + c]), maxDiagonal);
+          lambda = a.tau * maxDiagonal;
+          ni = 2.0;
+          lm_bad = 0;
+        }
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+          const bool ok2 = solve6(acc, lambda, &acc[21], x);  // on failure x keeps the previous solution, as g2o's _x does
+          const Pose Tn = compose(exp_se3(x), T);              // VertexSE3Expmap::oplusImpl
+          double c1[1] = {0.0};
+          for (int e = e0 + tid; e < e1; e += kPoseThreads) {
+            if (a.level[e]) continue;
+            const PoseEdge E = load_pose_edge(a, e);
+            double er[3];
+            Vec3 pc;
+            const double chi2 = pose_edge_chi2(Tn, cam, E, er, pc);
+            a.stored[e] = chi2;
+            double rho0, rho1;
+            huber(chi2, robust ? (E.stereo ? a.hub_stereo : a.hub_mono) : 0.0, rho0, rho1);
+            c1[0] += rho0;
+          }
+          block_sum<1>(c1, sbuf);
+          tempChi = ok2 ? c1[0] : 1.7976931348623157e308;
+          rho = currentChi - tempChi;
+          double scale = 0.0;  // computeScale, :182-189
+#pragma unroll
+          for (int c = 0; c < 6; ++c) scale += x[c] * (lambda * x[c] + acc[21 + c]);
+          scale += 1e-3;
+          rho /= scale;
+          if (rho > 0 && isfinite(tempChi)) {
+            double alpha = 1. - pow((2 * rho - 1), 3.0);
+            alpha = fmin(alpha, a.upper);
+            const double scaleFactor = fmax(a.lower, alpha);
+            lambda *= scaleFactor;
+            ni = 2.0;
+            currentChi = tempChi;
+            T = Tn;
+          } else {
+            lambda *= ni;
+            ni *= 2.0;
+          }
+          qmax++;
+          st.lm_trials++;
+        } while (rho < 0 && qmax < a.max_trials);
+        st.lm_iterations++;
+        st.chi2_final = currentChi;
+        if (qmax == a.max_trials || rho == 0) { ok = false; continue; }  // Terminate
+        if ((iniChi - currentChi) * 1e3 < iniChi) lm_bad++;
+        else lm_bad = 0;
+        if (lm_bad >= 3) ok = false;
+      }
+    }
+    // ---- classification, Optimizer.cc:389-446 ----
+    double bad[1] = {0.0};
+    for (int e = e0 + tid; e < e1; e += kPoseThreads) {
+      const PoseEdge E = load_pose_edge(a, e);
+      double c;
+      if (a.level[e]) {  // `if(pFrame->mvbOutlier[idx]) e->computeError()`: it did not take part in this round
+        double er[3];
+        Vec3 pc;
+        c = pose_edge_chi2(T, cam, E, er, pc);
+      } else {
+        c = a.stored[e];
+      }
+      const float chi2 = (float)c;
+      const bool out = chi2 > (E.stereo ? a.chi2_stereo : a.chi2_mono);
+      a.level[e] = out ? 1 : 0;
+      a.out_chi2[e] = c;
+      bad[0] += out ? 1.0 : 0.0;
+    }
+    block_sum<1>(bad, sbuf);
+    nBad = (int)bad[0];
+    st.rounds_run = it + 1;
+    if (n < a.min_edges) break;  // :448-449
+  }
+  if (tid == 0) {
+    double* o = &a.out_pose[7 * f];
+    o[0] = T.q.x; o[1] = T.q.y; o[2] = T.q.z; o[3] = T.q.w; o[4] = T.t.x; o[5] = T.t.y; o[6] = T.t.z;
+    a.n_inliers[f] = n - nBad;  // :458
+    st.n_bad = nBad;
+    st.lambda_final = lambda;
+    a.stats[f] = st;
+  }
+}
+
+}  // namespace ppo
+
+using namespace ppo;
+
+extern "C" {
+
+void ppo_pose_default_options(ppo_pose_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->abi_version = PPO_POSE_ABI_VERSION;
+  o->device_id = 0;
+  o->rounds = 4;                 // Optimizer.cc:377-382
+  o->iters_per_round = 10;
+  o->robust_rounds = 3;          // :415, 444
+  o->min_correspondences = 3;    // :372
+  o->min_edges = 10;             // :448
+  o->chi2_mono = 5.991f;
+  o->chi2_stereo = 7.815f;
+  o->huber_mono = (float)std::sqrt(5.991);    // `const float deltaMono = sqrt(5.991)`, :281
+  o->huber_stereo = (float)std::sqrt(7.815);
+  o->lm_tau = 1e-5;              // optimization_algorithm_levenberg.cpp:47-51
+  o->lm_max_trials = 10;
+  o->lm_lower = 1. / 3.;
+  o->lm_upper = 2. / 3.;
+}
+
+int ppo_pose_optimize(const ppo_pose_problem* p, const ppo_pose_options* o, ppo_pose_result* r) try {
+  if (!p || !o || !r || !r->pose_qt) return PPO_BA_ERR_ARG;
+  if (o->abi_version != PPO_POSE_ABI_VERSION) return PPO_BA_ERR_ARG;
+  if (p->n_frames < 0 || o->rounds < 0 || o->rounds > PPO_POSE_MAX_ROUNDS || o->iters_per_round < 0 || o->lm_max_trials < 1) return PPO_BA_ERR_ARG;
+  const int F = p->n_frames;
+  if (F == 0) return PPO_BA_OK;
+  if (!p->pose_qt || !p->cam || !p->edge_offsets) return PPO_BA_ERR_ARG;
+  if (p->edge_offsets[0] != 0) return PPO_BA_ERR_ARG;
+  for (int f = 0; f < F; ++f)
+    if (p->edge_offsets[f + 1] < p->edge_offsets[f]) return PPO_BA_ERR_ARG;
+  const size_t E = (size_t)p->edge_offsets[F];
+  if (E && (!p->xw || !p->obs || !p->inv_sigma2)) return PPO_BA_ERR_ARG;
+  auto finite = [](const double* v, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+      if (!std::isfinite(v[i])) return false;
+    return true;
+  };
+  if (!finite(p->pose_qt, (size_t)7 * F) || !finite(p->cam, (size_t)5 * F) || !finite(p->xw, 3 * E) || !finite(p->obs, 3 * E) || !finite(p->inv_sigma2, E))
+    return PPO_BA_ERR_NONFINITE;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    std::fprintf(stderr, "[ppo_ba] no HIP device: libppo_ba has no CPU path\n");
+    return PPO_BA_ERR_HIP;
+  }
+  if (o->device_id < 0 || o->device_id >= ndev) return PPO_BA_ERR_ARG;
+  if (hipSetDevice(o->device_id) != hipSuccess) return PPO_BA_ERR_HIP;
+  DevCtx ctx;
+  if (!g_ctx_pool.get(o->device_id, &ctx)) return PPO_BA_ERR_HIP;
+
+  // one packed block each way: [pose 7F | cam 5F | xw 3E | obs 3E | invs E | offsets F+1 (int32)] in,
+  // [pose 7F | chi2 E | stats F | n_inliers F (int32) | level E (bytes)] out; `stored` is device scratch
+  auto up8 = [](size_t b) { return (b + 7) & ~size_t(7); };
+  const size_t in_d = (size_t)12 * F + 7 * E;
+  const size_t in_bytes = in_d * 8 + up8((size_t)(F + 1) * 4);
+  const size_t out_bytes = ((size_t)7 * F + E) * 8 + up8((size_t)F * sizeof(ppo_pose_stats)) + up8((size_t)F * 4) + up8(E);
+  Stage stage;
+  int rc = PPO_BA_OK;
+  char* h_in = static_cast<char*>(stage.take(in_bytes));
+  char* h_out = static_cast<char*>(stage.take(out_bytes));
+  size_t cap_in = 0, cap_out = 0, cap_st = 0;
+  char* d_in = static_cast<char*>(g_pool.get(in_bytes, o->device_id, &cap_in));
+  char* d_out = static_cast<char*>(g_pool.get(out_bytes, o->device_id, &cap_out));
+  double* d_stored = static_cast<double*>(g_pool.get(std::max<size_t>(8, E * 8), o->device_id, &cap_st));
+  if (!h_in || !h_out || !d_in || !d_out || !d_stored) rc = PPO_BA_ERR_NOMEM;
+  if (rc == PPO_BA_OK) {
+    double* hd = reinterpret_cast<double*>(h_in);
+    std::memcpy(hd, p->pose_qt, (size_t)7 * F * 8);
+    std::memcpy(hd + 7 * F, p->cam, (size_t)5 * F * 8);
+    if (E) {
+      std::memcpy(hd + 12 * F, p->xw, 3 * E * 8);
+      std::memcpy(hd + 12 * F + 3 * E, p->obs, 3 * E * 8);
+      std::memcpy(hd + 12 * F + 6 * E, p->inv_sigma2, E * 8);
+    }
+    std::memcpy(hd + in_d, p->edge_offsets, (size_t)(F + 1) * 4);
+    PoseOnlyArgs a;
+    const double* dd = reinterpret_cast<const double*>(d_in);
+    a.pose_qt = dd; a.cam = dd + 7 * F; a.xw = dd + 12 * F; a.obs = dd + 12 * F + 3 * E; a.invs = dd + 12 * F + 6 * E;
+    a.off = reinterpret_cast<const int32_t*>(dd + in_d);
+    char* q = d_out;
+    a.out_pose = reinterpret_cast<double*>(q); q += (size_t)7 * F * 8;
+    a.out_chi2 = reinterpret_cast<double*>(q); q += E * 8;
+    a.stats = reinterpret_cast<ppo_pose_stats*>(q); q += up8((size_t)F * sizeof(ppo_pose_stats));
+    a.n_inliers = reinterpret_cast<int32_t*>(q); q += up8((size_t)F * 4);
+    a.level = reinterpret_cast<uint8_t*>(q);
+    a.stored = d_stored;
+    a.rounds = o->rounds; a.iters = o->iters_per_round; a.robust_rounds = o->robust_rounds; a.min_corr = o->min_correspondences;
+    a.min_edges = o->min_edges; a.max_trials = o->lm_max_trials;
+    a.chi2_mono = o->chi2_mono; a.chi2_stereo = o->chi2_stereo;
+    a.hub_mono = (double)o->huber_mono; a.hub_stereo = (double)o->huber_stereo;
+    a.tau = o->lm_tau; a.lower = o->lm_lower; a.upper = o->lm_upper;
+    bool ok = hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ctx.stream) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(k_pose_only, dim3(F), dim3(kPoseThreads), 0, ctx.stream, a);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    ok = ok && hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx.stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(ctx.stream) == hipSuccess;
+    if (!ok) {
+      std::fprintf(stderr, "[ppo_ba] ppo_pose_optimize: %s\n", hipGetErrorString(hipGetLastError()));
+      rc = PPO_BA_ERR_HIP;
+      (void)hipStreamSynchronize(ctx.stream);
+    } else {
+      const char* s = h_out;
+      std::memcpy(r->pose_qt, s, (size_t)7 * F * 8); s += (size_t)7 * F * 8;
+      if (r->chi2 && E) std::memcpy(r->chi2, s, E * 8);
+      s += E * 8;
+      if (r->stats) std::memcpy(r->stats, s, (size_t)F * sizeof(ppo_pose_stats));
+      s += up8((size_t)F * sizeof(ppo_pose_stats));
+      if (r->n_inliers) std::memcpy(r->n_inliers, s, (size_t)F * 4);
+      s += up8((size_t)F * 4);
+      if (r->outlier && E) std::memcpy(r->outlier, s, E);
+    }
+  }
+  if (d_in) g_pool.put(d_in, cap_in, o->device_id);
+  if (d_out) g_pool.put(d_out, cap_out, o->device_id);
+  if (d_stored) g_pool.put(d_stored, cap_st, o->device_id);
+  stage.release();
+  g_ctx_pool.put(ctx);
+  return rc;
+} catch (const std::bad_alloc&) {
+  return PPO_BA_ERR_NOMEM;
+}
+
+}  // extern "C"

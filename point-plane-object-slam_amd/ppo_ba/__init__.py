@@ -1,2 +1,2 @@
 """Host-side Python plumbing for libppo_ba.so (tests and bench.py only; the product is the HIP library)."""
-from . import binding, synth  # noqa: F401
+from . import binding, pose, synth  # noqa: F401

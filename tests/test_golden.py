@@ -38,7 +38,8 @@ def hc():
 
 
 def test_vector_counts():
-    assert {k: len(v) for k, v in GOLD.items()} == {"se3_exp": 39, "pose_oplus": 24, "huber": 28, "mono_project": 32, "stereo_project": 32}
+    assert {k: len(v) for k, v in GOLD.items()} == {"se3_exp": 39, "pose_oplus": 24, "huber": 28, "mono_project": 32, "stereo_project": 32,
+                                                    "onlypose_mono": 24, "onlypose_stereo": 24}
 
 
 def test_oracle_se3_exp_matches_prebuilt_g2o(oracle_lib):
