@@ -4,10 +4,10 @@
 // The problem is tiny (one 6-DoF pose, a few hundred to a few thousand unary reprojection edges) and strictly sequential
 // on the outside: 4 rounds x <= 10 Levenberg-Marquardt iterations x >= 1 trial, each needing a reduction over all edges.
 // Driving that from the host would cost a launch and a round trip per trial (~10 us each against ~1 us of arithmetic), so
-// the whole protocol runs on the device: one 256-thread workgroup per frame holds the pose, the 6x6 system and the LM
+// the whole protocol runs on the device: one workgroup per frame (256 or 512 threads) holds the pose, the 6x6 system and the LM
 // state redundantly in the registers of every thread, edges are dealt round-robin to the threads, and the only shared
-// traffic is the reduction (wave shuffles, then one LDS exchange between the four waves -- a fixed summation order, so the
-// result is bit-reproducible from run to run).  Independent frames go to different workgroups of the same launch.
+// traffic is the reduction (an LDS transpose for the 28 values of the normal equations, wave shuffles for the single chi2 of
+// a trial -- a fixed summation order, so the result is bit-reproducible from run to run).  Independent frames go to different workgroups of the same launch.
 //
 // Restated per thread, in the reference's order (G2O = Thirdparty/g2o/g2o):
 //   residuals / Jacobians   G2O/types/types_six_dof_expmap.h:236-240, 267-271, .cpp:298-338, 367-398
@@ -46,33 +46,51 @@ struct PoseOnlyArgs {
   double hub_mono, hub_stereo, tau, lower, upper;
 };
 
-constexpr int kPoseThreads = 256;
-constexpr int kPoseWaves = kPoseThreads / 64;
 
-// sum over the workgroup, the same value in every thread; order: xor-butterfly inside a wave, then waves 0..3
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double* sbuf) {
+// Sum of one value over the workgroup, the same result in every thread; order: xor-butterfly inside a wave, then the waves.
+template <int NT>
+__device__ __forceinline__ double block_sum1(double x, double* sbuf) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double x = v[i];
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+  if ((threadIdx.x & 63) == 0) sbuf[threadIdx.x >> 6] = x;
+  __syncthreads();
+  double r = sbuf[0];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-    v[i] = x;
+  for (int w = 1; w < NT / 64; ++w) r += sbuf[w];
+  __syncthreads();
+  return r;
+}
+
+// Sum of the 28 values of the normal equations (21 + 6 + chi2) over the workgroup through an LDS transpose: every thread
+// stores its 28 partials as one row (stride 29 doubles: the column reads below are conflict-free), thread (seg, v) adds 32
+// rows of column v, thread v adds the 8 segment sums, everybody reads the 28 totals back.  ~1 k cycles; the shuffle
+// butterfly this replaces (28 values x 6 steps x 2 ds_bpermute) took 8 k of the 11 k cycles of an LM iteration.
+constexpr int kAccN = 28, kAccStride = 29;
+template <int NT>
+__device__ __forceinline__ void block_sum_acc(double (&v)[kAccN], double* sP, double* sQ, double* sR) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < kAccN; ++k) sP[tid * kAccStride + k] = v[k];
+  __syncthreads();
+  {
+    const int col = tid & 31, seg = tid >> 5;
+    if (col < kAccN) {
+      double s = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) s += sP[(seg * 32 + j) * kAccStride + col];
+      sQ[seg * 32 + col] = s;
+    }
   }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
+  __syncthreads();
+  if (tid < kAccN) {
+    double s = sQ[tid];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) sbuf[wave * NV + i] = v[i];
+    for (int g = 1; g < NT / 32; ++g) s += sQ[g * 32 + tid];
+    sR[tid] = s;
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double x = sbuf[i];
-#pragma unroll
-    for (int w = 1; w < kPoseWaves; ++w) x += sbuf[w * NV + i];
-    v[i] = x;
-  }
-  __syncthreads();
+  for (int k = 0; k < kAccN; ++k) v[k] = sR[k];
 }
 
 struct PoseEdge {
@@ -109,9 +127,10 @@ __device__ __forceinline__ double pose_edge_chi2(const Pose& T, const double* ca
   return e[0] * (E.invs * e[0]) + e[1] * (E.invs * e[1]) + e[2] * (E.invs * e[2]);
 }
 
-// (H + lambda I) x = b with H packed lower (row r, column c <= r at r(r+1)/2 + c); false when a pivot is not positive
+// (H + lambda I) x = b with H packed lower (row r, column c <= r at r(r+1)/2 + c); false when a pivot is not positive.
+// Every thread walks this chain alone, so it is written for latency: one reciprocal square root per pivot, no division.
 __device__ __forceinline__ bool solve6(const double* H, double lambda, const double* b, double* x) {
-  double L[21];
+  double L[21], inv[6];
   bool ok = true;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -122,9 +141,10 @@ __device__ __forceinline__ bool solve6(const double* H, double lambda, const dou
       for (int k = 0; k < c; ++k) s -= L[r * (r + 1) / 2 + k] * L[c * (c + 1) / 2 + k];
       if (r == c) {
         ok = ok && (s > 0.0);
-        L[r * (r + 1) / 2 + c] = sqrt(s);
+        inv[r] = rsqrt(s);
+        L[r * (r + 1) / 2 + c] = s * inv[r];
       } else {
-        L[r * (r + 1) / 2 + c] = s / L[c * (c + 1) / 2 + c];
+        L[r * (r + 1) / 2 + c] = s * inv[c];
       }
     }
   }
@@ -135,20 +155,52 @@ __device__ __forceinline__ bool solve6(const double* H, double lambda, const dou
     double s = b[r];
 #pragma unroll
     for (int k = 0; k < r; ++k) s -= L[r * (r + 1) / 2 + k] * y[k];
-    y[r] = s / L[r * (r + 1) / 2 + r];
+    y[r] = s * inv[r];
   }
 #pragma unroll
   for (int r = 5; r >= 0; --r) {
     double s = y[r];
 #pragma unroll
     for (int k = r + 1; k < 6; ++k) s -= L[k * (k + 1) / 2 + r] * x[k];
-    x[r] = s / L[r * (r + 1) / 2 + r];
+    x[r] = s * inv[r];
   }
   return true;
 }
 
-__global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
-  __shared__ double sbuf[kPoseWaves * 28];
+// exp(u) * T (VertexSE3Expmap::oplusImpl) on the same latency diet: the rotation of exp(u) directly as a quaternion
+// (sin(th/2)/th * omega, cos(th/2)), sin th / cos th from the half angle, one reciprocal for the normalisation.  Equal to
+// compose(exp_se3(u), T) up to rounding; below g2o's small-angle threshold (se3quat.h:229-271 switches formula there) the
+// shared routine is used so that the branch is reproduced exactly.
+__device__ __forceinline__ Pose pose_boxplus_fast(const Pose& T, const double* u) {
+  const Vec3 om = v3(u[0], u[1], u[2]), up = v3(u[3], u[4], u[5]);
+  const double th2 = dot3(om, om);
+  if (th2 < 1e-10) return compose(exp_se3(u), T);
+  const double th = sqrt(th2), ith = 1.0 / th;
+  double sh, ch;
+  sincos(0.5 * th, &sh, &ch);
+  const double sn = 2.0 * sh * ch, vers = 2.0 * sh * sh;  // sin th, 1 - cos th
+  const double k = sh * ith;
+  Quat qe = Quat{k * om.x, k * om.y, k * om.z, ch};       // unit by construction, w >= 0 for th < pi
+  if (qe.w < 0) qe = Quat{-qe.x, -qe.y, -qe.z, -qe.w};
+  const double ith2 = ith * ith;
+  const double bb = vers * ith2, cc = (th - sn) * ith2 * ith;  // V = I + b W + c W^2
+  const Vec3 wu = cross3(om, up);
+  const Vec3 wwu = cross3(om, wu);
+  Pose r;
+  r.t = up + wu * bb + wwu * cc + qrot(qe, T.t);
+  Quat q = qmul(qe, T.q);
+  if (q.w < 0) q = Quat{-q.x, -q.y, -q.z, -q.w};
+  const double in = 1.0 / sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  r.q = Quat{q.x * in, q.y * in, q.z * in, q.w * in};
+  return r;
+}
+
+// NT threads per frame: 256 suit the usual few hundred observations (fewer waves to synchronise), 512 pay off above ~700
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
+  constexpr int kPoseThreads = NT;
+  __shared__ double sbuf[NT / 64];
+  __shared__ double sP[NT * kAccStride], sQ[(NT / 32) * 32], sR[32];
   const int f = blockIdx.x, tid = threadIdx.x;
   const int e0 = a.off[f], e1 = a.off[f + 1], n = e1 - e0;
   double cam[5];
@@ -181,10 +233,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
   for (int it = 0; it < a.rounds; ++it) {
     T = T0;                                   // :385
     const bool robust = it < a.robust_rounds;  // `if(it==2) e->setRobustKernel(0)` takes effect from the next round on
-    double cnt[1] = {0.0};
-    for (int e = e0 + tid; e < e1; e += kPoseThreads) cnt[0] += a.level[e] == 0 ? 1.0 : 0.0;
-    block_sum<1>(cnt, sbuf);
-    if (cnt[0] > 0.0) {  // initializeOptimization(0) found active edges; otherwise optimize() returns at once (sparse_optimizer.cpp:356-360)
+    double cnt = 0.0;
+    for (int e = e0 + tid; e < e1; e += kPoseThreads) cnt += a.level[e] == 0 ? 1.0 : 0.0;
+    cnt = block_sum1<NT>(cnt, sbuf);
+    if (cnt > 0.0) {  // initializeOptimization(0) found active edges; otherwise optimize() returns at once (sparse_optimizer.cpp:356-360)
       int lm_bad = 0;
       bool ok = true;
       for (int i = 0; i < a.iters && ok; ++i) {
@@ -226,7 +278,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
             }
           }
         }
-        block_sum<28>(acc, sbuf);
+        block_sum_acc<NT>(acc, sP, sQ, sR);
         double currentChi = acc[27];
         const double iniChi = currentChi;
         double tempChi = currentChi;
@@ -243,8 +295,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
         int qmax = 0;
         do {
           const bool ok2 = solve6(acc, lambda, &acc[21], x);  // on failure x keeps the previous solution, as g2o's _x does
-          const Pose Tn = compose(exp_se3(x), T);              // VertexSE3Expmap::oplusImpl
-          double c1[1] = {0.0};
+          const Pose Tn = pose_boxplus_fast(T, x);             // VertexSE3Expmap::oplusImpl
+          double c1 = 0.0;
           for (int e = e0 + tid; e < e1; e += kPoseThreads) {
             if (a.level[e]) continue;
             const PoseEdge E = load_pose_edge(a, e);
@@ -254,10 +306,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
             a.stored[e] = chi2;
             double rho0, rho1;
             huber(chi2, robust ? (E.stereo ? a.hub_stereo : a.hub_mono) : 0.0, rho0, rho1);
-            c1[0] += rho0;
+            c1 += rho0;
           }
-          block_sum<1>(c1, sbuf);
-          tempChi = ok2 ? c1[0] : 1.7976931348623157e308;
+          c1 = block_sum1<NT>(c1, sbuf);
+          tempChi = ok2 ? c1 : 1.7976931348623157e308;
           rho = currentChi - tempChi;
           double scale = 0.0;  // computeScale, :182-189
 #pragma unroll
@@ -265,7 +317,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
           scale += 1e-3;
           rho /= scale;
           if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - pow((2 * rho - 1), 3.0);
+            const double tr = 2 * rho - 1;
+            double alpha = 1. - tr * tr * tr;  // pow(2 rho - 1, 3)
             alpha = fmin(alpha, a.upper);
             const double scaleFactor = fmax(a.lower, alpha);
             lambda *= scaleFactor;
@@ -288,7 +341,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
       }
     }
     // ---- classification, Optimizer.cc:389-446 ----
-    double bad[1] = {0.0};
+    double bad = 0.0;
     for (int e = e0 + tid; e < e1; e += kPoseThreads) {
       const PoseEdge E = load_pose_edge(a, e);
       double c;
@@ -303,10 +356,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_only(PoseOnlyArgs a) {
       const bool out = chi2 > (E.stereo ? a.chi2_stereo : a.chi2_mono);
       a.level[e] = out ? 1 : 0;
       a.out_chi2[e] = c;
-      bad[0] += out ? 1.0 : 0.0;
+      bad += out ? 1.0 : 0.0;
     }
-    block_sum<1>(bad, sbuf);
-    nBad = (int)bad[0];
+    bad = block_sum1<NT>(bad, sbuf);
+    nBad = (int)bad;
     st.rounds_run = it + 1;
     if (n < a.min_edges) break;  // :448-449
   }
@@ -419,7 +472,10 @@ int ppo_pose_optimize(const ppo_pose_problem* p, const ppo_pose_options* o, ppo_
     a.tau = o->lm_tau; a.lower = o->lm_lower; a.upper = o->lm_upper;
     bool ok = hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ctx.stream) == hipSuccess;
     if (ok) {
-      hipLaunchKernelGGL(k_pose_only, dim3(F), dim3(kPoseThreads), 0, ctx.stream, a);
+      int max_n = 0;
+      for (int f = 0; f < F; ++f) max_n = std::max(max_n, p->edge_offsets[f + 1] - p->edge_offsets[f]);
+      if (max_n > 700) hipLaunchKernelGGL(k_pose_only<512>, dim3(F), dim3(512), 0, ctx.stream, a);
+      else hipLaunchKernelGGL(k_pose_only<256>, dim3(F), dim3(256), 0, ctx.stream, a);
       ok = hipGetLastError() == hipSuccess;
     }
     ok = ok && hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx.stream) == hipSuccess;

@@ -210,6 +210,7 @@ def test_pose_only_matches_the_committed_trace():
 
 @pytest.mark.gpu
 def test_pose_only_is_bit_reproducible_and_batching_does_not_change_a_frame():
+    # (same workgroup size in both launches: it is chosen from the largest frame of a call, 256 threads up to 700 observations)
     lib = B.load_library()
     fr = pose.make_frames(n_frames=16, n_obs=450, seed=9)
     a, b = pose.optimize(lib, fr), pose.optimize(lib, fr)
