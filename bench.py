@@ -197,6 +197,25 @@ def main():
         call_ms = {"create": 1e3 * (t_b - t_a), "run": 1e3 * (t_c2 - t_b), "read": 1e3 * (t_d - t_c2), "total": 1e3 * (t_d - t_a)}
 
     pose_only = pose_only_figures(B, not a.no_cpu_baseline) if world == 1 else {}
+    # where the device time of one 5+10 call goes (ppo_ba_stats.ms_*, HIP events on the stream, outside the timed region)
+    phases = {}
+    if world == 1:
+        vo = B.default_options(solver=a.solver, verbose=1)
+        err = os.dup(2)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 2)  # verbose also prints the phase times of ppo_ba_create on stderr
+        try:
+            vs = B.hip_backend().create(P, vo)
+            vs.run()
+            vs.reset()
+            tv = vs.run()
+            vs.close()
+        finally:
+            os.dup2(err, 2)
+            os.close(devnull)
+            os.close(err)
+        phases = {k: tv[k] for k in ("ms_linearize", "ms_schur", "ms_factor", "ms_backsub", "ms_chi2")}
+        phases["wall_ms_total"] = tv["wall_ms_total"]
 
     if rank == 0:
         out = {
@@ -213,7 +232,7 @@ def main():
                 "ms_per_lm_iter": 1e3 * dt / max(iters, 1), "solver_backend": int(a.solver),
                 "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
                 "first_create_ms_incl_module_load": create_ms, "steady_state_call_ms": call_ms, "kernels": kernels,
-                "pose_only": pose_only,
+                "pose_only": pose_only, "device_ms_per_phase_of_one_call": phases,
             },
             "roofline": {"bound": "hbm", "kernel": "k_linearize_all", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(int(k_bytes.value)),

@@ -530,9 +530,11 @@ struct PlaneModel {
     const PlaneEdge& ed = g.pl[i];
     PlaneC pl = load_plane(&st.plane[4 * ed.plane]);
     Pose T = load_pose(&st.pose_qt[7 * ed.pose]);
-    double u[6] = {0, 0, 0, 0, 0, 0};
-    if (c >= 0 && c < 3) { u[c] = step; pl = plane_boxplus(pl, u); }
-    else if (c >= 3) { u[c - 3] = step; T = pose_boxplus(T, u); }
+    double u[6];  // (filled by selects: u[c] = step with a run-time c would live in scratch memory)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = (k == (c < 3 ? c : c - 3)) ? step : 0.0;
+    if (c >= 0 && c < 3) pl = plane_boxplus(pl, u);
+    else if (c >= 3) T = pose_boxplus(T, u);
     const PlaneC local = plane_into_camera(T, pl);
     plane_residual(local, PlaneC{ed.meas[0], ed.meas[1], ed.meas[2], ed.meas[3]}, (ed.flags >> 8) & 3, e);
   }
@@ -571,10 +573,11 @@ struct CubProjModel {  // bbox (corner = false) or corner edges: cols 0-5 pose, 
     const CubEdge& ed = E(i);
     Pose T = load_pose(&st.pose_qt[7 * ed.pose]);
     Cub cb = load_cub(&st.cub[10 * ed.cuboid]);
-    double u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (c >= 0 && c < 6) { u[c] = step; T = pose_boxplus(T, u); }
+    double u[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) u[k] = (k == (c < 6 ? c : c - 6)) ? step : 0.0;
+    if (c >= 0 && c < 6) T = pose_boxplus(T, u);
     else if (c >= 6) {
-      u[c - 6] = step;
       const double* fs = &g.cub_fixedscale[3 * ed.cuboid];
       cb = cuboid_boxplus(cb, u, g.cub_flags[ed.cuboid], fs[0], fs[1], fs[2]);
     }
@@ -616,8 +619,9 @@ struct PtCubModel {  // unary: cols 0-8 cuboid
     const PtCubEdge& ed = g.ptcub[i];
     Cub cb = load_cub(&st.cub[10 * ed.cuboid]);
     if (c >= 0) {
-      double u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      u[c] = step;
+      double u[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) u[k] = (k == c) ? step : 0.0;
       const double* fs = &g.cub_fixedscale[3 * ed.cuboid];
       cb = cuboid_boxplus(cb, u, g.cub_flags[ed.cuboid], fs[0], fs[1], fs[2]);
     }
@@ -658,19 +662,33 @@ __device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st
     const bool fr = col && m.col_free(i, lane);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      if ((fr || (base && pass == 0))) m.residual(i, base ? -1 : lane, base ? 0.0 : (pass ? -delta : delta), st, pass ? em : ep);
+      if ((fr || (base && pass == 0))) {
+        double eo[DM];  // (written through a fixed array and moved by selects: `pass ? em : ep` as the target put both in scratch memory)
+        m.residual(i, base ? -1 : lane, base ? 0.0 : (pass ? -delta : delta), st, eo);
+#pragma unroll
+        for (int r = 0; r < DM; ++r) {
+          ep[r] = pass ? ep[r] : eo[r];
+          em[r] = pass ? eo[r] : em[r];
+        }
+      }
     }
     if (col) {
       const double scalar = 1.0 / (2 * delta);
-      for (int r = 0; r < dim; ++r) sJ[grp][r][lane] = fr ? scalar * (ep[r] - em[r]) : 0.0;
+#pragma unroll
+      for (int r = 0; r < DM; ++r)
+        if (r < dim) sJ[grp][r][lane] = fr ? scalar * (ep[r] - em[r]) : 0.0;
     } else if (base) {
       double chi2 = 0, nrm = 0;
-      for (int r = 0; r < dim; ++r) { chi2 += ep[r] * (m.info(i, r) * ep[r]); nrm += ep[r] * ep[r]; }
+#pragma unroll
+      for (int r = 0; r < DM; ++r)
+        if (r < dim) { chi2 += ep[r] * (m.info(i, r) * ep[r]); nrm += ep[r] * ep[r]; }
       m.store_chi2(i, chi2, sqrt(nrm));
       double rho0, rho1;
       huber(chi2, m.huber_delta(i), rho0, rho1);
       chi_local = rho0;
-      for (int r = 0; r < dim; ++r) { sW[grp][r] = rho1 * m.info(i, r); sG[grp][r] = -(m.info(i, r) * ep[r]) * rho1; }
+#pragma unroll
+      for (int r = 0; r < DM; ++r)
+        if (r < dim) { sW[grp][r] = rho1 * m.info(i, r); sG[grp][r] = -(m.info(i, r) * ep[r]) * rho1; }
     }
   }
   __syncthreads();

@@ -50,6 +50,10 @@ struct ppo_ba_solver {
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;        // the small numerically differentiated edge classes run here, next to the point kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_acc = nullptr;
+  // options.verbose: phase boundaries recorded as events on the stream, summed into stats.ms_* at the end of run()
+  std::vector<hipEvent_t> ph_events;
+  std::vector<int> ph_tags;  // phase that starts at event i (PH_*)
+  size_t ph_used = 0;
   bool S_is_zero = false;   // S (lower triangle) and bs are cleared and nothing has been accumulated into them yet
   bool lin_valid = false;   // the linearisation buffers hold the linearisation of state `cur` (speculated by the previous trial)
   double chi_cur = 0;       // robust chi2 of state `cur` when lin_valid
@@ -217,6 +221,8 @@ void free_all(ppo_ba_solver* s) {
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release();
   s->d_cub_Linv.release(); s->d_cub_Dinv.release(); s->d_xc.release();
   if (s->blas) rocblas_destroy_handle(s->blas);
+  for (hipEvent_t e : s->ph_events) (void)hipEventDestroy(e);
+  s->ph_events.clear();
   s->comm.destroy();
   if (s->stream) {  // hand the (drained) streams, events and mapped host block back
     DevCtx c;
@@ -230,6 +236,35 @@ void free_all(ppo_ba_solver* s) {
     delete s->stage;
     s->stage = nullptr;
   }
+}
+
+enum { PH_LIN = 0, PH_SCHUR, PH_FACTOR, PH_BACKSUB, PH_CHI2, PH_OTHER };
+inline void phase_mark(ppo_ba_solver* s, int tag) {
+  if (!s->opt.verbose) return;
+  if (s->ph_used == s->ph_events.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    s->ph_events.push_back(e);
+    s->ph_tags.push_back(PH_OTHER);
+  }
+  s->ph_tags[s->ph_used] = tag;
+  (void)hipEventRecord(s->ph_events[s->ph_used++], s->stream);
+}
+// (stream already synchronised) device time between consecutive marks, added to the phase the first one opened
+inline void phase_collect(ppo_ba_solver* s) {
+  for (size_t i = 0; i + 1 < s->ph_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ph_events[i], s->ph_events[i + 1]) != hipSuccess) continue;
+    switch (s->ph_tags[i]) {
+      case PH_LIN: s->stats.ms_linearize += ms; break;
+      case PH_SCHUR: s->stats.ms_schur += ms; break;
+      case PH_FACTOR: s->stats.ms_factor += ms; break;
+      case PH_BACKSUB: s->stats.ms_backsub += ms; break;
+      case PH_CHI2: s->stats.ms_chi2 += ms; break;
+      default: break;
+    }
+  }
+  s->ph_used = 0;
 }
 
 State make_state(double* base, int np, int npt, int npl, int nc) {
@@ -481,7 +516,9 @@ bool stop_requested(const volatile uint8_t* f) { return f && *f; }
 int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const volatile uint8_t* stop, ppo_ba_iter_stat& it) {
   const bool fresh = !s->lin_valid;
   if (fresh) {
+    phase_mark(s, PH_LIN);
     RC_TRY(launch_linearize(s));
+    phase_mark(s, PH_OTHER);
   }
   if (iteration == 0) RC_TRY(launch_maxdiag(s));
   double currentChi;
@@ -503,17 +540,23 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
   int qmax = 0;
   do {
     const double lambda = s->lambda;
+    phase_mark(s, PH_SCHUR);
     RC_TRY(launch_reduce(s, lambda));
+    phase_mark(s, PH_FACTOR);
     RC_TRY(launch_solve(s));
     s->have_system = true;
+    phase_mark(s, PH_BACKSUB);
     RC_TRY(launch_update(s, lambda));
+    phase_mark(s, PH_CHI2);
     RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
     const bool speculated = may_speculate && !stop_requested(stop);
     RC_TRY(fetch_acc_enqueue(s, true, speculated, false, !speculated));
     if (speculated) {
+      phase_mark(s, PH_LIN);
       RC_TRY(launch_linearize(s, s->cur ^ 1, true));
       HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
     }
+    phase_mark(s, PH_OTHER);
     RC_TRY(fetch_acc_wait(s));
     int info = 0;
     info = (int)s->h_pinned[ACC_N];
@@ -543,8 +586,10 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
       if (!(rho < 0)) rho = (info != 0) ? -1.0 : rho;
       if (speculated && rho < 0 && qmax + 1 < s->opt.lm_max_trials && !stop_requested(stop)) {
         // the buffers hold the rejected state's linearisation: restore the kept state's before the retry
+        phase_mark(s, PH_LIN);
         RC_TRY(launch_linearize(s));
-        }
+        phase_mark(s, PH_OTHER);
+      }
     }
     qmax++;
     s->stats.n_trials++;
@@ -1119,6 +1164,7 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
   const int n_red = s->stats.n_reduced;
   std::memset(&s->stats, 0, sizeof(s->stats));
   s->stats.n_reduced = n_red;
+  s->ph_used = 0;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
@@ -1149,6 +1195,7 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
     if (stop_requested(stop)) rc = PPO_BA_ABORTED;
   }
   const auto t3 = std::chrono::steady_clock::now();
+  if (s->opt.verbose) phase_collect(s);
   s->stats.wall_ms_total = ms(t0, t3);
   s->stats.wall_ms_pass1 = ms(t0, t1);
   s->stats.wall_ms_classify = ms(t1, t2);

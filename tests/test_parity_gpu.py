@@ -308,6 +308,25 @@ def test_kernel_timing_hook_reports_every_kernel(hip):
     s.close()
 
 
+def test_phase_times_are_collected_in_verbose_mode_and_do_not_change_the_result(hip):
+    """ppo_ba_stats.ms_*: device time per phase from events on the stream, only when options.verbose != 0."""
+    P = synth.make_problem("small", seed=1)
+    quiet = hip.create(P, B.default_options())
+    tq = quiet.run()
+    rq = quiet.read()
+    quiet.close()
+    assert tq["ms_linearize"] == 0 and tq["ms_factor"] == 0
+    loud = hip.create(P, B.default_options(verbose=1))
+    tl = loud.run()
+    rl = loud.read()
+    loud.close()
+    phases = [tl[k] for k in ("ms_linearize", "ms_schur", "ms_factor", "ms_backsub", "ms_chi2")]
+    assert all(v > 0 for v in phases), phases
+    assert sum(phases) <= tl["wall_ms_total"] * 1.05
+    assert [i["trials"] for i in tl["iters"]] == [i["trials"] for i in tq["iters"]]
+    assert np.abs(rl.pose_qt - rq.pose_qt).max() < 1e-5
+
+
 def test_sharded_code_path_with_a_one_rank_rccl_communicator(hip, monkeypatch):
     """PPO_BA_COMM_SELFTEST=1 makes the library open librccl.so, build a ONE-rank communicator and take every branch of the
     N > 1 path (all-reduce of the pose blocks after each linearisation, of (S, b) per solve attempt, of the chi2 / scale /
