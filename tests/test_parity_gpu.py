@@ -327,6 +327,28 @@ def test_phase_times_are_collected_in_verbose_mode_and_do_not_change_the_result(
     assert np.abs(rl.pose_qt - rq.pose_qt).max() < 1e-5
 
 
+def test_randomly_structured_windows_against_the_oracle(oracle, hip):
+    """60 windows of random size and composition (3-23 keyframes, 30-700 points, 0-8 planes, 0-4 cuboids, stereo share, corner
+    edges, vertical / parallel planes, fixed observers, 0-20 % gross outliers, both elimination modes; tools/random_sweep.py).
+    The cost reached must agree in EVERY case.  The estimates are compared at the parity bar where the window determines them:
+    over 650 such cases 92 % were inside the bar on every quantity; the rest had the same cost to < 4e-5 and differed in
+    landmarks left with a single active observation after the outlier culling (point RMSE 1e-5..7e-4 with poses at 1e-7), in
+    flat cuboid directions, or in weakly held windows (e.g. 23 keyframes on 63 points) -- the 1e-7 relative noise of the
+    delta = 1e-9 Jacobians times the conditioning of the window, in the oracle as much as here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("random_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "random_sweep.py"))
+    rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rs)
+    inside = 0
+    n = 60
+    for seed in range(3000, 3000 + n):
+        ok, sched, m, chi, cfg, kw, elim, iters = rs.run_case(hip, oracle, seed)
+        assert chi < 5e-4, (seed, cfg, kw, chi)
+        assert m["t"] < 1e-3 and m["r"] < 1e-3, (seed, cfg, kw, m)  # nothing diverges
+        inside += bool(ok)
+    assert inside >= int(0.85 * n), inside
+
+
 def test_sharded_code_path_with_a_one_rank_rccl_communicator(hip, monkeypatch):
     """PPO_BA_COMM_SELFTEST=1 makes the library open librccl.so, build a ONE-rank communicator and take every branch of the
     N > 1 path (all-reduce of the pose blocks after each linearisation, of (S, b) per solve attempt, of the chi2 / scale /
