@@ -738,59 +738,98 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   csr_sort(p->n_stereo, p->stereo_point, st_off, s->stereo_perm);
 
   mark("csr sort");
+  // ---- host threads for the plans below -------------------------------------------------------------------------------
+  // Everything from here to the uploads is counting / bucketing over the ~4e5 edges and ~9e5 landmark pose pairs of a
+  // BASELINE-size window.  It runs on a few threads over contiguous, ascending unit ranges, so every bucket keeps the order
+  // the sequential loops produced (the device layout does not depend on the thread count).
+  const int n_host_threads = ((long)p->n_mono + p->n_stereo >= 40000) ? 4 : 1;
+  auto run_threads = [&](int nt, auto&& fn) {
+    if (nt <= 1) { fn(0); return; }
+    Stage* const st = t_stage;
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { t_stage = st; fn(t); });
+    fn(0);
+    for (auto& x : th) x.join();
+  };
+  // stable bucket sort of the items the units [0, n_units) generate: count(u0, u1, hist) tallies keys, fill(u0, u1, cursor)
+  // places items at cursor[key]++ (after prepare(total) has sized the outputs); start gets n_keys + 1 bucket offsets
+  auto bucket_by_key = [&](int n_units, long n_keys, SVec<int32_t>& start, auto&& count, auto&& prepare, auto&& fill) {
+    const int nt = n_host_threads;
+    std::vector<SVec<int32_t>> hist(nt);
+    run_threads(nt, [&](int t) {
+      hist[t].assign(n_keys, 0);
+      count((int)((long)n_units * t / nt), (int)((long)n_units * (t + 1) / nt), hist[t].data());
+    });
+    start.assign(n_keys + 1, 0);
+    int32_t run = 0;
+    for (long k = 0; k < n_keys; ++k) {
+      start[k] = run;
+      for (int t = 0; t < nt; ++t) { const int32_t c = hist[t][k]; hist[t][k] = run; run += c; }
+    }
+    start[n_keys] = run;
+    prepare(run);
+    run_threads(nt, [&](int t) { fill((int)((long)n_units * t / nt), (int)((long)n_units * (t + 1) / nt), hist[t].data()); });
+  };
+
   // ---- (landmark, pose) slots: unique free poses seen by each free landmark, ascending column ----------
-  // flat two-pass layout (count, fill, sort + unique each landmark's short segment in place): no per-landmark allocations
-  SVec<int32_t> seg_off(g.n_lm + 1, 0), seg_col;
+  // per landmark from the CSR orders (points: mo_off / st_off; planes: a small CSR built here): gather, sort + unique the
+  // short segment in place, then compact
+  SVec<int32_t> pl_off, pl_perm;
   {
-    auto visit = [&](auto&& fn) {
-      for (int e = 0; e < p->n_mono; ++e) {
-        const int pt = p->mono_point[e], pc = pose_col[p->mono_pose[e]];
-        if (!point_fixed[pt] && pc >= 0) fn(pt, pc);
-      }
-      for (int e = 0; e < p->n_stereo; ++e) {
-        const int pt = p->stereo_point[e], pc = pose_col[p->stereo_pose[e]];
-        if (!point_fixed[pt] && pc >= 0) fn(pt, pc);
-      }
-      for (int e = 0; e < p->n_plane_edges; ++e) {
-        const int pc = pose_col[p->pl_pose[e]];
-        if (pc >= 0) fn(Npt + p->pl_plane[e], pc);
-      }
-    };
-    visit([&](int l, int) { seg_off[l + 1]++; });
-    for (int l = 0; l < g.n_lm; ++l) seg_off[l + 1] += seg_off[l];
-    seg_col.resize(seg_off[g.n_lm]);
-    SVec<int32_t> cursor(seg_off.begin(), seg_off.end() - 1);
-    visit([&](int l, int pc) { seg_col[cursor[l]++] = pc; });
+    pl_off.assign(Npl + 1, 0);
+    for (int e = 0; e < p->n_plane_edges; ++e) pl_off[p->pl_plane[e] + 1]++;
+    for (int j = 0; j < Npl; ++j) pl_off[j + 1] += pl_off[j];
+    pl_perm.resize(p->n_plane_edges);
+    SVec<int32_t> cursor(pl_off.begin(), pl_off.end() - 1);
+    for (int e = 0; e < p->n_plane_edges; ++e) pl_perm[cursor[p->pl_plane[e]]++] = e;
   }
+  SVec<int32_t> seg_off(g.n_lm + 1, 0), seg_col, seg_cnt(g.n_lm, 0);
+  for (int pt = 0; pt < Npt; ++pt) seg_off[pt + 1] = seg_off[pt] + (mo_off[pt + 1] - mo_off[pt]) + (st_off[pt + 1] - st_off[pt]);
+  for (int j = 0; j < Npl; ++j) seg_off[Npt + j + 1] = seg_off[Npt + j] + (pl_off[j + 1] - pl_off[j]);
+  seg_col.resize(seg_off[g.n_lm]);
+  run_threads(n_host_threads, [&](int t) {
+    const int l0 = (int)((long)g.n_lm * t / n_host_threads), l1 = (int)((long)g.n_lm * (t + 1) / n_host_threads);
+    for (int l = l0; l < l1; ++l) {
+      int32_t* b0 = seg_col.data() + seg_off[l];
+      int32_t* q = b0;
+      if (l < Npt) {
+        if (point_fixed[l]) continue;
+        for (int k = mo_off[l]; k < mo_off[l + 1]; ++k) { const int pc = pose_col[p->mono_pose[s->mono_perm[k]]]; if (pc >= 0) *q++ = pc; }
+        for (int k = st_off[l]; k < st_off[l + 1]; ++k) { const int pc = pose_col[p->stereo_pose[s->stereo_perm[k]]]; if (pc >= 0) *q++ = pc; }
+      } else {
+        for (int k = pl_off[l - Npt]; k < pl_off[l - Npt + 1]; ++k) { const int pc = pose_col[p->pl_pose[pl_perm[k]]]; if (pc >= 0) *q++ = pc; }
+      }
+      std::sort(b0, q);
+      seg_cnt[l] = (int32_t)(std::unique(b0, q) - b0);
+    }
+  });
   SVec<int32_t>& slot_off = s->h_slot_off;
   slot_off.assign(g.n_lm + 1, 0);
-  SVec<int32_t> slot_col, slot_lm;
-  slot_col.reserve(seg_col.size());
-  slot_lm.reserve(seg_col.size());
-  for (int l = 0; l < g.n_lm; ++l) {
-    int32_t* b0 = seg_col.data() + seg_off[l];
-    int32_t* e0 = seg_col.data() + seg_off[l + 1];
-    std::sort(b0, e0);
-    e0 = std::unique(b0, e0);
-    slot_off[l] = (int32_t)slot_col.size();
-    for (int32_t* q = b0; q != e0; ++q) { slot_col.push_back(*q); slot_lm.push_back(l); }
-  }
-  slot_off[g.n_lm] = (int32_t)slot_col.size();
-  g.n_slots = (int)slot_col.size();
+  for (int l = 0; l < g.n_lm; ++l) slot_off[l + 1] = slot_off[l] + seg_cnt[l];
+  g.n_slots = slot_off[g.n_lm];
+  SVec<int32_t> slot_col(g.n_slots), slot_lm(g.n_slots);
+  run_threads(n_host_threads, [&](int t) {
+    const int l0 = (int)((long)g.n_lm * t / n_host_threads), l1 = (int)((long)g.n_lm * (t + 1) / n_host_threads);
+    for (int l = l0; l < l1; ++l)
+      for (int k = 0; k < seg_cnt[l]; ++k) { slot_col[slot_off[l] + k] = seg_col[seg_off[l] + k]; slot_lm[slot_off[l] + k] = l; }
+  });
   // device numbering is POSE-MAJOR: point slots ordered by (pose column, point), then plane slots by (pose column, plane),
   // so that everything a keyframe touches is contiguous (the pose side of the linearisation and the Schur pair kernel stream it)
   const int n_point_slots = slot_off[Npt];
   SVec<int32_t> new_id(g.n_slots), d_slot_col_v(g.n_slots), d_slot_lm_v(g.n_slots);
   {
     auto renumber = [&](int first, int last, int base) {
-      SVec<int32_t> cntc(ncol / 1 + 2, 0);
-      for (int i = first; i < last; ++i) cntc[slot_col[i] + 1]++;
-      for (size_t c = 1; c < cntc.size(); ++c) cntc[c] += cntc[c - 1];
-      for (int i = first; i < last; ++i) new_id[i] = base + cntc[slot_col[i]]++;
+      SVec<int32_t> start;
+      bucket_by_key(last - first, ncol + 1, start,
+                    [&](int u0, int u1, int32_t* h) { for (int i = first + u0; i < first + u1; ++i) h[slot_col[i]]++; }, [](int32_t) {},
+                    [&](int u0, int u1, int32_t* c) { for (int i = first + u0; i < first + u1; ++i) new_id[i] = base + c[slot_col[i]]++; });
     };
     renumber(0, n_point_slots, 0);
     renumber(n_point_slots, g.n_slots, n_point_slots);
-    for (int i = 0; i < g.n_slots; ++i) { d_slot_col_v[new_id[i]] = slot_col[i]; d_slot_lm_v[new_id[i]] = slot_lm[i]; }
+    run_threads(n_host_threads, [&](int t) {
+      const int i0 = (int)((long)g.n_slots * t / n_host_threads), i1 = (int)((long)g.n_slots * (t + 1) / n_host_threads);
+      for (int i = i0; i < i1; ++i) { d_slot_col_v[new_id[i]] = slot_col[i]; d_slot_lm_v[new_id[i]] = slot_lm[i]; }
+    });
   }
   SVec<int32_t> pl_slot_off(Npl + 1, 0), pl_slots(g.n_slots - n_point_slots);
   for (int j = 0; j <= Npl; ++j) pl_slot_off[j] = slot_off[Npt + j] - n_point_slots;
@@ -820,31 +859,33 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     t_stage = s->stage;
     const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
     const long nkeys = (long)nfree * (nfree + 1) / 2;
-    SVec<int32_t> cnt(nkeys + 1, 0);
     SVec<int32_t> slot_pose(g.n_slots);
     for (int i = 0; i < g.n_slots; ++i) slot_pose[i] = slot_col[i] / 6;
     auto key_of = [&](int a, int b) { const long pj = slot_pose[a], pi = slot_pose[b]; return pj * (pj + 1) / 2 + pi; };
-    auto for_owned = [&](auto&& fn) {
-      for (int l = g.pt_first; l < g.pt_last; ++l) fn(l);
-      for (int l = Npt + g.plane_first; l < Npt + g.plane_last; ++l) fn(l);
-    };
-    for_owned([&](int l) {
-      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
-        for (int b = slot_off[l]; b <= a; ++b) cnt[key_of(a, b) + 1]++;
-    });
-    for (long k = 0; k < nkeys; ++k) cnt[k + 1] += cnt[k];
-    const long n_entries = cnt[nkeys];
-    pc_sj.resize(n_entries);
-    pc_si.resize(n_entries);
-    SVec<int32_t> cursor(cnt.begin(), cnt.end() - 1);
-    for_owned([&](int l) {
-      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
-        for (int b = slot_off[l]; b <= a; ++b) {
-          const int32_t pos = cursor[key_of(a, b)]++;
-          pc_sj[pos] = new_id[a];
-          pc_si[pos] = new_id[b];
-        }
-    });
+    // owned landmarks as one unit range: points [pt_first, pt_last) then planes [plane_first, plane_last)
+    const int n_own_pt = g.pt_last - g.pt_first, n_own = n_own_pt + (g.plane_last - g.plane_first);
+    auto lm_of = [&](int u) { return u < n_own_pt ? g.pt_first + u : Npt + g.plane_first + (u - n_own_pt); };
+    SVec<int32_t> cnt;
+    bucket_by_key(n_own, nkeys, cnt,
+                  [&](int u0, int u1, int32_t* h) {
+                    for (int u = u0; u < u1; ++u) {
+                      const int l = lm_of(u);
+                      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
+                        for (int b = slot_off[l]; b <= a; ++b) h[key_of(a, b)]++;
+                    }
+                  },
+                  [&](int32_t total) { pc_sj.resize(total); pc_si.resize(total); },
+                  [&](int u0, int u1, int32_t* c) {
+                    for (int u = u0; u < u1; ++u) {
+                      const int l = lm_of(u);
+                      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
+                        for (int b = slot_off[l]; b <= a; ++b) {
+                          const int32_t pos = c[key_of(a, b)]++;
+                          pc_sj[pos] = new_id[a];
+                          pc_si[pos] = new_id[b];
+                        }
+                    }
+                  });
     pc_start.push_back(0);
     for (long pj = 0, k = 0; pj < nfree; ++pj)
       for (long pi = 0; pi <= pj; ++pi, ++k)
@@ -945,6 +986,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   //  their termination tests compare absolute chi2 values)
 
   mark("edge records");
+  // the copy engine moves the landmark-major records (19 MB at the BASELINE size) while the host builds the rest
+  bool ok = s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream);
   // ---- pose-major static copies of the owned reprojection edges + chunks (pose side of the linearisation) -----------
   SVec<int32_t> po_start, po_end, po_pose;
   SVec<MonoEdgeP> h_monoP;
@@ -952,30 +995,31 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   {
     const int chunk = []() { const char* e = getenv("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     auto build = [&](int type) {
-      SVec<int32_t> cnt(Np + 1, 0);
-      auto visit = [&](auto&& fn) {
-        for (int pt = g.pt_first; pt < g.pt_last; ++pt) {
-          if (type == 0) for (int k = mo_off[pt]; k < mo_off[pt + 1]; ++k) fn(s->h_mono[k].pose, k);
-          else for (int k = st_off[pt]; k < st_off[pt + 1]; ++k) fn(s->h_stereo[k].pose, k);
-        }
-      };
-      visit([&](int pose, int) { if (pose_free_id[pose] >= 0) cnt[pose + 1]++; });
-      for (int i = 0; i < Np; ++i) cnt[i + 1] += cnt[i];
-      SVec<int32_t> cursor(cnt.begin(), cnt.end() - 1);
-      if (type == 0) h_monoP.resize(cnt[Np]); else h_stereoP.resize(cnt[Np]);
-      visit([&](int pose, int k) {
-        if (pose_free_id[pose] < 0) return;
-        const int q = cursor[pose]++;
-        if (type == 0) {
-          const MonoEdge& m = s->h_mono[k];
-          h_monoP[q] = MonoEdgeP{m.u, m.v, m.info, m.huber, m.point, k, m.slot, 0};
-        } else {
-          const StereoEdge& m = s->h_stereo[k];
-          StereoEdgeP e{};
-          e.u = m.u; e.v = m.v; e.ur = m.ur; e.info = m.info; e.huber = m.huber; e.point = m.point; e.eid = k; e.slot = m.slot;
-          h_stereoP[q] = e;
-        }
-      });
+      SVec<int32_t> cnt;
+      const SVec<int32_t>& off = type == 0 ? mo_off : st_off;
+      auto pose_of = [&](int k) { return type == 0 ? s->h_mono[k].pose : s->h_stereo[k].pose; };
+      bucket_by_key(g.pt_last - g.pt_first, Np, cnt,
+                    [&](int u0, int u1, int32_t* h) {
+                      for (int k = off[g.pt_first + u0]; k < off[g.pt_first + u1]; ++k)
+                        if (pose_free_id[pose_of(k)] >= 0) h[pose_of(k)]++;
+                    },
+                    [&](int32_t total) { if (type == 0) h_monoP.resize(total); else h_stereoP.resize(total); },
+                    [&](int u0, int u1, int32_t* c) {
+                      for (int k = off[g.pt_first + u0]; k < off[g.pt_first + u1]; ++k) {
+                        const int pose = pose_of(k);
+                        if (pose_free_id[pose] < 0) continue;
+                        const int q = c[pose]++;
+                        if (type == 0) {
+                          const MonoEdge& m = s->h_mono[k];
+                          h_monoP[q] = MonoEdgeP{m.u, m.v, m.info, m.huber, m.point, k, m.slot, 0};
+                        } else {
+                          const StereoEdge& m = s->h_stereo[k];
+                          StereoEdgeP e{};
+                          e.u = m.u; e.v = m.v; e.ur = m.ur; e.info = m.info; e.huber = m.huber; e.point = m.point; e.eid = k; e.slot = m.slot;
+                          h_stereoP[q] = e;
+                        }
+                      }
+                    });
       for (int i = 0; i < Np; ++i)
         for (int32_t e = cnt[i]; e < cnt[i + 1]; e += chunk) {
           po_pose.push_back((i << 1) | type);
@@ -986,6 +1030,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     build(0);
     build(1);
   }
+  ok = ok && s->d_monoP.upload(h_monoP, s->stream) && s->d_stereoP.upload(h_stereoP, s->stream);
   SVec<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
   for (int k = 0; k < p->n_mono; ++k) h_mono_flags[k] = s->h_mono[k].flags;
   for (int k = 0; k < p->n_stereo; ++k) h_stereo_flags[k] = s->h_stereo[k].flags;
@@ -1030,8 +1075,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   pair_plan_thread.join();
   mark("pose-major copies, cuboid plan, pair plan join");
-  // ---- uploads ----------------------------------------------------------------------------------------------------------
-  bool ok = true;
+  // ---- uploads (the two big record arrays are already on their way) -----------------------------------------------------
   SVec<double> v_cam(p->pose_cam, p->pose_cam + (size_t)5 * Np);
   SVec<double> v_fs((size_t)3 * Nc, 0.0);
   if (p->cuboid_fixedscale) std::copy(p->cuboid_fixedscale, p->cuboid_fixedscale + (size_t)3 * Nc, v_fs.begin());
@@ -1046,9 +1090,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_pl_slot_off.upload(pl_slot_off, s->stream) && s->d_pl_slots.upload(pl_slots, s->stream);
   ok = ok && s->d_mono_flags.upload(h_mono_flags, s->stream) && s->d_mono_flags0.upload(h_mono_flags, s->stream);
   ok = ok && s->d_stereo_flags.upload(h_stereo_flags, s->stream) && s->d_stereo_flags0.upload(h_stereo_flags, s->stream);
-  ok = ok && s->d_monoP.upload(h_monoP, s->stream) && s->d_stereoP.upload(h_stereoP, s->stream);
   ok = ok && s->d_point_fixed.upload(point_fixed, s->stream) && s->d_cub_flags.upload(v_cf, s->stream);
-  ok = ok && s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream) && s->d_pl.upload(s->h_pl, s->stream);
+  ok = ok && s->d_pl.upload(s->h_pl, s->stream);
   ok = ok && s->d_bbox.upload(s->h_bbox, s->stream) && s->d_corner.upload(s->h_corner, s->stream) && s->d_ptcub.upload(s->h_ptcub, s->stream);
   ok = ok && s->d_pl0.upload(s->h_pl, s->stream);
   ok = ok && s->d_bbox0.upload(s->h_bbox, s->stream) && s->d_corner0.upload(s->h_corner, s->stream);
