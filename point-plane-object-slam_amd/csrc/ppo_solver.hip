@@ -1254,8 +1254,21 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
   StageScope stage_scope(s->stage, true);  // the staging vectors below are gone (and their memory reusable) when read returns
   const Graph& g = s->g;
   const int Np = g.n_poses, Npt = g.n_points, Npl = g.n_planes, Nc = g.n_cuboids;
+  // everything that is needed from the device in one batch of asynchronous copies into page-locked staging memory, one wait.
+  // (The static parts of the reprojection records -- pose and point of an edge -- are still on the host from create.)
   SVec<double> hs(s->state_doubles);
-  if (s->state_doubles) HIP_TRY(hipMemcpy(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double), hipMemcpyDeviceToHost));
+  SVec<double> chi(s->d_chi2_all.n);
+  SVec<uint32_t> hmf(g.n_mono), hsf(g.n_stereo);
+  SVec<PlaneEdge> hp(g.n_pl);
+  SVec<CubEdge> hb(g.n_bbox), hc(g.n_corner);
+  if (s->state_doubles) HIP_TRY(hipMemcpyAsync(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (chi.size()) HIP_TRY(hipMemcpyAsync(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (g.n_mono) HIP_TRY(hipMemcpyAsync(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  if (g.n_stereo) HIP_TRY(hipMemcpyAsync(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  if (g.n_pl) HIP_TRY(hipMemcpyAsync(hp.data(), s->d_pl.p, hp.size() * sizeof(PlaneEdge), hipMemcpyDeviceToHost, s->stream));
+  if (g.n_bbox) HIP_TRY(hipMemcpyAsync(hb.data(), s->d_bbox.p, hb.size() * sizeof(CubEdge), hipMemcpyDeviceToHost, s->stream));
+  if (g.n_corner) HIP_TRY(hipMemcpyAsync(hc.data(), s->d_corner.p, hc.size() * sizeof(CubEdge), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   State h = make_state(hs.data(), Np, Npt, Npl, Nc);
   if (s->comm.active()) {
     // landmarks live on their owner, and with eliminated cuboids only the rank that owns the reduced terms back-substitutes
@@ -1284,20 +1297,6 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
     if (r->cuboid_scale) std::memcpy(&r->cuboid_scale[3 * i], &h.cub[10 * i + 7], 3 * sizeof(double));
   }
   // per-edge outputs
-  SVec<double> chi(s->d_chi2_all.n);
-  if (chi.size()) HIP_TRY(hipMemcpy(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost));
-  SVec<MonoEdge> hm(g.n_mono);
-  SVec<StereoEdge> hst(g.n_stereo);
-  SVec<uint32_t> hmf(g.n_mono), hsf(g.n_stereo);
-  if (g.n_mono) HIP_TRY(hipMemcpy(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (g.n_stereo) HIP_TRY(hipMemcpy(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  SVec<PlaneEdge> hp(g.n_pl);
-  SVec<CubEdge> hb(g.n_bbox), hc(g.n_corner);
-  if (g.n_mono) HIP_TRY(hipMemcpy(hm.data(), s->d_mono.p, hm.size() * sizeof(MonoEdge), hipMemcpyDeviceToHost));
-  if (g.n_stereo) HIP_TRY(hipMemcpy(hst.data(), s->d_stereo.p, hst.size() * sizeof(StereoEdge), hipMemcpyDeviceToHost));
-  if (g.n_pl) HIP_TRY(hipMemcpy(hp.data(), s->d_pl.p, hp.size() * sizeof(PlaneEdge), hipMemcpyDeviceToHost));
-  if (g.n_bbox) HIP_TRY(hipMemcpy(hb.data(), s->d_bbox.p, hb.size() * sizeof(CubEdge), hipMemcpyDeviceToHost));
-  if (g.n_corner) HIP_TRY(hipMemcpy(hc.data(), s->d_corner.p, hc.size() * sizeof(CubEdge), hipMemcpyDeviceToHost));
   const double* c = chi.data();
   const double* c_mono = c; c += g.n_mono;
   const double* c_st = c; c += g.n_stereo;
@@ -1313,30 +1312,17 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
     const Pose T{Quat{q[0], q[1], q[2], q[3]}, Vec3{q[4], q[5], q[6]}};
     return apply(T, v3(h.point[3 * pt], h.point[3 * pt + 1], h.point[3 * pt + 2])).z > 0.0;
   };
-  // sorted position -> point id for the reprojection edges
-  SVec<int32_t> mo_pt(g.n_mono), st_pt(g.n_stereo);
-  {
-    SVec<int32_t> off(Npt + 1);
-    if (Npt + 1 > 0 && g.n_mono) {
-      HIP_TRY(hipMemcpy(off.data(), s->d_mo_off.p, off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-      for (int pnt = 0; pnt < Npt; ++pnt) for (int k = off[pnt]; k < off[pnt + 1]; ++k) mo_pt[k] = pnt;
-    }
-    if (Npt + 1 > 0 && g.n_stereo) {
-      HIP_TRY(hipMemcpy(off.data(), s->d_st_off.p, off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-      for (int pnt = 0; pnt < Npt; ++pnt) for (int k = off[pnt]; k < off[pnt + 1]; ++k) st_pt[k] = pnt;
-    }
-  }
   for (int k = 0; k < g.n_mono; ++k) {
     const int e = s->mono_perm[k];
     if (r->mono_chi2) r->mono_chi2[e] = c_mono[k];
     if (r->mono_level) r->mono_level[e] = (hmf[k] & F_ACTIVE) ? 0 : 1;
-    if (r->mono_depth_positive) r->mono_depth_positive[e] = depth(hm[k].pose, mo_pt[k]);
+    if (r->mono_depth_positive) r->mono_depth_positive[e] = depth(s->h_mono[k].pose, s->h_mono[k].point);
   }
   for (int k = 0; k < g.n_stereo; ++k) {
     const int e = s->stereo_perm[k];
     if (r->stereo_chi2) r->stereo_chi2[e] = c_st[k];
     if (r->stereo_level) r->stereo_level[e] = (hsf[k] & F_ACTIVE) ? 0 : 1;
-    if (r->stereo_depth_positive) r->stereo_depth_positive[e] = depth(hst[k].pose, st_pt[k]);
+    if (r->stereo_depth_positive) r->stereo_depth_positive[e] = depth(s->h_stereo[k].pose, s->h_stereo[k].point);
   }
   for (int e = 0; e < g.n_pl; ++e) {
     if (r->pl_chi2) r->pl_chi2[e] = c_pl[e];
@@ -1366,8 +1352,8 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
         {r->corner_chi2, nullptr, (size_t)g.n_corner, 3}, {r->corner_errnorm, nullptr, (size_t)g.n_corner, 3}, {nullptr, r->corner_level, (size_t)g.n_corner, 3},
         {r->ptcub_chi2, nullptr, (size_t)g.n_ptcub, 3}};
     SVec<uint8_t> own_mono(g.n_mono, 0), own_stereo(g.n_stereo, 0), own_pl(g.n_pl, 0);
-    for (int k = 0; k < g.n_mono; ++k) own_mono[s->mono_perm[k]] = mo_pt[k] >= g.pt_first && mo_pt[k] < g.pt_last;
-    for (int k = 0; k < g.n_stereo; ++k) own_stereo[s->stereo_perm[k]] = st_pt[k] >= g.pt_first && st_pt[k] < g.pt_last;
+    for (int k = 0; k < g.n_mono; ++k) own_mono[s->mono_perm[k]] = s->h_mono[k].point >= g.pt_first && s->h_mono[k].point < g.pt_last;
+    for (int k = 0; k < g.n_stereo; ++k) own_stereo[s->stereo_perm[k]] = s->h_stereo[k].point >= g.pt_first && s->h_stereo[k].point < g.pt_last;
     for (int e = 0; e < g.n_pl; ++e) own_pl[e] = hp[e].plane >= g.plane_first && hp[e].plane < g.plane_last;
     size_t total = 0;
     for (const Item& it : items) total += it.n;
