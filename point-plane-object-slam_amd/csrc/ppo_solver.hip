@@ -464,9 +464,9 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linea
     grid = 1 + (int)std::min<size_t>(std::max<size_t>(1, tot / 2 / 64), (size_t)2 * s->n_cu);
   }
   hipLaunchKernelGGL(k_publish, dim3(grid), dim3(64), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, zp);
-  // (the event only backs up the host's spin on the sequence number; an event record costs a ~6 us bubble in the queue, so
-  //  with speculation it is recorded behind the linearisation instead of in front of it)
-  if (record_event) HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
+  // (no event behind it: a hipEventRecord costs a 6-8 us bubble in the queue in front of the next kernel -- measured with
+  //  tools/gap_report.py as idle time before k_reduce_stage1 in every iteration; the host's spin is backed up by the stream itself)
+  (void)record_event;
   return PPO_BA_OK;
 }
 int fetch_acc_wait(ppo_ba_solver* s) {
@@ -476,11 +476,11 @@ int fetch_acc_wait(ppo_ba_solver* s) {
   for (unsigned it = 0;; ++it) {
     if (*seq == s->pub_seq) { std::atomic_thread_fence(std::memory_order_acquire); return PPO_BA_OK; }
     if ((it & 1023) == 1023) {
-      if (hipEventQuery(s->ev_acc) == hipSuccess) break;  // the kernel is done: the value is there (or something failed)
+      if (hipStreamQuery(s->stream) == hipSuccess) break;  // the stream has drained: the value is there (or something failed)
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
     }
   }
-  HIP_TRY(hipEventSynchronize(s->ev_acc));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   if (*seq != s->pub_seq) return PPO_BA_ERR_HIP;
   return PPO_BA_OK;
 }
@@ -554,7 +554,6 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     if (speculated) {
       phase_mark(s, PH_LIN);
       RC_TRY(launch_linearize(s, s->cur ^ 1, true));
-      HIP_TRY(hipEventRecord(s->ev_acc, s->stream));
     }
     phase_mark(s, PH_OTHER);
     RC_TRY(fetch_acc_wait(s));
