@@ -818,6 +818,22 @@ __global__ __launch_bounds__(64) void k_publish(double* __restrict__ acc, const 
   if (gridDim.x > 1 && t < ACC_N) acc[t] = 0.0;
 }
 
+// reset of a solver in ONE launch: up to eight word-granular copies from the pristine device copies made at create, and the
+// zero ranges.  (Seven hipMemcpyAsync / hipMemsetAsync calls took the runtime's blit path: ~15 us of queue idle each.)
+struct CopyPlan {
+  uint32_t* dst[8];
+  const uint32_t* src[8];
+  unsigned long long n[8];  // 32-bit words
+};
+__global__ __launch_bounds__(256) void k_reset(CopyPlan cp, ZeroPlan zp) {
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const size_t n = cp.n[r];
+    for (size_t i = t0; i < n; i += stride) cp.dst[r][i] = cp.src[r][i];
+  }
+  zero_ranges_body(zp, t0, stride);
+}
 __global__ __launch_bounds__(256) void k_zero_ranges(ZeroPlan zp) {
   zero_ranges_body(zp, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }

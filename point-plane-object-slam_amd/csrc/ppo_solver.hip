@@ -283,21 +283,30 @@ inline int nblk(long n, int b) { return (int)std::max<long>(1, (n + b - 1) / b);
 int reset_device(ppo_ba_solver* s) {
   // edge flags back to "level 0, kernel on", estimates back to the inputs
   // (device-to-device from the pristine copies made at create: a reset never crosses PCIe)
-  auto up = [&](void* dst, const void* src, size_t bytes) {
-    return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
+  CopyPlan cp{};
+  int nc = 0;
+  size_t words = 0;
+  auto up = [&](void* dst, const void* src, size_t bytes) {  // (every record type is a multiple of 4 bytes)
+    if (bytes == 0) return;
+    cp.dst[nc] = static_cast<uint32_t*>(dst);
+    cp.src[nc] = static_cast<const uint32_t*>(src);
+    cp.n[nc] = bytes / 4;
+    words += bytes / 4;
+    ++nc;
   };
-  if (!up(s->d_mono_flags.p, s->d_mono_flags0.p, s->d_mono_flags.n * sizeof(uint32_t)) ||
-      !up(s->d_stereo_flags.p, s->d_stereo_flags0.p, s->d_stereo_flags.n * sizeof(uint32_t)) ||
-      !up(s->d_pl.p, s->d_pl0.p, s->d_pl.n * sizeof(PlaneEdge)) ||
-      !up(s->d_bbox.p, s->d_bbox0.p, s->d_bbox.n * sizeof(CubEdge)) ||
-      !up(s->d_corner.p, s->d_corner0.p, s->d_corner.n * sizeof(CubEdge)))
-    return PPO_BA_ERR_HIP;
-  if (s->state_doubles) {
-    HIP_TRY(hipMemcpyAsync(s->d_state[0].p, s->d_init.p, s->state_doubles * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->d_state[1].p, s->d_init.p, s->state_doubles * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  }
-  if (s->d_chi2_all.n) HIP_TRY(hipMemsetAsync(s->d_chi2_all.p, 0, s->d_chi2_all.n * sizeof(double), s->stream));
-  HIP_TRY(hipMemsetAsync(s->d_arena.p, 0, s->d_arena.n * sizeof(double), s->stream));
+  up(s->d_mono_flags.p, s->d_mono_flags0.p, s->d_mono_flags.n * sizeof(uint32_t));
+  up(s->d_stereo_flags.p, s->d_stereo_flags0.p, s->d_stereo_flags.n * sizeof(uint32_t));
+  up(s->d_pl.p, s->d_pl0.p, s->d_pl.n * sizeof(PlaneEdge));
+  up(s->d_bbox.p, s->d_bbox0.p, s->d_bbox.n * sizeof(CubEdge));
+  up(s->d_corner.p, s->d_corner0.p, s->d_corner.n * sizeof(CubEdge));
+  up(s->d_state[0].p, s->d_init.p, s->state_doubles * sizeof(double));
+  up(s->d_state[1].p, s->d_init.p, s->state_doubles * sizeof(double));
+  ZeroPlan zp{};
+  zp.p[0] = s->d_chi2_all.p; zp.n[0] = s->d_chi2_all.n;
+  zp.p[1] = s->d_arena.p; zp.n[1] = s->d_arena.n;
+  const size_t work = words + 2 * (zp.n[0] + zp.n[1]);
+  hipLaunchKernelGGL(k_reset, dim3(std::min(nblk((long)work / 4, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, cp, zp);
+  HIP_TRY(hipGetLastError());
   s->cur = 0;
   s->ran = false;
   s->have_system = false;
