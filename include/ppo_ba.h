@@ -291,6 +291,16 @@ int ppo_ba_problem_save(const ppo_ba_problem* problem, const char* path);
 int ppo_ba_problem_load(const char* path, ppo_ba_problem** problem);
 void ppo_ba_problem_free(ppo_ba_problem* problem);
 
+/* End-of-run text exports in the reference's formats (src/System.cc:402-494; the second half of SURVEY.md 8(f) N3).  Host only.
+ *   tum:     one line per keyframe "timestamp tx ty tz qx qy qz qw" -- camera centre and camera-to-world rotation of the
+ *            world->camera pose given, narrowed to float32 like the cv::Mat the reference prints (fixed, 6 / 7 decimals)
+ *   cuboids: "class x y z roll pitch yaw sx sy sz" = cuboid::toMinimalVector (include/g2o_cuboid.h:143-162), fixed, 6 decimals;
+ *            class_names may be NULL ("object")
+ *   planes:  "index a b c d" as float32, fixed, 6 decimals */
+int ppo_ba_export_tum(const char* path, int32_t n, const double* timestamps, const double* pose_qt);
+int ppo_ba_export_cuboids(const char* path, int32_t n, const char* const* class_names, const double* cuboid_qt, const double* cuboid_scale);
+int ppo_ba_export_planes(const char* path, int32_t n, const double* plane_coef);
+
 /* ppo_ba_destroy() keeps device blocks, streams and the mapped host block of the solver in a process-wide cache so that
  * the next ppo_ba_create() -- one per local-BA call in the reference -- does not pay for ~60 allocations again (capped at
  * 4 GiB).  This call returns everything cached to the driver; live solvers are not affected. */

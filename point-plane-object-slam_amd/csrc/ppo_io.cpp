@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -176,6 +177,65 @@ void ppo_ba_problem_free(ppo_ba_problem* p) {
   Loaded* L = reinterpret_cast<Loaded*>(p);  // p is the first member
   for (void* b : L->blocks) std::free(b);
   delete L;
+}
+
+
+// ---- end-of-run exports, src/System.cc:402-494 -----------------------------------------------------------------------------
+// SaveKeyFrameTrajectoryTUM (:402-436): R = Rcw^T as quaternion (x y z w), t = camera centre, both float32, `fixed`,
+// timestamp with 6 and the rest with 7 decimals
+int ppo_ba_export_tum(const char* path, int32_t n, const double* timestamps, const double* pose_qt) {
+  if (!path || n < 0 || (n && (!timestamps || !pose_qt))) return PPO_BA_ERR_ARG;
+  FILE* f = std::fopen(path, "w");
+  if (!f) return PPO_BA_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    const double* q = &pose_qt[7 * (size_t)i];
+    const double nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double x = q[0] / nq, y = q[1] / nq, z = q[2] / nq, w = q[3] / nq;
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    float c[3];  // Ow = -Rcw^T tcw (KeyFrame::GetCameraCenter)
+    for (int a = 0; a < 3; ++a) c[a] = (float)-(R[a] * q[4] + R[3 + a] * q[5] + R[6 + a] * q[6]);
+    // the conjugate is the camera-to-world rotation; Eigen's matrix -> quaternion yields w >= 0 when the trace is positive
+    const double sgn = w < 0 ? -1.0 : 1.0;
+    auto pz = [](double v) { return (double)(float)v + 0.0; };  // (+ 0.0: no "-0.0000000" in the file)
+    std::fprintf(f, "%.6f %.7f %.7f %.7f %.7f %.7f %.7f %.7f\n", timestamps[i], pz(c[0]), pz(c[1]), pz(c[2]), pz(-x * sgn), pz(-y * sgn), pz(-z * sgn),
+                 pz(w * sgn));
+  }
+  std::fclose(f);
+  return PPO_BA_OK;
+}
+
+// SaveCuboidOptimized (:439-466) with cuboid::toMinimalVector (include/g2o_cuboid.h:143-162)
+int ppo_ba_export_cuboids(const char* path, int32_t n, const char* const* class_names, const double* cuboid_qt, const double* cuboid_scale) {
+  if (!path || n < 0 || (n && (!cuboid_qt || !cuboid_scale))) return PPO_BA_ERR_ARG;
+  FILE* f = std::fopen(path, "w");
+  if (!f) return PPO_BA_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    const double* q = &cuboid_qt[7 * (size_t)i];
+    const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    const double roll = std::atan2(2 * (qw * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy));
+    const double pitch = std::asin(2 * (qw * qy - qz * qx));
+    const double yaw = std::atan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz));
+    const double* sc = &cuboid_scale[3 * (size_t)i];
+    std::fprintf(f, "%s %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", (class_names && class_names[i]) ? class_names[i] : "object", q[4], q[5], q[6], roll,
+                 pitch, yaw, sc[0], sc[1], sc[2]);
+  }
+  std::fclose(f);
+  return PPO_BA_OK;
+}
+
+// SavePlaneOptimized (:468-494)
+int ppo_ba_export_planes(const char* path, int32_t n, const double* plane_coef) {
+  if (!path || n < 0 || (n && !plane_coef)) return PPO_BA_ERR_ARG;
+  FILE* f = std::fopen(path, "w");
+  if (!f) return PPO_BA_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    const double* c = &plane_coef[4 * (size_t)i];
+    std::fprintf(f, "%d %.6f %.6f %.6f %.6f\n", i, (double)(float)c[0], (double)(float)c[1], (double)(float)c[2], (double)(float)c[3]);
+  }
+  std::fclose(f);
+  return PPO_BA_OK;
 }
 
 }  // extern "C"
