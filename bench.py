@@ -197,6 +197,27 @@ def main():
         call_ms = {"create": 1e3 * (t_b - t_a), "run": 1e3 * (t_c2 - t_b), "read": 1e3 * (t_d - t_c2), "total": 1e3 * (t_d - t_a)}
 
     pose_only = pose_only_figures(B, not a.no_cpu_baseline) if world == 1 else {}
+    # secondary figure, never `value`: two independent windows of the same size driven by two host threads on this GPU
+    # (distinct handles are thread-compatible); a single window is latency-bound, so two of them overlap
+    concurrent = {}
+    if world == 1:
+        import threading
+        hs = [solver, B.hip_backend().create(P, opt)]
+        hs[1].run()
+        counts = [0, 0]
+
+        def work(i):
+            for _ in range(10):
+                hs[i].reset()
+                counts[i] += len(hs[i].run()["iters"])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        t_c0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        concurrent = {"handles": 2, "lm_iters_per_s_aggregate": sum(counts) / (time.perf_counter() - t_c0)}
+        hs[1].close()
     # where the device time of one 5+10 call goes (ppo_ba_stats.ms_*, HIP events on the stream, outside the timed region)
     phases = {}
     if world == 1:
@@ -233,6 +254,7 @@ def main():
                 "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
                 "first_create_ms_incl_module_load": create_ms, "steady_state_call_ms": call_ms, "kernels": kernels,
                 "pose_only": pose_only, "device_ms_per_phase_of_one_call": phases,
+                "two_windows_concurrently": concurrent,
             },
             "roofline": {"bound": "hbm", "kernel": "k_linearize_all", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(int(k_bytes.value)),
