@@ -188,8 +188,7 @@ __device__ __forceinline__ void acc_landmark(const double* Jl, double w, const d
   }
 }
 template <int DIM>
-__device__ __forceinline__ void store_W(const double* Jp, const double* Jl, double w, double* Wd) {
-  double o[18];
+__device__ __forceinline__ void form_W(const double* Jp, const double* Jl, double w, double* o) {
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -199,9 +198,6 @@ __device__ __forceinline__ void store_W(const double* Jp, const double* Jl, doub
       for (int r = 0; r < DIM; ++r) h += Jp[6 * r + a] * w * Jl[3 * r + c];
       o[a * 3 + c] = h;
     }
-  double2* d2 = reinterpret_cast<double2*>(Wd);  // W records are 144 B = 9 x 16 B, 16-byte aligned
-#pragma unroll
-  for (int q = 0; q < 9; ++q) d2[q] = make_double2(o[2 * q], o[2 * q + 1]);
 }
 template <int DIM>
 __device__ __forceinline__ void acc_pose(const double* Jp, double w, const double* gr, double* A) {
@@ -217,11 +213,6 @@ __device__ __forceinline__ void acc_pose(const double* Jp, double w, const doubl
       A[a * (a + 1) / 2 + c] += h;
     }
   }
-}
-__device__ __forceinline__ void zero_W(double* Wd) {
-  double2* d2 = reinterpret_cast<double2*>(Wd);
-#pragma unroll
-  for (int q = 0; q < 9; ++q) d2[q] = make_double2(0.0, 0.0);
 }
 
 // ======================================================================================================
@@ -349,8 +340,37 @@ struct PoseChunks {
   const int32_t* pose;   // [n_chunks] (keyframe index << 1) | type
   int n_chunks;
 };
-__device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, const PoseChunks& pc, int bid, double (*s_buf)[14][65]) {
+// W records of one wave iteration.  The slots of a keyframe's edges are consecutive in the pose-major numbering, so a full wave
+// writes one contiguous 9216-byte run: transposed through LDS every store instruction covers eight whole cache lines instead
+// of 64 sixteen-byte pieces of 64 different records (pose side alone: 32.6 -> 20.2 us).  Anything else (segment tails,
+// fixed points without a slot) falls back to per-lane stores.
+__device__ __forceinline__ void store_W_wave(double* W, bool in, int slot, const double* o, double* wbuf) {
+  const int lane = threadIdx.x & 63;
+  const int slot0 = __builtin_amdgcn_readfirstlane(slot);
+  if (__all(in && slot >= 0 && slot == slot0 + lane)) {
+#pragma unroll
+    for (int k = 0; k < 18; ++k) wbuf[lane * 19 + k] = o[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double2* const dst = reinterpret_cast<double2*>(&W[(size_t)slot0 * 18]);
+#pragma unroll
+    for (int pz = 0; pz < 9; ++pz) {
+      const int c = pz * 64 + lane, src = c / 9, piece = c - 9 * src;
+      dst[c] = make_double2(wbuf[src * 19 + 2 * piece], wbuf[src * 19 + 2 * piece + 1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  } else if (in && slot >= 0) {
+    double2* d2 = reinterpret_cast<double2*>(&W[(size_t)slot * 18]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d2[k] = make_double2(o[2 * k], o[2 * k + 1]);
+  }
+}
+constexpr int kPoseWaveLds = 64 * 19;  // doubles per wave: W transpose buffer (64 records, row stride 19); the 14 x 65 reduction buffer aliases it
+__device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, const PoseChunks& pc, int bid, double* s_raw) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* const wbuf = s_raw + wave * kPoseWaveLds;
+  double (*const red)[65] = reinterpret_cast<double (*)[65]>(wbuf);
   const int t = bid * 4 + wave;  // one wave per chunk: lanes stride the chunk, records are read fully coalesced
   if (t >= pc.n_chunks) return;
   const int code = pc.pose[t], pose = code >> 1;
@@ -370,56 +390,68 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
   for (int k = 0; k < 28; ++k) A[k] = 0.0;
   const int q1 = pc.end[t];
   if (!(code & 1)) {
-    for (int q = pc.start[t] + lane; q < q1; q += 64) {
-      const MonoEdgeP ed = g.monoP[q];
-      const uint32_t fl = g.mono_flags[ed.eid];
-      if (!(fl & F_ACTIVE)) {
-        if (ed.slot >= 0) zero_W(&g.W[(size_t)ed.slot * 18]);
-        continue;
+    for (int q0 = pc.start[t]; q0 < q1; q0 += 64) {
+      const int q = q0 + lane;
+      const bool in = q < q1;
+      MonoEdgeP ed{};
+      ed.slot = -1;
+      uint32_t fl = 0;
+      if (in) { ed = g.monoP[q]; fl = g.mono_flags[ed.eid]; }
+      double o[18];
+#pragma unroll
+      for (int k = 0; k < 18; ++k) o[k] = 0.0;
+      if (in && (fl & F_ACTIVE)) {
+        const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
+        double ev[2], Jl[6], Jp[12], zc;
+        mono_eval(R, tr, X, fx, fy, cx, cy, ed.u, ed.v, ev, Jl, Jp, zc);
+        const double chi2 = ev[0] * (ed.info * ev[0]) + ev[1] * (ed.info * ev[1]);
+        double rho0, rho1;
+        huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+        const double w = rho1 * ed.info;
+        const double gr[2] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1};
+        acc_pose<2>(Jp, w, gr, A);
+        form_W<2>(Jp, Jl, w, o);
       }
-      const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
-      double ev[2], Jl[6], Jp[12], zc;
-      mono_eval(R, tr, X, fx, fy, cx, cy, ed.u, ed.v, ev, Jl, Jp, zc);
-      const double chi2 = ev[0] * (ed.info * ev[0]) + ev[1] * (ed.info * ev[1]);
-      double rho0, rho1;
-      huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
-      const double w = rho1 * ed.info;
-      const double gr[2] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1};
-      acc_pose<2>(Jp, w, gr, A);
-      if (ed.slot >= 0) store_W<2>(Jp, Jl, w, &g.W[(size_t)ed.slot * 18]);
+      store_W_wave(g.W, in, ed.slot, o, wbuf);
     }
   } else {
-    for (int q = pc.start[t] + lane; q < q1; q += 64) {
-      const StereoEdgeP ed = g.stereoP[q];
-      const uint32_t fl = g.stereo_flags[ed.eid];
-      if (!(fl & F_ACTIVE)) {
-        if (ed.slot >= 0) zero_W(&g.W[(size_t)ed.slot * 18]);
-        continue;
-      }
-      const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
-      double ev[3], Jl[9], Jp[18], zc;
-      stereo_eval(R, tr, X, fx, fy, cx, cy, bf, ed.u, ed.v, ed.ur, ev, Jl, Jp, zc);
-      double chi2 = 0;
+    for (int q0 = pc.start[t]; q0 < q1; q0 += 64) {
+      const int q = q0 + lane;
+      const bool in = q < q1;
+      StereoEdgeP ed{};
+      ed.slot = -1;
+      uint32_t fl = 0;
+      if (in) { ed = g.stereoP[q]; fl = g.stereo_flags[ed.eid]; }
+      double o[18];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) chi2 += ev[r] * (ed.info * ev[r]);
-      double rho0, rho1;
-      huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
-      const double w = rho1 * ed.info;
-      const double gr[3] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1, -(ed.info * ev[2]) * rho1};
-      acc_pose<3>(Jp, w, gr, A);
-      if (ed.slot >= 0) store_W<3>(Jp, Jl, w, &g.W[(size_t)ed.slot * 18]);
+      for (int k = 0; k < 18; ++k) o[k] = 0.0;
+      if (in && (fl & F_ACTIVE)) {
+        const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
+        double ev[3], Jl[9], Jp[18], zc;
+        stereo_eval(R, tr, X, fx, fy, cx, cy, bf, ed.u, ed.v, ed.ur, ev, Jl, Jp, zc);
+        double chi2 = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) chi2 += ev[r] * (ed.info * ev[r]);
+        double rho0, rho1;
+        huber(chi2, (fl & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+        const double w = rho1 * ed.info;
+        const double gr[3] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1, -(ed.info * ev[2]) * rho1};
+        acc_pose<3>(Jp, w, gr, A);
+        form_W<3>(Jp, Jl, w, o);
+      }
+      store_W_wave(g.W, in, ed.slot, o, wbuf);
     }
   }
   double* hb = &g.HB[(size_t)g.pose_free_id[pose] * 27];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {  // 27 values in two rounds of 14: lane v ends up with value 14 half + v
-    const double tot = wave_transpose_sum<14>(&A[14 * half], s_buf[wave]);
+    const double tot = wave_transpose_sum<14>(&A[14 * half], red);
     const int v = 14 * half + lane;
     if (lane < 14 && v < 27 && tot != 0.0) atomicAdd(&hb[v], tot);
   }
 }
 __global__ __launch_bounds__(256) void k_lin_poses(Graph g, State st, PoseChunks pc) {
-  __shared__ double s_buf[4][14][65];
+  __shared__ double s_buf[4 * kPoseWaveLds];
   lin_poses_body(g, st, pc, blockIdx.x, s_buf);
 }
 
@@ -761,7 +793,7 @@ __global__ __launch_bounds__(256, PPO_LIN_WAVES) void k_linearize_all(Graph g, S
   int b = blockIdx.x;
   if (b < lp.nb_num) { lin_numeric_dispatch(g, st, lp.num, delta, b, smem); return; }
   b -= lp.nb_num;
-  if (b < lp.nb_pose) { lin_poses_body(g, st, pc, b, reinterpret_cast<double (*)[14][65]>(smem)); return; }
+  if (b < lp.nb_pose) { lin_poses_body(g, st, pc, b, smem); return; }
   b -= lp.nb_pose;
   lin_points_body<USE_LDS>(g, st, b, lp.nb_pts, smem + 8, smem);
 }

@@ -1176,7 +1176,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
         hipFuncSetAttribute((const void*)k_update_all<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
   }
   s->use_lds_lin = s->use_lds && s->lds_bytes <= 40 * 1024;
-  s->lin_lds_bytes = std::max({(int)(4 * 14 * 65 * sizeof(double)), (int)(kNumericLdsDoubles * sizeof(double)),
+  s->lin_lds_bytes = std::max({(int)(4 * kPoseWaveLds * sizeof(double)), (int)(kNumericLdsDoubles * sizeof(double)),
                                s->use_lds_lin ? s->lds_bytes + 64 : 64});
   // derive the rotation matrices of the pristine state once
   {
