@@ -992,6 +992,7 @@ struct PairChunks {
   const int32_t* coli;   // [n_chunks] reduced column of pose i (column block of S)
   const int32_t* sj;     // [n_entries]
   const int32_t* si;     // [n_entries]
+  const int32_t* lm;     // [n_entries] landmark of the pair (saves the dependent slot -> landmark -> (D + lambda I)^-1 gather chain)
   int n_chunks;
 };
 __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunks& pc, int bid, int nblocks, double (*s_buf)[21][65]) {
@@ -1012,12 +1013,13 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
   for (int k = 0; k < 42; ++k) vals[k] = 0.0;
   for (int e = pc.start[t] + lane; e < e1; e += 64) {
     const int sj = pc.sj[e], si = pc.si[e];
-    const int l = g.slot_lm[sj];
+    const int l = pc.lm[e];
     double wj[18], y[18], w[18];
     const double2* wp = reinterpret_cast<const double2*>(&g.W[(size_t)sj * 18]);
     const double2* yp = reinterpret_cast<const double2*>(&g.W[(size_t)si * 18]);
-    const double* I = &g.Dinv[(size_t)l * 6];
-    const double v00 = I[0], v01 = I[1], v02 = I[2], v11 = I[3], v12 = I[4], v22 = I[5];
+    const double2* I2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l * 6]);  // 48-byte records: three 16-byte loads
+    const double2 i01 = I2[0], i23 = I2[1], i45 = I2[2];
+    const double v00 = i01.x, v01 = i01.y, v02 = i23.x, v11 = i23.y, v12 = i45.x, v22 = i45.y;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       const double2 a = wp[q], b = yp[q];

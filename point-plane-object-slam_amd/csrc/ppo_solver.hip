@@ -94,7 +94,7 @@ struct ppo_ba_solver {
   DevBuf<double> d_Wpc, d_Dinv, d_ul, d_S, d_xr, d_cholws;
   double* d_bs_p = nullptr;  // = d_S.p + ld * ld
   DevBuf<double> d_pack;     // sharded runs: lower-triangle tiles of S + b, contiguous, for the all-reduce
-  DevBuf<int32_t> d_pc_start, d_pc_colj, d_pc_coli, d_pc_sj, d_pc_si;  // pose-pair chunks of the Schur accumulation
+  DevBuf<int32_t> d_pc_start, d_pc_colj, d_pc_coli, d_pc_sj, d_pc_si, d_pc_lm;  // pose-pair chunks of the Schur accumulation
   PairChunks pc{};
   DevBuf<int32_t> d_po_start, d_po_end, d_po_pose;  // pose-major chunks of the reprojection edges
   PoseChunks posec{};
@@ -216,7 +216,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
   s->d_Wpc.release(); s->d_Dinv.release(); s->d_ul.release();
   s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
-  s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release();
+  s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release(); s->d_pc_lm.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release();
   s->d_cub_Linv.release(); s->d_cub_Dinv.release(); s->d_xc.release();
@@ -862,7 +862,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   // ---- Schur accumulation plan: (slot_j, slot_i) pairs of every owned landmark filed by pose pair, then chunked -----
   // (built on a helper thread while this one fills the edge records: both are ~3 ms of host work at the BASELINE size)
-  SVec<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si;
+  SVec<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si, pc_lm;
   std::thread pair_plan_thread([&]()   {
     t_stage = s->stage;
     const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
@@ -882,7 +882,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                         for (int b = slot_off[l]; b <= a; ++b) h[key_of(a, b)]++;
                     }
                   },
-                  [&](int32_t total) { pc_sj.resize(total); pc_si.resize(total); },
+                  [&](int32_t total) { pc_sj.resize(total); pc_si.resize(total); pc_lm.resize(total); },
                   [&](int u0, int u1, int32_t* c) {
                     for (int u = u0; u < u1; ++u) {
                       const int l = lm_of(u);
@@ -891,6 +891,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                           const int32_t pos = c[key_of(a, b)]++;
                           pc_sj[pos] = new_id[a];
                           pc_si[pos] = new_id[b];
+                          pc_lm[pos] = l;
                         }
                     }
                   });
@@ -1119,8 +1120,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
   ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_Dinv.alloc((size_t)Nc * 81) && s->d_xc.alloc((size_t)Nc * 9);
   ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
-  ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream);
-  s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, (int)pc_colj.size()};
+  ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream) && s->d_pc_lm.upload(pc_lm, s->stream);
+  s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, (int)pc_colj.size()};
   mark("hipMalloc + H2D enqueue");
   if (!ok) return fail(PPO_BA_ERR_NOMEM);
   {  // blocks come from the cache with stale contents: the work arrays that are only partially written start from zero
