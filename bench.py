@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--solver", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (pose-only, concurrent windows, phase times): "
+                    "used for the rocprofv3 runs so that the kernel statistics hold the headline workload only")
     ap.add_argument("--lin-reps", type=int, default=200)
     a = ap.parse_args()
 
@@ -196,11 +198,12 @@ def main():
         t_d = time.perf_counter()
         call_ms = {"create": 1e3 * (t_b - t_a), "run": 1e3 * (t_c2 - t_b), "read": 1e3 * (t_d - t_c2), "total": 1e3 * (t_d - t_a)}
 
-    pose_only = pose_only_figures(B, not a.no_cpu_baseline) if world == 1 else {}
+    extras = world == 1 and not a.no_extras
+    pose_only = pose_only_figures(B, not a.no_cpu_baseline) if extras else {}
     # secondary figure, never `value`: two independent windows of the same size driven by two host threads on this GPU
     # (distinct handles are thread-compatible); a single window is latency-bound, so two of them overlap
     concurrent = {}
-    if world == 1:
+    if extras:
         import threading
         hs = [solver, B.hip_backend().create(P, opt)]
         hs[1].run()
@@ -220,7 +223,7 @@ def main():
         hs[1].close()
     # where the device time of one 5+10 call goes (ppo_ba_stats.ms_*, HIP events on the stream, outside the timed region)
     phases = {}
-    if world == 1:
+    if extras:
         vo = B.default_options(solver=a.solver, verbose=1)
         err = os.dup(2)
         devnull = os.open(os.devnull, os.O_WRONLY)

@@ -5,7 +5,7 @@
 OUT="${1:-gpurun_out/pmc}"; mkdir -p "$OUT"; OUT="$(cd "$OUT" && pwd)"
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lin-reps 20"
+CMD="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --lin-reps 20"
 RE="k_linearize_all|k_lin_poses|k_lin_points|k_schur_z|k_schur_pairs|k_reduce_stage|k_zero_ranges|k_backsub|k_chi2_all|k_chi2_points|chol_step|chol_back_all"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$RE" --output-format csv -d "$OUT/fetch" -o p -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$RE" --output-format csv -d "$OUT/write" -o p -- $CMD > "$OUT/write.log" 2>&1
