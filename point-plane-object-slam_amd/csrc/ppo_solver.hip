@@ -1186,6 +1186,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   if (reset_device(s) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
   mark("reset + sync");
+  if (o->verbose) {
+    size_t cap = 0, used = 0;
+    for (const auto& b : s->stage->blocks) { cap += b.cap; used += b.used; }
+    std::fprintf(stderr, "[ppo_ba] create: page-locked staging held by this handle %.1f MB (%.1f MB used)\n", cap / 1e6, used / 1e6);
+  }
 
   // algorithmic bytes of one linearisation, SURVEY.md 8(d)
   {
