@@ -875,20 +875,30 @@ __global__ void k_hb_diag(Graph g, double* out) {  // out[6 f + a] = Hpp_f[a][a]
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < g.n_pose_free * 6) out[i] = g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)];
 }
-__global__ void k_maxdiag(Graph g) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double m = 0.0;
-  if (i < g.n_pose_free * 6) m = fabs(g.hb_diag ? g.hb_diag[i] : g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)]);
-  if (i < g.n_cuboids * 9 && g.owns_reduced) m = fmax(m, fabs(g.HC[(size_t)(i / 9) * 54 + packed_lower(i % 9, i % 9)]));
+// (grid-stride, one atomic per workgroup: with one atomic per wave of a 150 k-thread grid the 2 350 updates of the single
+//  address serialised into 29 us)
+__global__ __launch_bounds__(256) void k_maxdiag(Graph g) {
+  __shared__ double s_m[4];
   const int nl_owned = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
-  if (i < nl_owned * 3) {
-    const int k = i / 3, a = i % 3;
-    const int l = k < (g.pt_last - g.pt_first) ? g.pt_first + k : g.n_points + g.plane_first + (k - (g.pt_last - g.pt_first));
-    const bool fixed = l < g.n_points && g.point_fixed[l];
-    if (!fixed) m = fmax(m, fabs(g.D[(size_t)l * 6 + (a == 0 ? 0 : (a == 1 ? 3 : 5))]));
+  const int n = max(max(g.n_pose_free * 6, g.n_cuboids * 9), nl_owned * 3);
+  double m = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (i < g.n_pose_free * 6) m = fmax(m, fabs(g.hb_diag ? g.hb_diag[i] : g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)]));
+    if (i < g.n_cuboids * 9 && g.owns_reduced) m = fmax(m, fabs(g.HC[(size_t)(i / 9) * 54 + packed_lower(i % 9, i % 9)]));
+    if (i < nl_owned * 3) {
+      const int k = i / 3, a = i % 3;
+      const int l = k < (g.pt_last - g.pt_first) ? g.pt_first + k : g.n_points + g.plane_first + (k - (g.pt_last - g.pt_first));
+      const bool fixed = l < g.n_points && g.point_fixed[l];
+      if (!fixed) m = fmax(m, fabs(g.D[(size_t)l * 6 + (a == 0 ? 0 : (a == 1 ? 3 : 5))]));
+    }
   }
   for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.0) atomic_max_pos(&g.acc[ACC_MAXDIAG], m);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
+    if (m > 0.0) atomic_max_pos(&g.acc[ACC_MAXDIAG], m);
+  }
 }
 
 // S(lower) += Hpp (+ lambda), Hcc (+ lambda), pose-cuboid blocks; bs = b.   S was zeroed beforehand.

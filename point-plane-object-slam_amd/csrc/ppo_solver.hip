@@ -509,7 +509,7 @@ int launch_maxdiag(ppo_ba_solver* s) {
     g.hb_diag = s->d_xr.p;
   }
   const long nd = std::max<long>({npd, (long)g.n_cuboids * 9, 3L * ((g.pt_last - g.pt_first) + (g.plane_last - g.plane_first)), 1L});
-  hipLaunchKernelGGL(k_maxdiag, dim3(nblk(nd, 256)), dim3(256), 0, s->stream, g);
+  hipLaunchKernelGGL(k_maxdiag, dim3(std::min(nblk(nd, 256), 64)), dim3(256), 0, s->stream, g);
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
