@@ -201,7 +201,8 @@ typedef struct ppo_ba_stats {
   int32_t n_reduced;                                /* dimension of the dense reduced system */
   int32_t n_active_edges_pass1, n_active_edges_pass2;
   double wall_ms_total;                             /* host steady_clock around run() */
-  double wall_ms_pass1, wall_ms_pass2, wall_ms_classify;
+  double wall_ms_pass1, wall_ms_pass2, wall_ms_classify;  /* host clock; the classification kernels are only enqueued in
+                                                          * `classify` (no synchronisation between the passes), they run inside pass2 */
   /* device time per phase summed over the run, from HIP events on the stream; collected when options.verbose != 0 (0 otherwise:
    * the events cost a few us each).  linearize = k_linearize_all (incl. speculated and repeated ones), schur = reduction to the
    * pose system, factor = dense factor + solve, backsub = landmark back-substitution + state update, chi2 = trial chi2 + publish */

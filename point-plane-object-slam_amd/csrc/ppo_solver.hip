@@ -1230,7 +1230,8 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
   int rc = PPO_BA_OK;
   s->stats.n_active_edges_pass1 = s->g.n_mono + s->g.n_stereo + s->g.n_pl + s->g.n_bbox + s->g.n_corner + s->g.n_ptcub + s->n_cubpl;
   RC_TRY(optimize(s, 0, s->opt.iters_pass1, stop));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  // (the last trial of a pass is not speculated: the host has already waited for its result, the stream is idle here.
+  //  Synchronising again -- and once more behind the classification kernels -- only added round trips between the passes.)
   const auto t1 = std::chrono::steady_clock::now();
   auto t2 = t1;
   if (stop_requested(stop)) rc = PPO_BA_ABORTED;
@@ -1245,7 +1246,6 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
       hipLaunchKernelGGL(k_classify_small, dim3(nblk(nsm, 256)), dim3(256), 0, s->stream, g, s->opt.chi2_plane, s->opt.chi2_plane_vp,
                          s->opt.th_bbox_norm, s->opt.th_corner_norm);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s->stream));
     t2 = std::chrono::steady_clock::now();
     RC_TRY(optimize(s, 1, s->opt.iters_pass2, stop));
     HIP_TRY(hipStreamSynchronize(s->stream));
