@@ -75,12 +75,11 @@ struct DevPool {
 };
 inline DevPool g_pool;
 
-// Streams, events and the mapped host block of a solver are recycled the same way (creating and destroying them costs
+// The stream and the mapped host block of a solver are recycled the same way (creating and destroying them costs
 // several ms per solver, mostly the pinned allocation and the stream teardown).
 struct DevCtx {
   int dev = -1;
-  hipStream_t stream = nullptr, side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_acc = nullptr;
+  hipStream_t stream = nullptr;
   double* h_pinned = nullptr;
   double* h_pinned_dev = nullptr;
 };
@@ -100,9 +99,7 @@ struct CtxPool {
     }
     DevCtx n;
     n.dev = dev;
-    bool ok = hipStreamCreateWithFlags(&n.stream, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n.ev_join, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&n.ev_acc, hipEventDisableTiming) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&n.stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&n.h_pinned, kPinnedDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipHostGetDevicePointer((void**)&n.h_pinned_dev, n.h_pinned, 0) == hipSuccess;
     if (!ok) { destroy(n); return false; }
@@ -116,10 +113,6 @@ struct CtxPool {
   }
   static void destroy(const DevCtx& c) {
     if (c.h_pinned) (void)hipHostFree(c.h_pinned);
-    if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
-    if (c.ev_join) (void)hipEventDestroy(c.ev_join);
-    if (c.ev_acc) (void)hipEventDestroy(c.ev_acc);
-    if (c.side) (void)hipStreamDestroy(c.side);
     if (c.stream) (void)hipStreamDestroy(c.stream);
   }
   void trim() {

@@ -48,8 +48,6 @@ struct ppo_ba_solver {
   ppo_ba_options opt;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;        // the small numerically differentiated edge classes run here, next to the point kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_acc = nullptr;
   // options.verbose: phase boundaries recorded as events on the stream, summed into stats.ms_* at the end of run()
   std::vector<hipEvent_t> ph_events;
   std::vector<int> ph_tags;  // phase that starts at event i (PH_*)
@@ -205,7 +203,6 @@ void canon_plane_cv(const double* in, double* out) {  // Converter::toPlane3D (C
 void free_all(ppo_ba_solver* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  if (s->side) (void)hipStreamSynchronize(s->side);
   // (the captured Cholesky graph stays with the cached block of S: DevPool drops it when the block is really freed)
   s->d_pose_cam.release(); s->d_cub_fixedscale.release(); s->d_ptcub_pts.release();
   s->d_pose_col.release(); s->d_pose_free_id.release(); s->d_cub_col.release(); s->d_mo_off.release(); s->d_st_off.release();
@@ -224,12 +221,12 @@ void free_all(ppo_ba_solver* s) {
   for (hipEvent_t e : s->ph_events) (void)hipEventDestroy(e);
   s->ph_events.clear();
   s->comm.destroy();
-  if (s->stream) {  // hand the (drained) streams, events and mapped host block back
+  if (s->stream) {  // hand the (drained) stream and the mapped host block back
     DevCtx c;
-    c.dev = s->device; c.stream = s->stream; c.side = s->side; c.ev_fork = s->ev_fork; c.ev_join = s->ev_join; c.ev_acc = s->ev_acc;
+    c.dev = s->device; c.stream = s->stream;
     c.h_pinned = s->h_pinned; c.h_pinned_dev = s->h_pinned_dev;
     g_ctx_pool.put(c);
-    s->stream = s->side = nullptr;
+    s->stream = nullptr;
   }
   if (s->stage) {  // (the SVec members never touch their memory again: their deallocate is a no-op)
     s->stage->release();
@@ -459,7 +456,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 
 // bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
 // can be queued behind the copy before the host blocks on it.
-int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false, bool record_event = true) {
+int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false) {
   if (s->comm.active()) {
     // chi2 and scale are sums over ranks; the max-diagonal (first iteration of a pass only) is a max
     if (s->comm.sum(s->g.acc, 2, s->stream)) return PPO_BA_ERR_COMM;
@@ -475,7 +472,6 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linea
   hipLaunchKernelGGL(k_publish, dim3(grid), dim3(64), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, zp);
   // (no event behind it: a hipEventRecord costs a 6-8 us bubble in the queue in front of the next kernel -- measured with
   //  tools/gap_report.py as idle time before k_reduce_stage1 in every iteration; the host's spin is backed up by the stream itself)
-  (void)record_event;
   return PPO_BA_OK;
 }
 int fetch_acc_wait(ppo_ba_solver* s) {
@@ -559,7 +555,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     phase_mark(s, PH_CHI2);
     RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
     const bool speculated = may_speculate && !stop_requested(stop);
-    RC_TRY(fetch_acc_enqueue(s, true, speculated, false, !speculated));
+    RC_TRY(fetch_acc_enqueue(s, true, speculated, false));
     if (speculated) {
       phase_mark(s, PH_LIN);
       RC_TRY(launch_linearize(s, s->cur ^ 1, true));
@@ -668,7 +664,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   {
     DevCtx c;
     if (!g_ctx_pool.get(s->device, &c)) return fail(PPO_BA_ERR_HIP);
-    s->stream = c.stream; s->side = c.side; s->ev_fork = c.ev_fork; s->ev_join = c.ev_join; s->ev_acc = c.ev_acc;
+    s->stream = c.stream;
     s->h_pinned = c.h_pinned; s->h_pinned_dev = c.h_pinned_dev;
     std::memset(s->h_pinned, 0, kPinnedDoubles * sizeof(double));
     s->pub_seq = 0;
