@@ -126,15 +126,17 @@ struct ppo_ba_solver {
 
 namespace {
 
+// (branch-free over the array so that the loops vectorise: validation was 0.4 ms of a 6 ms create at the BASELINE size)
 bool finite_all(const double* p, size_t n) {
-  for (size_t i = 0; i < n; ++i)
-    if (!std::isfinite(p[i])) return false;
-  return true;
+  const uint64_t* u = reinterpret_cast<const uint64_t*>(p);
+  uint64_t bad = 0;
+  for (size_t i = 0; i < n; ++i) bad |= (uint64_t)((u[i] & 0x7ff0000000000000ull) == 0x7ff0000000000000ull);  // exponent all ones: NaN / Inf
+  return bad == 0;
 }
 bool idx_ok(const int32_t* p, int n, int hi) {
-  for (int i = 0; i < n; ++i)
-    if (p[i] < 0 || p[i] >= hi) return false;
-  return true;
+  uint32_t bad = 0;
+  for (int i = 0; i < n; ++i) bad |= (uint32_t)((uint32_t)p[i] >= (uint32_t)hi);  // negative values wrap above hi
+  return bad == 0;
 }
 #define REQ(cond) do { if (!(cond)) return PPO_BA_ERR_ARG; } while (0)
 #define FIN(ptr, n) do { if (!finite_all((ptr), (size_t)(n))) return PPO_BA_ERR_NONFINITE; } while (0)
