@@ -40,6 +40,9 @@ constexpr int kSpinCap = 400000;
 #ifndef STAMP1
 #define STAMP1(i)  // same, taken by wave 1
 #endif
+#ifndef STAMPB
+#define STAMPB(i)  // same, inside chol_back_all (workgroup of block 1)
+#endif
 #ifndef STAMP
 #define STAMP(i)  // tools/chol_probe.hip defines it to record wall-clock stamps
 #endif
@@ -577,7 +580,9 @@ __device__ __forceinline__ void store_sc1(double* p, double v) { __hip_atomic_st
 __global__ __launch_bounds__(256) void chol_back_all(const double* __restrict__ A, int ld, const double* __restrict__ y, double* x, int* __restrict__ info) {
   __shared__ double sL[NB][LP];
   __shared__ double sV[NB];
-  const int tid = threadIdx.x, j = blockIdx.x, nb = ld / NB, k0 = j * NB;
+  // every eighth workgroup works: workgroups are dealt to the 8 XCDs round-robin, so the whole pipeline sits behind ONE L2
+  if (blockIdx.x & 7) return;
+  const int tid = threadIdx.x, j = blockIdx.x >> 3, nb = ld / NB, k0 = j * NB;
   const int c = tid >> 2, part = tid & 3;  // 4 threads per column of block j, 16 rows of block i each
   // ---- everything that does not depend on other workgroups is fetched first
   double2 td[8];
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(256) void chol_back_all(const double* __restrict__ 
       }
       sX[i & 1][tid] = v;
     }
-    if (i < 10) STAMP(20 + i);
+    if (i < 10) STAMPB(20 + i);
     __syncthreads();
     const double* xs = &sX[i & 1][part * 16];
 #pragma unroll
@@ -647,9 +652,9 @@ __global__ __launch_bounds__(256) void chol_back_all(const double* __restrict__ 
   if (part == 0) sV[c] = acc;
   if (timeout) atomicMax(info, 1 << 30);
   __syncthreads();
-  STAMP(30);
+  STAMPB(30);
   if (tid < 64) store_sc1(&x[k0 + tid], bwd_vec_64(sV[tid], lcol, inv));
-  STAMP(31);
+  STAMPB(31);
 }
 
 struct GraphKey {
@@ -678,7 +683,7 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
     const int m = nb - k;  // column workgroups: 1 (diagonal) + 2 per block row below (row halves); then the trailing tiles
     hipLaunchKernelGGL(chol_step, dim3(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(256), 0, s, A, ld, k0, b, ws, x, info);
   }
-  hipLaunchKernelGGL(chol_back_all, dim3(nb), dim3(256), 0, s, (const double*)A, ld, (const double*)ws, x, info);
+  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(256), 0, s, (const double*)A, ld, (const double*)ws, x, info);
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
 }
 
