@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
         }
     return;
   }
+  STAMP(7);
   // ---- column workgroup: workgroup 0 owns the diagonal block, workgroups 1 + 2 (b - 1) + h the row halves h = 0, 1 of block b ----
   const int cw = blockIdx.x;
   const int b = cw == 0 ? 0 : 1 + ((cw - 1) >> 1);
@@ -436,8 +437,11 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
     const double* pQ = upd ? &A[(size_t)kp * ld + k0] : pC;   // L[k][k-1]
     const double* pB = own ? &A[(size_t)k0 * ld + row0] : pC;
     const double* pP = uo ? &A[(size_t)kp * ld + row0] : pC;  // L[k+b][k-1]
+    STAMP(15);
     load_tile(pC, ld, td);
+    STAMP(16);
     load_tile(pQ, ld, tq);
+    STAMP(17);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // the own half: 32 rows x 64 columns, 16 double2 per column
       const int p = tid + 256 * i, c = p >> 4, r = 32 * half + 2 * (p & 15);

@@ -169,6 +169,8 @@ int main() {
   hipStreamSynchronize(s);
   long long st[48];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
+  printf("  entry -> column path %.2f us -> addresses ready %.2f us; first tile issued %.2f us, second %.2f us, halves + rhs %.2f us\n", (st[7] - st[0]) * 0.01,
+         (st[15] - st[7]) * 0.01, (st[16] - st[15]) * 0.01, (st[17] - st[16]) * 0.01, (st[6] - st[17]) * 0.01);
   printf("  loads issued        +%.2f us\n", (st[6] - st[0]) * 0.01);
   printf("  tiles in LDS        +%.2f us\n", (st[5] - st[6]) * 0.01);
   printf("  column-0 update     +%.2f us\n", (st[1] - st[5]) * 0.01);
