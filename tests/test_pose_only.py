@@ -245,3 +245,18 @@ def test_pose_only_empty_batch_is_ok():
     fr = pose.Frames(np.zeros((0, 7)), np.zeros((0, 5)), [0], np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))
     out = pose.optimize(B.load_library(), fr)
     assert out["pose_qt"].shape == (0, 7)
+
+
+@pytest.mark.gpu
+def test_pose_only_cpp_caller_through_the_c_abi():
+    """examples/pose_only.cpp (plain g++ against libppo_ba.so): one frame per call like the reference, then the batch; it exits
+    non-zero unless the batched poses are bit-identical to the per-frame ones."""
+    import subprocess
+    exe = os.path.join(REPO, "examples", "pose_only")
+    if not os.path.exists(exe):
+        pytest.skip("examples/pose_only not built (run __graft_entry__.build())")
+    out = subprocess.run([exe, "300", "12"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bit-identical" in out.stdout
+    err = float(out.stdout.split("max |t - truth|")[1].split()[0])
+    assert err < 0.02  # noisy observations: the optimised translation is within 2 cm of the truth
