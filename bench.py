@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--solver", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-corners", action="store_true", help="add the 16-D cuboid corner edges (off in the BASELINE configuration)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (pose-only, concurrent windows, phase times): "
                     "used for the rocprofv3 runs so that the kernel statistics hold the headline workload only")
     ap.add_argument("--lin-reps", type=int, default=200)
@@ -120,7 +121,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     lib = B.load_library()
-    P = synth.make_problem(a.config, seed=a.seed)
+    P = synth.make_problem(a.config, seed=a.seed, with_corners=a.with_corners)
     sizes = P.sizes()
     opt = B.default_options(device_id=local_rank, rank=rank, world_size=world, solver=a.solver)
     if world > 1:
