@@ -23,6 +23,16 @@ sys.path.insert(0, os.path.join(REPO, "point-plane-object-slam_amd"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(P, B, seconds_budget=12.0):
     """The oracle (a port of the reference algorithm, 1 thread) on the same graph: the full 5+10 protocol, repeated
     until about `seconds_budget` seconds of CPU work have been timed (at least one complete call)."""
@@ -43,8 +53,8 @@ def cpu_baseline(P, B, seconds_budget=12.0):
     s.close()
     return dict(value=iters / dt, unit="LM iters/s", cores=1, kind="port", ms_per_call=1e3 * dt / calls,
                 sample="oracle/libppo_oracle.so (g2o algorithm restated, fixed-size blocks, -O3 -march=native, 1 thread): %d complete 5+10 calls "
-                       "on the same graph = %d LM iterations (%d solve attempts) in %.1f s; host has %d logical CPUs" % (
-                           calls, iters, trials, dt, os.cpu_count() or 0))
+                       "on the same graph = %d LM iterations (%d solve attempts) in %.1f s; host: %s, %d logical CPUs" % (
+                           calls, iters, trials, dt, cpu_model(), os.cpu_count() or 0))
 
 
 def committed_traffic(k_bytes):
