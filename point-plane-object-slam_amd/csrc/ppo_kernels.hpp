@@ -781,7 +781,9 @@ __device__ __forceinline__ void lin_numeric_dispatch(const Graph& g, const State
 // lasts as long as its slowest part instead of their sum; as separate kernels on two streams the fork/join events alone
 // cost ~12 us per linearisation (tools/gap_report.py).  All parts share one dynamic LDS allocation.
 #ifndef PPO_LIN_WAVES
-#define PPO_LIN_WAVES 2  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this)
+#define PPO_LIN_WAVES 3  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this): 3 beats 2 since the
+                        // pose side stopped being bound by its stores (46 vs 52 us; the ~60 spilled registers of the numeric and pose parts cost less
+                        // than the third resident wave gains), 4 spills too much (50 us)
 #endif
 struct LinPlan {
   NumericPlan num;
