@@ -112,7 +112,11 @@ struct Graph {
   double* HC;    // [Nc][54]: 45 packed lower entries of the 9x9 block, then b (9)
   double* D;     // [n_lm][6] packed upper (00,01,02,11,12,22)
   double* bl;    // [n_lm][3]
-  double* W;     // [n_slots][18] pose rows x landmark cols, row-major
+  double* W;     // [n_slots - n_pt_slots][18] coupling blocks of the PLANE slots (slot s at (s - n_pt_slots) * 18), pose rows x landmark cols
+  double* F;     // [n_pt_slots][4] factor record of a point slot's reprojection edge: x/z, y/z, 1/z in the camera frame and the weight
+                 // rho1 * info (negated for a stereo edge, 0 for an inactive one): W = M(record, intrinsics) * R is rebuilt where it is used
+  double* linR;  // [ld / 6 + 2][12] rotation (9) + fx, fy, bf of the linearisation point of the pose with reduced column c, at c / 6
+  int n_pt_slots;
   double* Wpc_bbox;    // [n_bbox][54] pose rows x cuboid cols
   double* Wpc_corner;  // [n_corner][54]
   double* Dinv;  // [n_lm][6] (D + lambda I)^-1, packed upper
@@ -229,7 +233,10 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
     }
     __syncthreads();
   }
-  constexpr int LPP = 4;  // = kLanesPerPoint
+#ifndef PPO_LIN_LPP
+#define PPO_LIN_LPP 4
+#endif
+  constexpr int LPP = PPO_LIN_LPP;  // lanes per point
   const int sub = threadIdx.x % LPP, ppb = blockDim.x / LPP;
   double chi_local = 0.0;
   for (int p = g.pt_first + bid * ppb + threadIdx.x / LPP; p < g.pt_last; p += nblocks * ppb) {
@@ -340,33 +347,42 @@ struct PoseChunks {
   const int32_t* pose;   // [n_chunks] (keyframe index << 1) | type
   int n_chunks;
 };
-// W records of one wave iteration.  The slots of a keyframe's edges are consecutive in the pose-major numbering, so a full wave
-// writes one contiguous 9216-byte run: transposed through LDS every store instruction covers eight whole cache lines instead
-// of 64 sixteen-byte pieces of 64 different records (pose side alone: 32.6 -> 20.2 us).  Anything else (segment tails,
-// fixed points without a slot) falls back to per-lane stores.
-__device__ __forceinline__ void store_W_wave(double* W, bool in, int slot, const double* o, double* wbuf) {
-  const int lane = threadIdx.x & 63;
-  const int slot0 = __builtin_amdgcn_readfirstlane(slot);
-  if (__all(in && slot >= 0 && slot == slot0 + lane)) {
+// Factor record of a reprojection edge (32 bytes instead of the 144-byte coupling block W = Jp' w Jl it stands for).  With
+// a = x/z, b = y/z, i = 1/z of the point in the camera frame, the Jacobians of EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ
+// (types_six_dof_expmap.cpp:65-103, :192-246) are polynomials in (a, b, i) and the intrinsics, and Jl = Jc R with R the
+// keyframe's rotation, so W = M R with the 6x3 matrix M = Jp' w Jc.  The pose side of the linearisation writes (a, b, i, +-w)
+// per slot; the Schur pair kernel forms M_j (R_j (D + lambda I)^-1 R_i') M_i' with R_j, R_i uniform over its wave.
+__device__ __forceinline__ double4 factor_record(const Mat3& R, Vec3 t, Vec3 X, double ws) {
+  const Vec3 pc = matvec(R, X) + t;
+  const double iz = 1.0 / pc.z;
+  return make_double4(pc.x * iz, pc.y * iz, iz, ws);
+}
+// M (row-major 6x3) of a record; `stereo_rows`: wave-uniform, some lane holds a stereo record (third residual row, bf)
+__device__ __forceinline__ void factor_M(const double4 f, double fx, double fy, double bf, bool stereo_rows, double* M) {
+  const double a = f.x, b = f.y, iz = f.z, w = fabs(f.w);
+  const double afx = a * fx, bfy = b * fy, izfx = iz * fx, izfy = iz * fy;
+  const double p0[6] = {afx * b, -__builtin_fma(afx, a, fx), b * fx, -izfx, 0.0, afx * iz};   // d e_u / d pose
+  const double p1[6] = {__builtin_fma(bfy, b, fy), -(bfy * a), -(a * fy), 0.0, -izfy, bfy * iz};  // d e_v / d pose
+  const double c00 = -(izfx * w), c02 = izfx * a * w, c11 = -(izfy * w), c12 = izfy * b * w;  // w Jc (camera-frame point)
 #pragma unroll
-    for (int k = 0; k < 18; ++k) wbuf[lane * 19 + k] = o[k];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double2* const dst = reinterpret_cast<double2*>(&W[(size_t)slot0 * 18]);
+  for (int k = 0; k < 6; ++k) {
+    M[3 * k] = p0[k] * c00;
+    M[3 * k + 1] = p1[k] * c11;
+    M[3 * k + 2] = __builtin_fma(p0[k], c02, p1[k] * c12);
+  }
+  if (stereo_rows) {
+    const double w2 = f.w < 0.0 ? w : 0.0;
+    const double bi = bf * iz;
+    const double p2[6] = {__builtin_fma(-bi, b, p0[0]), __builtin_fma(bi, a, p0[1]), p0[2], p0[3], 0.0, __builtin_fma(-bi, iz, p0[5])};
+    const double c20 = -(izfx * w2), c22 = (izfx * a - bi * iz) * w2;
 #pragma unroll
-    for (int pz = 0; pz < 9; ++pz) {
-      const int c = pz * 64 + lane, src = c / 9, piece = c - 9 * src;
-      dst[c] = make_double2(wbuf[src * 19 + 2 * piece], wbuf[src * 19 + 2 * piece + 1]);
+    for (int k = 0; k < 6; ++k) {
+      M[3 * k] = __builtin_fma(p2[k], c20, M[3 * k]);
+      M[3 * k + 2] = __builtin_fma(p2[k], c22, M[3 * k + 2]);
     }
-    __builtin_amdgcn_wave_barrier();
-  } else if (in && slot >= 0) {
-    double2* d2 = reinterpret_cast<double2*>(&W[(size_t)slot * 18]);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) d2[k] = make_double2(o[2 * k], o[2 * k + 1]);
   }
 }
-constexpr int kPoseWaveLds = 64 * 19;  // doubles per wave: W transpose buffer (64 records, row stride 19); the 14 x 65 reduction buffer aliases it
+constexpr int kPoseWaveLds = 14 * 65;  // doubles per wave: the 14 x 65 reduction buffer
 __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, const PoseChunks& pc, int bid, double* s_raw) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* const wbuf = s_raw + wave * kPoseWaveLds;
@@ -385,6 +401,10 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
   const Vec3 tr = v3(uni(rt[9]), uni(rt[10]), uni(rt[11]));
   const double* cm = &g.pose_cam[pose * 5];
   const double fx = uni(cm[0]), fy = uni(cm[1]), cx = uni(cm[2]), cy = uni(cm[3]), bf = uni(cm[4]);
+  // the Schur pair kernel rebuilds W = M R from the factor records: leave it the linearisation point's rotation and intrinsics
+  // (every chunk of a keyframe writes the same twelve values)
+  if (lane < 12) g.linR[(size_t)(g.pose_col[pose] / 6) * 12 + lane] = lane < 9 ? rt[lane] : cm[lane == 9 ? 0 : (lane == 10 ? 1 : 4)];
+  double4* const F4 = reinterpret_cast<double4*>(g.F);
   double A[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) A[k] = 0.0;
@@ -397,9 +417,7 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
       ed.slot = -1;
       uint32_t fl = 0;
       if (in) { ed = g.monoP[q]; fl = g.mono_flags[ed.eid]; }
-      double o[18];
-#pragma unroll
-      for (int k = 0; k < 18; ++k) o[k] = 0.0;
+      double4 rec = make_double4(0.0, 0.0, 0.0, 0.0);
       if (in && (fl & F_ACTIVE)) {
         const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
         double ev[2], Jl[6], Jp[12], zc;
@@ -410,9 +428,9 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
         const double w = rho1 * ed.info;
         const double gr[2] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1};
         acc_pose<2>(Jp, w, gr, A);
-        form_W<2>(Jp, Jl, w, o);
+        rec = factor_record(R, tr, X, w);
       }
-      store_W_wave(g.W, in, ed.slot, o, wbuf);
+      if (in && ed.slot >= 0) F4[ed.slot] = rec;  // consecutive lanes, consecutive slots: whole cache lines
     }
   } else {
     for (int q0 = pc.start[t]; q0 < q1; q0 += 64) {
@@ -422,9 +440,7 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
       ed.slot = -1;
       uint32_t fl = 0;
       if (in) { ed = g.stereoP[q]; fl = g.stereo_flags[ed.eid]; }
-      double o[18];
-#pragma unroll
-      for (int k = 0; k < 18; ++k) o[k] = 0.0;
+      double4 rec = make_double4(0.0, 0.0, 0.0, 0.0);
       if (in && (fl & F_ACTIVE)) {
         const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
         double ev[3], Jl[9], Jp[18], zc;
@@ -437,9 +453,9 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
         const double w = rho1 * ed.info;
         const double gr[3] = {-(ed.info * ev[0]) * rho1, -(ed.info * ev[1]) * rho1, -(ed.info * ev[2]) * rho1};
         acc_pose<3>(Jp, w, gr, A);
-        form_W<3>(Jp, Jl, w, o);
+        rec = factor_record(R, tr, X, -w);
       }
-      store_W_wave(g.W, in, ed.slot, o, wbuf);
+      if (in && ed.slot >= 0) F4[ed.slot] = rec;
     }
   }
   double* hb = &g.HB[(size_t)g.pose_free_id[pose] * 27];
@@ -588,7 +604,7 @@ struct PlaneModel {
       for (int c2 = 0; c2 <= a; ++c2) atomicAdd(&hb[packed_lower(a, c2)], Hrow[3 + c2]);
       atomicAdd(&hb[21 + a], bc);
       if (ed.slot >= 0)
-        for (int c2 = 0; c2 < 3; ++c2) atomicAdd(&g.W[(size_t)ed.slot * 18 + a * 3 + c2], Hrow[c2]);
+        for (int c2 = 0; c2 < 3; ++c2) atomicAdd(&g.W[(size_t)(ed.slot - g.n_pt_slots) * 18 + a * 3 + c2], Hrow[c2]);
     }
   }
 };
@@ -669,28 +685,38 @@ struct PtCubModel {  // unary: cols 0-8 cuboid
   }
 };
 
-// 16 lanes per edge, 16 edges per 256-thread block; lane c < NCOL differentiates column c, lane 15 evaluates the
-// base residual (base_binary_edge.hpp:217-320, base_unary_edge.hpp:82-123, then :55-120 / :43-72).
+// NCOL + 1 lanes per edge (NCOL columns + the base residual), packed densely into each wave: 6 edges per wave for the 9-column
+// models (plane, point-cuboid), 4 for the 15-column cuboid projections; lane c < NCOL differentiates column c, lane NCOL
+// evaluates the base residual (base_binary_edge.hpp:217-320, base_unary_edge.hpp:82-123, then :55-120 / :43-72).
+template <class Model>
+struct NumericShape {
+  static constexpr int LPE = Model::NCOL + 1;       // lanes per edge
+  static constexpr int EPW = 64 / LPE;              // edges per wave
+  static constexpr int EPB = 4 * EPW;               // edges per 256-thread workgroup
+};
 template <class Model>
 __device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st, int n_edges, bool corner, double delta, int vblock, double* smem) {
   constexpr int DM = Model::DIM_MAX, NC = Model::NCOL;
+  constexpr int LPE = NumericShape<Model>::LPE, EPW = NumericShape<Model>::EPW, EPB = NumericShape<Model>::EPB;
   double (*sJ)[DM][16] = reinterpret_cast<double (*)[DM][16]>(smem);  // [group][row][col]
-  double (*sW)[DM] = reinterpret_cast<double (*)[DM]>(smem + 16 * DM * 16);
-  double (*sG)[DM] = reinterpret_cast<double (*)[DM]>(smem + 16 * DM * 16 + 16 * DM);
-  double* s_red = smem + 16 * DM * 16 + 32 * DM;
+  double (*sW)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16);
+  double (*sG)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16 + EPB * DM);
+  double* s_red = smem + EPB * DM * 16 + 2 * EPB * DM;
   const Model m{g, corner};
-  const int grp = threadIdx.x >> 4, lane = threadIdx.x & 15;
-  const int i = vblock * 16 + grp;
-  const bool act = i < n_edges && m.active(i);
+  const int wl = threadIdx.x & 63, ew = wl / LPE;
+  const int lane = wl - ew * LPE;
+  const int grp = (threadIdx.x >> 6) * EPW + ew;
+  const int i = vblock * EPB + grp;
+  const bool act = ew < EPW && i < n_edges && m.active(i);
   const int dim = act ? m.dim(i) : 0;
   double chi_local = 0.0;
   if (act) {
     // Two passes over ONE call site of the residual: pass 0 evaluates e(x [+] delta e_c) in lane c < NC and the base
-    // residual e(x) in lane 15, pass 1 evaluates e(x [-] delta e_c).  (One call site instead of three keeps the code --
+    // residual e(x) in lane NC, pass 1 evaluates e(x [-] delta e_c).  (One call site instead of three keeps the code --
     // the residuals are thousands of FP64 instructions each -- small enough for the instruction cache, and the base
     // evaluation no longer runs as a serialised divergent branch.)
     double ep[DM], em[DM];
-    const bool col = lane < NC, base = lane == 15;
+    const bool col = lane < NC, base = lane == NC;
     const bool fr = col && m.col_free(i, lane);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -764,7 +790,10 @@ __device__ __forceinline__ void chi2_numeric_body(const Graph& g, const State& s
 struct NumericPlan {
   int nb_plane, nb_bbox, nb_corner, nb_ptcub;  // workgroups per edge class
 };
-constexpr int kNumericLdsDoubles = 16 * 16 * 16 + 32 * 16 + 8;  // lin_numeric_body at DIM_MAX = 16
+template <class Model>
+constexpr int numeric_lds_doubles() { return NumericShape<Model>::EPB * Model::DIM_MAX * 18 + 8; }  // sJ + sW + sG + s_red of lin_numeric_body
+constexpr int kNumericLdsDoubles = numeric_lds_doubles<CubProjModel>() > numeric_lds_doubles<PlaneModel>() ? numeric_lds_doubles<CubProjModel>() : numeric_lds_doubles<PlaneModel>();
+static_assert(kNumericLdsDoubles >= numeric_lds_doubles<PtCubModel>(), "LDS of the numeric part");
 __device__ __forceinline__ void lin_numeric_dispatch(const Graph& g, const State& st, const NumericPlan& np, double delta, int b, double* smem) {
   if (b < np.nb_plane) { lin_numeric_body<PlaneModel>(g, st, g.n_pl, false, delta, b, smem); return; }
   b -= np.nb_plane;
@@ -1019,6 +1048,19 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
   if (t >= pc.n_chunks) return;
   const int e1 = pc.start[t + 1];
   const int colj = pc.colj[t], coli = pc.coli[t];
+  // rotation + fx, fy, bf of both keyframes at the linearisation point (left there by the pose side of the linearisation):
+  // uniform over the wave, kept in scalar registers
+  auto uni = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  double Rj[12], Ri[12];
+  {
+    const double* rj = &g.linR[(size_t)(colj / 6) * 12];
+    const double* ri = &g.linR[(size_t)(coli / 6) * 12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { Rj[k] = uni(rj[k]); Ri[k] = uni(ri[k]); }
+  }
+  const double4* const F4 = reinterpret_cast<const double4*>(g.F);
   // vals[6 r + c] = element (row c of pose j, column r of pose i) so that consecutive values are consecutive in memory
   double vals[42];
 #pragma unroll
@@ -1026,32 +1068,61 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
   for (int e = pc.start[t] + lane; e < e1; e += 64) {
     const int sj = pc.sj[e], si = pc.si[e];
     const int l = pc.lm[e];
-    double wj[18], y[18], w[18];
-    const double2* wp = reinterpret_cast<const double2*>(&g.W[(size_t)sj * 18]);
-    const double2* yp = reinterpret_cast<const double2*>(&g.W[(size_t)si * 18]);
     const double2* I2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l * 6]);  // 48-byte records: three 16-byte loads
     const double2 i01 = I2[0], i23 = I2[1], i45 = I2[2];
     const double v00 = i01.x, v01 = i01.y, v02 = i23.x, v11 = i23.y, v12 = i45.x, v22 = i45.y;
+    // S(j, i) -= L T Y' with  points: L = M_j, Y = M_i, T = R_j (D + lambda I)^-1 R_i'   planes: L = W_j, Y = W_i, T = (D + lambda I)^-1
+    double L[18], y[18], T[9], w[18];
+    const bool self = sj == si;
+    double u0 = 0.0, u1 = 0.0, u2 = 0.0;  // self pairs: (D + lambda I)^-1 b_l, rotated like T
+    if (self) { u0 = g.ul[(size_t)l * 3]; u1 = g.ul[(size_t)l * 3 + 1]; u2 = g.ul[(size_t)l * 3 + 2]; }
+    if (l < g.n_points) {
+      const double4 fj = F4[sj], fi = F4[si];
+      const bool st_rows = __any(fj.w < 0.0 || fi.w < 0.0);
+      factor_M(fj, Rj[9], Rj[10], Rj[11], st_rows, L);
+      factor_M(fi, Ri[9], Ri[10], Ri[11], st_rows, y);
+      double A[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const double2 a = wp[q], b = yp[q];
-      wj[2 * q] = a.x; wj[2 * q + 1] = a.y; y[2 * q] = b.x; y[2 * q + 1] = b.y;
+      for (int r = 0; r < 3; ++r) {  // A = R_j (D + lambda I)^-1
+        A[3 * r] = __builtin_fma(Rj[3 * r], v00, __builtin_fma(Rj[3 * r + 1], v01, Rj[3 * r + 2] * v02));
+        A[3 * r + 1] = __builtin_fma(Rj[3 * r], v01, __builtin_fma(Rj[3 * r + 1], v11, Rj[3 * r + 2] * v12));
+        A[3 * r + 2] = __builtin_fma(Rj[3 * r], v02, __builtin_fma(Rj[3 * r + 1], v12, Rj[3 * r + 2] * v22));
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          T[3 * r + c] = __builtin_fma(A[3 * r], Ri[3 * c], __builtin_fma(A[3 * r + 1], Ri[3 * c + 1], A[3 * r + 2] * Ri[3 * c + 2]));
+      if (self) {
+        const double t0 = u0, t1 = u1, t2 = u2;
+        u0 = __builtin_fma(Rj[0], t0, __builtin_fma(Rj[1], t1, Rj[2] * t2));
+        u1 = __builtin_fma(Rj[3], t0, __builtin_fma(Rj[4], t1, Rj[5] * t2));
+        u2 = __builtin_fma(Rj[6], t0, __builtin_fma(Rj[7], t1, Rj[8] * t2));
+      }
+    } else {
+      const double2* wp = reinterpret_cast<const double2*>(&g.W[(size_t)(sj - g.n_pt_slots) * 18]);
+      const double2* yp = reinterpret_cast<const double2*>(&g.W[(size_t)(si - g.n_pt_slots) * 18]);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const double2 a = wp[q], b = yp[q];
+        L[2 * q] = a.x; L[2 * q + 1] = a.y; y[2 * q] = b.x; y[2 * q + 1] = b.y;
+      }
+      T[0] = v00; T[1] = v01; T[2] = v02; T[3] = v01; T[4] = v11; T[5] = v12; T[6] = v02; T[7] = v12; T[8] = v22;
     }
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {  // w = W_j (D + lambda I)^-1
-      w[a * 3] = __builtin_fma(wj[a * 3], v00, __builtin_fma(wj[a * 3 + 1], v01, wj[a * 3 + 2] * v02));
-      w[a * 3 + 1] = __builtin_fma(wj[a * 3], v01, __builtin_fma(wj[a * 3 + 1], v11, wj[a * 3 + 2] * v12));
-      w[a * 3 + 2] = __builtin_fma(wj[a * 3], v02, __builtin_fma(wj[a * 3 + 1], v12, wj[a * 3 + 2] * v22));
+    for (int a = 0; a < 6; ++a) {  // w = L T
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        w[a * 3 + c] = __builtin_fma(L[a * 3], T[c], __builtin_fma(L[a * 3 + 1], T[3 + c], L[a * 3 + 2] * T[6 + c]));
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = 0; c < 6; ++c)
         vals[6 * r + c] = __builtin_fma(w[c * 3], y[r * 3], __builtin_fma(w[c * 3 + 1], y[r * 3 + 1], __builtin_fma(w[c * 3 + 2], y[r * 3 + 2], vals[6 * r + c])));
-    if (sj == si) {
-      const double y0 = g.ul[(size_t)l * 3], y1 = g.ul[(size_t)l * 3 + 1], y2 = g.ul[(size_t)l * 3 + 2];  // (D + lambda I)^-1 b_l
+    if (self) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) vals[36 + c] += wj[c * 3] * y0 + wj[c * 3 + 1] * y1 + wj[c * 3 + 2] * y2;
+      for (int c = 0; c < 6; ++c) vals[36 + c] += L[c * 3] * u0 + L[c * 3 + 1] * u1 + L[c * 3 + 2] * u2;
     }
   }
   const int n = g.ld;
@@ -1379,7 +1450,7 @@ __device__ __forceinline__ void backsub_body(const Graph& g, const State& cur, c
         const int j = l - g.n_points;
         for (int q = g.pl_slot_off[j] + sub; q < g.pl_slot_off[j + 1]; q += LPP) {
           const int s = g.pl_slots[q];
-          const double* w = &g.W[(size_t)s * 18];
+          const double* w = &g.W[(size_t)(s - g.n_pt_slots) * 18];
           const double* x = &g.xr[g.slot_col[s]];
           for (int a = 0; a < 6; ++a) {
             c0 -= w[a * 3] * x[a]; c1 -= w[a * 3 + 1] * x[a]; c2 -= w[a * 3 + 2] * x[a];

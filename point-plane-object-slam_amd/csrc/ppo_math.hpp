@@ -174,16 +174,34 @@ PPO_HD PlaneC plane_canon(double nx, double ny, double nz, double d) {
 }
 PPO_HD double az_of(Vec3 v) { return atan2(v.y, v.x); }
 PPO_HD double el_of(Vec3 v) { return atan2(v.z, sqrt(v.x * v.x + v.y * v.y)); }
-// Rz(azimuth) * Ry(-elevation) through the half-angle quaternion product, like Eigen's AngleAxis * AngleAxis
+// sin / cos of a numeric-differentiation step: for |x| < 1e-8 the correctly rounded results are x and 1 exactly
+// (x^3/6 and x^2/2 lie below half an ulp), so the library calls are skipped on that path
+PPO_HD void sincos_step(double x, double& s, double& c) {
+  if (fabs(x) < 1e-8) { s = x; c = 1.0; }
+  else { s = sin(x); c = cos(x); }
+}
+// Rz(azimuth) * Ry(-elevation) of a direction n.  The reference builds it as AngleAxis(az, z) * AngleAxis(-el, y) from
+// az = atan2(y, x), el = atan2(z, |xy|) (include/G2O_Plane3D.h:66-72); the same matrix written with the sines and cosines
+// those angles have by construction -- cos az = x/r, sin az = y/r, cos el = r/|n|, sin el = z/|n| -- needs no inverse
+// trigonometry and no half-angle quaternion (2 atan2 + 4 sin/cos of ~150 FP64 instructions each per call).
 PPO_HD Mat3 plane_frame(Vec3 n) {
-  const double ha = 0.5 * az_of(n), he = 0.5 * -el_of(n);
-  const Quat qa = Quat{0, 0, sin(ha), cos(ha)};
-  const Quat qe = Quat{0, sin(he), 0, cos(he)};
-  return rotmat(qmul(qa, qe));
+  const double r2 = n.x * n.x + n.y * n.y;
+  const double r = sqrt(r2), nn = sqrt(r2 + n.z * n.z);
+  double ca = 1.0, sa = 0.0;  // atan2(0, 0) = 0
+  if (r > 0.0) { const double ir = 1.0 / r; ca = n.x * ir; sa = n.y * ir; }
+  double ce = 1.0, se = 0.0;
+  if (nn > 0.0) { const double in = 1.0 / nn; ce = r * in; se = n.z * in; }
+  Mat3 R;
+  R.a[0] = ca * ce; R.a[1] = -sa; R.a[2] = -(ca * se);
+  R.a[3] = sa * ce; R.a[4] = ca;  R.a[5] = -(sa * se);
+  R.a[6] = se;      R.a[7] = 0.0; R.a[8] = ce;
+  return R;
 }
 PPO_HD PlaneC plane_boxplus(const PlaneC& p, const double* u) {
-  const double s = sin(u[1]), c = cos(u[1]);
-  const Vec3 n = v3(c * cos(u[0]), c * sin(u[0]), s);
+  double s0, c0, s, c;
+  sincos_step(u[0], s0, c0);
+  sincos_step(u[1], s, c);
+  const Vec3 n = v3(c * c0, c * s0, s);
   const Vec3 rn = matvec(plane_frame(v3(p.nx, p.ny, p.nz)), n);
   const double dist = -p.d + u[2];
   return plane_canon(rn.x, rn.y, rn.z, -dist);
@@ -203,7 +221,7 @@ PPO_HD void plane_residual(const PlaneC& a, const PlaneC& m, int kind, double* e
     const double an = sqrt(dot3(ax, ax));
     ax = v3(ax.x / an, ax.y / an, ax.z / an);
     // rotate na by +90 degrees about ax (Rodrigues with the constants Eigen would compute for M_PI/2)
-    const double s = sin(M_PI / 2), c = cos(M_PI / 2);
+    const double s = 1.0, c = 6.123233995736766e-17;  // sin, cos of the double M_PI / 2
     const Vec3 sa = ax * s, ca = ax * (1.0 - c);
     Mat3 R;
     double t;
@@ -225,7 +243,8 @@ PPO_HD void plane_residual(const PlaneC& a, const PlaneC& m, int kind, double* e
 PPO_HD Pose exp_yaw_only(const double* u) {  // src/g2o_cuboid.cc:6-36
   const Vec3 om = v3(u[0], u[1], u[2]), up = v3(u[3], u[4], u[5]);
   const double th = sqrt(dot3(om, om));
-  const double cz = cos(om.z), sz = sin(om.z);
+  double cz, sz;
+  sincos_step(om.z, sz, cz);
   const Mat3 R = Mat3{{cz, -sz, 0, sz, cz, 0, 0, 0, 1}};
   Mat3 V = R;
   if (!(th < 0.00001)) {

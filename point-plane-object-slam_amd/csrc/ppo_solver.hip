@@ -343,16 +343,16 @@ int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool already_zeroed
 int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
   const Graph& g = s->g;
   LinPlan lp{};
-  lp.num.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, 16) : 0;
+  lp.num.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, NumericShape<PlaneModel>::EPB) : 0;
   if (g.owns_reduced) {
-    lp.num.nb_bbox = g.n_bbox ? nblk(g.n_bbox, 16) : 0;
-    lp.num.nb_corner = g.n_corner ? nblk(g.n_corner, 16) : 0;
-    lp.num.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, 16) : 0;
+    lp.num.nb_bbox = g.n_bbox ? nblk(g.n_bbox, NumericShape<CubProjModel>::EPB) : 0;
+    lp.num.nb_corner = g.n_corner ? nblk(g.n_corner, NumericShape<CubProjModel>::EPB) : 0;
+    lp.num.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, NumericShape<PtCubModel>::EPB) : 0;
   }
   lp.nb_num = lp.num.nb_plane + lp.num.nb_bbox + lp.num.nb_corner + lp.num.nb_ptcub;
   const int npts = g.pt_last - g.pt_first;
   lp.nb_pose = (npts > 0 && s->posec.n_chunks > 0) ? nblk(s->posec.n_chunks, 4) : 0;
-  lp.nb_pts = npts > 0 ? std::min(nblk(4L * npts, 256), 4 * s->n_cu) : 0;
+  lp.nb_pts = npts > 0 ? std::min(nblk((long)PPO_LIN_LPP * npts, 256), 4 * s->n_cu) : 0;
   if (const char* e = getenv("PPO_BA_LIN_PARTS")) {  // development aid: time the parts of the fused launch separately
     const int m = atoi(e);
     if (!(m & 1)) lp.num.nb_plane = 0;
@@ -1105,8 +1105,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_init.upload(h_state, s->stream) && s->d_state[0].alloc(s->state_doubles) && s->d_state[1].alloc(s->state_doubles);
   const size_t n_chi = (size_t)p->n_mono + p->n_stereo + p->n_plane_edges + 2 * (size_t)p->n_bbox + 2 * (size_t)p->n_corner + p->n_ptcub;
   ok = ok && s->d_chi2_all.alloc(n_chi);
-  // arena: HB | HC | acc | D | bl | W
-  const size_t nHB = (size_t)nfree * 27, nHC = (size_t)Nc * 54, nD = (size_t)g.n_lm * 6, nbl = (size_t)g.n_lm * 3, nW = (size_t)g.n_slots * 18;
+  // arena: HB | HC | acc | D | bl;  d_W: factor records of the point slots | linearisation-point rotations | W of the plane slots
+  g.n_pt_slots = slot_off[Npt];
+  const size_t nF = (size_t)g.n_pt_slots * 4, nLinR = (size_t)(ld / 6 + 2) * 12, nWpl = (size_t)(g.n_slots - g.n_pt_slots) * 18;
+  const size_t nHB = (size_t)nfree * 27, nHC = (size_t)Nc * 54, nD = (size_t)g.n_lm * 6, nbl = (size_t)g.n_lm * 3, nW = nF + nLinR + nWpl;
   ok = ok && s->d_arena.alloc(nHB + nHC + ACC_N + nD + nbl) && s->d_W.alloc(nW);
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
@@ -1156,7 +1158,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     s->zero_head = nHB + nHC + ACC_N;
     g.D = a; s->zD_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 6; s->zD_n = (size_t)Npl * 6; a += nD;
     g.bl = a; s->zbl_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 3; s->zbl_n = (size_t)Npl * 3; a += nbl;
-    g.W = s->d_W.p; s->zW_off = (size_t)slot_off[Npt] * 18; s->zW_n = (size_t)(g.n_slots - slot_off[Npt]) * 18;
+    g.F = s->d_W.p; g.linR = g.F + nF; g.W = g.linR + nLinR; s->zW_off = nF + nLinR; s->zW_n = nWpl;
     if (nW) (void)hipMemsetAsync(s->d_W.p, 0, nW * sizeof(double), s->stream);
   }
   g.Wpc_bbox = s->d_Wpc.p; g.Wpc_corner = s->d_Wpc.p + (size_t)p->n_bbox * 54;

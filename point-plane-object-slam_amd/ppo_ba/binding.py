@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
-LIB_PATH = os.path.join(PKG_ROOT, "csrc", "libppo_ba.so")
+LIB_PATH = os.environ.get("PPO_BA_LIB") or os.path.join(PKG_ROOT, "csrc", "libppo_ba.so")  # (PPO_BA_LIB: development aid, A/B builds)
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)

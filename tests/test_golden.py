@@ -129,7 +129,9 @@ def test_device_math_matches_oracle_on_plane_and_cuboid_functions(hc, oracle_lib
         a, b = np.zeros(4), np.zeros(4)
         oracle_lib.oracle_plane_oplus(dptr(p), dptr(v), dptr(a))
         hc.hc_plane_oplus(dptr(p), dptr(v), dptr(b))
-        np.testing.assert_allclose(a, b, rtol=0, atol=1e-15)
+        # (the product writes the plane frame algebraically, the oracle through atan2 and half-angle quaternions like the
+        # reference: a few ulp apart)
+        np.testing.assert_allclose(a, b, rtol=0, atol=4e-15)
         q = rng.normal(size=4); q /= np.linalg.norm(q)
         if q[3] < 0:
             q = -q
@@ -160,6 +162,32 @@ def test_device_math_matches_oracle_on_plane_and_cuboid_functions(hc, oracle_lib
         hc.hc_corner(dptr(cam), dptr(c10), dptr(K), dptr(np.zeros(16)), dptr(ec))
         np.testing.assert_allclose(eb, bb, rtol=0, atol=1e-11)
         np.testing.assert_allclose(ec, uv, rtol=0, atol=1e-11)
+
+
+def test_plane_frame_without_trigonometry_matches_oracle_at_steps_and_poles(hc, oracle_lib):
+    """ppo_math.hpp writes Rz(az) Ry(-el) from the direction cosines and skips sin/cos for numeric-differentiation steps;
+    the oracle follows include/G2O_Plane3D.h:66-87 through atan2 and angle-axis quaternions.  Held against each other at the
+    steps the numeric Jacobians take (+-1e-9 per column) and for normals on / near the z axis (azimuth undefined)."""
+    rng = np.random.default_rng(12)
+    normals = [np.array([0, 0, 1.0]), np.array([0, 0, -1.0]), np.array([1e-12, 0, 1.0]), np.array([0, -1e-9, -1.0]),
+               np.array([1.0, 0, 0]), np.array([-1.0, 0, 0]), np.array([0, 1.0, 0])] + [rng.normal(size=3) for _ in range(40)]
+    for n in normals:
+        p = np.concatenate([n / np.linalg.norm(n), [rng.uniform(0.5, 3.0)]])
+        for c in range(3):
+            for step in (1e-9, -1e-9, 9.9e-9, 1.1e-8, 1e-3):
+                v = np.zeros(3); v[c] = step
+                a, b = np.zeros(4), np.zeros(4)
+                oracle_lib.oracle_plane_oplus(dptr(p), dptr(v), dptr(a))
+                hc.hc_plane_oplus(dptr(p), dptr(v), dptr(b))
+                np.testing.assert_allclose(a, b, rtol=0, atol=4e-15)
+        qt = np.array([0, 0, 0, 1, 0.1, -0.2, 0.3])
+        m = np.concatenate([p[:3] + rng.normal(size=3) * 0.02, [p[3] + 0.01]])
+        m[:3] /= np.linalg.norm(m[:3])
+        loc, eo, eh = np.zeros(4), np.zeros(3), np.zeros(3)
+        oracle_lib.oracle_plane_transform(dptr(qt), dptr(p), dptr(loc))
+        oracle_lib.oracle_plane_ominus(dptr(loc), dptr(m), 0, dptr(eo))
+        hc.hc_plane_residual(dptr(qt), dptr(p), dptr(m), 0, dptr(eh))
+        np.testing.assert_allclose(eo, eh, rtol=0, atol=1e-13)
 
 
 # ---- regression trace of the oracle -----------------------------------------------------------------------------------------

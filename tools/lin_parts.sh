@@ -1,4 +1,3 @@
-#!/bin/bash
-# development aid: time the parts of k_linearize_all alone (1 plane, 2 bbox, 4 point-cuboid, 8 pose side, 16 landmark side)
-P='import json,sys; j=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(sys.argv[1], round(j["config"]["kernels"]["k_linearize_all"]["us"],1))'
-for m in 1 2 4 7 8 16 24 31; do PPO_BA_LIN_PARTS=$m python bench.py --no-cpu-baseline --steps 2 --warmup 1 2>&1 | python -c "$P" "parts=$m"; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+for m in 1 2 4 8 16 31; do echo "parts=$m"; PPO_BA_LIN_PARTS=$m python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['roofline']['launch_ms']*1e3,'us')"; done
+python bench.py --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['roofline']['launch_ms']*1e3, j['roofline']['frac'], {k:round(v['us'],1) for k,v in j['config']['kernels'].items()})"
