@@ -234,7 +234,7 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
     __syncthreads();
   }
 #ifndef PPO_LIN_LPP
-#define PPO_LIN_LPP 4
+#define PPO_LIN_LPP 2  // 2 lanes per point: half the workgroups (and camera-table loads) of 4 lanes at ~2.5 edges per lane: 19 vs 27 us alone, 33.0 vs 34.5 us fused
 #endif
   constexpr int LPP = PPO_LIN_LPP;  // lanes per point
   const int sub = threadIdx.x % LPP, ppb = blockDim.x / LPP;
@@ -609,10 +609,12 @@ struct PlaneModel {
   }
 };
 
-struct CubProjModel {  // bbox (corner = false) or corner edges: cols 0-5 pose, 6-14 cuboid
-  static constexpr int DIM_MAX = 16, NCOL = 15;
+template <bool CORNER>
+struct CubProjModelT {  // bbox (CORNER = false, 4 residual rows) or corner edges (16 rows): cols 0-5 pose, 6-14 cuboid
+  static constexpr int DIM_MAX = CORNER ? 16 : 4, NCOL = 15;
+  static constexpr bool corner = CORNER;
   const Graph& g;
-  bool corner;
+  bool unused;
   __device__ const CubEdge& E(int i) const { return corner ? g.corner[i] : g.bbox[i]; }
   __device__ bool active(int i) const { return E(i).flags & F_ACTIVE; }
   __device__ int dim(int i) const { return E(i).dim; }
@@ -685,12 +687,15 @@ struct PtCubModel {  // unary: cols 0-8 cuboid
   }
 };
 
-// NCOL + 1 lanes per edge (NCOL columns + the base residual), packed densely into each wave: 6 edges per wave for the 9-column
-// models (plane, point-cuboid), 4 for the 15-column cuboid projections; lane c < NCOL differentiates column c, lane NCOL
-// evaluates the base residual (base_binary_edge.hpp:217-320, base_unary_edge.hpp:82-123, then :55-120 / :43-72).
+// 2 NCOL + 1 lanes per edge, packed densely into each wave (3 edges per wave for the 9-column models -- plane, point-cuboid --
+// and 2 for the 15-column cuboid projections): lanes 2c and 2c + 1 evaluate e(x [+] delta e_c) and e(x [-] delta e_c), lane
+// 2 NCOL the base residual (base_binary_edge.hpp:217-320, base_unary_edge.hpp:82-123, then :55-120 / :43-72).  A residual is a
+// chain of several thousand dependent FP64 instructions and a lone wave issues one every ~8 cycles: with both signs in one
+// lane every numeric class took ~21 us however few edges it had (50 point-cuboid edges: 22 us), which set the floor of the
+// whole fused launch.
 template <class Model>
 struct NumericShape {
-  static constexpr int LPE = Model::NCOL + 1;       // lanes per edge
+  static constexpr int LPE = 2 * Model::NCOL + 1;   // lanes per edge
   static constexpr int EPW = 64 / LPE;              // edges per wave
   static constexpr int EPB = 4 * EPW;               // edges per 256-thread workgroup
 };
@@ -711,42 +716,34 @@ __device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st
   const int dim = act ? m.dim(i) : 0;
   double chi_local = 0.0;
   if (act) {
-    // Two passes over ONE call site of the residual: pass 0 evaluates e(x [+] delta e_c) in lane c < NC and the base
-    // residual e(x) in lane NC, pass 1 evaluates e(x [-] delta e_c).  (One call site instead of three keeps the code --
-    // the residuals are thousands of FP64 instructions each -- small enough for the instruction cache, and the base
-    // evaluation no longer runs as a serialised divergent branch.)
-    double ep[DM], em[DM];
-    const bool col = lane < NC, base = lane == NC;
-    const bool fr = col && m.col_free(i, lane);
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      if ((fr || (base && pass == 0))) {
-        double eo[DM];  // (written through a fixed array and moved by selects: `pass ? em : ep` as the target put both in scratch memory)
-        m.residual(i, base ? -1 : lane, base ? 0.0 : (pass ? -delta : delta), st, eo);
+    // ONE call site of the residual (thousands of FP64 instructions: the instruction cache matters); the two lanes of a column
+    // are neighbours, so the central difference is one lane shuffle per residual row
+    const int c = lane >> 1;
+    const bool col = lane < 2 * NC, base = lane == 2 * NC;
+    const bool fr = col && m.col_free(i, c);
+    double eo[DM];
 #pragma unroll
-        for (int r = 0; r < DM; ++r) {
-          ep[r] = pass ? ep[r] : eo[r];
-          em[r] = pass ? eo[r] : em[r];
-        }
-      }
-    }
+    for (int r = 0; r < DM; ++r) eo[r] = 0.0;
+    if (fr || base) m.residual(i, base ? -1 : c, base ? 0.0 : ((lane & 1) ? -delta : delta), st, eo);
     if (col) {
       const double scalar = 1.0 / (2 * delta);
 #pragma unroll
-      for (int r = 0; r < DM; ++r)
-        if (r < dim) sJ[grp][r][lane] = fr ? scalar * (ep[r] - em[r]) : 0.0;
+      for (int r = 0; r < DM; ++r) {
+        const double em = __shfl_down(eo[r], 1, 64);  // (lane 2c + 1 holds e(x [-] delta e_c); both lanes of a column are active together)
+        if (r < dim && !(lane & 1)) sJ[grp][r][c] = fr ? scalar * (eo[r] - em) : 0.0;
+      }
     } else if (base) {
       double chi2 = 0, nrm = 0;
 #pragma unroll
       for (int r = 0; r < DM; ++r)
-        if (r < dim) { chi2 += ep[r] * (m.info(i, r) * ep[r]); nrm += ep[r] * ep[r]; }
+        if (r < dim) { chi2 += eo[r] * (m.info(i, r) * eo[r]); nrm += eo[r] * eo[r]; }
       m.store_chi2(i, chi2, sqrt(nrm));
       double rho0, rho1;
       huber(chi2, m.huber_delta(i), rho0, rho1);
       chi_local = rho0;
 #pragma unroll
       for (int r = 0; r < DM; ++r)
-        if (r < dim) { sW[grp][r] = rho1 * m.info(i, r); sG[grp][r] = -(m.info(i, r) * ep[r]) * rho1; }
+        if (r < dim) { sW[grp][r] = rho1 * m.info(i, r); sG[grp][r] = -(m.info(i, r) * eo[r]) * rho1; }
     }
   }
   __syncthreads();
@@ -792,37 +789,43 @@ struct NumericPlan {
 };
 template <class Model>
 constexpr int numeric_lds_doubles() { return NumericShape<Model>::EPB * Model::DIM_MAX * 18 + 8; }  // sJ + sW + sG + s_red of lin_numeric_body
-constexpr int kNumericLdsDoubles = numeric_lds_doubles<CubProjModel>() > numeric_lds_doubles<PlaneModel>() ? numeric_lds_doubles<CubProjModel>() : numeric_lds_doubles<PlaneModel>();
+using BboxModel = CubProjModelT<false>;
+using CornerModel = CubProjModelT<true>;
+constexpr int kNumericLdsDoubles = numeric_lds_doubles<CornerModel>() > numeric_lds_doubles<PlaneModel>() ? numeric_lds_doubles<CornerModel>() : numeric_lds_doubles<PlaneModel>();
+static_assert(kNumericLdsDoubles >= numeric_lds_doubles<BboxModel>(), "LDS of the numeric part");
 static_assert(kNumericLdsDoubles >= numeric_lds_doubles<PtCubModel>(), "LDS of the numeric part");
+template <bool WITH_CORNERS>
 __device__ __forceinline__ void lin_numeric_dispatch(const Graph& g, const State& st, const NumericPlan& np, double delta, int b, double* smem) {
   if (b < np.nb_plane) { lin_numeric_body<PlaneModel>(g, st, g.n_pl, false, delta, b, smem); return; }
   b -= np.nb_plane;
-  if (b < np.nb_bbox) { lin_numeric_body<CubProjModel>(g, st, g.n_bbox, false, delta, b, smem); return; }
+  if (b < np.nb_bbox) { lin_numeric_body<BboxModel>(g, st, g.n_bbox, false, delta, b, smem); return; }
   b -= np.nb_bbox;
-  if (b < np.nb_corner) { lin_numeric_body<CubProjModel>(g, st, g.n_corner, true, delta, b, smem); return; }
+  if (WITH_CORNERS) {  // the 16-row corner edges hold 48 residual values per lane: compiled in only for windows that have them
+    if (b < np.nb_corner) { lin_numeric_body<CornerModel>(g, st, g.n_corner, true, delta, b, smem); return; }
+  }
   b -= np.nb_corner;
   lin_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, delta, b, smem);
 }
 
 // ONE launch for the whole linearisation (horizontal fusion): the workgroups of the numerically differentiated edge
-// classes come first (longest running, 16 lanes per edge), then one wave per pose-major chunk (pose side, W), then the
+// classes come first (longest running, 2 NCOL + 1 lanes per edge), then one wave per pose-major chunk (pose side, factor records), then the
 // landmark-major point workgroups.  The three parts are independent (they meet only in atomics on H_pp), so the launch
 // lasts as long as its slowest part instead of their sum; as separate kernels on two streams the fork/join events alone
 // cost ~12 us per linearisation (tools/gap_report.py).  All parts share one dynamic LDS allocation.
 #ifndef PPO_LIN_WAVES
-#define PPO_LIN_WAVES 3  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this): 3 beats 2 since the
-                        // pose side stopped being bound by its stores (46 vs 52 us; the ~60 spilled registers of the numeric and pose parts cost less
-                        // than the third resident wave gains), 4 spills too much (50 us)
+#define PPO_LIN_WAVES 3  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this).  Without the 16-row corner
+                        // edges the launch needs 140 VGPRs and nothing spills; 4 and 5 waves (128 / 96 VGPRs, 32 B / more of scratch) measure
+                        // the same within 0.5 us: the launch is not occupancy-bound
 #endif
 struct LinPlan {
   NumericPlan num;
   int nb_num, nb_pose, nb_pts;
 };
-template <bool USE_LDS>
+template <bool USE_LDS, bool WITH_CORNERS>
 __global__ __launch_bounds__(256, PPO_LIN_WAVES) void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
   extern __shared__ double smem[];
   int b = blockIdx.x;
-  if (b < lp.nb_num) { lin_numeric_dispatch(g, st, lp.num, delta, b, smem); return; }
+  if (b < lp.nb_num) { lin_numeric_dispatch<WITH_CORNERS>(g, st, lp.num, delta, b, smem); return; }
   b -= lp.nb_num;
   if (b < lp.nb_pose) { lin_poses_body(g, st, pc, b, smem); return; }
   b -= lp.nb_pose;
@@ -835,9 +838,9 @@ __global__ __launch_bounds__(256) void k_chi2_all(Graph g, State st, NumericPlan
   if (b >= nb_num) { chi2_points_body(g, st, b - nb_num, nb_pts, s_red); return; }
   if (b < np.nb_plane) { chi2_numeric_body<PlaneModel>(g, st, g.n_pl, false, b); return; }
   b -= np.nb_plane;
-  if (b < np.nb_bbox) { chi2_numeric_body<CubProjModel>(g, st, g.n_bbox, false, b); return; }
+  if (b < np.nb_bbox) { chi2_numeric_body<BboxModel>(g, st, g.n_bbox, false, b); return; }
   b -= np.nb_bbox;
-  if (b < np.nb_corner) { chi2_numeric_body<CubProjModel>(g, st, g.n_corner, true, b); return; }
+  if (b < np.nb_corner) { chi2_numeric_body<CornerModel>(g, st, g.n_corner, true, b); return; }
   b -= np.nb_corner;
   chi2_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, b);
 }

@@ -298,6 +298,7 @@ PPO_HD void cuboid_corner_px(const Cub& c, const Mat3& Rwo, const Mat3& Rcw, Vec
 PPO_HD void bbox_residual(const Pose& Tcw, const Cub& c, const double* K, const double* meas, double* e) {
   const Mat3 Rwo = rotmat(c.T.q), Rcw = rotmat(Tcw.q);
   double ulo = 0, uhi = 0, vlo = 0, vhi = 0;
+#pragma unroll 1  // (on the GPU a residual is executed once per wave: unrolled, the eight corners are eight times the instruction fetch)
   for (int k = 0; k < 8; ++k) {
     double u, v;
     cuboid_corner_px(c, Rwo, Rcw, Tcw.t, K, k, u, v);
@@ -323,15 +324,26 @@ PPO_HD void ptcub_residual(const Cub& c, const double* pts, int npts, double mar
   const Pose inv = inverse(c.T);
   double acc[3] = {0, 0, 0};
   const double s[3] = {c.s.x, c.s.y, c.s.z};
-  for (int p = 0; p < npts; ++p) {
-    const Vec3 l = apply(inv, v3(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]));
-    const double a[3] = {fabs(l.x), fabs(l.y), fabs(l.z)};
-    for (int i = 0; i < 3; ++i) {
-      double pe;
-      if (a[i] < s[i]) pe = 0;
-      else if (a[i] < (margin + 1) * s[i]) pe = a[i] - s[i];
-      else pe = margin * s[i];
-      acc[i] += fabs(pe);
+  // (points are taken six at a time, all loads first: one point per trip is one dependent memory round trip per point on the GPU)
+  constexpr int G = 6;
+  for (int p0 = 0; p0 < npts; p0 += G) {
+    double xyz[3 * G];
+#pragma unroll
+    for (int k = 0; k < 3 * G; ++k) xyz[k] = pts[(3 * p0 + k < 3 * npts) ? 3 * p0 + k : 3 * npts - 1];  // unconditional loads (clamped index)
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      if (p0 + q < npts) {
+        const Vec3 l = apply(inv, v3(xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2]));
+        const double a[3] = {fabs(l.x), fabs(l.y), fabs(l.z)};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          double pe;
+          if (a[i] < s[i]) pe = 0;
+          else if (a[i] < (margin + 1) * s[i]) pe = a[i] - s[i];
+          else pe = margin * s[i];
+          acc[i] += fabs(pe);
+        }
+      }
     }
   }
   for (int i = 0; i < 3; ++i) {

@@ -345,8 +345,8 @@ int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
   LinPlan lp{};
   lp.num.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, NumericShape<PlaneModel>::EPB) : 0;
   if (g.owns_reduced) {
-    lp.num.nb_bbox = g.n_bbox ? nblk(g.n_bbox, NumericShape<CubProjModel>::EPB) : 0;
-    lp.num.nb_corner = g.n_corner ? nblk(g.n_corner, NumericShape<CubProjModel>::EPB) : 0;
+    lp.num.nb_bbox = g.n_bbox ? nblk(g.n_bbox, NumericShape<BboxModel>::EPB) : 0;
+    lp.num.nb_corner = g.n_corner ? nblk(g.n_corner, NumericShape<CornerModel>::EPB) : 0;
     lp.num.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, NumericShape<PtCubModel>::EPB) : 0;
   }
   lp.nb_num = lp.num.nb_plane + lp.num.nb_bbox + lp.num.nb_corner + lp.num.nb_ptcub;
@@ -364,8 +364,11 @@ int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
   }
   const int grid = lp.nb_num + lp.nb_pose + lp.nb_pts;
   if (grid > 0) {
-    if (s->use_lds_lin) hipLaunchKernelGGL(k_linearize_all<true>, dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
-    else hipLaunchKernelGGL(k_linearize_all<false>, dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
+    const bool cor = lp.num.nb_corner > 0;
+    if (s->use_lds_lin && cor) hipLaunchKernelGGL((k_linearize_all<true, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
+    else if (s->use_lds_lin) hipLaunchKernelGGL((k_linearize_all<true, false>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
+    else if (cor) hipLaunchKernelGGL((k_linearize_all<false, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
+    else hipLaunchKernelGGL((k_linearize_all<false, false>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
   }
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
