@@ -1515,6 +1515,9 @@ __global__ __launch_bounds__(256) void k_pack_lower_tiles(double* __restrict__ S
 // The whole update of a trial in ONE launch (horizontal fusion; none of the parts reads another's output): cuboid
 // back-substitution + update | pose updates | landmark back-substitution + update | and, since the factor in S is dead once
 // the backward substitution has run, the zeroing of S (lower-triangle 64x64 tiles) and b for the NEXT reduction.
+#ifndef PPO_UPD_LPP
+#define PPO_UPD_LPP 4  // lanes per landmark in the update launch
+#endif
 struct UpdatePlan {
   int nb_red, nb_lm, nb_zero;  // workgroups of the reduced part (cuboids + poses), landmarks, S tiles
   double* S;
@@ -1529,7 +1532,7 @@ __global__ __launch_bounds__(256) void k_update_all(Graph g, State cur, State tr
   int b = blockIdx.x;
   if (b < up.nb_red) { update_reduced_body(g, cur, trial, lambda, b, sp, st, sy, sx); return; }
   b -= up.nb_red;
-  if (b < up.nb_lm) { backsub_body<USE_LDS, 4>(g, cur, trial, lambda, b, smem, s_red); return; }
+  if (b < up.nb_lm) { backsub_body<USE_LDS, PPO_UPD_LPP>(g, cur, trial, lambda, b, smem, s_red); return; }
   b -= up.nb_lm;
   // zero one 64x64 tile of the lower triangle of S (tile index b -> (bi >= bj)); the last workgroup also clears b
   int bi = 0;

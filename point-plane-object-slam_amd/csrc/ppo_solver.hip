@@ -448,7 +448,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   const int nb = g.ld / 64;
   UpdatePlan up{};
   up.nb_red = g.n_cuboids + nblk(g.n_poses, 256);
-  up.nb_lm = nl > 0 ? nblk(4L * nl, 256) : 0;
+  up.nb_lm = nl > 0 ? nblk((long)PPO_UPD_LPP * nl, 256) : 0;
   up.nb_zero = nb * (nb + 1) / 2;
   up.S = s->d_S.p; up.bs = s->d_bs_p; up.ld = g.ld;
   const int grid = up.nb_red + up.nb_lm + up.nb_zero;
