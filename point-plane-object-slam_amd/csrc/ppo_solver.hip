@@ -557,13 +557,29 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     s->have_system = true;
     phase_mark(s, PH_BACKSUB);
     RC_TRY(launch_update(s, lambda));
-    phase_mark(s, PH_CHI2);
-    RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
     const bool speculated = may_speculate && !stop_requested(stop);
-    RC_TRY(fetch_acc_enqueue(s, true, speculated, false));
-    if (speculated) {
+    // An accepted trial is the common case and its state is linearised next anyway.  That linearisation sums rho over every
+    // active edge of the trial state -- exactly the chi2 the accept test needs (computeActiveErrors + activeRobustChi2,
+    // levenberg.cpp:113-116) -- and stores the per-edge chi2 like the residual-only pass, so when the linearisation is
+    // speculated it REPLACES that pass: update -> zero -> linearise(trial) -> publish.  (acc[ACC_CHI2] is still 0 from
+    // k_reduce_stage1, acc[ACC_SCALE] comes from the update and is left alone by the zeroing.)  The residual-only pass
+    // remains for the last trial of a pass and for PPO_BA_CHI2_PASS=1 (A/B switch).
+    static const bool chi2_pass = []() { const char* e = getenv("PPO_BA_CHI2_PASS"); return e && e[0] == '1'; }();
+    if (speculated && !chi2_pass) {
       phase_mark(s, PH_LIN);
+      const ZeroPlan zp = linearize_zero_plan(s, false);
+      const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
+      hipLaunchKernelGGL(k_zero_ranges, dim3(std::min(nblk((long)tot / 2, 256), 2 * s->n_cu)), dim3(256), 0, s->stream, zp);
       RC_TRY(launch_linearize(s, s->cur ^ 1, true));
+      RC_TRY(fetch_acc_enqueue(s, true, false, false));
+    } else {
+      phase_mark(s, PH_CHI2);
+      RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
+      RC_TRY(fetch_acc_enqueue(s, true, speculated, false));
+      if (speculated) {
+        phase_mark(s, PH_LIN);
+        RC_TRY(launch_linearize(s, s->cur ^ 1, true));
+      }
     }
     phase_mark(s, PH_OTHER);
     RC_TRY(fetch_acc_wait(s));
