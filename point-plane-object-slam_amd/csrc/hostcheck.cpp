@@ -55,4 +55,13 @@ void hc_ptcub(const double* c10, const double* pts, int npts, double margin, con
   const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};
   ptcub_residual(c, pts, npts, margin, prior, e);
 }
+// W = Jp' w Jl (6x3, row-major) of a reprojection edge rebuilt from its 32-byte factor record: M(record, intrinsics) * R
+void hc_factor_W(const double* qt, const double* X, const double* cam, double w, int stereo, double* W) {
+  const Mat3 R = rotmat(Quat{qt[0], qt[1], qt[2], qt[3]});
+  const FactorRec f = factor_record(R, Vec3{qt[4], qt[5], qt[6]}, Vec3{X[0], X[1], X[2]}, stereo ? -w : w);
+  double M[18];
+  factor_M(f, cam[0], cam[1], cam[4], stereo != 0, M);
+  for (int a = 0; a < 6; ++a)
+    for (int c = 0; c < 3; ++c) W[3 * a + c] = M[3 * a] * R.a[c] + M[3 * a + 1] * R.a[3 + c] + M[3 * a + 2] * R.a[6 + c];
+}
 }

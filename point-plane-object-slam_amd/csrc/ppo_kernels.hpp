@@ -347,41 +347,7 @@ struct PoseChunks {
   const int32_t* pose;   // [n_chunks] (keyframe index << 1) | type
   int n_chunks;
 };
-// Factor record of a reprojection edge (32 bytes instead of the 144-byte coupling block W = Jp' w Jl it stands for).  With
-// a = x/z, b = y/z, i = 1/z of the point in the camera frame, the Jacobians of EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ
-// (types_six_dof_expmap.cpp:65-103, :192-246) are polynomials in (a, b, i) and the intrinsics, and Jl = Jc R with R the
-// keyframe's rotation, so W = M R with the 6x3 matrix M = Jp' w Jc.  The pose side of the linearisation writes (a, b, i, +-w)
-// per slot; the Schur pair kernel forms M_j (R_j (D + lambda I)^-1 R_i') M_i' with R_j, R_i uniform over its wave.
-__device__ __forceinline__ double4 factor_record(const Mat3& R, Vec3 t, Vec3 X, double ws) {
-  const Vec3 pc = matvec(R, X) + t;
-  const double iz = 1.0 / pc.z;
-  return make_double4(pc.x * iz, pc.y * iz, iz, ws);
-}
-// M (row-major 6x3) of a record; `stereo_rows`: wave-uniform, some lane holds a stereo record (third residual row, bf)
-__device__ __forceinline__ void factor_M(const double4 f, double fx, double fy, double bf, bool stereo_rows, double* M) {
-  const double a = f.x, b = f.y, iz = f.z, w = fabs(f.w);
-  const double afx = a * fx, bfy = b * fy, izfx = iz * fx, izfy = iz * fy;
-  const double p0[6] = {afx * b, -__builtin_fma(afx, a, fx), b * fx, -izfx, 0.0, afx * iz};   // d e_u / d pose
-  const double p1[6] = {__builtin_fma(bfy, b, fy), -(bfy * a), -(a * fy), 0.0, -izfy, bfy * iz};  // d e_v / d pose
-  const double c00 = -(izfx * w), c02 = izfx * a * w, c11 = -(izfy * w), c12 = izfy * b * w;  // w Jc (camera-frame point)
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    M[3 * k] = p0[k] * c00;
-    M[3 * k + 1] = p1[k] * c11;
-    M[3 * k + 2] = __builtin_fma(p0[k], c02, p1[k] * c12);
-  }
-  if (stereo_rows) {
-    const double w2 = f.w < 0.0 ? w : 0.0;
-    const double bi = bf * iz;
-    const double p2[6] = {__builtin_fma(-bi, b, p0[0]), __builtin_fma(bi, a, p0[1]), p0[2], p0[3], 0.0, __builtin_fma(-bi, iz, p0[5])};
-    const double c20 = -(izfx * w2), c22 = (izfx * a - bi * iz) * w2;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      M[3 * k] = __builtin_fma(p2[k], c20, M[3 * k]);
-      M[3 * k + 2] = __builtin_fma(p2[k], c22, M[3 * k + 2]);
-    }
-  }
-}
+// (factor records: factor_record / factor_M in ppo_math.hpp)
 constexpr int kPoseWaveLds = 14 * 65;  // doubles per wave: the 14 x 65 reduction buffer
 __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, const PoseChunks& pc, int bid, double* s_raw) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -404,7 +370,7 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
   // the Schur pair kernel rebuilds W = M R from the factor records: leave it the linearisation point's rotation and intrinsics
   // (every chunk of a keyframe writes the same twelve values)
   if (lane < 12) g.linR[(size_t)(g.pose_col[pose] / 6) * 12 + lane] = lane < 9 ? rt[lane] : cm[lane == 9 ? 0 : (lane == 10 ? 1 : 4)];
-  double4* const F4 = reinterpret_cast<double4*>(g.F);
+  FactorRec* const F4 = reinterpret_cast<FactorRec*>(g.F);
   double A[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) A[k] = 0.0;
@@ -417,7 +383,7 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
       ed.slot = -1;
       uint32_t fl = 0;
       if (in) { ed = g.monoP[q]; fl = g.mono_flags[ed.eid]; }
-      double4 rec = make_double4(0.0, 0.0, 0.0, 0.0);
+      FactorRec rec{0.0, 0.0, 0.0, 0.0};
       if (in && (fl & F_ACTIVE)) {
         const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
         double ev[2], Jl[6], Jp[12], zc;
@@ -440,7 +406,7 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
       ed.slot = -1;
       uint32_t fl = 0;
       if (in) { ed = g.stereoP[q]; fl = g.stereo_flags[ed.eid]; }
-      double4 rec = make_double4(0.0, 0.0, 0.0, 0.0);
+      FactorRec rec{0.0, 0.0, 0.0, 0.0};
       if (in && (fl & F_ACTIVE)) {
         const Vec3 X = v3(st.point[3 * ed.point], st.point[3 * ed.point + 1], st.point[3 * ed.point + 2]);
         double ev[3], Jl[9], Jp[18], zc;
@@ -1063,7 +1029,7 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
 #pragma unroll
     for (int k = 0; k < 12; ++k) { Rj[k] = uni(rj[k]); Ri[k] = uni(ri[k]); }
   }
-  const double4* const F4 = reinterpret_cast<const double4*>(g.F);
+  const FactorRec* const F4 = reinterpret_cast<const FactorRec*>(g.F);
   // vals[6 r + c] = element (row c of pose j, column r of pose i) so that consecutive values are consecutive in memory
   double vals[42];
 #pragma unroll
@@ -1080,8 +1046,8 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
     double u0 = 0.0, u1 = 0.0, u2 = 0.0;  // self pairs: (D + lambda I)^-1 b_l, rotated like T
     if (self) { u0 = g.ul[(size_t)l * 3]; u1 = g.ul[(size_t)l * 3 + 1]; u2 = g.ul[(size_t)l * 3 + 2]; }
     if (l < g.n_points) {
-      const double4 fj = F4[sj], fi = F4[si];
-      const bool st_rows = __any(fj.w < 0.0 || fi.w < 0.0);
+      const FactorRec fj = F4[sj], fi = F4[si];
+      const bool st_rows = __any(fj.ws < 0.0 || fi.ws < 0.0);
       factor_M(fj, Rj[9], Rj[10], Rj[11], st_rows, L);
       factor_M(fi, Ri[9], Ri[10], Ri[11], st_rows, y);
       double A[9];

@@ -412,6 +412,45 @@ PPO_HD void stereo_eval(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy, dou
   Jp[15] = Jp[3];          Jp[16] = 0;                       Jp[17] = Jp[5] - bf / z2;
 }
 
+struct alignas(32) FactorRec {
+  double a, b, iz, ws;  // x/z, y/z, 1/z of the point in the camera frame; rho1 * info, negated for a stereo edge, 0 for an inactive one
+};
+// Factor record of a reprojection edge (32 bytes instead of the 144-byte coupling block W = Jp' w Jl it stands for).  With
+// a = x/z, b = y/z, i = 1/z of the point in the camera frame, the Jacobians of EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ
+// (types_six_dof_expmap.cpp:65-103, :192-246) are polynomials in (a, b, i) and the intrinsics, and Jl = Jc R with R the
+// keyframe's rotation, so W = M R with the 6x3 matrix M = Jp' w Jc.  The pose side of the linearisation writes (a, b, i, +-w)
+// per slot; the Schur pair kernel (ppo_kernels.hpp, schur_pairs_body) forms M_j (R_j (D + lambda I)^-1 R_i') M_i' with R_j, R_i uniform over its wave.
+PPO_HD FactorRec factor_record(const Mat3& R, Vec3 t, Vec3 X, double ws) {
+  const Vec3 pc = matvec(R, X) + t;
+  const double iz = 1.0 / pc.z;
+  return FactorRec{pc.x * iz, pc.y * iz, iz, ws};
+}
+// M (row-major 6x3) of a record; `stereo_rows`: wave-uniform, some lane holds a stereo record (third residual row, bf)
+PPO_HD void factor_M(const FactorRec f, double fx, double fy, double bf, bool stereo_rows, double* M) {
+  const double a = f.a, b = f.b, iz = f.iz, w = fabs(f.ws);
+  const double afx = a * fx, bfy = b * fy, izfx = iz * fx, izfy = iz * fy;
+  const double p0[6] = {afx * b, -__builtin_fma(afx, a, fx), b * fx, -izfx, 0.0, afx * iz};   // d e_u / d pose
+  const double p1[6] = {__builtin_fma(bfy, b, fy), -(bfy * a), -(a * fy), 0.0, -izfy, bfy * iz};  // d e_v / d pose
+  const double c00 = -(izfx * w), c02 = izfx * a * w, c11 = -(izfy * w), c12 = izfy * b * w;  // w Jc (camera-frame point)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    M[3 * k] = p0[k] * c00;
+    M[3 * k + 1] = p1[k] * c11;
+    M[3 * k + 2] = __builtin_fma(p0[k], c02, p1[k] * c12);
+  }
+  if (stereo_rows) {
+    const double w2 = f.ws < 0.0 ? w : 0.0;
+    const double bi = bf * iz;
+    const double p2[6] = {__builtin_fma(-bi, b, p0[0]), __builtin_fma(bi, a, p0[1]), p0[2], p0[3], 0.0, __builtin_fma(-bi, iz, p0[5])};
+    const double c20 = -(izfx * w2), c22 = (izfx * a - bi * iz) * w2;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      M[3 * k] = __builtin_fma(p2[k], c20, M[3 * k]);
+      M[3 * k + 2] = __builtin_fma(p2[k], c22, M[3 * k + 2]);
+    }
+  }
+}
+
 // Huber weight: rho0 (robustified chi2) and rho1 (weight); delta <= 0 disables the kernel
 PPO_HD void huber(double chi2, double delta, double& rho0, double& rho1) {
   rho0 = chi2;

@@ -34,6 +34,7 @@ def hc():
         pytest.skip("libppo_hostcheck.so not built (run __graft_entry__.build())")
     lib = C.CDLL(path)
     lib.hc_huber.argtypes = [C.c_double, C.c_double, B.c_dp]
+    lib.hc_factor_W.argtypes = [B.c_dp, B.c_dp, B.c_dp, C.c_double, C.c_int, B.c_dp]
     return lib
 
 
@@ -188,6 +189,36 @@ def test_plane_frame_without_trigonometry_matches_oracle_at_steps_and_poles(hc, 
         oracle_lib.oracle_plane_ominus(dptr(loc), dptr(m), 0, dptr(eo))
         hc.hc_plane_residual(dptr(qt), dptr(p), dptr(m), 0, dptr(eh))
         np.testing.assert_allclose(eo, eh, rtol=0, atol=1e-13)
+
+
+def test_factor_record_rebuilds_the_coupling_block(hc):
+    """The linearisation keeps 32 bytes per reprojection edge -- (x/z, y/z, 1/z, +-w) -- instead of the 6x3 block
+    W = Jp' w Jl, and the Schur pair kernel rebuilds W = M(record, intrinsics) R.  The rebuilt block must
+    equal the one formed from the Jacobians of EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (which test_golden pins on the
+    reference's libg2o) to rounding."""
+    rng = np.random.default_rng(13)
+    for case in range(200):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        if q[3] < 0:
+            q = -q
+        qt = np.concatenate([q, rng.normal(size=3)])
+        Rm = np.array([[1 - 2 * (q[1] ** 2 + q[2] ** 2), 2 * (q[0] * q[1] - q[2] * q[3]), 2 * (q[0] * q[2] + q[1] * q[3])],
+                       [2 * (q[0] * q[1] + q[2] * q[3]), 1 - 2 * (q[0] ** 2 + q[2] ** 2), 2 * (q[1] * q[2] - q[0] * q[3])],
+                       [2 * (q[0] * q[2] - q[1] * q[3]), 2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)]])
+        pc = np.array([rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), rng.uniform(0.3, 8.0)])
+        X = Rm.T @ (pc - qt[4:])
+        cam = np.array([rng.uniform(300, 600), rng.uniform(300, 600), 320.0, 240.0, rng.uniform(20, 60)])
+        w = float(rng.uniform(0.05, 2.0))
+        for stereo, dim, fn in ((0, 2, hc.hc_mono), (1, 3, hc.hc_stereo)):
+            e, Jl, Jp = np.zeros(dim), np.zeros(3 * dim), np.zeros(6 * dim)
+            fn(dptr(qt), dptr(X), dptr(cam), dptr(np.zeros(dim)), dptr(e), dptr(Jl), dptr(Jp))
+            W_ref = Jp.reshape(dim, 6).T @ (w * Jl.reshape(dim, 3))
+            W = np.zeros(18)
+            hc.hc_factor_W(dptr(qt), dptr(X), dptr(cam), w, stereo, dptr(W))
+            np.testing.assert_allclose(W.reshape(6, 3), W_ref, rtol=0, atol=1e-12 * max(1.0, np.abs(W_ref).max()))
+        # an inactive edge (w = 0) contributes nothing
+        hc.hc_factor_W(dptr(qt), dptr(X), dptr(cam), 0.0, 0, dptr(W))
+        assert not W.any()
 
 
 # ---- regression trace of the oracle -----------------------------------------------------------------------------------------
