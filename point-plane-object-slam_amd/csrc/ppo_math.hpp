@@ -360,21 +360,25 @@ PPO_HD void ptcub_residual(const Cub& c, const double* pts, int npts, double mar
 PPO_HD void mono_eval(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy, double cx, double cy, double ou, double ov,
                       double* e, double* Jl, double* Jp, double& zc) {
   const Vec3 pc = matvec(R, X) + t;
-  const double x = pc.x, y = pc.y, z = pc.z, z2 = z * z;
-  zc = z;
-  e[0] = ou - (x / z * fx + cx);
-  e[1] = ov - (y / z * fy + cy);
-  const double s = -1. / z;
-  const double r0[3] = {s * fx, s * 0.0, s * (-x / z * fx)};
-  const double r1[3] = {s * 0.0, s * fy, s * (-y / z * fy)};
+  zc = pc.z;
+  // Three divisions instead of the eight distinct quotients of types_six_dof_expmap.cpp:65-103 (an FP64 division is ~15
+  // instructions on the device and this routine runs three times per edge and LM iteration).  The residual and every Jacobian
+  // entry that is a single quotient in the reference keep their bits (x/z, y/z, 1/z); x y / z^2, x^2 / z^2, y^2 / z^2, x / z^2
+  // and y / z^2 become products of those quotients (an ulp or two apart; the parity bar on J is 1e-13 relative).
+  const double a = pc.x / pc.z, b = pc.y / pc.z, iz = 1. / pc.z;
+  e[0] = ou - (a * fx + cx);
+  e[1] = ov - (b * fy + cy);
+  const double s = -iz;
+  const double r0[3] = {s * fx, s * 0.0, s * (-a * fx)};
+  const double r1[3] = {s * 0.0, s * fy, s * (-b * fy)};
   for (int c = 0; c < 3; ++c) {
     Jl[c] = r0[0] * R.a[c] + r0[1] * R.a[3 + c] + r0[2] * R.a[6 + c];
     Jl[3 + c] = r1[0] * R.a[c] + r1[1] * R.a[3 + c] + r1[2] * R.a[6 + c];
   }
-  Jp[0] = x * y / z2 * fx; Jp[1] = -(1 + (x * x / z2)) * fx; Jp[2] = y / z * fx;
-  Jp[3] = -1. / z * fx;    Jp[4] = 0;                        Jp[5] = x / z2 * fx;
-  Jp[6] = (1 + y * y / z2) * fy; Jp[7] = -x * y / z2 * fy;   Jp[8] = -x / z * fy;
-  Jp[9] = 0;               Jp[10] = -1. / z * fy;            Jp[11] = y / z2 * fy;
+  Jp[0] = a * b * fx;        Jp[1] = -(1 + a * a) * fx; Jp[2] = b * fx;
+  Jp[3] = -iz * fx;          Jp[4] = 0;                 Jp[5] = a * iz * fx;
+  Jp[6] = (1 + b * b) * fy;  Jp[7] = -(a * b) * fy;     Jp[8] = -a * fy;
+  Jp[9] = 0;                 Jp[10] = -iz * fy;         Jp[11] = b * iz * fy;
 }
 PPO_HD void mono_residual(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy, double cx, double cy, double ou, double ov, double* e, double& zc) {
   const Vec3 pc = matvec(R, X) + t;
