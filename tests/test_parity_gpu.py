@@ -477,3 +477,34 @@ def test_cpp_caller_through_the_c_abi(hip, tmp_path):
     last = float(lines[-1].split("->")[1].split()[0])
     assert abs(last - st["iters"][-1]["chi2_after"]) <= 1e-5 * st["iters"][-1]["chi2_after"]
     assert "call 1:" in out.stdout
+
+
+def test_linearisation_standing_in_for_the_residual_pass_changes_nothing(hip):
+    """By default the speculated linearisation of a trial state supplies that trial's chi2; PPO_BA_CHI2_PASS=1
+    keeps the separate residual-only launch.  Both orders must walk the same LM schedule to the same estimates (the switch
+    is read once per process, hence the child processes)."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from ppo_ba import binding as B, synth\n"
+        "P = synth.make_problem('small', seed=3, outlier_frac=0.2)\n"
+        "s = B.hip_backend().create(P, B.default_options())\n"
+        "t = s.run(); r = s.read()\n"
+        "print(json.dumps({'iters': [[i['trials'], i['accepted'], i['chi2_after']] for i in t['iters']],\n"
+        "                  'pose': r.pose_qt.tolist(), 'lvl': int(r.mono_level.sum())}))\n" % os.path.join(B.PKG_ROOT))
+    out = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, PPO_BA_CHI2_PASS=flag)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[flag] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = out["0"], out["1"]
+    assert len(a["iters"]) == len(b["iters"]) > 0
+    for x, y in zip(a["iters"], b["iters"]):
+        assert x[:2] == y[:2]
+        assert abs(x[2] - y[2]) <= 1e-7 * abs(y[2])  # (atomic summation order alone moves chi2 by ~1e-9 from run to run)
+    assert a["lvl"] == b["lvl"]
+    assert np.abs(np.array(a["pose"]) - np.array(b["pose"])).max() < 1e-6
