@@ -219,6 +219,25 @@ __device__ __forceinline__ void acc_pose(const double* Jp, double w, const doubl
   }
 }
 
+// Camera table of a workgroup: R, t (12) and fx, fy, cx, cy of every keyframe, 16 doubles each, into LDS.  Eight loads per thread are
+// issued before the first store (sixteen measure the same): written as one load + one store per trip the loop waited for memory 13 times in a row
+// (200 keyframes, 256 threads) before the workgroup could touch its first edge.
+__device__ __forceinline__ void stage_camera_table(double* smem, const double* __restrict__ pose_rt, const double* __restrict__ pose_cam, int n_poses) {
+  const int n = n_poses * 16;
+  for (int base = threadIdx.x; base < n; base += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + 256 * k < n ? base + 256 * k : n - 1;  // clamped: the loads stay unconditional
+      const int p = i >> 4, q = i & 15;
+      v[k] = q < 12 ? pose_rt[p * 12 + q] : pose_cam[p * 5 + (q - 12)];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (base + 256 * k < n) smem[base + 256 * k] = v[k];
+  }
+}
+
 // ======================================================================================================
 // k_lin_points: landmark side of the reprojection edges, one thread per point.  The camera table (R, t, intrinsics of
 // every keyframe: 128 B each) is staged in LDS once per workgroup (USE_LDS); D_l / b_l / W are written exactly once,
@@ -227,10 +246,7 @@ __device__ __forceinline__ void acc_pose(const double* Jp, double w, const doubl
 template <bool USE_LDS>
 __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st, int bid, int nblocks, double* smem, double* s_red) {
   if (USE_LDS) {
-    for (int i = threadIdx.x; i < g.n_poses * 16; i += blockDim.x) {
-      const int p = i >> 4, k = i & 15;
-      smem[i] = k < 12 ? st.pose_rt[p * 12 + k] : g.pose_cam[p * 5 + (k - 12)];
-    }
+    stage_camera_table(smem, st.pose_rt, g.pose_cam, g.n_poses);
     __syncthreads();
   }
 #ifndef PPO_LIN_LPP
@@ -1341,10 +1357,7 @@ __device__ __forceinline__ void update_reduced_body(const Graph& g, const State&
 template <bool USE_LDS, int LPP>
 __device__ __forceinline__ void backsub_body(const Graph& g, const State& cur, const State& trial, double lambda, int vb, double* smem, double* s_red) {
   if (USE_LDS) {  // camera table: R, t, intrinsics of every keyframe
-    for (int i = threadIdx.x; i < g.n_poses * 16; i += blockDim.x) {
-      const int p = i >> 4, q = i & 15;
-      smem[i] = q < 12 ? cur.pose_rt[p * 12 + q] : g.pose_cam[p * 5 + (q - 12)];
-    }
+    stage_camera_table(smem, cur.pose_rt, g.pose_cam, g.n_poses);
     __syncthreads();
   }
   const int nl_pts = g.pt_last - g.pt_first;
