@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
   // instead of being streamed from HBM once per pair (264 MB -> ~36 MB at the BASELINE size).
   const int per_xcd = (nblocks + 7) >> 3;
   const int vb = (bid & 7) * per_xcd + (bid >> 3);
-  const int t = vb * 4 + wave;
+  const int t = __builtin_amdgcn_readfirstlane(vb * 4 + wave);  // (uniform: the chunk header and the keyframe data become scalar loads)
   if (t >= pc.n_chunks) return;
   const int e1 = pc.start[t + 1];
   const int colj = pc.colj[t], coli = pc.coli[t];
@@ -1038,6 +1038,14 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
   auto uni = [](double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
   };
+  // plan entries of the first trip, requested together with the keyframe data below (both hang on the chunk header only);
+  // inside the loop the next trip's entries are requested before this trip's arithmetic.  (clamped indices: unconditional loads)
+  int e = pc.start[t] + lane;
+  int sj, si, l;
+  {
+    const int ec = e < e1 ? e : (e1 > 0 ? e1 - 1 : 0);
+    sj = pc.sj[ec]; si = pc.si[ec]; l = pc.lm[ec];
+  }
   double Rj[12], Ri[12];
   {
     const double* rj = &g.linR[(size_t)(colj / 6) * 12];
@@ -1050,12 +1058,12 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
   double vals[42];
 #pragma unroll
   for (int k = 0; k < 42; ++k) vals[k] = 0.0;
-  for (int e = pc.start[t] + lane; e < e1; e += 64) {
-    const int sj = pc.sj[e], si = pc.si[e];
-    const int l = pc.lm[e];
+  for (; e < e1; e += 64) {
     const double2* I2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l * 6]);  // 48-byte records: three 16-byte loads
     const double2 i01 = I2[0], i23 = I2[1], i45 = I2[2];
     const double v00 = i01.x, v01 = i01.y, v02 = i23.x, v11 = i23.y, v12 = i45.x, v22 = i45.y;
+    const int en = e + 64 < e1 ? e + 64 : e1 - 1;
+    const int sj_n = pc.sj[en], si_n = pc.si[en], l_n = pc.lm[en];
     // S(j, i) -= L T Y' with  points: L = M_j, Y = M_i, T = R_j (D + lambda I)^-1 R_i'   planes: L = W_j, Y = W_i, T = (D + lambda I)^-1
     double L[18], y[18], T[9], w[18];
     const bool self = sj == si;
@@ -1109,6 +1117,7 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
 #pragma unroll
       for (int c = 0; c < 6; ++c) vals[36 + c] += L[c * 3] * u0 + L[c * 3 + 1] * u1 + L[c * 3 + 2] * u2;
     }
+    sj = sj_n; si = si_n; l = l_n;
   }
   const int n = g.ld;
   const bool diag = colj == coli;
