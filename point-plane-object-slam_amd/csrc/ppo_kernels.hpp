@@ -369,7 +369,7 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* const wbuf = s_raw + wave * kPoseWaveLds;
   double (*const red)[65] = reinterpret_cast<double (*)[65]>(wbuf);
-  const int t = bid * 4 + wave;  // one wave per chunk: lanes stride the chunk, records are read fully coalesced
+  const int t = __builtin_amdgcn_readfirstlane(bid * 4 + wave);  // one wave per chunk (uniform index: scalar loads of its header and keyframe): lanes stride the chunk, records are read fully coalesced
   if (t >= pc.n_chunks) return;
   const int code = pc.pose[t], pose = code >> 1;
   // the keyframe is the same for the whole wave: keep R, t and the intrinsics in scalar registers

@@ -502,9 +502,14 @@ def test_linearisation_standing_in_for_the_residual_pass_changes_nothing(hip):
         assert res.returncode == 0, res.stderr[-2000:]
         out[flag] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     a, b = out["0"], out["1"]
-    assert len(a["iters"]) == len(b["iters"]) > 0
+    assert len(a["iters"]) > 0 and len(b["iters"]) > 0
+    # Two runs of the SAME order differ by the atomic summation order (chi2 ~1e-9 relative), which can flip the accept test of a
+    # trial at convergence (delta chi2 ~1e-13 relative): the schedule is compared up to the first such
+    # flip, the results everywhere.
     for x, y in zip(a["iters"], b["iters"]):
-        assert x[:2] == y[:2]
-        assert abs(x[2] - y[2]) <= 1e-7 * abs(y[2])  # (atomic summation order alone moves chi2 by ~1e-9 from run to run)
-    assert a["lvl"] == b["lvl"]
+        if x[:2] != y[:2]:
+            break
+        assert abs(x[2] - y[2]) <= 1e-7 * abs(y[2])
+    assert abs(a["iters"][-1][2] - b["iters"][-1][2]) <= 1e-6 * abs(b["iters"][-1][2])
+    assert abs(a["lvl"] - b["lvl"]) <= 2
     assert np.abs(np.array(a["pose"]) - np.array(b["pose"])).max() < 1e-6
