@@ -1260,16 +1260,19 @@ struct ReducePlan {
 __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp) {
   int b = blockIdx.x;
   if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
+  // (the cuboid workgroup first: one thread per cuboid walks a 9x9 Cholesky + inverse, the longest chain of the launch)
+  if (b < rp.nb_cubprep) { cub_prep_body(g, lambda, b); return; }
+  b -= rp.nb_cubprep;
   if (b < rp.nb_asm) { assemble_body(g, lambda, b); return; }
-  b -= rp.nb_asm;
-  if (b < rp.nb_prep) { schur_prep_body(g, lambda, b); return; }
-  cub_prep_body(g, lambda, b - rp.nb_prep);
+  schur_prep_body(g, lambda, b - rp.nb_asm);
 }
 __global__ __launch_bounds__(256) void k_reduce_stage3(Graph g, PairChunks pc, ReducePlan rp) {
   __shared__ double s_buf[4][21][65];
   const int b = blockIdx.x;
-  if (b < rp.nb_pairs) { schur_pairs_body(g, pc, b, rp.nb_pairs, s_buf); return; }
-  cub_schur_body(g, b - rp.nb_pairs);
+  // the few cuboid workgroups first (a chain of dependent gathers: at the end of the grid they were a 5 us tail behind the pair
+  // workgroups); their count is a multiple of 8, so the pair workgroups keep their workgroup -> XCD phase
+  if (b < rp.nb_cubschur) { cub_schur_body(g, b); return; }
+  schur_pairs_body(g, pc, b - rp.nb_cubschur, rp.nb_pairs, s_buf);
 }
 // single-part wrappers (measurement hooks)
 __global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {

@@ -410,7 +410,7 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
   rp.nb_prep = nl > 0 ? nblk(nl, 256) : 0;
   rp.nb_cubprep = cub_stage ? nblk(g.n_cuboids, 256) : 0;
   rp.nb_pairs = (nl > 0 && s->pc.n_chunks > 0) ? (nblk(s->pc.n_chunks, 4) + 7) / 8 * 8 : 0;
-  rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? nblk((long)g.n_cub_pairs * 8, 256) : 0;
+  rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? (nblk((long)g.n_cub_pairs * 8, 256) + 7) / 8 * 8 : 0;  // (multiple of 8: see k_reduce_stage3)
   hipLaunchKernelGGL(k_reduce_stage1, dim3(rp.nb_asm + rp.nb_prep + rp.nb_cubprep), dim3(256), 0, s->stream, g, lambda, rp);
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
   HIP_TRY(hipGetLastError());
