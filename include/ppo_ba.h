@@ -265,7 +265,7 @@ int ppo_ba_time_linearize(ppo_ba_handle h, int reps, double* ms);
  * *bytes = the algorithmic bytes that kernel must move per launch.  State is not advanced;
  * call after ppo_ba_linearize() / ppo_ba_debug_reduced() so that the kernel's inputs exist. */
 enum {
-  PPO_BA_KERNEL_LIN_POSES = 0,   /* reprojection residual + Jacobians, pose side: W blocks, Hpp, b_p */
+  PPO_BA_KERNEL_LIN_POSES = 0,   /* reprojection residual + Jacobians, pose side: factor records of the coupling blocks, Hpp, b_p */
   PPO_BA_KERNEL_LIN_POINTS = 1,  /* reprojection residual + Jacobians, landmark side: D, b_l, chi2 */
   PPO_BA_KERNEL_SCHUR_Z = 2,     /* retired (folded into the pair kernel): reports 0 ms */
   PPO_BA_KERNEL_SCHUR_PAIRS = 3,

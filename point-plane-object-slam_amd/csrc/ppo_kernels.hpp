@@ -2,17 +2,21 @@
 //
 // Launches of one LM iteration (DESIGN.md section 4 has the table with bounds, bytes and measured times).  Independent parts
 // are fused HORIZONTALLY: one launch, block ranges select the part, one shared LDS allocation.
-//   k_linearize_all   numerically differentiated edges (16 lanes per plane / bbox / corner / point-cuboid edge, one lane per
-//                     Jacobian column, central differences through the vertex box-plus exactly like g2o, delta = 1e-9)
-//                     | pose side of the reprojection edges (wave per keyframe segment: W = Jp' w Jl, Hpp, b_p)
-//                     | landmark side (4 lanes per point: D_l, b_l, per-edge chi2, robust sum)
-//   k_reduce_stage1   assemble Hpp + lambda I into S | (D_l + lambda I)^-1 per landmark | 9x9 inverse per cuboid
-//   k_reduce_stage3   S -= W_j (D_l + lambda I)^-1 W_i' by pose pair (wave per pair chunk) | cuboid edge pairs
+//   k_reduce_stage1   9x9 inverse per cuboid | assemble Hpp + lambda I into S | (D_l + lambda I)^-1 per landmark
+//   k_reduce_stage3   cuboid edge pairs | S -= W_j (D_l + lambda I)^-1 W_i' by pose pair (wave per pair chunk; W rebuilt from the
+//                     32-byte factor records of the two slots, ppo_math.hpp factor_M)
 //   [dense Cholesky of S: ppo_chol.hip (chol_step x ld/64, chol_back_all) or rocSOLVER]
 //   k_update_all      cuboid back-substitution + update | pose updates | landmark back-substitution + update (matrix-free)
 //                     | clearing S for the next reduction
-//   k_chi2_all        residual-only pass on the trial state, per-edge chi2 kept (g2o's stored _error)
-//   k_publish         chi2 / scale / factorisation flag -> mapped host memory (+ clearing for the speculated linearisation)
+//   k_zero_ranges     the accumulation ranges of the linearisation
+//   k_linearize_all   (on the TRIAL state: its sum of rho is the trial's chi2)
+//                     numerically differentiated edges (2 NCOL + 1 lanes per plane / bbox / corner / point-cuboid edge: the two
+//                     signs of a Jacobian column in neighbouring lanes, central differences through the vertex box-plus exactly
+//                     like g2o, delta = 1e-9)
+//                     | pose side of the reprojection edges (wave per keyframe segment: factor records of W = Jp' w Jl, Hpp, b_p)
+//                     | landmark side (2 lanes per point: D_l, b_l, per-edge chi2, robust sum)
+//   k_publish         chi2 / scale / factorisation flag -> mapped host memory
+//   k_chi2_all        residual-only pass on the trial state (last trial of a pass only), per-edge chi2 kept (g2o's stored _error)
 // The single-part kernels further down (k_lin_points, k_lin_poses, k_schur_pairs, k_backsub, k_chi2_points) wrap the same
 // bodies for the measurement hook ppo_ba_time_kernel().
 #pragma once
@@ -354,7 +358,7 @@ __device__ __forceinline__ double wave_transpose_sum(const double* vals, double 
 // ======================================================================================================
 // k_lin_poses: pose side + coupling blocks of the reprojection edges, streamed POSE-MAJOR.  The edges of every free
 // keyframe are stored contiguously (static copies monoP / stereoP) and cut into chunks; one thread re-evaluates the
-// edges of one chunk against its keyframe (held in registers), writes W = Jp' w Jl to consecutive slots and
+// edges of one chunk against its keyframe (held in registers), writes the factor record of W = Jp' w Jl to consecutive slots and
 // accumulates Jp' w Jp / Jp' g in 27 registers: 27 atomics per CHUNK.  Points are gathered from the L2-resident array.
 // ======================================================================================================
 struct PoseChunks {
