@@ -172,10 +172,167 @@ def generate():
     out["cases"]["onlypose_mono"] = only["mono"]
     out["cases"]["onlypose_stereo"] = only["stereo"]
 
+    out["cases"].update(generate_binary_edges(lib))
+
     os.makedirs(os.path.dirname(GOLD), exist_ok=True)
     with open(GOLD, "w") as fh:
         json.dump(out, fh, indent=1)
     print("wrote", GOLD, {k: len(v) for k, v in out["cases"].items()})
+
+
+# ---- binary reprojection edges: computeError, analytic linearizeOplus, NUMERIC linearizeOplusXi/Xj, constructQuadraticForm ----
+# Real objects this time: the edge and both vertices are built by their exported constructors (so every virtual call the
+# numeric differentiation makes -- computeError, push, oplus, pop -- goes through the reference's own vtables), then the
+# fields are written at the offsets read off the disassembly:
+#   vertex   _fixed +0x54 (constructQuadraticForm tests it), Hessian map pointer +0x70 (BaseVertex::mapHessianMemory),
+#            _b +0x80 (BaseVertex::b), point estimate +0x98, pose q +0xb0 / t +0xd0
+#   edge     _vertices.data() at *(this+0x8), robust kernel pointer +0x30, _measurement +0xa0,
+#            mono (D = 2): _information +0xb0, _error +0xd0, Jacobian map pointers +0x108 / +0x118, fx fy cx cy +0x128
+#            stereo (D = 3): _information +0xb8, _error +0x100, Jacobian map pointers +0x140 / +0x150, fx fy cx cy bf +0x160
+#            the off-diagonal Hessian map is set through the exported mapHessianMemory(double*, int, int, bool rowMajor)
+#   kernel   RobustKernelHuber = exported vtable + 16, _delta / dsqr written by the exported setDelta
+_BB2 = "_ZN3g2o14BaseBinaryEdgeILi2EN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEENS_17VertexSBAPointXYZENS_15VertexSE3ExpmapEE"
+_BB3 = "_ZN3g2o14BaseBinaryEdgeILi3EN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEENS_17VertexSBAPointXYZENS_15VertexSE3ExpmapEE"
+_KIND = {
+    "mono": dict(D=2, ctor="_ZN3g2o17EdgeSE3ProjectXYZC1Ev", err_fn="_ZN3g2o17EdgeSE3ProjectXYZ12computeErrorEv",
+                 lin="_ZN3g2o17EdgeSE3ProjectXYZ14linearizeOplusEv", xi=_BB2 + "16linearizeOplusXiEv", xj=_BB2 + "16linearizeOplusXjEv",
+                 cqf=_BB2 + "22constructQuadraticFormEv", mhm=_BB2 + "16mapHessianMemoryEPdiib",
+                 meas=0xa0, info=0xb0, err=0xd0, jxi=0x108, jxj=0x118, cam=0x128, ncam=4),
+    "stereo": dict(D=3, ctor="_ZN3g2o23EdgeStereoSE3ProjectXYZC1Ev", err_fn="_ZN3g2o23EdgeStereoSE3ProjectXYZ12computeErrorEv",
+                   lin="_ZN3g2o23EdgeStereoSE3ProjectXYZ14linearizeOplusEv", xi=_BB3 + "16linearizeOplusXiEv", xj=_BB3 + "16linearizeOplusXjEv",
+                   cqf=_BB3 + "22constructQuadraticFormEv", mhm=_BB3 + "16mapHessianMemoryEPdiib",
+                   meas=0xa0, info=0xb8, err=0x100, jxi=0x140, jxj=0x150, cam=0x160, ncam=5),
+}
+
+
+def _aligned(nbytes):
+    a = np.zeros(nbytes // 8 + 4)
+    o = (-a.ctypes.data // 8) % 2
+    return a[o:o + nbytes // 8]
+
+
+def _rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def drive_binary_edge(lib, kind, q, t, Xw, cam, obs, w, delta, fix_pt, fix_ps, row_major):
+    """One edge through the prebuilt library; returns every array row-major."""
+    vp = C.c_void_p
+    u64 = lambda a: a.view(np.uint64)  # noqa: E731
+
+    def fn(name, *argtypes):
+        f = getattr(lib, name)
+        f.argtypes = list(argtypes)
+        f.restype = None
+        return f
+    K = _KIND[kind]
+    D = K["D"]
+    e, pt, ps = _aligned(0x200), _aligned(0x200), _aligned(0x200)
+    fn(K["ctor"], vp)(e.ctypes.data)
+    fn("_ZN3g2o17VertexSBAPointXYZC1Ev", vp)(pt.ctypes.data)
+    fn("_ZN3g2o15VertexSE3ExpmapC1Ev", vp)(ps.ctypes.data)
+    pt[0x98 // 8:0x98 // 8 + 3] = Xw
+    pt.view(np.uint8)[0x54] = fix_pt
+    ps[0xb0 // 8:0xb0 // 8 + 4] = q
+    ps[0xd0 // 8:0xd0 // 8 + 3] = t
+    ps.view(np.uint8)[0x54] = fix_ps
+    vptr = C.cast(int(u64(e)[1]), C.POINTER(C.c_uint64))  # _vertices was resized to 2 by the constructor
+    vptr[0] = pt.ctypes.data
+    vptr[1] = ps.ctypes.data
+    e[K["meas"] // 8:K["meas"] // 8 + D] = obs[:D]
+    e[K["info"] // 8:K["info"] // 8 + D * D] = (np.eye(D) * w).reshape(-1)
+    e[K["cam"] // 8:K["cam"] // 8 + K["ncam"]] = cam[:K["ncam"]]
+    kern = None
+    if delta > 0:
+        kern = _aligned(64)
+        u64(kern)[0] = C.addressof(C.c_void_p.in_dll(lib, "_ZTVN3g2o17RobustKernelHuberE")) + 16
+        f = lib._ZN3g2o17RobustKernelHuber8setDeltaEd
+        f.argtypes = [vp, C.c_double]
+        f(kern.ctypes.data, delta)
+        u64(e)[0x30 // 8] = kern.ctypes.data
+    Jxi, Jxj = _aligned(8 * 3 * D + 64), _aligned(8 * 6 * D + 64)
+    u64(e)[K["jxi"] // 8] = Jxi.ctypes.data
+    u64(e)[K["jxj"] // 8] = Jxj.ctypes.data
+    fn(K["err_fn"], vp)(e.ctypes.data)
+    err = e[K["err"] // 8:K["err"] // 8 + D].copy()
+    fn(K["lin"], vp)(e.ctypes.data)  # Eigen stores the D x Di Jacobians column-major
+    Ja_i, Ja_j = Jxi[:3 * D].reshape(3, D).T.copy(), Jxj[:6 * D].reshape(6, D).T.copy()
+    Hii, Hjj, Hij = _aligned(8 * 9 + 64), _aligned(8 * 36 + 64), _aligned(8 * 18 + 64)
+    u64(pt)[0x70 // 8] = Hii.ctypes.data
+    u64(ps)[0x70 // 8] = Hjj.ctypes.data
+    f = getattr(lib, K["mhm"])
+    f.argtypes = [vp, vp, C.c_int, C.c_int, C.c_bool]
+    f.restype = None
+    f(e.ctypes.data, Hij.ctypes.data, 0, 1, bool(row_major))
+    fn(K["cqf"], vp)(e.ctypes.data)
+    bi, bj = pt[0x80 // 8:0x80 // 8 + 3].copy(), ps[0x80 // 8:0x80 // 8 + 6].copy()
+    Hii_m, Hjj_m = Hii[:9].reshape(3, 3).T.copy(), Hjj[:36].reshape(6, 6).T.copy()
+    # _hessian is Di x Dj = 3 x 6 column-major; with rowMajor the 6 x 3 transposed map is written instead
+    Hij_m = Hij[:18].reshape(3, 6).copy() if row_major else Hij[:18].reshape(6, 3).T.copy()
+    Jxi[:] = 0
+    Jxj[:] = 0
+    fn(K["xi"], vp)(e.ctypes.data)
+    fn(K["xj"], vp)(e.ctypes.data)
+    Jn_i, Jn_j = Jxi[:3 * D].reshape(3, D).T.copy(), Jxj[:6 * D].reshape(6, D).T.copy()
+    err_after = e[K["err"] // 8:K["err"] // 8 + D].copy()
+    assert np.array_equal(err, err_after)  # base_binary_edge.hpp:258 / :318 restore _error
+    flat = lambda m: np.asarray(m).reshape(-1).tolist()  # noqa: E731
+    return {"error": err.tolist(), "J_point": flat(Ja_i), "J_pose": flat(Ja_j), "Jnum_point": flat(Jn_i), "Jnum_pose": flat(Jn_j),
+            "H_point": flat(Hii_m), "H_pose": flat(Hjj_m), "H_point_pose": flat(Hij_m), "b_point": bi.tolist(), "b_pose": bj.tolist()}
+
+
+def generate_binary_edges(lib):
+    rng = np.random.default_rng(20260930)  # its own stream: the vectors above stay bit-identical
+    out = {"binary_mono": [], "binary_stereo": []}
+    for kind in ("mono", "stereo"):
+        for k in range(32):
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            if q[3] < 0:
+                q = -q
+            t = rng.normal(size=3)
+            pc = np.array([rng.normal() * 1.2, rng.normal() * 0.9, rng.uniform(0.4, 9.0)])
+            Xw = _rot(q).T @ (pc - t)
+            cam = [rng.uniform(300, 700), rng.uniform(300, 700), rng.uniform(300, 340), rng.uniform(220, 260), float(np.float32(rng.uniform(20, 60)))]
+            proj = np.array([cam[0] * pc[0] / pc[2] + cam[2], cam[1] * pc[1] / pc[2] + cam[3], 0.0])
+            proj[2] = proj[0] - cam[4] / pc[2]
+            # residuals below the Huber knee, around it and far above it (gross outliers)
+            mag = [0.5, 1.0, 2.0, 4.0, 30.0, 300.0][k % 6]
+            obs = proj + rng.normal(size=3) * mag
+            w = float(1.2 ** (-2 * int(rng.integers(0, 8))))  # ORB pyramid inverse variances, Optimizer.cc:2376-2377
+            delta = 0.0 if k % 4 == 3 else float(np.float32(np.sqrt(5.991 if kind == "mono" else 7.815)))  # Optimizer.cc:2326-2327 (const float)
+            fix_pt, fix_ps = (1, 0) if k % 8 == 5 else ((0, 1) if k % 8 == 6 else (0, 0))
+            row_major = bool(k % 2)
+            res = drive_binary_edge(lib, kind, q, t, Xw, cam, obs, w, delta, fix_pt, fix_ps, row_major)
+            res.update({"qt": q.tolist() + t.tolist(), "cam": cam, "xw": Xw.tolist(), "obs": obs.tolist(), "info": w, "huber_delta": delta,
+                        "fix_point": fix_pt, "fix_pose": fix_ps, "row_major": int(row_major)})
+            out["binary_" + kind].append(res)
+    return out
+
+
+def check_binary_edges(lib, gold, worst):
+    """Oracle (oracle_binary_edge_pin) against the binary-edge vectors; the same comparison tests/test_golden.py makes."""
+    c_dp = C.POINTER(C.c_double)
+    lib.oracle_binary_edge_pin.argtypes = [c_dp] * 4 + [C.c_int, C.c_double, C.c_double, C.c_int, C.c_int] + [c_dp] * 10
+    lib.oracle_binary_edge_pin.restype = C.c_int
+    for kind in ("mono", "stereo"):
+        for c in gold.get("binary_" + kind, []):
+            D = len(c["error"])
+            o = {"error": np.zeros(3), "J_point": np.zeros(9), "J_pose": np.zeros(18), "Jnum_point": np.zeros(9), "Jnum_pose": np.zeros(18),
+                 "H_point": np.zeros(9), "H_pose": np.zeros(36), "H_point_pose": np.zeros(18), "b_point": np.zeros(3), "b_pose": np.zeros(6)}
+            lib.oracle_binary_edge_pin(dptr(np.array(c["qt"])), dptr(np.array(c["cam"])), dptr(np.array(c["xw"])), dptr(np.array(c["obs"])),
+                                       int(kind == "stereo"), c["info"], c["huber_delta"], c["fix_point"], c["fix_pose"],
+                                       *[dptr(o[k]) for k in ("error", "J_point", "J_pose", "Jnum_point", "Jnum_pose", "H_point", "H_pose", "H_point_pose", "b_point", "b_pose")])
+            for k, n in (("error", D), ("J_point", 3 * D), ("J_pose", 6 * D), ("Jnum_point", 3 * D), ("Jnum_pose", 6 * D), ("H_point", 9), ("H_pose", 36),
+                         ("H_point_pose", 18), ("b_point", 3), ("b_pose", 6)):
+                ref = np.array(c[k])
+                dev = float((np.abs(o[k][:n] - ref) / np.maximum(1.0, np.abs(ref))).max())
+                key = "binary_%s_%s" % (kind, k)
+                worst[key] = max(worst.get(key, 0.0), dev)
+    return worst
 
 
 def check():
@@ -232,6 +389,7 @@ def check():
             worst["onlypose_" + kind + "_error"] = max(worst.get("onlypose_" + kind + "_error", 0), float(np.abs(e[:d] - c["error"]).max()))
             ref = np.array(c["J"])
             worst["onlypose_" + kind + "_J"] = max(worst.get("onlypose_" + kind + "_J", 0), float((np.abs(J[:6 * d] - ref) / np.maximum(1.0, np.abs(ref))).max()))
+    check_binary_edges(lib, gold, worst)
     print("max abs deviation oracle vs prebuilt g2o:", worst)
     return worst
 

@@ -252,12 +252,13 @@ const void* oplus_copy(const Oracle& o, int t, int i, const double* upd, VTemp& 
   return nullptr;
 }
 
+void linearize_numeric(const Oracle& o, int type, int idx, double* J0, double* J1);
+
 // linearizeOplus: analytic for the two reprojection edges, central differences otherwise.
 // J0 is dim x d0 (row-major), J1 is dim x d1.
 void linearize(const Oracle& o, int type, int idx, double* J0, double* J1) {
   int t0, i0, t1, i1;
   edge_vertices(o, type, idx, t0, i0, t1, i1);
-  const int dim = edge_dim(o, type, idx);
   if (type == E_MONO || type == E_STEREO) {
     // types_six_dof_expmap.cpp:135-171 and :220-266
     const V3& X = o.point[i0];
@@ -327,7 +328,17 @@ void linearize(const Oracle& o, int type, int idx, double* J0, double* J1) {
     }
     return;
   }
-  // base_binary_edge.hpp:217-320 / base_unary_edge.hpp:82-123
+  linearize_numeric(o, type, idx, J0, J1);
+}
+
+// BaseBinaryEdge::linearizeOplusXi / Xj, base_binary_edge.hpp:217-320 (unary: base_unary_edge.hpp:82-123): central differences
+// with delta = 1e-9 through the vertex oplus, one column at a time, the other vertex untouched; nothing is written for a
+// fixed vertex (:223-226, :275-278).  Usable on every edge class (the reprojection edges override it with the analytic form
+// above; the pinning vectors of the prebuilt libg2o.so drive this routine on them, oracle_binary_edge_pin below).
+void linearize_numeric(const Oracle& o, int type, int idx, double* J0, double* J1) {
+  int t0, i0, t1, i1;
+  edge_vertices(o, type, idx, t0, i0, t1, i1);
+  const int dim = edge_dim(o, type, idx);
   const double delta = o.opt.numeric_delta;
   const double scalar = 1.0 / (2 * delta);
   VTemp tmp;
@@ -1286,6 +1297,55 @@ void oracle_onlypose_eval(const double qt[7], const double cam[5], const double 
   compute_error(o, type, 0, &o.point[0], &o.pose[0], e);
   double J0[9];
   linearize(o, type, 0, J0, J);
+}
+
+// One binary reprojection edge (point = vertex 0, pose = vertex 1) taken through computeError, the analytic linearizeOplus,
+// the NUMERIC linearizeOplusXi/Xj of the base class and constructQuadraticForm, for the golden vectors that
+// oracle/pin_g2o_prebuilt.py produced by calling exactly those functions in the prebuilt libg2o.so.
+// Outputs (row-major): e[dim], Jpt[dim x 3], Jpose[dim x 6] analytic, Jnpt / Jnpose numeric (left untouched for a fixed
+// vertex), Hll[3 x 3], Hpp[6 x 6], Hlp[3 x 6] (point rows, pose columns), bl[3], bp[6] (zero where g2o writes nothing).
+int oracle_binary_edge_pin(const double qt[7], const double cam[5], const double xw[3], const double obs[3], int stereo, double info_w,
+                           double huber_delta, int fix_point, int fix_pose, double* e, double* Jpt, double* Jpose, double* Jnpt,
+                           double* Jnpose, double* Hll, double* Hpp, double* Hlp, double* bl, double* bp) {
+  Oracle o;
+  ppo_ba_options O{};
+  O.numeric_delta = 1e-9;
+  o.opt = O;
+  o.n_poses = 1; o.n_points = 1;
+  // the pinning script writes q and t straight into the vertex (no SE3Quat constructor, no normalisation)
+  SE3 T;
+  T.r = Quat{qt[0], qt[1], qt[2], qt[3]};
+  T.t = mk(qt[4], qt[5], qt[6]);
+  o.pose0.assign(1, T);
+  o.point0.assign(1, mk(xw[0], xw[1], xw[2]));
+  o.pose_cam.assign(cam, cam + 5);
+  o.pose_fixed.assign(1, (uint8_t)(fix_pose != 0));
+  o.point_fixed.assign(1, (uint8_t)(fix_point != 0));
+  const int type = stereo ? E_STEREO : E_MONO, dim = stereo ? 3 : 2;
+  o.n_edges[type] = 1;
+  o.e_v0[type].assign(1, 0); o.e_v1[type].assign(1, 0);
+  o.e_meas[type].assign(obs, obs + dim);
+  o.e_info[type].assign(1, info_w);
+  o.e_huber[type].assign(1, huber_delta);
+  reset_state(o);
+  if (fix_point && fix_pose) return 0;  // all vertices fixed: the edge is not active (sparse_optimizer.cpp:234)
+  initialize_optimization(o, 0);
+  compute_active_errors(o);
+  std::copy(&o.err[type][0], &o.err[type][0] + dim, e);
+  double J0[kMaxDim * 9] = {0}, J1[kMaxDim * 9] = {0};
+  linearize(o, type, 0, J0, J1);
+  std::copy(J0, J0 + dim * 3, Jpt);
+  std::copy(J1, J1 + dim * 6, Jpose);
+  linearize_numeric(o, type, 0, Jnpt, Jnpose);
+  build_system(o);
+  for (int i = 0; i < 9; ++i) Hll[i] = o.n_lm ? o.Hll[i] : 0.0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) Hpp[r * 6 + c] = o.n_red ? o.Hpp[(size_t)c * o.n_red + r] : 0.0;
+  for (int a = 0; a < 6; ++a)
+    for (int c = 0; c < 3; ++c) Hlp[c * 6 + a] = (o.n_lm && o.n_red) ? o.hpl[a * 3 + c] : 0.0;
+  for (int i = 0; i < 3; ++i) bl[i] = o.n_lm ? o.b[(size_t)o.n_red + i] : 0.0;
+  for (int i = 0; i < 6; ++i) bp[i] = o.n_red ? o.b[i] : 0.0;
+  return dim;
 }
 
 }  // extern "C"

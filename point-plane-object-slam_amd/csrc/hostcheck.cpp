@@ -64,4 +64,40 @@ void hc_factor_W(const double* qt, const double* X, const double* cam, double w,
   for (int a = 0; a < 6; ++a)
     for (int c = 0; c < 3; ++c) W[3 * a + c] = M[3 * a] * R.a[c] + M[3 * a + 1] * R.a[3 + c] + M[3 * a + 2] * R.a[6 + c];
 }
+// One reprojection edge through exactly the per-edge arithmetic of the linearisation kernels (lin_points_body / lin_poses_body of
+// ppo_kernels.hpp): residual + Jacobians, chi2, Huber, the landmark block D (packed upper 00 01 02 11 12 22) and b_l, the pose
+// block A (packed lower 21, then b_p 6) and the coupling block W (6x3 row-major) rebuilt from the 32-byte factor record as the
+// Schur pair kernel does.  For the constructQuadraticForm vectors of the reference's prebuilt libg2o.so.
+void hc_quadform(const double* qt, const double* X, const double* cam, const double* obs, int stereo, double info, double hub,
+                 double* e, double* D, double* bl, double* A, double* W) {
+  const Mat3 R = rotmat(Quat{qt[0], qt[1], qt[2], qt[3]});
+  const Vec3 t{qt[4], qt[5], qt[6]}, P{X[0], X[1], X[2]};
+  for (int k = 0; k < 6; ++k) D[k] = 0;
+  for (int k = 0; k < 3; ++k) bl[k] = 0;
+  for (int k = 0; k < 27; ++k) A[k] = 0;
+  double Jl[9], Jp[18], zc, rho0, rho1, w;
+  if (!stereo) {
+    mono_eval(R, t, P, cam[0], cam[1], cam[2], cam[3], obs[0], obs[1], e, Jl, Jp, zc);
+    const double chi2 = e[0] * (info * e[0]) + e[1] * (info * e[1]);
+    huber(chi2, hub, rho0, rho1);
+    w = rho1 * info;
+    const double gr[2] = {-(info * e[0]) * rho1, -(info * e[1]) * rho1};
+    acc_landmark<2>(Jl, w, gr, D, bl);
+    acc_pose<2>(Jp, w, gr, A);
+  } else {
+    stereo_eval(R, t, P, cam[0], cam[1], cam[2], cam[3], cam[4], obs[0], obs[1], obs[2], e, Jl, Jp, zc);
+    double chi2 = 0;
+    for (int r = 0; r < 3; ++r) chi2 += e[r] * (info * e[r]);
+    huber(chi2, hub, rho0, rho1);
+    w = rho1 * info;
+    const double gr[3] = {-(info * e[0]) * rho1, -(info * e[1]) * rho1, -(info * e[2]) * rho1};
+    acc_landmark<3>(Jl, w, gr, D, bl);
+    acc_pose<3>(Jp, w, gr, A);
+  }
+  const FactorRec f = factor_record(R, t, P, stereo ? -w : w);
+  double M[18];
+  factor_M(f, cam[0], cam[1], cam[4], stereo != 0, M);
+  for (int a = 0; a < 6; ++a)
+    for (int c = 0; c < 3; ++c) W[3 * a + c] = M[3 * a] * R.a[c] + M[3 * a + 1] * R.a[3 + c] + M[3 * a + 2] * R.a[6 + c];
+}
 }

@@ -181,47 +181,8 @@ __device__ __forceinline__ Cub load_cub(const double* c) {
 }
 __device__ __forceinline__ PlaneC load_plane(const double* p) { return PlaneC{p[0], p[1], p[2], p[3]}; }
 
-// Quadratic-form pieces of one reprojection edge with a compile-time residual dimension.
-//   landmark side: D += Jl' w Jl (packed upper), bl += Jl' g          (g = -rho1 Omega e)
-//   coupling:      W = Jp' w Jl (6x3)
-//   pose side:     A += Jp' w Jp (packed lower, 21), bp += Jp' g (6)
-template <int DIM>
-__device__ __forceinline__ void acc_landmark(const double* Jl, double w, const double* gr, double* D, double* bl) {
-#pragma unroll
-  for (int r = 0; r < DIM; ++r) {
-    const double* j = &Jl[3 * r];
-    D[0] += j[0] * w * j[0]; D[1] += j[0] * w * j[1]; D[2] += j[0] * w * j[2];
-    D[3] += j[1] * w * j[1]; D[4] += j[1] * w * j[2]; D[5] += j[2] * w * j[2];
-    bl[0] += j[0] * gr[r]; bl[1] += j[1] * gr[r]; bl[2] += j[2] * gr[r];
-  }
-}
-template <int DIM>
-__device__ __forceinline__ void form_W(const double* Jp, const double* Jl, double w, double* o) {
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      double h = 0;
-#pragma unroll
-      for (int r = 0; r < DIM; ++r) h += Jp[6 * r + a] * w * Jl[3 * r + c];
-      o[a * 3 + c] = h;
-    }
-}
-template <int DIM>
-__device__ __forceinline__ void acc_pose(const double* Jp, double w, const double* gr, double* A) {
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-#pragma unroll
-    for (int r = 0; r < DIM; ++r) A[21 + a] += Jp[6 * r + a] * gr[r];
-#pragma unroll
-    for (int c = 0; c <= a; ++c) {
-      double h = 0;
-#pragma unroll
-      for (int r = 0; r < DIM; ++r) h += Jp[6 * r + a] * w * Jp[6 * r + c];
-      A[a * (a + 1) / 2 + c] += h;
-    }
-  }
-}
+// (acc_landmark / form_W / acc_pose: the quadratic-form pieces of one reprojection edge live in ppo_math.hpp, where the host
+// test build checks them against constructQuadraticForm of the reference's prebuilt libg2o.so)
 
 // Camera table of a workgroup: R, t (12) and fx, fy, cx, cy of every keyframe, 16 doubles each, into LDS.  Eight loads per thread are
 // issued before the first store (sixteen measure the same): written as one load + one store per trip the loop waited for memory 13 times in a row

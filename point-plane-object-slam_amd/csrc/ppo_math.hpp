@@ -416,6 +416,49 @@ PPO_HD void stereo_eval(const Mat3& R, Vec3 t, Vec3 X, double fx, double fy, dou
   Jp[15] = Jp[3];          Jp[16] = 0;                       Jp[17] = Jp[5] - bf / z2;
 }
 
+// Quadratic-form pieces of one reprojection edge with a compile-time residual dimension (BaseBinaryEdge::constructQuadraticForm,
+// G2O/core/base_binary_edge.hpp:55-120, with Omega = info * I and the Huber weight rho1 folded into w and g).
+//   landmark side: D += Jl' w Jl (packed upper), bl += Jl' g          (g = -rho1 Omega e)
+//   coupling:      W = Jp' w Jl (6x3)
+//   pose side:     A += Jp' w Jp (packed lower, 21), bp += Jp' g (6)
+template <int DIM>
+PPO_HD void acc_landmark(const double* Jl, double w, const double* gr, double* D, double* bl) {
+#pragma unroll
+  for (int r = 0; r < DIM; ++r) {
+    const double* j = &Jl[3 * r];
+    D[0] += j[0] * w * j[0]; D[1] += j[0] * w * j[1]; D[2] += j[0] * w * j[2];
+    D[3] += j[1] * w * j[1]; D[4] += j[1] * w * j[2]; D[5] += j[2] * w * j[2];
+    bl[0] += j[0] * gr[r]; bl[1] += j[1] * gr[r]; bl[2] += j[2] * gr[r];
+  }
+}
+template <int DIM>
+PPO_HD void form_W(const double* Jp, const double* Jl, double w, double* o) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double h = 0;
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) h += Jp[6 * r + a] * w * Jl[3 * r + c];
+      o[a * 3 + c] = h;
+    }
+}
+template <int DIM>
+PPO_HD void acc_pose(const double* Jp, double w, const double* gr, double* A) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) A[21 + a] += Jp[6 * r + a] * gr[r];
+#pragma unroll
+    for (int c = 0; c <= a; ++c) {
+      double h = 0;
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) h += Jp[6 * r + a] * w * Jp[6 * r + c];
+      A[a * (a + 1) / 2 + c] += h;
+    }
+  }
+}
+
 struct alignas(32) FactorRec {
   double a, b, iz, ws;  // x/z, y/z, 1/z of the point in the camera frame; rho1 * info, negated for a stereo edge, 0 for an inactive one
 };
