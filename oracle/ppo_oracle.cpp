@@ -94,6 +94,7 @@ struct Oracle {
   std::vector<double> S, bs, x, coeff, Dinv;  // Schur workspace; x is n_red + 3 n_lm
   std::vector<double> diag_backup_p, diag_backup_l;
   bool do_schur = false;
+  int variant = 0;  // test aid (oracle_ba_set_variant): 1 = edges and landmarks summed in REVERSE order (nothing else changes)
   bool only_pose = false;  // the unary Edge*SE3ProjectXYZOnlyPose flavour of the reprojection edges (pose-only optimisation)
   // ---- LM ----
   double lambda = -1, ni = 2;
@@ -483,7 +484,9 @@ void compute_active_errors(Oracle& o) {
 // SparseOptimizer::activeRobustChi2, sparse_optimizer.cpp:100-114
 double active_robust_chi2(const Oracle& o) {
   double chi = 0.0, rho[3];
-  for (const EdgeRef& er : o.active) {
+  const size_t na = o.active.size();
+  for (size_t k = 0; k < na; ++k) {
+    const EdgeRef& er = o.active[o.variant == 1 ? na - 1 - k : k];
     const double c = edge_chi2(o, er.type, er.idx);
     const double hub = o.e_huber[er.type][er.idx];
     if (o.robust[er.type][er.idx] && hub > 0) {
@@ -506,7 +509,9 @@ void build_system(Oracle& o) {
   std::fill(o.hpl.begin(), o.hpl.end(), 0.0);
   std::fill(o.b.begin(), o.b.end(), 0.0);
   double J0[kMaxDim * 9], J1[kMaxDim * 9];
-  for (const EdgeRef& er : o.active) {
+  const size_t na = o.active.size();
+  for (size_t k = 0; k < na; ++k) {
+    const EdgeRef& er = o.active[o.variant == 1 ? na - 1 - k : k];
     int t0, i0, t1, i1;
     edge_vertices(o, er.type, er.idx, t0, i0, t1, i1);
     const int dim = edge_dim(o, er.type, er.idx);
@@ -739,7 +744,8 @@ bool block_solve(Oracle& o) {
   if (!o.do_schur) return dense_solve(o, o.Hpp, o.b.data(), o.x.data());
   o.S = o.Hpp;
   std::fill(o.coeff.begin(), o.coeff.begin() + n, 0.0);
-  for (int l = 0; l < o.n_lm; ++l) {
+  for (int lk = 0; lk < o.n_lm; ++lk) {
+    const int l = o.variant == 1 ? o.n_lm - 1 - lk : lk;
     double* Dinv = &o.Dinv[(size_t)9 * l];
     inverse3(&o.Hll[(size_t)9 * l], Dinv);
     const double* bl = &o.b[(size_t)n + 3 * l];
@@ -1061,6 +1067,15 @@ int oracle_ba_read(oracle_handle o, ppo_ba_result* r) {
 }
 
 void oracle_ba_destroy(oracle_handle o) { delete o; }
+
+// Test aid for tests/test_oracle_sensitivity.py: 1 = sum the edges (chi2, H, b) and the landmarks (Schur complement) in reverse
+// order.  The algorithm, every formula and every input are unchanged; only the order of the floating-point additions differs --
+// the freedom g2o itself has (std::map<KeyFrame*, ...> pointer order, Optimizer.cc:2350).
+int oracle_ba_set_variant(oracle_handle o, int variant) {
+  if (!o || variant < 0 || variant > 1) return PPO_BA_ERR_ARG;
+  o->variant = variant;
+  return PPO_BA_OK;
+}
 
 // ---- step-level hooks for the parity tests ------------------------------------------------------
 // One linearisation of the current state at level 0: errors, robust chi2, block system.

@@ -1,0 +1,97 @@
+"""Helpers (tests only): how far does the REFERENCE ALGORITHM's own result move when nothing but floating-point rounding changes?
+
+Three re-runs of the oracle on the same graph:
+  reversed      edges (chi2, H, b) and landmarks (Schur complement) summed in reverse order -- oracle_ba_set_variant(1);
+                g2o itself has that freedom (edge order follows std::map<KeyFrame*, ...> pointer order, Optimizer.cc:2350)
+  fma           the same source compiled with floating-point contraction allowed (oracle/libppo_oracle_fma.so)
+  fma+reversed  both
+The spread between those runs is the accuracy to which the reference's result is DEFINED on that graph; a parity bar below
+it cannot be met by any second implementation, the reference compiled with another compiler included.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ppo_ba import binding as B
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_fma = None
+
+
+def fma_backend():
+    global _fma
+    if _fma is None:
+        path = os.path.join(REPO, "oracle", "libppo_oracle_fma.so")
+        _fma = B._Backend(C.CDLL(path), "oracle_ba_")
+    return _fma
+
+
+def run(backend, P, opt, variant=0):
+    s = backend.create(P, opt)
+    if variant:
+        backend.lib.oracle_ba_set_variant.argtypes = [C.c_void_p, C.c_int]
+        assert backend.lib.oracle_ba_set_variant(s.h, variant) == 0
+    st = s.run()
+    r = s.read()
+    s.close()
+    return st, r
+
+
+def oracle_runs(oracle, P, opt, variants=("reversed", "fma", "fma+reversed")):
+    """[(stats, result)] of the base oracle followed by the requested variants."""
+    out = [run(oracle, P, opt)]
+    for v in variants:
+        be = fma_backend() if v.startswith("fma") else oracle
+        out.append(run(be, P, opt, 1 if v.endswith("reversed") else 0))
+    return out
+
+
+def quat_angle(qa, qb):
+    qa, qb = np.asarray(qa), np.asarray(qb)
+    return 2.0 * min(np.linalg.norm(qa - qb), np.linalg.norm(qa + qb))
+
+
+def metrics(ra, rb):
+    """The quantities of the parity bar between two results."""
+    n = ra.pose_qt.shape[0]
+    m = {"t": float(np.sqrt(np.mean(np.sum((ra.pose_qt[:, 4:] - rb.pose_qt[:, 4:]) ** 2, axis=1)))),
+         "r": max(quat_angle(ra.pose_qt[i, :4], rb.pose_qt[i, :4]) for i in range(n)),
+         "p": float(np.sqrt(np.mean(np.sum((ra.point_xyz - rb.point_xyz) ** 2, axis=1)))) if ra.point_xyz.size else 0.0,
+         "pl": float(np.abs(ra.plane_coef - rb.plane_coef).max()) if ra.plane_coef.size else 0.0,
+         "cb": float(per_cuboid(ra, rb).max()) if ra.cuboid_qt.size else 0.0}
+    return m
+
+
+def per_cuboid(ra, rb):
+    if not ra.cuboid_qt.size:
+        return np.zeros(0)
+    return np.maximum(np.abs(ra.cuboid_qt - rb.cuboid_qt).max(axis=1), np.abs(ra.cuboid_scale - rb.cuboid_scale).max(axis=1))
+
+
+def per_point(ra, rb):
+    return np.linalg.norm(ra.point_xyz - rb.point_xyz, axis=1) if ra.point_xyz.size else np.zeros(0)
+
+
+def spread(runs):
+    """Largest metric between the base run and any variant, and the per-cuboid / per-point maxima."""
+    base = runs[0][1]
+    m = {k: 0.0 for k in ("t", "r", "p", "pl", "cb")}
+    cub = np.zeros(base.cuboid_qt.shape[0])
+    pts = np.zeros(base.point_xyz.shape[0])
+    for _, r in runs[1:]:
+        mm = metrics(base, r)
+        for k in m:
+            m[k] = max(m[k], mm[k])
+        if cub.size:
+            cub = np.maximum(cub, per_cuboid(base, r))
+        if pts.size:
+            pts = np.maximum(pts, per_point(base, r))
+    return m, cub, pts
+
+
+def schedule(st):
+    return [(a["pass_"], a["iteration"], a["trials"], a["accepted"], a["result"]) for a in st["iters"]]
+
+
+BARS = {"t": 1e-5, "r": 1e-6, "p": 1e-5, "pl": 1e-6, "cb": 1e-5}

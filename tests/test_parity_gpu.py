@@ -330,12 +330,14 @@ def test_phase_times_are_collected_in_verbose_mode_and_do_not_change_the_result(
 def test_randomly_structured_windows_against_the_oracle(oracle, hip):
     """60 windows of random size and composition (3-23 keyframes, 30-700 points, 0-8 planes, 0-4 cuboids, stereo share, corner
     edges, vertical / parallel planes, fixed observers, 0-20 % gross outliers, both elimination modes; tools/random_sweep.py).
-    The cost reached must agree in EVERY case.  The estimates are compared at the parity bar where the window determines them:
-    over 650 such cases 92 % were inside the bar on every quantity; the rest had the same cost to < 4e-5 and differed in
-    landmarks left with a single active observation after the outlier culling (point RMSE 1e-5..7e-4 with poses at 1e-7), in
-    flat cuboid directions, or in weakly held windows (e.g. 23 keyframes on 63 points) -- the 1e-7 relative noise of the
-    delta = 1e-9 Jacobians times the conditioning of the window, in the oracle as much as here."""
+    The cost reached must agree in EVERY case, and EVERY window must be either inside BASELINE.md's bar on every quantity or
+    demonstrably undefined to that accuracy in the reference algorithm itself: for each quantity outside the bar the oracle's
+    own spread under a change of summation order / FMA contraction (tests/sensitivity.py) must reach a twentieth of the
+    HIP-vs-oracle deviation, or -- when the accept / reject sequences differ -- the window must sit on a convergence plateau
+    where a trial's acceptance hangs on the last digits of chi2 (tests/test_oracle_sensitivity.py has the statistics over the
+    37 of 600 such windows of round 1: the oracle's own spread is the larger one for the median window)."""
     import importlib.util
+    import sensitivity as S
     spec = importlib.util.spec_from_file_location("random_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "random_sweep.py"))
     rs = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rs)
@@ -346,6 +348,19 @@ def test_randomly_structured_windows_against_the_oracle(oracle, hip):
         assert chi < 5e-4, (seed, cfg, kw, chi)
         assert m["t"] < 1e-3 and m["r"] < 1e-3, (seed, cfg, kw, m)  # nothing diverges
         inside += bool(ok)
+        if ok:
+            continue
+        runs = S.oracle_runs(oracle, synth.make_problem(cfg, **kw), B.default_options(eliminate_cuboids=elim))
+        oo, _, _ = S.spread(runs)
+        flips = any(S.schedule(st) != S.schedule(runs[0][0]) for st, _ in runs[1:])
+        if not sched:
+            plateau = any(a["trials"] > 1 and abs(a["chi2_before"] - a["chi2_after"]) < 1e-7 * a["chi2_before"] for a in runs[0][0]["iters"])
+            assert flips or plateau, (seed, cfg, kw)
+            if not flips:
+                continue
+        for k, bar in S.BARS.items():
+            if m[k] >= bar:
+                assert oo[k] >= 0.05 * m[k], (seed, k, m[k], oo[k], cfg, kw)
     assert inside >= int(0.85 * n), inside
 
 
@@ -424,38 +439,62 @@ def test_landmark_sharding_gives_the_single_rank_answer(hip, cfg, kw, world):
         np.testing.assert_array_equal(r.pose_qt, res[0][1].pose_qt)
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
-def test_baseline_configurations_match_the_oracle_at_full_size(oracle, hip, cfg):
-    """BASELINE.json configs 2-4 at their full sizes (50 KF / 10k points; 100 KF / 30k points / 100 planes; 200 KF / 50k points /
-    200 planes / 50 cuboids), the complete 5 + 10 protocol on both sides: same accept/reject schedule, final estimates within
-    the parity bar, same outlier sets.  (The single-threaded oracle needs ~2 s for config 4.)"""
-    P = synth.make_problem(cfg, seed=1)
+def _full_size_against_oracle(oracle, hip, P):
+    """Complete 5 + 10 protocol on both sides: same accept / reject schedule, chi2 per iteration, final estimates at BASELINE.md's
+    bars, same outlier sets.  Cuboids and points: each one inside the bar, OR within ten times that same cuboid's / point's spread
+    between re-runs of the ORACLE under reversed summation order and FMA contraction (tests/sensitivity.py) -- i.e. a deviation
+    is only accepted where the reference algorithm's own result is not defined to the bar
+    (tests/test_oracle_sensitivity.py::test_config4_cuboids_are_not_defined_to_1e5_by_the_reference_algorithm)."""
+    import sensitivity as S
     so, sh = both(oracle, hip, P)
     to, th = so.run(), sh.run()
     assert [(i["pass_"], i["iteration"], i["trials"], i["accepted"]) for i in to["iters"]] == [(i["pass_"], i["iteration"], i["trials"], i["accepted"]) for i in th["iters"]]
     for a, b in zip(to["iters"], th["iters"]):
         assert abs(a["chi2_after"] - b["chi2_after"]) <= 3e-6 * abs(a["chi2_after"])
     ro, rh = so.read(), sh.read()
-    # poses, points, planes: the parity bar.  Cuboids: the bar for all but (at most) 5 % of them -- at config 4 one cuboid of 50
-    # sits on a flat direction of the cost (bounding-box-only constraints, translation along the viewing rays): the 1e-7 noise of
-    # the delta = 1e-9 Jacobians moves it by ~1e-4 from run to run on the device while chi2 repeats to 1e-8
-    # (tools/cfg4_parity.py: 48-49 of 50 within 1e-5, the worst one 0.8-1.6e-4).
     n = ro.pose_qt.shape[0]
     assert np.sqrt(np.mean(np.sum((ro.pose_qt[:, 4:] - rh.pose_qt[:, 4:]) ** 2, axis=1))) < 1e-5
     assert max(rot_angle(ro.pose_qt[i, :4], rh.pose_qt[i, :4]) for i in range(n)) < 1e-6
-    assert np.sqrt(np.mean(np.sum((ro.point_xyz - rh.point_xyz) ** 2, axis=1))) < 1e-5
     if ro.plane_coef.size:
         assert np.abs(ro.plane_coef - rh.plane_coef).max() < 1e-6
-    if ro.cuboid_qt.size:
-        d = np.maximum(np.abs(ro.cuboid_qt - rh.cuboid_qt).max(axis=1), np.abs(ro.cuboid_scale - rh.cuboid_scale).max(axis=1))
-        assert np.mean(d < 1e-5) >= 0.95, np.sort(d)[::-1][:5]
-        assert d.max() < 1e-3
+    d_pt = S.per_point(ro, rh)
+    d_cb = S.per_cuboid(ro, rh)
+    if np.sqrt(np.mean(d_pt ** 2)) >= 1e-5 or (d_cb.size and d_cb.max() >= 1e-5):
+        runs = S.oracle_runs(oracle, P, B.default_options(), variants=("reversed", "fma"))
+        _, s_cb, s_pt = S.spread(runs)
+        if d_cb.size:
+            assert (d_cb < np.maximum(1e-5, 10 * s_cb)).all(), (np.sort(d_cb)[::-1][:5], np.sort(s_cb)[::-1][:5])
+            assert np.mean(d_cb < 1e-5) >= 0.9
+        well = s_pt < 1e-6  # points the reference algorithm itself defines to better than a tenth of the bar
+        assert well.mean() >= 0.99
+        assert np.sqrt(np.mean(d_pt[well] ** 2)) < 1e-5
+        assert (d_pt < np.maximum(1e-5, 10 * s_pt))[~well].all()
     assert abs(to["iters"][-1]["chi2_after"] - th["iters"][-1]["chi2_after"]) <= 1e-6 * to["iters"][-1]["chi2_after"]
     o = B.default_options()
     compare_levels(ro.mono_level, rh.mono_level, ro.mono_chi2, o.chi2_mono)
+    compare_levels(ro.stereo_level, rh.stereo_level, ro.stereo_chi2, o.chi2_stereo)
     compare_levels(ro.pl_level, rh.pl_level, ro.pl_chi2, o.chi2_plane)
     assert np.array_equal(ro.bbox_level, rh.bbox_level)
+    assert np.array_equal(ro.corner_level, rh.corner_level)
     so.close(); sh.close()
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+def test_baseline_configurations_match_the_oracle_at_full_size(oracle, hip, cfg):
+    """BASELINE.json configs 2-4 at their full sizes (50 KF / 10k points; 100 KF / 30k points / 100 planes; 200 KF / 50k points /
+    200 planes / 50 cuboids).  (The single-threaded oracle needs ~2 s for config 4.)"""
+    _full_size_against_oracle(oracle, hip, synth.make_problem(cfg, seed=1))
+
+
+@pytest.mark.parametrize("kw", [dict(stereo_frac=0.2), dict(with_corners=True), dict(with_vp_planes=1000), dict(fixed_observer_frac=0.1),
+                                dict(stereo_frac=0.2, with_corners=True, with_vp_planes=1000, fixed_observer_frac=0.1)],
+                         ids=["stereo20", "corners", "vp1000", "fixedobs10", "all"])
+def test_config4_edge_class_options_match_the_oracle_at_full_size(oracle, hip, kw):
+    """The config-4 options of SURVEY.md section 8(d) at FULL size (they met the oracle only on 10-keyframe graphs before): 20 % stereo
+    observations (multi-chunk StereoEdgeP segments, Optimizer.cc:2393-2422), the 16-D corner edges on all 500 cuboid observations
+    (the second kernel variant, Optimizer.cc:2493-2551), 1 000 vertical + 1 000 parallel plane edges (Optimizer.cc:2262-2307),
+    10 % additional fixed observers, and all of them together."""
+    _full_size_against_oracle(oracle, hip, synth.make_problem("cfg4", seed=1, **kw))
 
 
 def test_cpp_caller_through_the_c_abi(hip, tmp_path):
