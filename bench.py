@@ -8,7 +8,9 @@ the per-iteration time is in config.ms_per_lm_iter.  The graph is uploaded once 
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4] [--no-cpu-baseline]
 For N > 1 launch under torch.distributed.run (one rank per GPU); the landmark range is sharded over the ranks
-and the reduced pose system is all-reduced with RCCL once per solve attempt (strong scaling of ONE graph).
+and the reduced pose system is all-reduced with RCCL once per solve attempt (strong scaling of ONE graph, BASELINE config 5).
+`--config cfg5w` is the weak-scaling companion: the same 200 keyframes with 50 000 points PER rank (400 000 on 8
+GPUs); `value` stays LM iterations/s of that N-times larger graph, so perfect weak scaling is a constant `value`.
 """
 import argparse
 import ctypes as C
@@ -57,16 +59,21 @@ def cpu_baseline(P, B, seconds_budget=12.0):
                            calls, iters, trials, dt, cpu_model(), os.cpu_count() or 0))
 
 
+TRAFFIC_FILES = ("r02_lin_traffic.json", "r01_lin_traffic.json")  # newest first
+
+
 def committed_traffic(k_bytes):
-    """HBM bytes per launch of the roofline kernel from the committed PMC pass (profiles/r01_lin_traffic.json, made by
-    tools/pmc_probe.sh on this exact workload); None when absent or made for a different graph."""
-    try:
-        j = json.load(open(os.path.join(REPO, "profiles", "r01_lin_traffic.json")))
-        if int(j.get("algorithmic_bytes", -1)) == int(k_bytes):
-            return float(j["hbm_bytes_per_launch"])
-    except Exception:
-        pass
-    return None
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/rNN_lin_traffic.json, made by
+    tools/pmc_traffic.sh on this exact workload: FETCH_SIZE / WRITE_SIZE in separate --pmc runs), and the file they came from;
+    (None, None) when absent or made for a different graph.  The counters are not collected inside this run."""
+    for name in TRAFFIC_FILES:
+        try:
+            j = json.load(open(os.path.join(REPO, "profiles", name)))
+            if int(j.get("algorithmic_bytes", -1)) == int(k_bytes):
+                return float(j["hbm_bytes_per_launch"]), "profiles/" + name
+        except Exception:
+            pass
+    return None, None
 
 
 def pose_only_figures(B, with_cpu):
@@ -131,7 +138,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     lib = B.load_library()
-    P = synth.make_problem(a.config, seed=a.seed, with_corners=a.with_corners)
+    P = synth.make_problem(a.config, seed=a.seed, with_corners=a.with_corners, world_size=world)  # (cfg5w: 50 000 points per rank)
+    weak = isinstance(synth.CONFIGS.get(a.config), dict) and synth.CONFIGS[a.config].get("points_per_rank", False)
     sizes = P.sizes()
     opt = B.default_options(device_id=local_rank, rank=rank, world_size=world, solver=a.solver)
     if world > 1:
@@ -194,6 +202,9 @@ def main():
     fac_ms = C.c_double()
     assert lib.ppo_ba_time_factor(solver.h, 10, C.byref(fac_ms)) == 0
     achieved = k_bytes.value / (k_ms.value * 1e-3) / 1e9 if k_ms.value > 0 else 0.0
+    traffic, traffic_source = committed_traffic(int(k_bytes.value))
+    ld_dense = C.c_int32()
+    lib.ppo_ba_debug_reduced(solver.h, None, None, None, C.byref(ld_dense))  # dimension of the system the dense solve factors
 
     # what a per-call user pays around the LM iterations (host flattening + PCIe upload, read-back): steady state, i.e. with
     # the library's block cache warm as in a running SLAM process; never part of `value`
@@ -256,13 +267,16 @@ def main():
         out = {
             "metric": "LM iters/sec on 200KF/50k-pt/200-plane/50-cuboid local BA",
             "value": iters / dt, "unit": "LM iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "%s seed %d: %d KF / %d points / %d planes / %d cuboids; %d mono + %d plane + %d bbox + %d point-cuboid + %d cuboid-plane edges; "
-                            "reduced system %d; step = one 5+10 LM call (reset + run)" % (
+                            "reduced system %d in the reference's partition (poses + cuboids); dense system actually factored: %d (cuboids eliminated "
+                            "too, leading dimension %d); step = one 5+10 LM call (reset + run)" % (
                                 a.config, a.seed, sizes["n_poses"], sizes["n_points"], sizes["n_planes"], sizes["n_cuboids"], sizes["n_mono"],
-                                sizes["n_plane_edges"], sizes["n_bbox"], sizes["n_ptcub"], sizes["n_cubpl"], st["n_reduced"]),
+                                sizes["n_plane_edges"], sizes["n_bbox"], sizes["n_ptcub"], sizes["n_cubpl"], st["n_reduced"], ld_dense.value,
+                                (ld_dense.value + 63) // 64 * 64),
+                "dense_dim": int(ld_dense.value), "dense_ld": int((ld_dense.value + 63) // 64 * 64), "reference_reduced_dim": int(st["n_reduced"]),
                 "lm_iters_per_step": iters / a.steps, "solve_attempts_per_step": trials / a.steps,
                 "ms_per_lm_iter": 1e3 * dt / max(iters, 1), "solver_backend": int(a.solver),
                 "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
@@ -271,7 +285,7 @@ def main():
                 "two_windows_concurrently": concurrent,
             },
             "roofline": {"bound": "hbm", "kernel": "k_linearize_all", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(int(k_bytes.value)),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": int(k_bytes.value), "launch_ms": k_ms.value,
                          "linearise_group": {"kernels": "k_zero_ranges + k_linearize_all",
                                              "algorithmic_bytes": lin_bytes, "launch_ms": lin_ms.value,

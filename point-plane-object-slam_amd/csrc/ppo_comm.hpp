@@ -1,11 +1,14 @@
 // ppo_comm.hpp -- the one exchange step of the sharded solver: sum the partial reduced systems over ranks.
 //
 // One process per GPU.  librccl.so is opened lazily (dlopen) so that the library loads on machines without RCCL
-// and single-GPU runs never touch it.  Only sum/max all-reduce on doubles are needed:
-//   - after linearisation: pose blocks HB (n_pose_free * 27 doubles) and the partial robust chi2,
-//   - per solve attempt:   S (lower triangle travels inside the full column-major buffer) and bs,
-//   - per solve attempt:   the trial chi2 / scale scalars.
+// and single-GPU runs never touch it.  Only sum/max all-reduce on doubles are needed (DESIGN.md section 5):
+//   - per solve attempt:   the packed lower-triangle 64x64 tiles of S and b (each rank's S holds its partial Hpp, kept per
+//                          rank, and its landmarks' Schur terms),
+//   - per solve attempt:   the trial chi2 / scale scalars and the stop vote,
+//   - first iteration of a pass: the diagonal of Hpp (sum) and the largest diagonal entry (max) for lambda_0.
 #pragma once
+#include "ppo_dev.hpp"
+
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,7 +24,7 @@
 
 namespace ppo {
 
-// ---- loopback communicator (tests only) ---------------------------------------------------------------------------------------
+// ---- loopback communicator (tests only: compiled in with -DPPO_BA_TEST_HOOKS, csrc/libppo_ba_test.so) ---------------------------
 // A comm_id that starts with "PPOLOOP0" selects an in-process communicator: `world` solver handles of ONE process, each driven
 // by its own host thread on the SAME device, meet at every collective; the last thread to arrive reduces the buffers with a
 // small kernel and copies the result back.  It exists so that the sharded arithmetic of the N > 1 path (partial systems,
@@ -95,14 +98,16 @@ struct Comm {
     world = world_;
     forced = false;
     loop.reset();
+#ifdef PPO_BA_TEST_HOOKS
     if (world > 1 && std::memcmp(id_bytes, "PPOLOOP0", 8) == 0) {
       unsigned long long key = 0;
       std::memcpy(&key, id_bytes + 8, 8);
       loop = loop_group(key, world);
-      return loop->world == world ? 0 : -1;
+      return loop->world == world && rank >= 0 && rank < world ? 0 : -1;
     }
+#endif
     if (world <= 1) {
-      const char* e = getenv("PPO_BA_COMM_SELFTEST");
+      const char* e = PPO_DEV_ENV("PPO_BA_COMM_SELFTEST");
       if (!(e && e[0] == '1')) return 0;
       if (!load()) return -1;
       UniqueId self;

@@ -69,7 +69,7 @@ struct PtCubEdge {
 };
 
 enum { F_ACTIVE = 1u, F_ROBUST = 2u };
-enum { ACC_CHI2 = 0, ACC_SCALE = 1, ACC_MAXDIAG = 2, ACC_N = 8 };
+enum { ACC_CHI2 = 0, ACC_SCALE = 1, ACC_STOP = 2, ACC_MAXDIAG = 3, ACC_N = 8 };  // ACC_STOP: sharded runs, the ranks' stop votes (summed)
 
 struct State {       // one copy of all estimates
   double* pose_qt;   // [Np][7]

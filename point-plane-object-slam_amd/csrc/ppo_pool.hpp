@@ -1,6 +1,7 @@
 // ppo_pool.hpp -- process-wide caches shared by the entry points of libppo_ba.so: device blocks, stream/event contexts,
 // page-locked host staging memory (and the arena + vector type built on it).
 #pragma once
+#include "ppo_dev.hpp"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -147,7 +148,7 @@ struct HostPool {
       }
     }
     void* p = nullptr;
-    static const bool heap = getenv("PPO_BA_STAGE_HEAP") != nullptr;  // A/B switch: stage through ordinary heap memory
+    static const bool heap = PPO_DEV_ENV("PPO_BA_STAGE_HEAP") != nullptr;  // A/B switch: stage through ordinary heap memory
     if (!heap && hipHostMalloc(&p, b, hipHostMallocDefault) == hipSuccess) return p;
     (void)hipGetLastError();
     *pinned = false;  // page-locked memory exhausted: pageable memory still works, only slower

@@ -122,6 +122,11 @@ struct ppo_ba_solver {
   int64_t lin_bytes = 0;
   int solver_kind = PPO_SOLVER_ROCSOLVER;
   bool have_system = false;  // S/bs/xr hold the last solve attempt
+  // sharded runs: the stop flag is a process-local byte, so the ranks VOTE on it -- every exchange of the (chi2, scale) scalars
+  // carries each rank's current reading, and control flow follows only the summed value (ranks that branched on their own
+  // reading would fall out of step and leave their peers waiting in the next collective)
+  const volatile uint8_t* stop_ptr = nullptr;
+  bool stop_agreed = false;
 };
 
 namespace {
@@ -145,9 +150,11 @@ int validate(const ppo_ba_problem* p) {
   REQ(p->n_poses >= 0 && p->n_points >= 0 && p->n_planes >= 0 && p->n_cuboids >= 0);
   REQ(p->n_mono >= 0 && p->n_stereo >= 0 && p->n_plane_edges >= 0 && p->n_bbox >= 0 && p->n_corner >= 0 && p->n_ptcub >= 0 && p->n_cubpl >= 0);
   if (p->n_poses) { REQ(p->pose_qt && p->pose_fixed && p->pose_cam); FIN(p->pose_qt, 7 * (size_t)p->n_poses); FIN(p->pose_cam, 5 * (size_t)p->n_poses); }
+  for (int i = 0; i < p->n_poses; ++i) { const double* q = &p->pose_qt[7 * (size_t)i]; REQ(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] > 0.0); }  // (canon_quat divides by the norm)
   if (p->n_points) { REQ(p->point_xyz); FIN(p->point_xyz, 3 * (size_t)p->n_points); }
   if (p->n_planes) { REQ(p->plane_coef); FIN(p->plane_coef, 4 * (size_t)p->n_planes); }
   if (p->n_cuboids) { REQ(p->cuboid_qt && p->cuboid_scale); FIN(p->cuboid_qt, 7 * (size_t)p->n_cuboids); FIN(p->cuboid_scale, 3 * (size_t)p->n_cuboids); }
+  for (int i = 0; i < p->n_cuboids; ++i) { const double* q = &p->cuboid_qt[7 * (size_t)i]; REQ(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] > 0.0); }
   if (p->n_mono) {
     REQ(p->mono_point && p->mono_pose && p->mono_obs && p->mono_info && p->mono_huber);
     REQ(idx_ok(p->mono_point, p->n_mono, p->n_points) && idx_ok(p->mono_pose, p->n_mono, p->n_poses));
@@ -353,7 +360,7 @@ int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
   const int npts = g.pt_last - g.pt_first;
   lp.nb_pose = (npts > 0 && s->posec.n_chunks > 0) ? nblk(s->posec.n_chunks, 4) : 0;
   lp.nb_pts = npts > 0 ? std::min(nblk((long)PPO_LIN_LPP * npts, 256), 4 * s->n_cu) : 0;
-  if (const char* e = getenv("PPO_BA_LIN_PARTS")) {  // development aid: time the parts of the fused launch separately
+  if (const char* e = PPO_DEV_ENV("PPO_BA_LIN_PARTS")) {  // development aid: time the parts of the fused launch separately
     const int m = atoi(e);
     if (!(m & 1)) lp.num.nb_plane = 0;
     if (!(m & 2)) lp.num.nb_bbox = 0;
@@ -464,7 +471,10 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false) {
   if (s->comm.active()) {
     // chi2 and scale are sums over ranks; the max-diagonal (first iteration of a pass only) is a max
-    if (s->comm.sum(s->g.acc, 2, s->stream)) return PPO_BA_ERR_COMM;
+    // chi2, scale and the stop vote: this rank's reading of the flag goes up through the mapped host block (slot ACC_N + 2)
+    s->h_pinned[ACC_N + 2] = (s->stop_ptr && *s->stop_ptr) ? 1.0 : 0.0;
+    HIP_TRY(hipMemcpyAsync(s->g.acc + ACC_STOP, s->h_pinned + ACC_N + 2, sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if (s->comm.sum(s->g.acc, 3, s->stream)) return PPO_BA_ERR_COMM;
     if (with_maxdiag && s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
   }
   ZeroPlan zp{};
@@ -484,7 +494,11 @@ int fetch_acc_wait(ppo_ba_solver* s) {
   volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(s->h_pinned + ACC_N + 1);
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned it = 0;; ++it) {
-    if (*seq == s->pub_seq) { std::atomic_thread_fence(std::memory_order_acquire); return PPO_BA_OK; }
+    if (*seq == s->pub_seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (s->comm.active()) s->stop_agreed = s->stop_agreed || s->h_pinned[ACC_STOP] > 0.0;
+      return PPO_BA_OK;
+    }
     if ((it & 1023) == 1023) {
       if (hipStreamQuery(s->stream) == hipSuccess) break;  // the stream has drained: the value is there (or something failed)
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
@@ -492,7 +506,13 @@ int fetch_acc_wait(ppo_ba_solver* s) {
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (*seq != s->pub_seq) return PPO_BA_ERR_HIP;
+  if (s->comm.active()) s->stop_agreed = s->stop_agreed || s->h_pinned[ACC_STOP] > 0.0;
   return PPO_BA_OK;
+}
+// the stop decision every rank takes alike (single rank: the flag itself)
+bool stop_now(const ppo_ba_solver* s) {
+  if (s->comm.active()) return s->stop_agreed;
+  return s->stop_ptr && *s->stop_ptr;
 }
 int fetch_acc(ppo_ba_solver* s, bool with_info, bool with_maxdiag = false) {
   RC_TRY(fetch_acc_enqueue(s, with_info, false, with_maxdiag));
@@ -557,14 +577,14 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     s->have_system = true;
     phase_mark(s, PH_BACKSUB);
     RC_TRY(launch_update(s, lambda));
-    const bool speculated = may_speculate && !stop_requested(stop);
+    const bool speculated = may_speculate && !stop_now(s);
     // An accepted trial is the common case and its state is linearised next anyway.  That linearisation sums rho over every
     // active edge of the trial state -- exactly the chi2 the accept test needs (computeActiveErrors + activeRobustChi2,
     // levenberg.cpp:113-116) -- and stores the per-edge chi2 like the residual-only pass, so when the linearisation is
     // speculated it REPLACES that pass: update -> zero -> linearise(trial) -> publish.  (acc[ACC_CHI2] is still 0 from
     // k_reduce_stage1, acc[ACC_SCALE] comes from the update and is left alone by the zeroing.)  The residual-only pass
     // remains for the last trial of a pass and for PPO_BA_CHI2_PASS=1 (A/B switch).
-    static const bool chi2_pass = []() { const char* e = getenv("PPO_BA_CHI2_PASS"); return e && e[0] == '1'; }();
+    static const bool chi2_pass = []() { const char* e = PPO_DEV_ENV("PPO_BA_CHI2_PASS"); return e && e[0] == '1'; }();
     if (speculated && !chi2_pass) {
       phase_mark(s, PH_LIN);
       const ZeroPlan zp = linearize_zero_plan(s, false);
@@ -609,7 +629,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
       s->ni *= 2;
       it.accepted = 0;  // pop(): keep the current state
       if (!(rho < 0)) rho = (info != 0) ? -1.0 : rho;
-      if (speculated && rho < 0 && qmax + 1 < s->opt.lm_max_trials && !stop_requested(stop)) {
+      if (speculated && rho < 0 && qmax + 1 < s->opt.lm_max_trials && !stop_now(s)) {
         // the buffers hold the rejected state's linearisation: restore the kept state's before the retry
         phase_mark(s, PH_LIN);
         RC_TRY(launch_linearize(s));
@@ -618,7 +638,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     }
     qmax++;
     s->stats.n_trials++;
-  } while (rho < 0 && qmax < s->opt.lm_max_trials && !stop_requested(stop));
+  } while (rho < 0 && qmax < s->opt.lm_max_trials && !stop_now(s));
   it.trials = qmax;
   it.chi2_after = currentChi;
   if (qmax == s->opt.lm_max_trials || rho == 0) return 1;
@@ -633,7 +653,7 @@ int optimize(ppo_ba_solver* s, int pass, int iterations, const volatile uint8_t*
   if (s->g.n_red == 0) return 0;
   bool ok = true;
   s->lin_valid = false;
-  for (int i = 0; i < iterations && !stop_requested(stop) && ok; ++i) {
+  for (int i = 0; i < iterations && !stop_now(s) && ok; ++i) {
     ppo_ba_iter_stat it{};
     it.pass = pass;
     it.iteration = i;
@@ -670,6 +690,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     return PPO_BA_ERR_HIP;
   }
   if (o->device_id < 0 || o->device_id >= ndev) return PPO_BA_ERR_ARG;
+  if (o->world_size < 1 || o->rank < 0 || o->rank >= o->world_size) return PPO_BA_ERR_ARG;
   ppo_ba_solver* s = new (std::nothrow) ppo_ba_solver();
   if (!s) return PPO_BA_ERR_NOMEM;
   s->opt = *o;
@@ -882,7 +903,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   SVec<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si, pc_lm;
   std::thread pair_plan_thread([&]()   {
     t_stage = s->stage;
-    const int chunk = []() { const char* e = getenv("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    const int chunk = []() { const char* e = PPO_DEV_ENV("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
     const long nkeys = (long)nfree * (nfree + 1) / 2;
     SVec<int32_t> slot_pose(g.n_slots);
     for (int i = 0; i < g.n_slots; ++i) slot_pose[i] = slot_col[i] / 6;
@@ -1019,7 +1040,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   SVec<MonoEdgeP> h_monoP;
   SVec<StereoEdgeP> h_stereoP;
   {
-    const int chunk = []() { const char* e = getenv("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    const int chunk = []() { const char* e = PPO_DEV_ENV("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     auto build = [&](int type) {
       SVec<int32_t> cnt;
       const SVec<int32_t>& off = type == 0 ? mo_off : st_off;
@@ -1148,7 +1169,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_ul); zero(s->d_xr); zero(s->d_cholws);
     zero(s->d_cub_Linv); zero(s->d_cub_Dinv); zero(s->d_xc); zero(s->d_S);
   }
-  static_assert(ACC_N + 2 <= kPinnedDoubles, "mapped host block too small");
+  static_assert(ACC_N + 3 <= kPinnedDoubles, "mapped host block too small");
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
 
   g.pose_cam = s->d_pose_cam.p; g.pose_col = s->d_pose_col.p; g.pose_free_id = s->d_pose_free_id.p; g.cub_col = s->d_cub_col.p;
@@ -1245,7 +1266,10 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
   };
-  if (stop_requested(stop)) return PPO_BA_ABORTED;
+  s->stop_ptr = stop;
+  s->stop_agreed = false;
+  if (s->comm.active()) RC_TRY(fetch_acc(s, false));  // agree on the flag before anything depends on it
+  if (stop_now(s)) return PPO_BA_ABORTED;
   int rc = PPO_BA_OK;
   s->stats.n_active_edges_pass1 = s->g.n_mono + s->g.n_stereo + s->g.n_pl + s->g.n_bbox + s->g.n_corner + s->g.n_ptcub + s->n_cubpl;
   RC_TRY(optimize(s, 0, s->opt.iters_pass1, stop));
@@ -1253,7 +1277,7 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
   //  Synchronising again -- and once more behind the classification kernels -- only added round trips between the passes.)
   const auto t1 = std::chrono::steady_clock::now();
   auto t2 = t1;
-  if (stop_requested(stop)) rc = PPO_BA_ABORTED;
+  if (stop_now(s)) rc = PPO_BA_ABORTED;
   if (rc == PPO_BA_OK && s->opt.iters_pass2 > 0) {
     const Graph& g = s->g;
     const State& st = s->st[s->cur];
@@ -1268,7 +1292,7 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
     t2 = std::chrono::steady_clock::now();
     RC_TRY(optimize(s, 1, s->opt.iters_pass2, stop));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (stop_requested(stop)) rc = PPO_BA_ABORTED;
+    if (stop_now(s)) rc = PPO_BA_ABORTED;
   }
   const auto t3 = std::chrono::steady_clock::now();
   if (s->opt.verbose) phase_collect(s);
@@ -1505,14 +1529,17 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
   // algorithmic bytes: what the kernel must read and write once (records, flags, vertex estimates, output blocks)
   const long nP = (long)s->d_monoP.n, nSP = (long)s->d_stereoP.n;
   switch (which) {
-    case PPO_BA_KERNEL_LIN_POSES:  // pose-major record + flag + W block per edge; point per landmark; pose R|t + cam + packed Hpp|b per keyframe
-      bytes = nP * (long)(sizeof(MonoEdgeP) + 4 + 144) + nSP * (long)(sizeof(StereoEdgeP) + 4 + 144) + 24L * npts + (96L + 40 + 216) * g.n_pose_free;
+    case PPO_BA_KERNEL_LIN_POSES:  // what THIS kernel moves: pose-major record + flag per edge, one 32-byte factor record per point slot (the 144-byte
+                                   // W blocks of SURVEY 8d are no longer written), point per landmark; R|t + intrinsics in, packed Hpp|b + linR out per keyframe
+      bytes = nP * (long)(sizeof(MonoEdgeP) + 4) + nSP * (long)(sizeof(StereoEdgeP) + 4) + 32L * g.n_pt_slots + 24L * npts + (96L + 40 + 216 + 96) * g.n_pose_free;
       break;
     case PPO_BA_KERNEL_LIN_POINTS:  // landmark-major record + flag + chi2 per edge; point in, D + b_l out
       bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4 + 8) + (long)g.n_stereo * (sizeof(StereoEdge) + 4 + 8) + 96L * npts + 136L * g.n_poses;
       break;
     case PPO_BA_KERNEL_SCHUR_Z: bytes = 0; break;
-    case PPO_BA_KERNEL_SCHUR_PAIRS: bytes = 144L * g.n_slots + 72L * nl + 8L * ((long)g.n_red * (g.n_red + 1) / 2 + g.n_red); break;  // W once, Dinv + v per landmark, S + b
+    case PPO_BA_KERNEL_SCHUR_PAIRS:  // unique bytes: factor record per point slot, W block per plane slot, the pair plan (3 x int32 per pair), (D + lambda I)^-1 + v per landmark, S + b
+      bytes = 32L * g.n_pt_slots + 144L * (g.n_slots - g.n_pt_slots) + 12L * s->d_pc_sj.n + 72L * nl + 8L * ((long)g.n_red * (g.n_red + 1) / 2 + g.n_red);
+      break;
     case PPO_BA_KERNEL_BACKSUB: bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4) + (long)g.n_stereo * (sizeof(StereoEdge) + 4) + 96L * nl + 8L * g.n_red; break;
     case PPO_BA_KERNEL_LINEARIZE_ALL: bytes = s->lin_bytes; break;
     case PPO_BA_KERNEL_CHI2_POINTS: bytes = (long)g.n_mono * (sizeof(MonoEdge) + 4 + 8) + (long)g.n_stereo * (sizeof(StereoEdge) + 4 + 8) + 24L * npts + 136L * g.n_poses; break;

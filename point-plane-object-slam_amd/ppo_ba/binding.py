@@ -336,6 +336,37 @@ def default_options(**over):
 _lib = None
 
 
+TEST_LIB_PATH = os.path.join(PKG_ROOT, "csrc", "libppo_ba_test.so")  # built with -DPPO_BA_TEST_HOOKS (csrc/ppo_dev.hpp)
+_test_lib = None
+
+
+def _declare(lib):
+    lib.ppo_ba_strerror.restype = C.c_char_p
+    lib.ppo_ba_strerror.argtypes = [C.c_int]
+    lib.ppo_ba_version.restype = C.c_int
+    lib.ppo_ba_linearize_bytes.restype = C.c_int64
+    lib.ppo_ba_linearize_bytes.argtypes = [C.c_void_p]
+    lib.ppo_ba_time_linearize.argtypes = [C.c_void_p, C.c_int, c_dp]
+    lib.ppo_ba_time_factor.argtypes = [C.c_void_p, C.c_int, c_dp]
+    lib.ppo_ba_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, C.POINTER(C.c_int64)]
+    lib.ppo_ba_debug_reduced.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip]
+    lib.ppo_ba_partition.argtypes = [C.POINTER(CProblem), C.c_int32, c_ip, c_ip]
+    lib.ppo_ba_comm_unique_id.argtypes = [c_bp]
+    lib.ppo_ba_default_options.argtypes = [C.POINTER(COptions)]
+    lib.ppo_ba_default_options.restype = None
+    return lib
+
+
+def load_test_library():
+    """The build with the development / test switches compiled in (A/B environment switches, loopback communicator)."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise RuntimeError("libppo_ba_test.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % TEST_LIB_PATH)
+        _test_lib = _declare(C.CDLL(TEST_LIB_PATH))
+    return _test_lib
+
+
 def load_library(path=LIB_PATH):
     """Load the HIP product library.  Raises if it has not been built -- there is no CPU fallback."""
     global _lib
@@ -360,5 +391,5 @@ def load_library(path=LIB_PATH):
     return _lib
 
 
-def hip_backend():
-    return _Backend(load_library(), "ppo_ba_")
+def hip_backend(test_hooks=False):
+    return _Backend(load_test_library() if test_hooks else load_library(), "ppo_ba_")

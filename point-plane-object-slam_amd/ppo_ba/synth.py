@@ -25,6 +25,10 @@ CONFIGS = {
     "cfg2": dict(n_kf=50, n_points=10000, n_planes=0, n_cuboids=0),
     "cfg3": dict(n_kf=100, n_points=30000, n_planes=100, n_cuboids=0),
     "cfg4": dict(n_kf=200, n_points=50000, n_planes=200, n_cuboids=50),
+    # BASELINE config 5 (the config-4 graph sharded over N GPUs) is "cfg4" with world_size = N.  "cfg5w" is the weak-scaling
+    # companion SURVEY 8(e) asks for: the same 200 keyframes / planes / cuboids with 50 000 points PER GPU (400 000 on 8), so that
+    # the sharded part (linearisation, Schur complement, back-substitution) stays constant per rank while the all-reduce does not grow
+    "cfg5w": dict(n_kf=200, n_points=50000, n_planes=200, n_cuboids=50, points_per_rank=True),
 }
 
 
@@ -180,9 +184,11 @@ class _ScaledRng:
 
 
 def make_problem(config="cfg4", seed=1, outlier_frac=0.05, stereo_frac=0.0, with_corners=False, with_vp_planes=0,
-                 fixed_observer_frac=0.0, flags=None, noise_scale=1.0):
+                 fixed_observer_frac=0.0, flags=None, noise_scale=1.0, world_size=1):
     """Build one seeded graph.  ``config`` is a key of CONFIGS or a dict with n_kf/n_points/n_planes/n_cuboids."""
     cfg = dict(CONFIGS[config]) if isinstance(config, str) else dict(config)
+    if cfg.pop("points_per_rank", False):
+        cfg["n_points"] *= max(1, int(world_size))
     rng = _ScaledRng(np.random.default_rng(seed), noise_scale)
     n_kf, n_pt, n_pl, n_cb = cfg["n_kf"], cfg["n_points"], cfg["n_planes"], cfg["n_cuboids"]
     on = dict(plane_3d=n_pl > 0, cuboid_2d=n_cb > 0, pt_obj_3d=n_cb > 0, cuboid_plane=n_cb > 0 and n_pl > 0, corners_2d=with_corners)

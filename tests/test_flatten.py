@@ -1,0 +1,28 @@
+"""include/ppo_flatten.hpp -- the host adapter either side of the library: construction rules of
+Optimizer.cc:2120-2714 and write-back rules of :2840-2966 on mock containers, in plain C++ (no GPU, no OpenCV)."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def test_flatten_rules_on_mock_containers(tmp_path):
+    exe = tmp_path / "flatten_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-o", str(exe), os.path.join(HERE, "flatten_test.cpp")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "flatten_test ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_window_through_flatten_and_the_library():
+    """examples/flatten_demo.cpp: a synthetic window in the adapter's plain structs -> flatten() -> ppo_ba_create / run / read ->
+    write_back(): the whole seam of INTEGRATION.md from a C++ caller."""
+    exe = os.path.join(REPO, "examples", "flatten_demo")
+    if not os.path.exists(exe):
+        pytest.skip("examples/flatten_demo not built (run __graft_entry__.build())")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "flatten_demo ok" in out.stdout
