@@ -165,8 +165,10 @@ typedef struct ppo_ba_options {
   double chi2_plane_vp;     /* 200 */
   double th_bbox_norm;      /* thHuberBbox2d, compared with |e| (not chi2) Optimizer.cc:2774 */
   double th_corner_norm;    /* thHuberConer2d Optimizer.cc:2783 */
-  int32_t deterministic;    /* reserved, must be 0: the HIP backend sums with atomics (run-to-run differences ~1e-9 in chi2,
-                             * DESIGN.md section 6); ppo_ba_create() fails with PPO_BA_ERR_ARG for any other value */
+  int32_t deterministic;    /* 0 (default): cross-wave sums are floating-point atomics (run-to-run differences ~1e-9 in chi2, DESIGN.md
+                             * section 6).  1: the same atomics add 2^-24 fixed-point INTEGERS (exact, hence independent of arrival
+                             * order): two runs on the same device and build give bit-identical results; ~10 % slower.
+                             * Any other value -> PPO_BA_ERR_ARG */
   int32_t solver;           /* PPO_SOLVER_* */
   int32_t eliminate_cuboids; /* 1 (default): cuboids are Schur-eliminated too and the dense system is poses only --
                               * the same linear solve as the reference (which keeps them dense, Optimizer.cc:2172),

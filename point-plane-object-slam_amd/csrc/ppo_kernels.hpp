@@ -69,7 +69,7 @@ struct PtCubEdge {
 };
 
 enum { F_ACTIVE = 1u, F_ROBUST = 2u };
-enum { ACC_CHI2 = 0, ACC_SCALE = 1, ACC_STOP = 2, ACC_MAXDIAG = 3, ACC_N = 8 };  // ACC_STOP: sharded runs, the ranks' stop votes (summed)
+enum { ACC_CHI2 = 0, ACC_SCALE = 1, ACC_STOP = 2, ACC_MAXDIAG = 3, ACC_DETBAD = 4, ACC_N = 8 };  // ACC_STOP: sharded runs, the ranks' stop votes (summed)
 
 struct State {       // one copy of all estimates
   double* pose_qt;   // [Np][7]
@@ -143,6 +143,8 @@ struct Graph {
   double* xc;                   // [Nc][9]  cuboid update
   int pt_first, pt_last, plane_first, plane_last;
   int owns_reduced;  // 1 on the rank that adds Hcc / lambda / cuboid terms
+  int det;           // options.deterministic: every cross-wave accumulation is an INTEGER atomic on a 2^-24 fixed-point image of the
+                     // addend (exact, hence independent of the order the atomics arrive in); k_fix_to_double turns the ranges back into doubles
   const double* hb_diag;  // sharded runs, first iteration: diagonal of Hpp summed over ranks (NULL: read it from HB)
 };
 
@@ -153,7 +155,21 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 // block-wide sum to one global atomic (blockDim.x multiple of 64, <= 1024)
-__device__ __forceinline__ void block_atomic_add(double v, double* dst, double* s_red) {
+// ---- deterministic mode (options.deterministic = 1) -------------------------------------------------------------------
+// Floating-point atomics make every sum that crosses a wave depend on arrival order (chi2 repeats to 1e-9 from run to run).
+// In deterministic mode the same atomics add INTEGERS: the addend is rounded to a multiple of 2^-24 and added as a 64-bit
+// two's-complement number, which is exact and therefore order-independent; the accumulation ranges are converted back to
+// doubles by k_fix_to_double before anybody reads them.  Range +-5.5e11 (the largest entries, diagonal of H_pp / S, are ~1e9),
+// resolution 6e-8 absolute, i.e. <= 1e-15 of the norm of the matrices that are factored; an addend that is not finite or out
+// of range raises ACC_DETBAD (reported like a failed factorisation) instead of being added.
+constexpr double kFixScale = 16777216.0, kFixInv = 1.0 / 16777216.0;
+__device__ __forceinline__ void fixed_add(double* p, double v, double* bad) {
+  if (!(fabs(v) < 4.0e11)) { *bad = 1.0; return; }
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn(v * kFixScale));
+}
+#define acc_add(g_, p_, v_) do { if ((g_).det) fixed_add((p_), (v_), &(g_).acc[ACC_DETBAD]); else atomicAdd((p_), (v_)); } while (0)
+
+__device__ __forceinline__ void block_atomic_add(const Graph& g, double v, double* dst, double* s_red) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) s_red[wid] = v;
@@ -161,7 +177,7 @@ __device__ __forceinline__ void block_atomic_add(double v, double* dst, double* 
   if (threadIdx.x == 0) {
     double t = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_red[i];
-    if (t != 0.0) atomicAdd(dst, t);
+    if (t != 0.0) acc_add(g, dst, t);
   }
   __syncthreads();
 }
@@ -287,7 +303,7 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
       for (int k = 0; k < 3; ++k) g.bl[(size_t)p * 3 + k] = bl[k];
     }
   }
-  block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
 }
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
@@ -410,7 +426,7 @@ __device__ __forceinline__ void lin_poses_body(const Graph& g, const State& st, 
   for (int half = 0; half < 2; ++half) {  // 27 values in two rounds of 14: lane v ends up with value 14 half + v
     const double tot = wave_transpose_sum<14>(&A[14 * half], red);
     const int v = 14 * half + lane;
-    if (lane < 14 && v < 27 && tot != 0.0) atomicAdd(&hb[v], tot);
+    if (lane < 14 && v < 27 && tot != 0.0) acc_add(g, &hb[v], tot);
   }
 }
 __global__ __launch_bounds__(256) void k_lin_poses(Graph g, State st, PoseChunks pc) {
@@ -459,7 +475,7 @@ __device__ __forceinline__ void chi2_points_body(const Graph& g, const State& st
       chi_local += rho0;
     }
   }
-  block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
 }
 __global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
   __shared__ double s_red[4];
@@ -541,17 +557,17 @@ struct PlaneModel {
     const PlaneEdge& ed = g.pl[i];
     const int l = g.n_points + ed.plane;
     if (c < 3) {
-      for (int c2 = c; c2 < 3; ++c2) atomicAdd(&g.D[(size_t)l * 6 + (c == 0 ? c2 : (c == 1 ? 2 + c2 : 5))], Hrow[c2]);
-      atomicAdd(&g.bl[(size_t)l * 3 + c], bc);
+      for (int c2 = c; c2 < 3; ++c2) acc_add(g, &g.D[(size_t)l * 6 + (c == 0 ? c2 : (c == 1 ? 2 + c2 : 5))], Hrow[c2]);
+      acc_add(g, &g.bl[(size_t)l * 3 + c], bc);
     } else {
       const int fid = g.pose_free_id[ed.pose];
       if (fid < 0) return;
       const int a = c - 3;
       double* hb = &g.HB[(size_t)fid * 27];
-      for (int c2 = 0; c2 <= a; ++c2) atomicAdd(&hb[packed_lower(a, c2)], Hrow[3 + c2]);
-      atomicAdd(&hb[21 + a], bc);
+      for (int c2 = 0; c2 <= a; ++c2) acc_add(g, &hb[packed_lower(a, c2)], Hrow[3 + c2]);
+      acc_add(g, &hb[21 + a], bc);
       if (ed.slot >= 0)
-        for (int c2 = 0; c2 < 3; ++c2) atomicAdd(&g.W[(size_t)(ed.slot - g.n_pt_slots) * 18 + a * 3 + c2], Hrow[c2]);
+        for (int c2 = 0; c2 < 3; ++c2) acc_add(g, &g.W[(size_t)(ed.slot - g.n_pt_slots) * 18 + a * 3 + c2], Hrow[c2]);
     }
   }
 };
@@ -592,15 +608,15 @@ struct CubProjModelT {  // bbox (CORNER = false, 4 residual rows) or corner edge
       const int fid = g.pose_free_id[ed.pose];
       if (fid < 0) return;
       double* hb = &g.HB[(size_t)fid * 27];
-      for (int c2 = 0; c2 <= c; ++c2) atomicAdd(&hb[packed_lower(c, c2)], Hrow[c2]);
-      atomicAdd(&hb[21 + c], bc);
+      for (int c2 = 0; c2 <= c; ++c2) acc_add(g, &hb[packed_lower(c, c2)], Hrow[c2]);
+      acc_add(g, &hb[21 + c], bc);
       double* w = (corner ? g.Wpc_corner : g.Wpc_bbox) + (size_t)i * 54 + c * 9;
       for (int c2 = 0; c2 < 9; ++c2) w[c2] = Hrow[6 + c2];
     } else {
       const int a = c - 6;
       double* hc = &g.HC[(size_t)ed.cuboid * 54];
-      for (int c2 = 0; c2 <= a; ++c2) atomicAdd(&hc[packed_lower(a, c2)], Hrow[6 + c2]);
-      atomicAdd(&hc[45 + a], bc);
+      for (int c2 = 0; c2 <= a; ++c2) acc_add(g, &hc[packed_lower(a, c2)], Hrow[6 + c2]);
+      acc_add(g, &hc[45 + a], bc);
     }
   }
 };
@@ -629,8 +645,8 @@ struct PtCubModel {  // unary: cols 0-8 cuboid
   __device__ void store_chi2(int i, double chi2, double) const { g.ptcub_chi2[i] = chi2; }
   __device__ void scatter(int i, int c, const double* Hrow, double bc) const {
     double* hc = &g.HC[(size_t)g.ptcub[i].cuboid * 54];
-    for (int c2 = 0; c2 <= c; ++c2) atomicAdd(&hc[packed_lower(c, c2)], Hrow[c2]);
-    atomicAdd(&hc[45 + c], bc);
+    for (int c2 = 0; c2 <= c; ++c2) acc_add(g, &hc[packed_lower(c, c2)], Hrow[c2]);
+    acc_add(g, &hc[45 + c], bc);
   }
 };
 
@@ -704,7 +720,7 @@ __device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st
     }
     m.scatter(i, lane, Hrow, bc);
   }
-  block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
 }
 
 template <class Model>
@@ -725,7 +741,7 @@ __device__ __forceinline__ void chi2_numeric_body(const Graph& g, const State& s
     huber(chi2, m.huber_delta(i), rho0, rho1);
     chi_local = rho0;
   }
-  block_atomic_add(chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
 }
 
 // All numerically differentiated edge classes in ONE launch (they are tiny and latency-bound: 4000 plane, 500 bbox,
@@ -850,6 +866,16 @@ __global__ __launch_bounds__(256) void k_reset(CopyPlan cp, ZeroPlan zp) {
 __global__ __launch_bounds__(256) void k_zero_ranges(ZeroPlan zp) {
   zero_ranges_body(zp, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
+// deterministic mode: the accumulation ranges hold 2^-24 fixed-point integers after a kernel that summed into them -> doubles, in place
+__global__ __launch_bounds__(256) void k_fix_to_double(ZeroPlan zp) {
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    double* p = zp.p[q];
+    const size_t n = zp.n[q];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+      p[i] = (double)__double_as_longlong(p[i]) * kFixInv;
+  }
+}
 
 // max |H_jj| over every active diagonal (computeLambdaInit, levenberg.cpp:166-180)
 __global__ void k_hb_diag(Graph g, double* out) {  // out[6 f + a] = Hpp_f[a][a]
@@ -892,7 +918,7 @@ __device__ __forceinline__ void assemble_body(const Graph& g, double lambda, int
   if (!g.owns_reduced && i >= nP) return;
   if (i >= nP + nC + nB + nK) {  // identity on the padding so that the padded matrix stays positive definite
     const int k = g.n_red + (i - (nP + nC + nB + nK));
-    if (k < g.ld) g.S[(size_t)k * n + k] = 1.0;
+    if (k < g.ld) g.S[(size_t)k * n + k] = g.det ? __longlong_as_double((long long)kFixScale) : 1.0;  // (deterministic mode: S holds fixed-point integers until k_fix_to_double)
     return;
   }
   if (i < nP) {
@@ -904,9 +930,9 @@ __device__ __forceinline__ void assemble_body(const Graph& g, double lambda, int
       while ((r + 1) * (r + 2) / 2 <= k) ++r;
       const int c = k - r * (r + 1) / 2;
       const double add = v + ((r == c && g.owns_reduced) ? lambda : 0.0);
-      atomicAdd(&g.S[(size_t)(col0 + c) * n + col0 + r], add);
+      acc_add(g, &g.S[(size_t)(col0 + c) * n + col0 + r], add);
     } else {
-      atomicAdd(&g.bs[col0 + (k - 21)], v);
+      acc_add(g, &g.bs[col0 + (k - 21)], v);
     }
     return;
   }
@@ -922,9 +948,9 @@ __device__ __forceinline__ void assemble_body(const Graph& g, double lambda, int
       int r = 0;
       while ((r + 1) * (r + 2) / 2 <= k) ++r;
       const int c = k - r * (r + 1) / 2;
-      atomicAdd(&g.S[(size_t)(col0 + c) * n + col0 + r], v + (r == c ? lambda : 0.0));
+      acc_add(g, &g.S[(size_t)(col0 + c) * n + col0 + r], v + (r == c ? lambda : 0.0));
     } else {
-      atomicAdd(&g.bs[col0 + (k - 45)], v);
+      acc_add(g, &g.bs[col0 + (k - 45)], v);
     }
     return;
   }
@@ -939,7 +965,7 @@ __device__ __forceinline__ void assemble_body(const Graph& g, double lambda, int
     const int pc = g.pose_col[ed.pose], cc = g.cub_col[ed.cuboid];
     if (pc < 0 || cc < 0) return;
     const double v = (corner ? g.Wpc_corner : g.Wpc_bbox)[(size_t)e * 54 + k];
-    atomicAdd(&g.S[(size_t)(pc + a) * n + cc + c], v);  // row = cuboid column (cuboids come after poses)
+    acc_add(g, &g.S[(size_t)(pc + a) * n + cc + c], v);  // row = cuboid column (cuboids come after poses)
   }
 }
 
@@ -1093,9 +1119,9 @@ __device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunk
     if (lane < 21 && tot != 0.0) {
       if (v < 36) {
         const int r = v / 6, c = v - 6 * r;
-        if (!diag || c >= r) atomicAdd(&g.S[(size_t)(coli + r) * n + colj + c], -tot);
+        if (!diag || c >= r) acc_add(g, &g.S[(size_t)(coli + r) * n + colj + c], -tot);
       } else if (diag) {
-        atomicAdd(&g.bs[colj + (v - 36)], -tot);
+        acc_add(g, &g.bs[colj + (v - 36)], -tot);
       }
     }
   }
@@ -1194,21 +1220,21 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
     double m = 0.0;  // M[i][j] = (Za Zb')[i][j]: row index on pose a, column index on pose b
     for (int q = 0; q < 9; ++q) m += za[q] * Zb[j * 9 + q];
     if (self) {
-      if (i >= j) atomicAdd(&g.S[(size_t)(cola + j) * n + cola + i], -m);
+      if (i >= j) acc_add(g, &g.S[(size_t)(cola + j) * n + cola + i], -m);
     } else if (cola > colb) {
-      atomicAdd(&g.S[(size_t)(colb + j) * n + cola + i], -m);
+      acc_add(g, &g.S[(size_t)(colb + j) * n + cola + i], -m);
     } else if (cola < colb) {
-      atomicAdd(&g.S[(size_t)(cola + i) * n + colb + j], -m);
+      acc_add(g, &g.S[(size_t)(cola + i) * n + colb + j], -m);
     } else {  // two different edges on the same keyframe: M + M' lands in one diagonal block
-      if (i >= j) atomicAdd(&g.S[(size_t)(cola + j) * n + cola + i], -m);
-      if (j >= i) atomicAdd(&g.S[(size_t)(cola + i) * n + cola + j], -m);
+      if (i >= j) acc_add(g, &g.S[(size_t)(cola + j) * n + cola + i], -m);
+      if (j >= i) acc_add(g, &g.S[(size_t)(cola + i) * n + cola + j], -m);
     }
   }
   if (self) {
     const double* u = &g.HC[(size_t)c * 54 + 45];  // b_c
     double v = 0.0;
     for (int q = 0; q < 9; ++q) v += za[q] * u[q];
-    atomicAdd(&g.bs[cola + i], -v);
+    acc_add(g, &g.bs[cola + i], -v);
   }
 }
 
@@ -1225,6 +1251,7 @@ struct ReducePlan {
 __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp) {
   int b = blockIdx.x;
   if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
+  if (b == 0 && threadIdx.x == 2) g.acc[ACC_DETBAD] = 0.0;
   // (the cuboid workgroup first: one thread per cuboid walks a 9x9 Cholesky + inverse, the longest chain of the launch)
   if (b < rp.nb_cubprep) { cub_prep_body(g, lambda, b); return; }
   b -= rp.nb_cubprep;
@@ -1323,7 +1350,7 @@ __device__ __forceinline__ void update_reduced_body(const Graph& g, const State&
     }
   }
   sc = wave_sum(sc);
-  if ((lane & 63) == 0 && sc != 0.0) atomicAdd(&g.acc[ACC_SCALE], sc);
+  if ((lane & 63) == 0 && sc != 0.0) acc_add(g, &g.acc[ACC_SCALE], sc);
 }
 
 // landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term.
@@ -1436,7 +1463,7 @@ __device__ __forceinline__ void backsub_body(const Graph& g, const State& cur, c
       trial.plane[4 * j] = p.nx; trial.plane[4 * j + 1] = p.ny; trial.plane[4 * j + 2] = p.nz; trial.plane[4 * j + 3] = p.d;
     }
   }
-  block_atomic_add(sc, &g.acc[ACC_SCALE], s_red);
+  block_atomic_add(g, sc, &g.acc[ACC_SCALE], s_red);
 }
 template <bool USE_LDS, int LPP>
 __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial, double lambda) {

@@ -127,6 +127,7 @@ struct ppo_ba_solver {
   // reading would fall out of step and leave their peers waiting in the next collective)
   const volatile uint8_t* stop_ptr = nullptr;
   bool stop_agreed = false;
+  bool acc_fixed = false;  // deterministic mode: acc[ACC_CHI2 / ACC_SCALE] currently hold fixed-point integers
 };
 
 namespace {
@@ -342,6 +343,12 @@ int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool already_zeroed
   }
   (void)g;
   RC_TRY(launch_linearize_kernel(s, st));
+  if (g.det) {  // the ranges the launch summed into (H_pp | H_cc, the planes' D / b_l / W) back to doubles
+    const ZeroPlan zp = linearize_zero_plan(s, false);
+    const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
+    hipLaunchKernelGGL(k_fix_to_double, dim3(std::max(1, std::min(nblk((long)tot, 256), 2 * s->n_cu))), dim3(256), 0, s->stream, zp);
+    s->acc_fixed = true;
+  }
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -394,6 +401,7 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
   const int nb_num = np.nb_plane + np.nb_bbox + np.nb_corner + np.nb_ptcub;
   const int nb_pts = npts > 0 ? std::min(nblk((long)kLanesPerPoint * npts, 256), 4 * s->n_cu) : 0;
   if (nb_num + nb_pts > 0) hipLaunchKernelGGL(k_chi2_all, dim3(nb_num + nb_pts), dim3(256), 0, s->stream, g, st, np, nb_num, nb_pts);
+  if (g.det) s->acc_fixed = true;
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -420,6 +428,11 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
   rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? (nblk((long)g.n_cub_pairs * 8, 256) + 7) / 8 * 8 : 0;  // (multiple of 8: see k_reduce_stage3)
   hipLaunchKernelGGL(k_reduce_stage1, dim3(rp.nb_asm + rp.nb_prep + rp.nb_cubprep), dim3(256), 0, s->stream, g, lambda, rp);
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
+  if (g.det) {  // S and b were summed as fixed-point integers (assembly, pair chunks, cuboid terms): back to doubles before anybody factors them
+    ZeroPlan zp{};
+    zp.p[0] = s->d_S.p; zp.n[0] = n * n + n;
+    hipLaunchKernelGGL(k_fix_to_double, dim3(2 * s->n_cu), dim3(256), 0, s->stream, zp);
+  }
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
     // ONE collective per solve attempt: the lower-triangle tiles of S and b, packed (the owner's identity on the padding
@@ -462,6 +475,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   if (s->use_lds) hipLaunchKernelGGL(k_update_all<true>, dim3(grid), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda, up);
   else hipLaunchKernelGGL(k_update_all<false>, dim3(grid), dim3(256), 0, s->stream, g, cur, tr, lambda, up);
   s->S_is_zero = true;  // the factor is dead after the backward substitution: the next reduction finds S and b cleared
+  if (g.det) s->acc_fixed = true;  // (the scale of the gain ratio was summed in fixed point)
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
@@ -469,6 +483,12 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 // bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
 // can be queued behind the copy before the host blocks on it.
 int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false) {
+  if (s->g.det && s->acc_fixed) {  // chi2 and scale -> doubles (before they are summed over ranks / published)
+    ZeroPlan zp{};
+    zp.p[0] = s->g.acc; zp.n[0] = 2;
+    hipLaunchKernelGGL(k_fix_to_double, dim3(1), dim3(64), 0, s->stream, zp);
+    s->acc_fixed = false;
+  }
   if (s->comm.active()) {
     // chi2 and scale are sums over ranks; the max-diagonal (first iteration of a pass only) is a max
     // chi2, scale and the stop vote: this rank's reading of the flag goes up through the mapped host block (slot ACC_N + 2)
@@ -605,6 +625,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     RC_TRY(fetch_acc_wait(s));
     int info = 0;
     info = (int)s->h_pinned[ACC_N];
+    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) info = 1 << 29;  // an addend that was not finite / out of the fixed-point range: the system is not usable
     double tempChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
     if (info != 0 || !std::isfinite(s->h_pinned[ACC_SCALE])) tempChi = std::numeric_limits<double>::max();  // solver not ok (:126-127)
     rho = currentChi - tempChi;
@@ -678,10 +699,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (!p || !o || !out) return PPO_BA_ERR_ARG;
   *out = nullptr;
   if (o->abi_version != PPO_BA_ABI_VERSION) return PPO_BA_ERR_ARG;
-  if (o->deterministic != 0 || o->jacobian_mode != PPO_JAC_NUMERIC) {
-    std::fprintf(stderr, "[ppo_ba] options.deterministic / jacobian_mode: only 0 / PPO_JAC_NUMERIC are implemented\n");
+  if ((o->deterministic != 0 && o->deterministic != 1) || o->jacobian_mode != PPO_JAC_NUMERIC) {
+    std::fprintf(stderr, "[ppo_ba] options.deterministic must be 0 or 1, jacobian_mode PPO_JAC_NUMERIC (the only one implemented)\n");
     return PPO_BA_ERR_ARG;
   }
+  if (o->world_size < 1 || o->rank < 0 || o->rank >= o->world_size) return PPO_BA_ERR_ARG;
   const auto t_begin = std::chrono::steady_clock::now();
   RC_TRY(validate(p));
   int ndev = 0;
@@ -690,7 +712,6 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     return PPO_BA_ERR_HIP;
   }
   if (o->device_id < 0 || o->device_id >= ndev) return PPO_BA_ERR_ARG;
-  if (o->world_size < 1 || o->rank < 0 || o->rank >= o->world_size) return PPO_BA_ERR_ARG;
   ppo_ba_solver* s = new (std::nothrow) ppo_ba_solver();
   if (!s) return PPO_BA_ERR_NOMEM;
   s->opt = *o;
@@ -890,6 +911,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   // ---- landmark ownership (multi-GPU): contiguous edge-balanced ranges; rank 0 owns the reduced-only terms ----
   g.pt_first = 0; g.pt_last = Npt; g.plane_first = 0; g.plane_last = Npl; g.owns_reduced = 1;
+  g.det = o->deterministic ? 1 : 0;
   if (o->world_size > 1) {
     SVec<int32_t> fp(o->world_size + 1), fl(o->world_size + 1);
     if (ppo_ba_partition(p, o->world_size, fp.data(), fl.data()) != PPO_BA_OK) return fail(PPO_BA_ERR_ARG);

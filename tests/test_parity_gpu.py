@@ -586,6 +586,42 @@ def test_stop_flag_is_a_collective_decision_in_sharded_runs(hip_hooks):
             assert out[0][0] in (0, 1) and (out[0][0] == 0 or out[0][1] < full), (out, full)
 
 
+@pytest.mark.parametrize("cfg,kw", [("small", dict(seed=3, with_corners=True, with_vp_planes=2, stereo_frac=0.3)), ("cfg3", dict(seed=1))])
+def test_deterministic_mode_is_bit_reproducible_and_inside_the_bar(oracle, hip, cfg, kw):
+    """options.deterministic = 1: every cross-wave sum is an integer atomic on a 2^-24 fixed-point image of the addend, so
+    the result cannot depend on the order in which workgroups arrive.  Three runs (two handles, a reset in between) must agree BIT
+    FOR BIT in every output -- poses, landmarks, per-edge chi2, the chi2 / lambda trace -- and sit inside the same parity bar
+    against the oracle as the default mode, from which they differ only by that rounding."""
+    P = synth.make_problem(cfg, **kw)
+    outs = []
+    for rep in range(2):
+        s = hip.create(P, B.default_options(deterministic=1))
+        for again in range(2 if rep == 0 else 1):
+            if again:
+                s.reset()
+            st, r = s.run(), s.read()
+            outs.append((st, r))
+        s.close()
+    st0, r0 = outs[0]
+    for st, r in outs[1:]:
+        assert [(i["trials"], i["accepted"], i["chi2_before"], i["chi2_after"], i["lambda_"]) for i in st["iters"]] == \
+               [(i["trials"], i["accepted"], i["chi2_before"], i["chi2_after"], i["lambda_"]) for i in st0["iters"]]
+        for name in ("pose_qt", "point_xyz", "plane_coef", "cuboid_qt", "cuboid_scale", "mono_chi2", "stereo_chi2", "pl_chi2", "bbox_chi2", "corner_chi2",
+                     "mono_level", "pl_level"):
+            assert np.array_equal(getattr(r, name), getattr(r0, name)), name
+    so = oracle.create(P, B.default_options())
+    to, ro = so.run(), so.read()
+    so.close()
+    assert [(i["trials"], i["accepted"]) for i in to["iters"]] == [(i["trials"], i["accepted"]) for i in st0["iters"]]
+    assert abs(to["iters"][-1]["chi2_after"] - st0["iters"][-1]["chi2_after"]) <= 1e-6 * to["iters"][-1]["chi2_after"]
+    compare_states(ro, r0)
+    # the default mode (floating-point atomics) lands on the same answer to the bar
+    sd = hip.create(P, B.default_options())
+    sd.run()
+    compare_states(sd.read(), r0)
+    sd.close()
+
+
 def test_cpp_caller_through_the_c_abi(hip, tmp_path):
     """examples/replay.cpp (plain g++, links libppo_ba.so) replays a dumped window: the boundary as a C++ host would use it."""
     import subprocess
