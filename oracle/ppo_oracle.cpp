@@ -2,11 +2,16 @@
 // the reference's local bundle adjustment, used as parity checker and as bench.py's cpu_baseline leg.
 // Nothing in the product path (libppo_ba.so, the host adapter) links, includes or calls this file.
 //
-// Parity status: the reference cannot be compiled here (Eigen3/OpenCV/PCL/Pangolin absent) and ships no
-// tests for this path, so this restatement is pinned by (a) golden vectors produced by the reference's
-// OWN prebuilt Thirdparty/g2o/lib/libg2o.so for the pieces that library exports (oracle/pin_g2o_prebuilt.py
-// -> tests/golden/g2o_prebuilt.json) and (b) analytic known-answer tests.  The custom plane/cuboid edges
-// live only in lib/libORB_SLAM2.so, which does not load here: for them parity is UNPINNED.
+// Parity status: the reference cannot be compiled here (Eigen3/OpenCV/PCL/Pangolin absent) and ships no tests for this path,
+// so this restatement is pinned by golden vectors produced by the reference's OWN prebuilt Thirdparty/g2o/lib/libg2o.so
+//   (a) per function: SE3 exp, pose oplus, Huber, projections, the unary OnlyPose edges, and the two binary reprojection edges
+//       through computeError / linearizeOplus / numeric linearizeOplusXi,Xj / constructQuadraticForm -- residual, Jacobians and
+//       H / b blocks agree BIT FOR BIT (oracle/pin_g2o_prebuilt.py -> tests/golden/g2o_prebuilt.json);
+//   (b) as a whole: the library's own SparseOptimizer + OptimizationAlgorithmLevenberg run the two-pass protocol on six
+//       points-only windows and this file follows them with a bit-identical lambda sequence through pass 1
+//       (oracle/pin_g2o_lm.py -> tests/golden/g2o_prebuilt_lm.json);
+// and by analytic known-answer tests.  The custom plane / cuboid edges live only in lib/libORB_SLAM2.so, which does not load
+// here, and BlockSolverX / Eigen::LDLT are header templates: for those parts parity is UNPINNED.
 //
 // What is restated, in the reference's own order (paths relative to the reference checkout, G2O =
 // Thirdparty/g2o/g2o):
@@ -474,7 +479,11 @@ void initialize_optimization(Oracle& o, int lvl) {
 
 // SparseOptimizer::computeActiveErrors, sparse_optimizer.cpp:61-76
 void compute_active_errors(Oracle& o) {
-  for (const EdgeRef& er : o.active) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (size_t k = 0; k < o.active.size(); ++k) {
+    const EdgeRef& er = o.active[k];
     int t0, i0, t1, i1;
     edge_vertices(o, er.type, er.idx, t0, i0, t1, i1);
     compute_error(o, er.type, er.idx, vertex_ptr(o, t0, i0), t1 == V_NONE ? nullptr : vertex_ptr(o, t1, i1),
@@ -655,14 +664,26 @@ bool ldlt_solve(std::vector<double>& A, int n, const double* rhs, double* xout) 
       double s = 0;
       for (int j = 0; j < k; ++j) s += M(k, j) * temp[j];
       M(k, k) -= s;
-      if (rs > 0)
+      if (rs > 0) {
+        double* colk = &A[(size_t)k * n + k + 1];
+#ifdef _OPENMP
+        // (libppo_oracle_omp.so, bench.py's secondary "best CPU" line only: the rows of the column update are independent; every row
+        //  still sums over j in ascending order, so the result is bit-identical to the serial build)
+#pragma omp parallel for schedule(static) if (rs * (long)k > 20000)
+        for (int i = 0; i < rs; ++i) {
+          double v = colk[i];
+          for (int j = 0; j < k; ++j) v -= A[(size_t)j * n + k + 1 + i] * temp[j];
+          colk[i] = v;
+        }
+#else
         for (int j = 0; j < k; ++j) {
           const double tj = temp[j];
           if (tj == 0.0) continue;
           double* colj = &A[(size_t)j * n + k + 1];
-          double* colk = &A[(size_t)k * n + k + 1];
           for (int i = 0; i < rs; ++i) colk[i] -= colj[i] * tj;
         }
+#endif
+      }
     }
     const double akk = M(k, k);
     const bool pivot_ok = std::fabs(akk) > 0.0;

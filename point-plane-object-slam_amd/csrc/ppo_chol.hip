@@ -70,6 +70,15 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ base, int l
     t[i] = *reinterpret_cast<const double2*>(&base[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
   }
 }
+// the same tile spread over NT threads (chol_step: the four compute waves plus four loader waves)
+template <int NT>
+__device__ __forceinline__ void load_tile_nt(const double* __restrict__ base, int ld, double2 (&t)[2048 / NT]) {
+#pragma unroll
+  for (int i = 0; i < 2048 / NT; ++i) {
+    const int p = threadIdx.x + NT * i;
+    t[i] = *reinterpret_cast<const double2*>(&base[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
+  }
+}
 
 // All MFMA helpers below fetch EVERY LDS operand of a job (and the old values of the output tile) into registers before
 // the first MFMA: left to itself the compiler emitted ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs per k-step, i.e. one full
@@ -374,7 +383,16 @@ __device__ __forceinline__ void solve_rhs_row(double (*sB)[LP], int kk, const do
 // the phases were bound by the side waves (2.3 us); with halves (<= 36) they are bound by the factorisation again
 // (1.8 us), and the kernel went from 16 to 13.5 us per panel at n = 1216.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info) {
+// Launched with kStepThreads = 512 threads: waves 4..7 are LOADER waves.  A workgroup pulls 64-96 KB through one CU before it can
+// start, and that prologue is bound by the requests a wave may have in flight, not by bandwidth (4.6 us of a 13.5 us panel step
+// with four waves issuing 24 requests each); the loader waves issue half of the requests, write their share into LDS, meet the
+// compute waves at the first barrier and end (an ended wave no longer counts at later barriers).
+#ifndef PPO_CHOL_STEP_THREADS
+#define PPO_CHOL_STEP_THREADS 512
+#endif
+constexpr int kStepThreads = PPO_CHOL_STEP_THREADS;  // (256: no loader waves -- A/B builds)
+__global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info) {
+  constexpr int NT = kStepThreads, NI = 2048 / NT;
   __shared__ double sL[NB][LP];
   __shared__ double sB[NB + 1][LP];  // row NB carries r_k^T: the forward substitution is one more row of the block solve
   __shared__ double sT[NB / SB][SB][17];
@@ -395,23 +413,26 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     const int bj = t - bi * (bi + 1) / 2;
     const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
-    double2 tp[8], tq[8];
-    load_tile(&A[(size_t)kp * ld + r0], ld, tp);
-    load_tile(&A[(size_t)kp * ld + c0], ld, tq);
-    double cold[2][2][4];  // old values of the output quadrant, fetched while the panel tiles land
+    double2 tp[NI], tq[NI];
+    load_tile_nt<NT>(&A[(size_t)kp * ld + r0], ld, tp);
+    load_tile_nt<NT>(&A[(size_t)kp * ld + c0], ld, tq);
+    double cold[2][2][4] = {};  // old values of the output quadrant, fetched while the panel tiles land (compute waves)
+    if (tid < 256) {
 #pragma unroll
-    for (int jc = 0; jc < 2; ++jc)
+      for (int jc = 0; jc < 2; ++jc)
 #pragma unroll
-      for (int ir = 0; ir < 2; ++ir)
+        for (int ir = 0; ir < 2; ++ir)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) cold[jc][ir][reg] = A[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li];
+          for (int reg = 0; reg < 4; ++reg) cold[jc][ir][reg] = A[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li];
+    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = tid + 256 * i, mm = p >> 5, r = 2 * (p & 31);
+    for (int i = 0; i < NI; ++i) {
+      const int p = tid + NT * i, mm = p >> 5, r = 2 * (p & 31);
       *reinterpret_cast<double2*>(&sP[mm][r]) = tp[i];
       *reinterpret_cast<double2*>(&sQ[mm][r]) = tq[i];
     }
     __syncthreads();
+    if (tid >= 256) return;  // loader waves
     v4d acc[2][2] = {};
     quadrant_product(sP, sQ, wr, wc, li, lk, acc);
 #pragma unroll
@@ -439,43 +460,44 @@ __global__ __launch_bounds__(256) void chol_step(double* __restrict__ A, int ld,
   {
     // Everything is requested unconditionally and back to back (what is not needed aliases the diagonal tile): with the
     // loads under `if`s the compiler drained each group before issuing the next, four memory round trips in a row.
-    double2 td[8], tq[8], tb[4], tp[4];
+    double2 td[NI], tq[NI], tb[NI / 2], tp[NI / 2];
     const double* pC = &A[(size_t)k0 * ld + k0];
     const double* pQ = upd ? &A[(size_t)kp * ld + k0] : pC;   // L[k][k-1]
     const double* pB = own ? &A[(size_t)k0 * ld + row0] : pC;
     const double* pP = uo ? &A[(size_t)kp * ld + row0] : pC;  // L[k+b][k-1]
     STAMP(15);
-    load_tile(pC, ld, td);
+    load_tile_nt<NT>(pC, ld, td);
     STAMP(16);
-    load_tile(pQ, ld, tq);
+    load_tile_nt<NT>(pQ, ld, tq);
     STAMP(17);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // the own half: 32 rows x 64 columns, 16 double2 per column
-      const int p = tid + 256 * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
+    for (int i = 0; i < NI / 2; ++i) {  // the own half: 32 rows x 64 columns, 16 double2 per column
+      const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
       tb[i] = *reinterpret_cast<const double2*>(&pB[(size_t)c * ld + r]);
       tp[i] = *reinterpret_cast<const double2*>(&pP[(size_t)c * ld + r]);
     }
     const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
     STAMP(6);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
+    for (int i = 0; i < NI; ++i) {
+      const int p = tid + NT * i, c = p >> 5, r = 2 * (p & 31);
       sL[r][c] = (r >= c) ? td[i].x : 0.0;
       sL[r + 1][c] = (r + 1 >= c) ? td[i].y : 0.0;
       *reinterpret_cast<double2*>(&sQ[c][r]) = tq[i];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = tid + 256 * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
+    for (int i = 0; i < NI / 2; ++i) {
+      const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
       sB[r][c] = tb[i].x;
       sB[r + 1][c] = tb[i].y;
       *reinterpret_cast<double2*>(&sP[c][r]) = tp[i];
     }
     if (tid < NB) sB[NB][tid] = rv;
     if (tid == 0) sBad = 0;
-    for (int i = tid; i < (SB + 1) * SB; i += 256) sId[i / SB][i % SB] = (i / SB == i % SB) ? 1.0 : 0.0;
+    for (int i = tid; i < (SB + 1) * SB; i += NT) sId[i / SB][i % SB] = (i / SB == i % SB) ? 1.0 : 0.0;
   }
   __syncthreads();
+  if (tid >= 256) return;  // loader waves
   STAMP(5);
   if (upd) {
     tile_update1(sL, wave, 0, wave == 0, sQ, sQ);  // block column 0 of the diagonal block: what potf2(0) needs
@@ -1110,7 +1132,7 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
     for (int k = 0; k < nb; ++k) {
       const int k0 = k * NB;
       const int m = nb - k;  // column workgroups: 1 (diagonal) + 2 per block row below (row halves); then the trailing tiles
-      hipLaunchKernelGGL(chol_step, dim3(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(256), 0, s, A, ld, k0, b, w.y, x, info);
+      hipLaunchKernelGGL(chol_step, dim3(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(kStepThreads), 0, s, A, ld, k0, b, w.y, x, info);
     }
   } else {
     hipLaunchKernelGGL(chol_fwd_all, dim3(nb < 2 ? 1 : 1 + nb * (nb - 1) / 2), dim3(256), 0, s, A, ld, b, x, info, w);

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <string>
 #include <mutex>
 #include <vector>
 
@@ -74,7 +75,23 @@ struct Comm {
 
   bool load() {
     if (lib) return true;
-    lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // RCCL must sit on the SAME HIP runtime instance as this library (a process that also imported PyTorch holds two: ROCm's and
+    // the one bundled with torch, each with its own librccl): look next to the libamdhip64 this library is bound to first.
+    {
+      Dl_info di;
+      if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+          dir.resize(slash + 1);
+          for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            lib = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+          }
+        }
+      }
+    }
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) {
       std::fprintf(stderr, "[ppo_ba] cannot open librccl.so: %s\n", dlerror());

@@ -12,8 +12,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _gpus():
-    import torch
-    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    # (counted in a child process: importing torch here would load its bundled HIP runtime and RCCL into the pytest process, next
+    #  to ROCm's that libppo_ba.so is bound to -- the one-rank RCCL self-test of test_parity_gpu.py then meets the wrong pair)
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)"],
+                             capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return 0
 
 
 def _launch(n, *args):
