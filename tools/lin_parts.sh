@@ -1,3 +1,6 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-for m in 1 2 4 8 16 31; do echo "parts=$m"; PPO_BA_LIN_PARTS=$m python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['roofline']['launch_ms']*1e3,'us')"; done
-python bench.py --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['roofline']['launch_ms']*1e3, j['roofline']['frac'], {k:round(v['us'],1) for k,v in j['config']['kernels'].items()})"
+#!/bin/bash
+# development aid: duration of the fused linearisation with only some of its parts in the grid
+# (1 plane, 2 bbox, 4 point-cuboid, 8 pose side, 16 point side; 7 = numeric classes, 24 = reprojection, 31 = all)
+# (the PPO_BA_* switches exist only in the test-hooks build)
+export PPO_BA_LIB="${PPO_BA_LIB:-$(cd "$(dirname "$0")/.." && pwd)/point-plane-object-slam_amd/csrc/libppo_ba_test.so}"
+for m in ${PARTS:-1 2 4 7 8 16 24 31}; do echo -n "parts=$m: "; PPO_BA_LIN_PARTS=$m python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('%.1f us' % (j['roofline']['launch_ms']*1e3))"; done

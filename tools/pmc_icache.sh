@@ -1,5 +1,7 @@
 #!/bin/bash
 # development aid: instruction-cache counters of the fused linearisation (whole launch and the numeric part alone)
+# (the PPO_BA_* switches exist only in the test-hooks build)
+export PPO_BA_LIB="${PPO_BA_LIB:-$(cd "$(dirname "$0")/.." && pwd)/point-plane-object-slam_amd/csrc/libppo_ba_test.so}"
 OUT="${1:-gpurun_out/ic}"; mkdir -p "$OUT"; OUT="$(cd "$OUT" && pwd)"
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
