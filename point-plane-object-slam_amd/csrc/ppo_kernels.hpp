@@ -146,7 +146,16 @@ struct Graph {
   int det;           // options.deterministic: every cross-wave accumulation is an INTEGER atomic on a 2^-24 fixed-point image of the
                      // addend (exact, hence independent of the order the atomics arrive in); k_fix_to_double turns the ranges back into doubles
   const double* hb_diag;  // sharded runs, first iteration: diagonal of Hpp summed over ranks (NULL: read it from HB)
+#ifdef PPO_BA_TEST_HOOKS
+  int dbg;                     // development aid (PPO_BA_LIN_DBG): bit 0 numeric classes skip their scatter, bit 1 plain stores instead of atomics
+  unsigned long long* stamps;  // development aid (PPO_BA_LIN_STAMPS): [grid][8] wall-clock stamps of the fused linearisation's workgroups
+#endif
 };
+#ifdef PPO_BA_TEST_HOOKS
+#define LIN_STAMP(g_, k_) do { if ((g_).stamps && threadIdx.x == 0) (g_).stamps[(size_t)blockIdx.x * 8 + (k_)] = wall_clock64(); } while (0)
+#else
+#define LIN_STAMP(g_, k_) ((void)0)
+#endif
 
 __device__ __forceinline__ int packed_lower(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
 
@@ -167,7 +176,11 @@ __device__ __forceinline__ void fixed_add(double* p, double v, double* bad) {
   if (!(fabs(v) < 4.0e11)) { *bad = 1.0; return; }
   atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn(v * kFixScale));
 }
+#ifdef PPO_BA_TEST_HOOKS  // PPO_BA_LIN_DBG bit 1: plain (racy) stores instead of atomics -- timing experiments only
+#define acc_add(g_, p_, v_) do { if ((g_).det) fixed_add((p_), (v_), &(g_).acc[ACC_DETBAD]); else if ((g_).dbg & 2) *(p_) = (v_); else atomicAdd((p_), (v_)); } while (0)
+#else
 #define acc_add(g_, p_, v_) do { if ((g_).det) fixed_add((p_), (v_), &(g_).acc[ACC_DETBAD]); else atomicAdd((p_), (v_)); } while (0)
+#endif
 
 __device__ __forceinline__ void block_atomic_add(const Graph& g, double v, double* dst, double* s_red) {
   v = wave_sum(v);
@@ -177,6 +190,9 @@ __device__ __forceinline__ void block_atomic_add(const Graph& g, double v, doubl
   if (threadIdx.x == 0) {
     double t = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_red[i];
+#ifdef PPO_BA_TEST_HOOKS
+    if (g.dbg & 4) t = 0.0;  // timing experiment: no same-address atomics from the workgroups
+#endif
     if (t != 0.0) acc_add(g, dst, t);
   }
   __syncthreads();
@@ -662,19 +678,51 @@ struct NumericShape {
   static constexpr int EPW = 64 / LPE;              // edges per wave
   static constexpr int EPB = 4 * EPW;               // edges per 256-thread workgroup
 };
-template <class Model>
-__device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st, int n_edges, bool corner, double delta, int vblock, double* smem) {
+// (a, c) of the packed lower-triangle index k = a (a + 1) / 2 + c
+__device__ __forceinline__ void unpack_lower(int k, int& a, int& c) {
+  a = 0;
+  while ((a + 1) * (a + 2) / 2 <= k) ++a;
+  c = k - a * (a + 1) / 2;
+}
+// element (row, col) of J' (rho1 Omega) J and element row of -J' (rho1 Omega e) from the Jacobian staged in LDS ([r][column], 16 per row)
+template <int DM>
+__device__ __forceinline__ double quad_H(const double (*sJ)[16], const double* sW, int dim, int row, int col) {
+  double h = 0;
+#pragma unroll
+  for (int r = 0; r < DM; ++r)
+    if (r < dim) h += sJ[r][row] * sW[r] * sJ[r][col];
+  return h;
+}
+template <int DM>
+__device__ __forceinline__ double quad_b(const double (*sJ)[16], const double* sG, int dim, int row) {
+  double b = 0;
+#pragma unroll
+  for (int r = 0; r < DM; ++r)
+    if (r < dim) b += sJ[r][row] * sG[r];
+  return b;
+}
+
+// The accumulation of a numerically differentiated edge is LANE-CONTIGUOUS: the entries one edge adds to a block (D_l | b_l, the packed
+// pose block, W, the packed cuboid block) are consecutive doubles, and consecutive lanes add consecutive entries, so one atomic
+// instruction touches 1-4 cache lines.  With one lane per Jacobian column adding "its" row (up to 15 single-lane atomics in a loop) the
+// 4 000 plane edges alone issued 216 000 line operations, 135-180 of them per hot line (a plane's D_l, a keyframe's pose block): the
+// accumulation phase took 6 us of a 14 us workgroup (tools/lin_stamps.py), against 2 us now.
+
+// ---- plane edges: 19 lanes per edge (the two signs of a column in neighbouring lanes + the base residual), 3 edges per wave ----------
+__device__ __forceinline__ void lin_plane_body(const Graph& g, const State& st, int n_edges, double delta, int vblock, double* smem) {
+  using Model = PlaneModel;
   constexpr int DM = Model::DIM_MAX, NC = Model::NCOL;
   constexpr int LPE = NumericShape<Model>::LPE, EPW = NumericShape<Model>::EPW, EPB = NumericShape<Model>::EPB;
   double (*sJ)[DM][16] = reinterpret_cast<double (*)[DM][16]>(smem);  // [group][row][col]
   double (*sW)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16);
   double (*sG)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16 + EPB * DM);
   double* s_red = smem + EPB * DM * 16 + 2 * EPB * DM;
-  const Model m{g, corner};
+  const Model m{g, false};
   const int wl = threadIdx.x & 63, ew = wl / LPE;
   const int lane = wl - ew * LPE;
   const int grp = (threadIdx.x >> 6) * EPW + ew;
   const int i = vblock * EPB + grp;
+  LIN_STAMP(g, 0);
   const bool act = ew < EPW && i < n_edges && m.active(i);
   const int dim = act ? m.dim(i) : 0;
   double chi_local = 0.0;
@@ -688,6 +736,7 @@ __device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st
 #pragma unroll
     for (int r = 0; r < DM; ++r) eo[r] = 0.0;
     if (fr || base) m.residual(i, base ? -1 : c, base ? 0.0 : ((lane & 1) ? -delta : delta), st, eo);
+    LIN_STAMP(g, 1);
     if (col) {
       const double scalar = 1.0 / (2 * delta);
 #pragma unroll
@@ -710,17 +759,224 @@ __device__ __forceinline__ void lin_numeric_body(const Graph& g, const State& st
     }
   }
   __syncthreads();
-  if (act && lane < NC && m.col_free(i, lane)) {
-    double Hrow[NC], bc = 0;
-    for (int r = 0; r < dim; ++r) bc += sJ[grp][r][lane] * sG[grp][r];
-    for (int c2 = 0; c2 < NC; ++c2) {
-      double h = 0;
-      for (int r = 0; r < dim; ++r) h += sJ[grp][r][lane] * sW[grp][r] * sJ[grp][r][c2];
-      Hrow[c2] = h;
+  LIN_STAMP(g, 2);
+#ifdef PPO_BA_TEST_HOOKS
+  if (!(g.dbg & 1))
+#endif
+  if (act) {
+    // 54 entries per edge: D_l (6, packed upper) | b_l (3) | pose block (21 packed lower + 6) | W (6 x 3)
+    const PlaneEdge& ed = g.pl[i];
+    const int l = g.n_points + ed.plane, fid = g.pose_free_id[ed.pose];
+    for (int o = lane; o < 54; o += LPE) {
+      if (o < 9) {
+        double* dst = o < 6 ? &g.D[(size_t)l * 6 + o] : &g.bl[(size_t)l * 3 + (o - 6)];
+        const int c = o < 3 ? 0 : (o < 5 ? 1 : 2), c2 = o < 3 ? o : (o < 5 ? o - 2 : 2);
+        acc_add(g, dst, o < 6 ? quad_H<DM>(sJ[grp], sW[grp], dim, c, c2) : quad_b<DM>(sJ[grp], sG[grp], dim, o - 6));
+      } else if (fid >= 0) {
+        if (o < 36) {
+          const int q = o - 9;
+          double v;
+          if (q < 21) { int a, c2; unpack_lower(q, a, c2); v = quad_H<DM>(sJ[grp], sW[grp], dim, 3 + a, 3 + c2); }
+          else v = quad_b<DM>(sJ[grp], sG[grp], dim, 3 + (q - 21));
+          acc_add(g, &g.HB[(size_t)fid * 27 + q], v);
+        } else if (ed.slot >= 0) {
+          const int q = o - 36;
+          acc_add(g, &g.W[(size_t)(ed.slot - g.n_pt_slots) * 18 + q], quad_H<DM>(sJ[grp], sW[grp], dim, 3 + q / 3, q % 3));
+        }
+      }
     }
-    m.scatter(i, lane, Hrow, bc);
   }
+  LIN_STAMP(g, 3);
   block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  LIN_STAMP(g, 4);
+}
+
+// ---- cuboid projections (bbox / corner edges): ONE edge per workgroup, 8 lanes -- one per cuboid corner -- per residual ------------------
+// 31 residuals (the two signs of 15 columns + the base) x 8 corners = 248 lanes.  A residual is a latency chain (box-plus, two rotation
+// matrices, then the corners one after the other: ~1 400 dependent FP64 instructions, 7 us for a lone lane); with the corners across lanes
+// the chain is the box-plus and ONE corner, and the hull (bbox) is three lane exchanges.
+template <bool CORNER>
+struct NumericShape<CubProjModelT<CORNER>> {
+  static constexpr int EPB = 1;
+};
+template <bool CORNER>
+__device__ __forceinline__ void lin_cubproj_body(const Graph& g, const State& st, int i, double delta, double* smem) {
+  constexpr int DM = CORNER ? 16 : 4, NC = 15;
+  double (*sJ)[16] = reinterpret_cast<double (*)[16]>(smem);  // [row][col]
+  double* sW = smem + DM * 16;
+  double* sG = sW + DM;
+  double* s_red = sG + DM;
+  const CubEdge& ed = CORNER ? g.corner[i] : g.bbox[i];
+  const int tid = threadIdx.x, r = tid >> 3, k = tid & 7;
+  const int c = r >> 1;
+  const bool act = ed.flags & F_ACTIVE;  // (uniform)
+  const bool col = r < 2 * NC, base = r == 2 * NC;
+  const int fid = g.pose_free_id[ed.pose];
+  const bool fr = col && (c >= 6 || g.pose_col[ed.pose] >= 0);
+  LIN_STAMP(g, 0);
+  double chi_local = 0.0;
+  if (act) {
+    double u = 0.0, v = 0.0;
+    if (fr || base) {
+      Pose T = load_pose(&st.pose_qt[7 * ed.pose]);
+      Cub cb = load_cub(&st.cub[10 * ed.cuboid]);
+      const double step = (r & 1) ? -delta : delta;
+      double d[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) d[q] = (!base && q == (c < 6 ? c : c - 6)) ? step : 0.0;
+      if (!base && c < 6) T = pose_boxplus(T, d);
+      else if (!base) {
+        const double* fs = &g.cub_fixedscale[3 * ed.cuboid];
+        cb = cuboid_boxplus(cb, d, g.cub_flags[ed.cuboid], fs[0], fs[1], fs[2]);
+      }
+      const Mat3 Rwo = rotmat(cb.T.q), Rcw = rotmat(T.q);
+      cuboid_corner_px(cb, Rwo, Rcw, T.t, ed.K, k, u, v);
+    }
+    LIN_STAMP(g, 1);
+    // residual rows owned by this lane: bbox row k (k < 4) of the hull, corner rows 2k and 2k + 1
+    double e0, e1 = 0.0;
+    if (CORNER) {
+      e0 = u - ed.meas[2 * k];
+      e1 = v - ed.meas[2 * k + 1];
+    } else {
+      double ulo = u, uhi = u, vlo = v, vhi = v;
+#pragma unroll
+      for (int sft = 1; sft < 8; sft <<= 1) {  // (min / max are exact: the order of the corners does not matter)
+        ulo = fmin(ulo, __shfl_xor(ulo, sft, 64)); uhi = fmax(uhi, __shfl_xor(uhi, sft, 64));
+        vlo = fmin(vlo, __shfl_xor(vlo, sft, 64)); vhi = fmax(vhi, __shfl_xor(vhi, sft, 64));
+      }
+      e0 = k == 0 ? (uhi + ulo) / 2 - ed.meas[0] : (k == 1 ? (vhi + vlo) / 2 - ed.meas[1] : (k == 2 ? (uhi - ulo) - ed.meas[2] : (vhi - vlo) - ed.meas[3]));
+    }
+    const double scalar = 1.0 / (2 * delta);
+    const double m0 = __shfl_down(e0, 8, 64), m1 = __shfl_down(e1, 8, 64);  // the minus-sign residual sits 8 lanes up
+    if (col && !(r & 1)) {
+      if (CORNER) { sJ[2 * k][c] = fr ? scalar * (e0 - m0) : 0.0; sJ[2 * k + 1][c] = fr ? scalar * (e1 - m1) : 0.0; }
+      else if (k < 4) sJ[k][c] = fr ? scalar * (e0 - m0) : 0.0;
+    }
+    if (base) {  // rows gathered in order: chi2 is summed exactly like the thread-per-edge residual pass does
+      double chi2 = 0, nrm = 0;
+      const int lane0 = (threadIdx.x & 63) & ~7;
+#pragma unroll
+      for (int row = 0; row < DM; ++row) {
+        const double er = CORNER ? __shfl((row & 1) ? e1 : e0, lane0 + (row >> 1), 64) : __shfl(e0, lane0 + row, 64);
+        chi2 += er * (ed.info[row] * er);
+        nrm += er * er;
+      }
+      double rho0, rho1;
+      huber(chi2, (ed.flags & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      if (k == 0) {
+        if (CORNER) { g.corner_chi2[i] = chi2; g.corner_norm[i] = sqrt(nrm); } else { g.bbox_chi2[i] = chi2; g.bbox_norm[i] = sqrt(nrm); }
+        chi_local = rho0;
+      }
+      if (CORNER) {
+        sW[2 * k] = rho1 * ed.info[2 * k]; sG[2 * k] = -(ed.info[2 * k] * e0) * rho1;
+        sW[2 * k + 1] = rho1 * ed.info[2 * k + 1]; sG[2 * k + 1] = -(ed.info[2 * k + 1] * e1) * rho1;
+      } else if (k < 4) {
+        sW[k] = rho1 * ed.info[k]; sG[k] = -(ed.info[k] * e0) * rho1;
+      }
+    }
+  }
+  __syncthreads();
+  LIN_STAMP(g, 2);
+#ifdef PPO_BA_TEST_HOOKS
+  if (!(g.dbg & 1))
+#endif
+  if (act && tid < 135) {
+    // 135 entries, one per lane: pose block (21 packed lower + 6) | cuboid block (45 packed lower + 9) | W pose rows x cuboid cols (6 x 9)
+    if (tid < 27) {
+      if (fid >= 0) {
+        double val;
+        if (tid < 21) { int a, c2; unpack_lower(tid, a, c2); val = quad_H<DM>(sJ, sW, DM, a, c2); }
+        else val = quad_b<DM>(sJ, sG, DM, tid - 21);
+        acc_add(g, &g.HB[(size_t)fid * 27 + tid], val);
+      }
+    } else if (tid < 81) {
+      const int q = tid - 27;
+      double val;
+      if (q < 45) { int a, c2; unpack_lower(q, a, c2); val = quad_H<DM>(sJ, sW, DM, 6 + a, 6 + c2); }
+      else val = quad_b<DM>(sJ, sG, DM, 6 + (q - 45));
+      acc_add(g, &g.HC[(size_t)ed.cuboid * 54 + q], val);
+    } else if (fid >= 0) {
+      const int q = tid - 81;
+      ((CORNER ? g.Wpc_corner : g.Wpc_bbox) + (size_t)i * 54)[q] = quad_H<DM>(sJ, sW, DM, q / 9, 6 + q % 9);
+    }
+  }
+  LIN_STAMP(g, 3);
+  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  LIN_STAMP(g, 4);
+}
+
+// ---- point-cuboid edges: ONE edge per workgroup, 8 lanes per residual, each summing every eighth point -----------------------------------
+// (19 residuals x 8 = 152 lanes.  The residual is a mean over the cuboid's points, ~13 us as one chain for the 30-40 points of a
+//  BASELINE cuboid; the eight partial sums are combined by a fixed exchange tree, so the result does not depend on anything but the edge.)
+template <>
+struct NumericShape<PtCubModel> {
+  static constexpr int EPB = 1;
+};
+__device__ __forceinline__ void lin_ptcub_body(const Graph& g, const State& st, int i, double delta, double* smem) {
+  constexpr int DM = 3, NC = 9;
+  double (*sJ)[16] = reinterpret_cast<double (*)[16]>(smem);
+  double* sW = smem + DM * 16;
+  double* sG = sW + DM;
+  double* s_red = sG + DM;
+  const PtCubEdge& ed = g.ptcub[i];
+  const int tid = threadIdx.x, r = tid >> 3, k = tid & 7;
+  const int c = r >> 1;
+  const bool act = ed.flags & F_ACTIVE;
+  const bool col = r < 2 * NC, base = r == 2 * NC;
+  LIN_STAMP(g, 0);
+  double chi_local = 0.0;
+  if (act && (col || base)) {
+    Cub cb = load_cub(&st.cub[10 * ed.cuboid]);
+    if (col) {
+      double d[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) d[q] = (q == c) ? ((r & 1) ? -delta : delta) : 0.0;
+      const double* fs = &g.cub_fixedscale[3 * ed.cuboid];
+      cb = cuboid_boxplus(cb, d, g.cub_flags[ed.cuboid], fs[0], fs[1], fs[2]);
+    }
+    const int npts = ed.p1 - ed.p0;
+    double acc[3];
+    ptcub_partial(cb, &g.ptcub_pts[3 * (size_t)ed.p0], npts, k, 8, ed.margin, acc);
+#pragma unroll
+    for (int sft = 1; sft < 8; sft <<= 1)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] += __shfl_xor(acc[q], sft, 64);
+    double e[3];
+    ptcub_finish(cb, acc, npts, ed.prior, e);
+    LIN_STAMP(g, 1);
+    const double scalar = 1.0 / (2 * delta);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double em = __shfl_down(e[q], 8, 64);
+      if (col && !(r & 1) && k == q) sJ[q][c] = scalar * (e[q] - em);
+    }
+    if (base && k == 0) {
+      double chi2 = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) chi2 += e[q] * (ed.info[q] * e[q]);
+      g.ptcub_chi2[i] = chi2;
+      double rho0, rho1;
+      huber(chi2, (ed.flags & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      chi_local = rho0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { sW[q] = rho1 * ed.info[q]; sG[q] = -(ed.info[q] * e[q]) * rho1; }
+    }
+  }
+  __syncthreads();
+  LIN_STAMP(g, 2);
+#ifdef PPO_BA_TEST_HOOKS
+  if (!(g.dbg & 1))
+#endif
+  if (act && tid < 54) {  // the cuboid block: 45 packed lower + 9
+    double val;
+    if (tid < 45) { int a, c2; unpack_lower(tid, a, c2); val = quad_H<DM>(sJ, sW, DM, a, c2); }
+    else val = quad_b<DM>(sJ, sG, DM, tid - 45);
+    acc_add(g, &g.HC[(size_t)ed.cuboid * 54 + tid], val);
+  }
+  LIN_STAMP(g, 3);
+  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  LIN_STAMP(g, 4);
 }
 
 template <class Model>
@@ -750,49 +1006,48 @@ __device__ __forceinline__ void chi2_numeric_body(const Graph& g, const State& s
 struct NumericPlan {
   int nb_plane, nb_bbox, nb_corner, nb_ptcub;  // workgroups per edge class
 };
-template <class Model>
-constexpr int numeric_lds_doubles() { return NumericShape<Model>::EPB * Model::DIM_MAX * 18 + 8; }  // sJ + sW + sG + s_red of lin_numeric_body
+constexpr int kNumericLdsDoubles = NumericShape<PlaneModel>::EPB * PlaneModel::DIM_MAX * 18 + 8 > 16 * 18 + 8 ? NumericShape<PlaneModel>::EPB * PlaneModel::DIM_MAX * 18 + 8
+                                                                                                         : 16 * 18 + 8;  // planes: sJ + sW + sG + s_red of 12 edges; corner edges: 16 rows
 using BboxModel = CubProjModelT<false>;
 using CornerModel = CubProjModelT<true>;
-constexpr int kNumericLdsDoubles = numeric_lds_doubles<CornerModel>() > numeric_lds_doubles<PlaneModel>() ? numeric_lds_doubles<CornerModel>() : numeric_lds_doubles<PlaneModel>();
-static_assert(kNumericLdsDoubles >= numeric_lds_doubles<BboxModel>(), "LDS of the numeric part");
-static_assert(kNumericLdsDoubles >= numeric_lds_doubles<PtCubModel>(), "LDS of the numeric part");
-template <bool WITH_CORNERS>
-__device__ __forceinline__ void lin_numeric_dispatch(const Graph& g, const State& st, const NumericPlan& np, double delta, int b, double* smem) {
-  if (b < np.nb_plane) { lin_numeric_body<PlaneModel>(g, st, g.n_pl, false, delta, b, smem); return; }
-  b -= np.nb_plane;
-  if (b < np.nb_bbox) { lin_numeric_body<BboxModel>(g, st, g.n_bbox, false, delta, b, smem); return; }
-  b -= np.nb_bbox;
-  if (WITH_CORNERS) {  // the 16-row corner edges hold 48 residual values per lane: compiled in only for windows that have them
-    if (b < np.nb_corner) { lin_numeric_body<CornerModel>(g, st, g.n_corner, true, delta, b, smem); return; }
-  }
-  b -= np.nb_corner;
-  lin_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, delta, b, smem);
-}
-
-// ONE launch for the whole linearisation (horizontal fusion): the workgroups of the numerically differentiated edge
-// classes come first (longest running, 2 NCOL + 1 lanes per edge), then one wave per pose-major chunk (pose side, factor records), then the
-// landmark-major point workgroups.  The three parts are independent (they meet only in atomics on H_pp), so the launch
-// lasts as long as its slowest part instead of their sum; as separate kernels on two streams the fork/join events alone
+// ONE launch for the whole linearisation (horizontal fusion): numerically differentiated edge classes | one wave per pose-major chunk
+// (pose side, factor records) | landmark-major point workgroups.  The parts are independent (they meet only in atomics on H_pp), so
+// the launch lasts as long as its slowest part instead of their sum; as separate kernels on two streams the fork/join events alone
 // cost ~12 us per linearisation (tools/gap_report.py).  All parts share one dynamic LDS allocation.
+// The launch holds more waves than the chip has slots (6 000 against 4 096 at the BASELINE size), so the ORDER of the parts in the
+// grid is a scheduling decision: longest-running workgroups first (tools/lin_stamps.py prints every part's timeline).
 #ifndef PPO_LIN_WAVES
-#define PPO_LIN_WAVES 3  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this).  Without the 16-row corner
-                        // edges the launch needs 140 VGPRs and nothing spills; 4 and 5 waves (128 / 96 VGPRs, 32 B / more of scratch) measure
-                        // the same within 0.5 us: the launch is not occupancy-bound
+#define PPO_LIN_WAVES 3  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this): 120 VGPRs, nothing spills,
+                        // 4 waves per SIMD resident
 #endif
+enum { LIN_PLANE = 0, LIN_BBOX = 1, LIN_CORNER = 2, LIN_PTCUB = 3, LIN_POSE = 4, LIN_POINTS = 5, LIN_PARTS = 6 };
 struct LinPlan {
-  NumericPlan num;
-  int nb_num, nb_pose, nb_pts;
+  int nb[LIN_PARTS];     // workgroups per part
+  int order[LIN_PARTS];  // grid order of the parts
 };
 template <bool USE_LDS, bool WITH_CORNERS>
 __global__ __launch_bounds__(256, PPO_LIN_WAVES) void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
   extern __shared__ double smem[];
-  int b = blockIdx.x;
-  if (b < lp.nb_num) { lin_numeric_dispatch<WITH_CORNERS>(g, st, lp.num, delta, b, smem); return; }
-  b -= lp.nb_num;
-  if (b < lp.nb_pose) { lin_poses_body(g, st, pc, b, smem); return; }
-  b -= lp.nb_pose;
-  lin_points_body<USE_LDS>(g, st, b, lp.nb_pts, smem + 8, smem);
+  int b = blockIdx.x, part = -1;
+#pragma unroll
+  for (int oi = 0; oi < LIN_PARTS; ++oi) {
+    const int n = lp.nb[lp.order[oi]];
+    if (part < 0) {
+      if (b < n) part = lp.order[oi];
+      else b -= n;
+    }
+  }
+  switch (part) {
+    case LIN_PLANE: lin_plane_body(g, st, g.n_pl, delta, b, smem); break;
+    case LIN_BBOX: lin_cubproj_body<false>(g, st, b, delta, smem); break;
+    case LIN_CORNER:
+      if (WITH_CORNERS) lin_cubproj_body<true>(g, st, b, delta, smem);  // compiled in only for windows that have corner edges
+      break;
+    case LIN_PTCUB: lin_ptcub_body(g, st, b, delta, smem); break;
+    case LIN_POSE: LIN_STAMP(g, 0); lin_poses_body(g, st, pc, b, smem); LIN_STAMP(g, 4); break;
+    case LIN_POINTS: LIN_STAMP(g, 0); lin_points_body<USE_LDS>(g, st, b, lp.nb[LIN_POINTS], smem + 8, smem); LIN_STAMP(g, 4); break;
+    default: break;
+  }
 }
 // residual-only pass of a trial state in ONE launch: numeric edge classes (thread per edge) | points (thread per point)
 __global__ __launch_bounds__(256) void k_chi2_all(Graph g, State st, NumericPlan np, int nb_num, int nb_pts) {

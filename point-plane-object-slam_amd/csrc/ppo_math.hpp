@@ -319,20 +319,24 @@ PPO_HD void corner_residual(const Pose& Tcw, const Cub& c, const double* K, cons
     e[2 * k + 1] = v - meas[2 * k + 1];
   }
 }
-// EdgePointCuboidOnlyObject::computeError, src/g2o_cuboid.cc:132-160
-PPO_HD void ptcub_residual(const Cub& c, const double* pts, int npts, double margin, const double* prior_half, double* e) {
+// EdgePointCuboidOnlyObject::computeError, src/g2o_cuboid.cc:132-160, in two steps: the sum over the points first + k stride, k = 0, 1, ...
+// (the whole list with first = 0, stride = 1; one of several interleaved partial sums otherwise), then the mean and the prior terms
+PPO_HD void ptcub_partial(const Cub& c, const double* pts, int npts, int first, int stride, double margin, double* acc) {
   const Pose inv = inverse(c.T);
-  double acc[3] = {0, 0, 0};
+  acc[0] = acc[1] = acc[2] = 0.0;
   const double s[3] = {c.s.x, c.s.y, c.s.z};
   // (points are taken six at a time, all loads first: one point per trip is one dependent memory round trip per point on the GPU)
   constexpr int G = 6;
-  for (int p0 = 0; p0 < npts; p0 += G) {
+  for (int p0 = first; p0 < npts; p0 += G * stride) {
     double xyz[3 * G];
 #pragma unroll
-    for (int k = 0; k < 3 * G; ++k) xyz[k] = pts[(3 * p0 + k < 3 * npts) ? 3 * p0 + k : 3 * npts - 1];  // unconditional loads (clamped index)
+    for (int q = 0; q < G; ++q) {
+      const int pi = (p0 + q * stride < npts) ? p0 + q * stride : npts - 1;  // unconditional loads (clamped index)
+      xyz[3 * q] = pts[3 * pi]; xyz[3 * q + 1] = pts[3 * pi + 1]; xyz[3 * q + 2] = pts[3 * pi + 2];
+    }
 #pragma unroll
     for (int q = 0; q < G; ++q) {
-      if (p0 + q < npts) {
+      if (p0 + q * stride < npts) {
         const Vec3 l = apply(inv, v3(xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2]));
         const double a[3] = {fabs(l.x), fabs(l.y), fabs(l.z)};
 #pragma unroll
@@ -346,13 +350,22 @@ PPO_HD void ptcub_residual(const Cub& c, const double* pts, int npts, double mar
       }
     }
   }
+}
+PPO_HD void ptcub_finish(const Cub& c, const double* sum, int npts, const double* prior_half, double* e) {
+  const double s[3] = {c.s.x, c.s.y, c.s.z};
   for (int i = 0; i < 3; ++i) {
-    if (npts > 0) acc[i] = acc[i] / (double)npts;
-    acc[i] = acc[i] / s[i];
+    double acc = sum[i];
+    if (npts > 0) acc = acc / (double)npts;
+    acc = acc / s[i];
     double pw = 0.2, pr = s[i];
     if (prior_half[0] > 0) { pw = 50.0; pr = fabs((s[i] - prior_half[i]) / prior_half[i]); }
-    e[i] = 1.0 * acc[i] + pw * pr;
+    e[i] = 1.0 * acc + pw * pr;
   }
+}
+PPO_HD void ptcub_residual(const Cub& c, const double* pts, int npts, double margin, const double* prior_half, double* e) {
+  double acc[3];
+  ptcub_partial(c, pts, npts, 0, 1, margin, acc);
+  ptcub_finish(c, acc, npts, prior_half, e);
 }
 
 // ---- reprojection edges ------------------------------------------------------------------------------

@@ -5,10 +5,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <new>
+#include <thread>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "ppo_chol.hpp"
@@ -246,6 +252,13 @@ struct StageAlloc {
     return static_cast<T*>(p);
   }
   void deallocate(T*, size_t) {}  // see Stage: a copy enqueued from this memory may still be in flight
+  // resize(n) / vector(n) DEFAULT-initialise (no zero fill): the big staging arrays (19 MB of edge records, 11 MB of pair plan)
+  // are written completely by the passes that size them, and a serial memset of each was ~0.3 ms of ppo_ba_create.
+  // Code that needs zeros says so: assign(n, 0) / vector(n, 0).
+  template <class U>
+  void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
   template <class U>
   bool operator==(const StageAlloc<U>&) const { return true; }
   template <class U>
@@ -253,6 +266,131 @@ struct StageAlloc {
 };
 template <class T>
 using SVec = std::vector<T, StageAlloc<T>>;
+
+// Host worker team.  ppo_ba_create is counting / bucketing over ~4e5 edges and ~9e5 landmark pose pairs, cut into a dozen
+// fork-join phases; spawning std::threads per phase cost ~50 us per thread and phase.  The team is started once per process
+// (on first use), its workers sleep on a condition variable between phases.  Several callers may fork at the same time (two
+// solvers being created, or the pair-plan helper thread next to the edge records): jobs queue up, every caller also works on
+// its own job, so a call never waits for workers that are busy elsewhere.
+class HostTeam {
+ public:
+  static HostTeam& get() {
+    static HostTeam t;
+    return t;
+  }
+  int size() const { return (int)workers_.size() + 1; }
+  // fn(t) for t in [0, nt): t = 0 on the caller, the rest on whoever is free (the caller included).  std::bad_alloc thrown by a
+  // task is rethrown here once the whole job has ended.
+  template <class F>
+  void run(int nt, F&& fn) {
+    if (nt <= 1 || workers_.empty()) {
+      for (int t = 0; t < nt; ++t) fn(t);
+      return;
+    }
+    Stage* const st = t_stage;
+    Job job;
+    job.call = [&fn, st](int t) {
+      Stage* const prev = t_stage;
+      t_stage = st;
+      try { fn(t); } catch (...) { t_stage = prev; throw; }
+      t_stage = prev;
+    };
+    job.n = nt;
+    job.next = 1;
+    job.pending.store(nt, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      queue_.push_back(&job);
+      n_queued_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    execute(&job, 0);
+    for (;;) {  // unclaimed tasks of my own job: do them instead of waiting
+      int t = -1;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (job.next < job.n) t = claim(&job);
+      }
+      if (t < 0) break;
+      execute(&job, t);
+    }
+    // the phases of a create are 50-300 us long: spin for the stragglers before sleeping (a condition-variable wake-up costs 20-50 us)
+    for (int i = 0; i < kSpin && job.pending.load(std::memory_order_acquire) != 0; ++i) relax();
+    if (job.pending.load(std::memory_order_acquire) != 0) {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_cv_.wait(lk, [&]() { return job.pending.load(std::memory_order_acquire) == 0; });
+    }
+    if (job.failed.load(std::memory_order_acquire)) throw std::bad_alloc();
+  }
+
+ private:
+  static constexpr int kSpin = 4000;  // x ~40 ns
+  static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+  struct Job {
+    std::function<void(int)> call;
+    int n = 0, next = 0;            // (mu_)
+    std::atomic<int> pending{0};    // tasks not finished yet; the job (on its caller's stack) dies when this reaches 0
+    std::atomic<bool> failed{false};
+  };
+  HostTeam() {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = hw > 1 ? (int)std::min(hw - 1, 15u) : 0;  // (two jobs of 8 slices run side by side: edge records next to the pair plan)
+    if (const char* e = std::getenv("PPO_BA_HOST_THREADS")) n = std::max(0, std::min(atoi(e) - 1, 31));  // total threads a create may use
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this]() { loop(); });
+  }
+  ~HostTeam() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  int claim(Job* j) {  // (mu_ held) next task of j; a fully claimed job leaves the queue
+    const int t = j->next++;
+    if (j->next >= j->n) {
+      queue_.erase(std::find(queue_.begin(), queue_.end(), j));
+      n_queued_.fetch_sub(1, std::memory_order_release);
+    }
+    return t;
+  }
+  void execute(Job* j, int t) {
+    try { j->call(t); } catch (...) { j->failed.store(true, std::memory_order_release); }
+    if (j->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // (j may be gone from here on)
+      { std::lock_guard<std::mutex> lk(mu_); }
+      done_cv_.notify_all();
+    }
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      if (queue_.empty() && !stop_) {  // the next phase usually follows within microseconds: look for it before going to sleep
+        lk.unlock();
+        for (int i = 0; i < kSpin && n_queued_.load(std::memory_order_acquire) == 0; ++i) relax();
+        lk.lock();
+        cv_.wait(lk, [this]() { return stop_ || !queue_.empty(); });
+      }
+      if (stop_) return;
+      Job* j = queue_.front();
+      const int t = claim(j);
+      lk.unlock();
+      execute(j, t);
+      lk.lock();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<Job*> queue_;
+  std::atomic<int> n_queued_{0};
+  std::vector<std::thread> workers_;
+  bool stop_ = false;
+};
 
 template <class T>
 struct DevBuf {

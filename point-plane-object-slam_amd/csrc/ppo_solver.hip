@@ -100,6 +100,11 @@ struct ppo_ba_solver {
   DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cp_cub, d_cp_a, d_cp_b;  // cuboid elimination plan
   DevBuf<double> d_cub_Linv, d_cub_Dinv, d_xc;
   DevBuf<int> d_info;
+#ifdef PPO_BA_TEST_HOOKS
+  DevBuf<unsigned long long> d_stamps;  // PPO_BA_LIN_STAMPS (development aid)
+  std::string stamp_path;
+  int stamp_plan[6] = {0, 0, 0, 0, 0, 0}, stamp_order[6] = {0, 1, 2, 3, 4, 5};
+#endif
   size_t state_doubles = 0;
   double* h_pinned = nullptr;  // mapped host memory: ACC_N doubles, the factorisation info (as a double), a sequence number
   double* h_pinned_dev = nullptr;
@@ -133,17 +138,29 @@ struct ppo_ba_solver {
 namespace {
 
 // (branch-free over the array so that the loops vectorise: validation was 0.4 ms of a 6 ms create at the BASELINE size)
-bool finite_all(const double* p, size_t n) {
+bool finite_range(const double* p, size_t n) {
   const uint64_t* u = reinterpret_cast<const uint64_t*>(p);
   uint64_t bad = 0;
   for (size_t i = 0; i < n; ++i) bad |= (uint64_t)((u[i] & 0x7ff0000000000000ull) == 0x7ff0000000000000ull);  // exponent all ones: NaN / Inf
   return bad == 0;
 }
-bool idx_ok(const int32_t* p, int n, int hi) {
+bool idx_range_ok(const int32_t* p, size_t n, int hi) {
   uint32_t bad = 0;
-  for (int i = 0; i < n; ++i) bad |= (uint32_t)((uint32_t)p[i] >= (uint32_t)hi);  // negative values wrap above hi
+  for (size_t i = 0; i < n; ++i) bad |= (uint32_t)((uint32_t)p[i] >= (uint32_t)hi);  // negative values wrap above hi
   return bad == 0;
 }
+// the large arrays (reprojection edges) are checked by the host team in slices
+template <class F>
+bool all_slices(size_t n, F&& ok) {
+  HostTeam& team = HostTeam::get();
+  const int nt = n >= (size_t(1) << 16) ? std::min(team.size(), 8) : 1;
+  if (nt == 1) return ok(size_t(0), n);
+  std::atomic<int> bad{0};
+  team.run(nt, [&](int t) { if (!ok(n * t / nt, n * (t + 1) / nt)) bad.store(1, std::memory_order_relaxed); });
+  return bad.load() == 0;
+}
+bool finite_all(const double* p, size_t n) { return all_slices(n, [&](size_t a, size_t b) { return finite_range(p + a, b - a); }); }
+bool idx_ok(const int32_t* p, int n, int hi) { return all_slices((size_t)n, [&](size_t a, size_t b) { return idx_range_ok(p + a, b - a, hi); }); }
 #define REQ(cond) do { if (!(cond)) return PPO_BA_ERR_ARG; } while (0)
 #define FIN(ptr, n) do { if (!finite_all((ptr), (size_t)(n))) return PPO_BA_ERR_NONFINITE; } while (0)
 
@@ -213,6 +230,28 @@ void canon_plane_cv(const double* in, double* out) {  // Converter::toPlane3D (C
 void free_all(ppo_ba_solver* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+#ifdef PPO_BA_TEST_HOOKS
+  if (s->g.stamps && !s->stamp_path.empty()) {  // one line per workgroup: part, then the stamps in 10 ns ticks relative to the earliest entry
+    const size_t n = s->d_stamps.n;
+    std::vector<unsigned long long> h(n);
+    if (hipMemcpy(h.data(), s->d_stamps.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+      unsigned long long t0 = ~0ull;
+      for (size_t b = 0; b < n / 8; ++b) if (h[8 * b] && h[8 * b] < t0) t0 = h[8 * b];
+      if (FILE* f = std::fopen(s->stamp_path.c_str(), "w")) {
+        static const char* names[6] = {"plane", "bbox", "corner", "ptcub", "pose", "points"};
+        size_t b = 0;
+        for (int oi = 0; oi < 6; ++oi)
+          for (int k = 0, part = s->stamp_order[oi]; k < s->stamp_plan[part]; ++k, ++b) {
+            std::fprintf(f, "%s", names[part]);
+            for (int j = 0; j < 5; ++j) std::fprintf(f, " %lld", h[8 * b + j] ? (long long)(h[8 * b + j] - t0) : -1LL);
+            std::fprintf(f, "\n");
+          }
+        std::fclose(f);
+      }
+    }
+  }
+  s->d_stamps.release();
+#endif
   // (the captured Cholesky graph stays with the cached block of S: DevPool drops it when the block is really freed)
   s->d_pose_cam.release(); s->d_cub_fixedscale.release(); s->d_ptcub_pts.release();
   s->d_pose_col.release(); s->d_pose_free_id.release(); s->d_cub_col.release(); s->d_mo_off.release(); s->d_st_off.release();
@@ -357,28 +396,43 @@ int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool already_zeroed
 int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
   const Graph& g = s->g;
   LinPlan lp{};
-  lp.num.nb_plane = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, NumericShape<PlaneModel>::EPB) : 0;
+  lp.nb[LIN_PLANE] = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, NumericShape<PlaneModel>::EPB) : 0;
   if (g.owns_reduced) {
-    lp.num.nb_bbox = g.n_bbox ? nblk(g.n_bbox, NumericShape<BboxModel>::EPB) : 0;
-    lp.num.nb_corner = g.n_corner ? nblk(g.n_corner, NumericShape<CornerModel>::EPB) : 0;
-    lp.num.nb_ptcub = g.n_ptcub ? nblk(g.n_ptcub, NumericShape<PtCubModel>::EPB) : 0;
+    lp.nb[LIN_BBOX] = g.n_bbox;
+    lp.nb[LIN_CORNER] = g.n_corner;
+    lp.nb[LIN_PTCUB] = g.n_ptcub;
   }
-  lp.nb_num = lp.num.nb_plane + lp.num.nb_bbox + lp.num.nb_corner + lp.num.nb_ptcub;
   const int npts = g.pt_last - g.pt_first;
-  lp.nb_pose = (npts > 0 && s->posec.n_chunks > 0) ? nblk(s->posec.n_chunks, 4) : 0;
-  lp.nb_pts = npts > 0 ? std::min(nblk((long)PPO_LIN_LPP * npts, 256), 4 * s->n_cu) : 0;
+  lp.nb[LIN_POSE] = (npts > 0 && s->posec.n_chunks > 0) ? nblk(s->posec.n_chunks, 4) : 0;
+  lp.nb[LIN_POINTS] = npts > 0 ? std::min(nblk((long)PPO_LIN_LPP * npts, 256), 4 * s->n_cu) : 0;
+  // longest-running workgroups first (tools/lin_stamps.py): landmark side 19 us, planes 16, pose side 14, cuboid projections 8, point-cuboid 6
+  static const int kOrder[LIN_PARTS] = {LIN_POINTS, LIN_PLANE, LIN_POSE, LIN_CORNER, LIN_BBOX, LIN_PTCUB};
+  for (int i = 0; i < LIN_PARTS; ++i) lp.order[i] = kOrder[i];
+  if (const char* e = PPO_DEV_ENV("PPO_BA_LIN_ORDER")) {  // development aid: six digits, a permutation of 012345 (plane bbox corner ptcub pose points)
+    int seen = 0;
+    for (int i = 0; i < LIN_PARTS && e[i] >= '0' && e[i] < '0' + LIN_PARTS; ++i) { lp.order[i] = e[i] - '0'; seen |= 1 << (e[i] - '0'); }
+    if (seen != (1 << LIN_PARTS) - 1) for (int i = 0; i < LIN_PARTS; ++i) lp.order[i] = kOrder[i];
+  }
   if (const char* e = PPO_DEV_ENV("PPO_BA_LIN_PARTS")) {  // development aid: time the parts of the fused launch separately
     const int m = atoi(e);
-    if (!(m & 1)) lp.num.nb_plane = 0;
-    if (!(m & 2)) lp.num.nb_bbox = 0;
-    if (!(m & 4)) lp.num.nb_ptcub = 0;
-    lp.nb_num = lp.num.nb_plane + lp.num.nb_bbox + lp.num.nb_corner + lp.num.nb_ptcub;
-    if (!(m & 8)) lp.nb_pose = 0;
-    if (!(m & 16)) lp.nb_pts = 0;
+    if (!(m & 1)) lp.nb[LIN_PLANE] = 0;
+    if (!(m & 2)) lp.nb[LIN_BBOX] = lp.nb[LIN_CORNER] = 0;
+    if (!(m & 4)) lp.nb[LIN_PTCUB] = 0;
+    if (!(m & 8)) lp.nb[LIN_POSE] = 0;
+    if (!(m & 16)) lp.nb[LIN_POINTS] = 0;
   }
-  const int grid = lp.nb_num + lp.nb_pose + lp.nb_pts;
+  int grid = 0;
+  for (int i = 0; i < LIN_PARTS; ++i) grid += lp.nb[i];
+#ifdef PPO_BA_TEST_HOOKS
+  if (const char* path = PPO_DEV_ENV("PPO_BA_LIN_STAMPS")) {  // development aid: wall-clock stamps of every workgroup of the LAST launch
+    if (!s->d_stamps.p && grid > 0 && s->d_stamps.alloc((size_t)grid * 8)) s->g.stamps = s->d_stamps.p;
+    s->stamp_path = path;
+    for (int i = 0; i < LIN_PARTS; ++i) { s->stamp_plan[i] = lp.nb[i]; s->stamp_order[i] = lp.order[i]; }
+    if (s->g.stamps) (void)hipMemsetAsync(s->d_stamps.p, 0, (size_t)grid * 8 * sizeof(unsigned long long), s->stream);
+  }
+#endif
   if (grid > 0) {
-    const bool cor = lp.num.nb_corner > 0;
+    const bool cor = lp.nb[LIN_CORNER] > 0;
     if (s->use_lds_lin && cor) hipLaunchKernelGGL((k_linearize_all<true, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
     else if (s->use_lds_lin) hipLaunchKernelGGL((k_linearize_all<true, false>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
     else if (cor) hipLaunchKernelGGL((k_linearize_all<false, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
@@ -793,6 +847,23 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   // ---- reprojection edges sorted by point (stable counting sort), CSR offsets -------------------------
   auto csr_sort = [&](int n, const int32_t* key, SVec<int32_t>& off, SVec<int32_t>& perm) {
+    // the reference adds the observations point by point (Optimizer.cc:2350-2422), so the edges normally ARRIVE sorted: then the
+    // permutation is the identity and the offsets are the positions where the key changes (both filled in slices by the team)
+    if (n >= (1 << 16) && all_slices((size_t)n - 1, [&](size_t a, size_t b) { int32_t bad = 0; for (size_t e = a; e < b; ++e) bad |= (int32_t)(key[e] > key[e + 1]); return bad == 0; })) {
+      off.resize(Npt + 1);
+      perm.resize(n);
+      const int nt = std::min(HostTeam::get().size(), 8);
+      HostTeam::get().run(nt, [&](int t) {
+        const int e0 = (int)((long)n * t / nt), e1 = (int)((long)n * (t + 1) / nt);
+        for (int e = e0; e < e1; ++e) perm[e] = e;
+        // off[k] = first edge with key >= k: the slice owns the keys in (key[e0 - 1], key[e1 - 1]]
+        int k = e0 == 0 ? 0 : key[e0 - 1] + 1;
+        for (int e = e0; e < e1; ++e)
+          for (; k <= key[e]; ++k) off[k] = e;
+        if (e1 == n) for (; k <= Npt; ++k) off[k] = n;
+      });
+      return;
+    }
     off.assign(Npt + 1, 0);
     for (int e = 0; e < n; ++e) off[key[e] + 1]++;
     for (int i = 0; i < Npt; ++i) off[i + 1] += off[i];
@@ -809,15 +880,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // Everything from here to the uploads is counting / bucketing over the ~4e5 edges and ~9e5 landmark pose pairs of a
   // BASELINE-size window.  It runs on a few threads over contiguous, ascending unit ranges, so every bucket keeps the order
   // the sequential loops produced (the device layout does not depend on the thread count).
-  const int n_host_threads = ((long)p->n_mono + p->n_stereo >= 40000) ? 4 : 1;
-  auto run_threads = [&](int nt, auto&& fn) {
-    if (nt <= 1) { fn(0); return; }
-    Stage* const st = t_stage;
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { t_stage = st; fn(t); });
-    fn(0);
-    for (auto& x : th) x.join();
-  };
+  HostTeam& team = HostTeam::get();
+  const int n_host_threads = ((long)p->n_mono + p->n_stereo >= 40000) ? std::min(team.size(), 8) : 1;
+  auto run_threads = [&](int nt, auto&& fn) { team.run(nt, fn); };
   // stable bucket sort of the items the units [0, n_units) generate: count(u0, u1, hist) tallies keys, fill(u0, u1, cursor)
   // places items at cursor[key]++ (after prepare(total) has sized the outputs); start gets n_keys + 1 bucket offsets
   auto bucket_by_key = [&](int n_units, long n_keys, SVec<int32_t>& start, auto&& count, auto&& prepare, auto&& fill) {
@@ -909,9 +974,14 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     return (it != e && *it == pc) ? new_id[it - slot_col.data()] : -1;
   };
 
+  mark("slots, pose-major numbering");
   // ---- landmark ownership (multi-GPU): contiguous edge-balanced ranges; rank 0 owns the reduced-only terms ----
   g.pt_first = 0; g.pt_last = Npt; g.plane_first = 0; g.plane_last = Npl; g.owns_reduced = 1;
   g.det = o->deterministic ? 1 : 0;
+#ifdef PPO_BA_TEST_HOOKS
+  g.dbg = PPO_DEV_ENV("PPO_BA_LIN_DBG") ? atoi(PPO_DEV_ENV("PPO_BA_LIN_DBG")) : 0;
+  g.stamps = nullptr;
+#endif
   if (o->world_size > 1) {
     SVec<int32_t> fp(o->world_size + 1), fl(o->world_size + 1);
     if (ppo_ba_partition(p, o->world_size, fp.data(), fl.data()) != PPO_BA_OK) return fail(PPO_BA_ERR_ARG);
@@ -967,13 +1037,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   // ---- edge records -----------------------------------------------------------------------------------------
   // (independent per edge: large blocks are filled by a few host threads; this was the longest phase of create)
-  auto parallel_for = [](int n, auto&& body) {
-    const int nt = n >= 40000 ? 4 : 1;
-    if (nt == 1) { body(0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body((int)((long)n * t / nt), (int)((long)n * (t + 1) / nt)); });
-    body(0, (int)((long)n / nt));
-    for (auto& x : th) x.join();
+  auto parallel_for = [&](int n, auto&& body) {
+    const int nt = n >= 40000 ? n_host_threads : 1;
+    team.run(nt, [&](int t) { body((int)((long)n * t / nt), (int)((long)n * (t + 1) / nt)); });
   };
   s->h_mono.resize(p->n_mono);
   parallel_for(p->n_mono, [&](int k0, int k1) {
@@ -1003,6 +1069,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
   }
   });
+  mark("reprojection edge records");
   s->h_pl.resize(p->n_plane_edges);
   for (int e = 0; e < p->n_plane_edges; ++e) {
     PlaneEdge& m = s->h_pl[e];
@@ -1054,7 +1121,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // (the constant chi2 of the cuboid-plane edges is added on the host by EVERY rank: all ranks must see the same totals,
   //  their termination tests compare absolute chi2 values)
 
-  mark("edge records");
+  mark("other edge records");
   // the copy engine moves the landmark-major records (19 MB at the BASELINE size) while the host builds the rest
   bool ok = s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream);
   // ---- pose-major static copies of the owned reprojection edges + chunks (pose side of the linearisation) -----------
@@ -1101,8 +1168,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   ok = ok && s->d_monoP.upload(h_monoP, s->stream) && s->d_stereoP.upload(h_stereoP, s->stream);
   SVec<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
-  for (int k = 0; k < p->n_mono; ++k) h_mono_flags[k] = s->h_mono[k].flags;
-  for (int k = 0; k < p->n_stereo; ++k) h_stereo_flags[k] = s->h_stereo[k].flags;
+  parallel_for(p->n_mono, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) h_mono_flags[k] = s->h_mono[k].flags; });
+  parallel_for(p->n_stereo, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) h_stereo_flags[k] = s->h_stereo[k].flags; });
 
   // ---- cuboid elimination plan: edges per cuboid and all (a >= b) pairs of them -----------------------------------------
   SVec<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cp_cub, cp_a, cp_b;
@@ -1142,8 +1209,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     }
   }
 
+  mark("pose-major copies, cuboid plan, state");
   pair_plan_thread.join();
-  mark("pose-major copies, cuboid plan, pair plan join");
+  mark("pair plan join");
   // ---- uploads (the two big record arrays are already on their way) -----------------------------------------------------
   SVec<double> v_cam(p->pose_cam, p->pose_cam + (size_t)5 * Np);
   SVec<double> v_fs((size_t)3 * Nc, 0.0);
@@ -1341,9 +1409,11 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
   SVec<PlaneEdge> hp(g.n_pl);
   SVec<CubEdge> hb(g.n_bbox), hc(g.n_corner);
   if (s->state_doubles) HIP_TRY(hipMemcpyAsync(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  if (chi.size()) HIP_TRY(hipMemcpyAsync(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  if (g.n_mono) HIP_TRY(hipMemcpyAsync(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-  if (g.n_stereo) HIP_TRY(hipMemcpyAsync(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  // (only what the caller's non-NULL pointers ask for crosses the bus: the per-edge chi2 block is the largest part of a read)
+  const bool want_chi = r->mono_chi2 || r->stereo_chi2 || r->pl_chi2 || r->bbox_chi2 || r->bbox_errnorm || r->corner_chi2 || r->corner_errnorm || r->ptcub_chi2;
+  if (chi.size() && want_chi) HIP_TRY(hipMemcpyAsync(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (g.n_mono && r->mono_level) HIP_TRY(hipMemcpyAsync(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  if (g.n_stereo && r->stereo_level) HIP_TRY(hipMemcpyAsync(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
   if (g.n_pl) HIP_TRY(hipMemcpyAsync(hp.data(), s->d_pl.p, hp.size() * sizeof(PlaneEdge), hipMemcpyDeviceToHost, s->stream));
   if (g.n_bbox) HIP_TRY(hipMemcpyAsync(hb.data(), s->d_bbox.p, hb.size() * sizeof(CubEdge), hipMemcpyDeviceToHost, s->stream));
   if (g.n_corner) HIP_TRY(hipMemcpyAsync(hc.data(), s->d_corner.p, hc.size() * sizeof(CubEdge), hipMemcpyDeviceToHost, s->stream));
@@ -1391,18 +1461,27 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
     const Pose T{Quat{q[0], q[1], q[2], q[3]}, Vec3{q[4], q[5], q[6]}};
     return apply(T, v3(h.point[3 * pt], h.point[3 * pt + 1], h.point[3 * pt + 2])).z > 0.0;
   };
-  for (int k = 0; k < g.n_mono; ++k) {
-    const int e = s->mono_perm[k];
-    if (r->mono_chi2) r->mono_chi2[e] = c_mono[k];
-    if (r->mono_level) r->mono_level[e] = (hmf[k] & F_ACTIVE) ? 0 : 1;
-    if (r->mono_depth_positive) r->mono_depth_positive[e] = depth(s->h_mono[k].pose, s->h_mono[k].point);
-  }
-  for (int k = 0; k < g.n_stereo; ++k) {
-    const int e = s->stereo_perm[k];
-    if (r->stereo_chi2) r->stereo_chi2[e] = c_st[k];
-    if (r->stereo_level) r->stereo_level[e] = (hsf[k] & F_ACTIVE) ? 0 : 1;
-    if (r->stereo_depth_positive) r->stereo_depth_positive[e] = depth(s->h_stereo[k].pose, s->h_stereo[k].point);
-  }
+  // (the reprojection edges in slices on the host team: 4e5 scattered writes and depth tests were half of a 1 ms read)
+  auto in_slices = [&](int n, auto&& body) {
+    const int nt = n >= (1 << 16) ? std::min(HostTeam::get().size(), 8) : 1;
+    HostTeam::get().run(nt, [&](int t) { body((int)((long)n * t / nt), (int)((long)n * (t + 1) / nt)); });
+  };
+  in_slices(g.n_mono, [&](int k0, int k1) {
+    for (int k = k0; k < k1; ++k) {
+      const int e = s->mono_perm[k];
+      if (r->mono_chi2) r->mono_chi2[e] = c_mono[k];
+      if (r->mono_level) r->mono_level[e] = (hmf[k] & F_ACTIVE) ? 0 : 1;
+      if (r->mono_depth_positive) r->mono_depth_positive[e] = depth(s->h_mono[k].pose, s->h_mono[k].point);
+    }
+  });
+  in_slices(g.n_stereo, [&](int k0, int k1) {
+    for (int k = k0; k < k1; ++k) {
+      const int e = s->stereo_perm[k];
+      if (r->stereo_chi2) r->stereo_chi2[e] = c_st[k];
+      if (r->stereo_level) r->stereo_level[e] = (hsf[k] & F_ACTIVE) ? 0 : 1;
+      if (r->stereo_depth_positive) r->stereo_depth_positive[e] = depth(s->h_stereo[k].pose, s->h_stereo[k].point);
+    }
+  });
   for (int e = 0; e < g.n_pl; ++e) {
     if (r->pl_chi2) r->pl_chi2[e] = c_pl[e];
     if (r->pl_level) r->pl_level[e] = (hp[e].flags & F_ACTIVE) ? 0 : 1;

@@ -677,3 +677,31 @@ def test_linearisation_standing_in_for_the_residual_pass_changes_nothing(hip):
     assert abs(a["iters"][-1][2] - b["iters"][-1][2]) <= 1e-6 * abs(b["iters"][-1][2])
     assert abs(a["lvl"] - b["lvl"]) <= 2
     assert np.abs(np.array(a["pose"]) - np.array(b["pose"])).max() < 1e-6
+
+
+def test_the_order_of_the_callers_edge_list_does_not_matter(hip):
+    """ppo_ba_create sorts the reprojection edges by point itself.  A list that arrives sorted (the reference adds the observations
+    point by point, Optimizer.cc:2350-2422) takes a short cut -- identity permutation, offsets from the key changes; a shuffled
+    list takes the counting sort.  Both must build the same graph: same iteration history, same estimates (to the round-off the
+    order of the edges inside a landmark leaves), and the per-edge outputs come back in the CALLER's order either way."""
+    P = synth.make_problem("cfg3", seed=4, stereo_frac=0.2)
+    n_mono, n_stereo = P.count("n_mono"), P.count("n_stereo")
+    assert n_mono >= 1 << 16 and np.all(np.diff(P["mono_point"]) >= 0)  # the sorted short cut applies to this one
+    rng = np.random.default_rng(5)
+    pm, ps = rng.permutation(n_mono), rng.permutation(n_stereo)
+    Q = B.Problem(**P.arrays)
+    for name, w in (("mono_point", 1), ("mono_pose", 1), ("mono_obs", 2), ("mono_info", 1), ("mono_huber", 1)):
+        Q.set(name, P[name].reshape(n_mono, w)[pm].reshape(-1))
+    for name, w in (("stereo_point", 1), ("stereo_pose", 1), ("stereo_obs", 3), ("stereo_info", 1), ("stereo_huber", 1)):
+        Q.set(name, P[name].reshape(n_stereo, w)[ps].reshape(-1))
+    sp, sq = hip.create(P, B.default_options()), hip.create(Q, B.default_options())
+    a, b = sp.run(), sq.run()
+    rp, rq = sp.read(), sq.read()
+    assert [it["trials"] for it in a["iters"]] == [it["trials"] for it in b["iters"]]
+    assert abs(a["iters"][-1]["chi2_after"] - b["iters"][-1]["chi2_after"]) <= 1e-7 * a["iters"][-1]["chi2_after"]
+    np.testing.assert_allclose(rp.pose_qt, rq.pose_qt, atol=2e-6)
+    np.testing.assert_allclose(rp.point_xyz, rq.point_xyz, atol=1e-5)
+    np.testing.assert_allclose(rp.mono_chi2[pm], rq.mono_chi2, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rp.stereo_chi2[ps], rq.stereo_chi2, rtol=1e-5, atol=1e-7)
+    assert np.mean(rp.mono_level[pm] != rq.mono_level) < 1e-4 and np.mean(rp.stereo_level[ps] != rq.stereo_level) < 1e-4
+    sp.close(); sq.close()
