@@ -70,6 +70,10 @@ struct PtCubEdge {
 
 enum { F_ACTIVE = 1u, F_ROBUST = 2u };
 enum { ACC_CHI2 = 0, ACC_SCALE = 1, ACC_STOP = 2, ACC_MAXDIAG = 3, ACC_DETBAD = 4, ACC_N = 8 };  // ACC_STOP: sharded runs, the ranks' stop votes (summed)
+// chi2 and the gain-ratio scale are sums over ALL workgroups of a launch: 1 300 atomics on one address retire one after the other and
+// were 4 us of the 31 us fused linearisation (PPO_BA_LIN_DBG=4).  Workgroups add to one of kAccParts partial sums, 128 bytes apart,
+// behind the accumulator block; whoever reads the block folds them in first (fold_acc_parts: k_publish, k_fold_acc).
+constexpr int kAccParts = 64, kAccPartStride = 16, ACC_TOTAL = ACC_N + kAccParts * kAccPartStride;
 
 struct State {       // one copy of all estimates
   double* pose_qt;   // [Np][7]
@@ -128,7 +132,7 @@ struct Graph {
   double* S;     // [n_red][n_red] column-major, lower triangle
   double* bs;    // [n_red]
   double* xr;    // [n_red]
-  double* acc;   // [ACC_N]
+  double* acc;   // [ACC_TOTAL]: ACC_N values, then kAccParts partial sums of (chi2, scale), kAccPartStride doubles apart
   // landmark range owned by this rank (multi-GPU) -- single GPU: [0, n_points) and [0, n_planes)
   // cuboid elimination (second-level Schur complement on the 9x9 cuboid blocks; the dense system is poses only)
   int elim_cub;
@@ -182,7 +186,31 @@ __device__ __forceinline__ void fixed_add(double* p, double v, double* bad) {
 #define acc_add(g_, p_, v_) do { if ((g_).det) fixed_add((p_), (v_), &(g_).acc[ACC_DETBAD]); else atomicAdd((p_), (v_)); } while (0)
 #endif
 
-__device__ __forceinline__ void block_atomic_add(const Graph& g, double v, double* dst, double* s_red) {
+// where this workgroup (wave) adds its share of acc[which], which = ACC_CHI2 or ACC_SCALE
+__device__ __forceinline__ double* acc_part(const Graph& g, int which, unsigned salt) {
+  return g.acc + ACC_N + ((blockIdx.x + salt) & (kAccParts - 1)) * kAccPartStride + which;
+}
+// (one wave) partial sums -> acc[0..1], partial sums cleared.  Deterministic mode adds the fixed-point images as integers.
+__device__ __forceinline__ void fold_acc_parts(double* acc, int det) {
+  const int t = threadIdx.x & 63;
+  double* p = acc + ACC_N + t * kAccPartStride;
+  if (det) {
+    long long c = __double_as_longlong(p[0]), sc = __double_as_longlong(p[1]);
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); sc += __shfl_down(sc, off, 64); }
+    if (t == 0) {
+      acc[ACC_CHI2] = __longlong_as_double(__double_as_longlong(acc[ACC_CHI2]) + c);
+      acc[ACC_SCALE] = __longlong_as_double(__double_as_longlong(acc[ACC_SCALE]) + sc);
+    }
+  } else {
+    double c = p[0], sc = p[1];
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); sc += __shfl_down(sc, off, 64); }
+    if (t == 0) { acc[ACC_CHI2] += c; acc[ACC_SCALE] += sc; }
+  }
+  p[0] = 0.0;
+  p[1] = 0.0;
+}
+__device__ __forceinline__ void block_atomic_add(const Graph& g, double v, int which, double* s_red) {
+  double* const dst = acc_part(g, which, 0);
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) s_red[wid] = v;
@@ -319,7 +347,7 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
       for (int k = 0; k < 3; ++k) g.bl[(size_t)p * 3 + k] = bl[k];
     }
   }
-  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
 }
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
@@ -491,7 +519,7 @@ __device__ __forceinline__ void chi2_points_body(const Graph& g, const State& st
       chi_local += rho0;
     }
   }
-  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
 }
 __global__ __launch_bounds__(256) void k_chi2_points(Graph g, State st) {
   __shared__ double s_red[4];
@@ -787,7 +815,7 @@ __device__ __forceinline__ void lin_plane_body(const Graph& g, const State& st, 
     }
   }
   LIN_STAMP(g, 3);
-  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
   LIN_STAMP(g, 4);
 }
 
@@ -902,7 +930,7 @@ __device__ __forceinline__ void lin_cubproj_body(const Graph& g, const State& st
     }
   }
   LIN_STAMP(g, 3);
-  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
   LIN_STAMP(g, 4);
 }
 
@@ -975,7 +1003,7 @@ __device__ __forceinline__ void lin_ptcub_body(const Graph& g, const State& st, 
     acc_add(g, &g.HC[(size_t)ed.cuboid * 54 + tid], val);
   }
   LIN_STAMP(g, 3);
-  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
   LIN_STAMP(g, 4);
 }
 
@@ -997,7 +1025,7 @@ __device__ __forceinline__ void chi2_numeric_body(const Graph& g, const State& s
     huber(chi2, m.huber_delta(i), rho0, rho1);
     chi_local = rho0;
   }
-  block_atomic_add(g, chi_local, &g.acc[ACC_CHI2], s_red);
+  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
 }
 
 // All numerically differentiated edge classes in ONE launch (they are tiny and latency-bound: 4000 plane, 500 bbox,
@@ -1087,12 +1115,14 @@ __device__ __forceinline__ void zero_ranges_body(const ZeroPlan& zp, size_t t0, 
 // (k_publish) Workgroup 0 hands the accumulator block and the factorisation flag to the host; when the next linearisation is
 // queued right behind (speculation), the remaining workgroups clear its accumulation ranges in the same launch and
 // workgroup 0 clears the accumulator block after copying it.
-__global__ __launch_bounds__(64) void k_publish(double* __restrict__ acc, const int* __restrict__ info, double* host, unsigned long long seq, ZeroPlan zp) {
+__global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restrict__ info, double* host, unsigned long long seq, ZeroPlan zp) {
   const int t = threadIdx.x;
   if (blockIdx.x > 0) {
     zero_ranges_body(zp, (size_t)(blockIdx.x - 1) * 64 + t, (size_t)(gridDim.x - 1) * 64);
     return;
   }
+  fold_acc_parts(acc, 0);  // (deterministic / sharded runs have folded already -- k_fold_acc -- and find zeros here)
+  __syncthreads();
   double v = 0.0;
   if (t < ACC_N) { v = acc[t]; host[t] = v; }
   if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
@@ -1101,6 +1131,9 @@ __global__ __launch_bounds__(64) void k_publish(double* __restrict__ acc, const 
   if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + ACC_N + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (gridDim.x > 1 && t < ACC_N) acc[t] = 0.0;
 }
+
+// the partial sums into acc[0..1] ahead of a reader other than k_publish (fixed-point conversion, sum over ranks)
+__global__ __launch_bounds__(64) void k_fold_acc(double* acc, int det) { fold_acc_parts(acc, det); }
 
 // reset of a solver in ONE launch: up to eight word-granular copies from the pristine device copies made at create, and the
 // zero ranges.  (Seven hipMemcpyAsync / hipMemsetAsync calls took the runtime's blit path: ~15 us of queue idle each.)
@@ -1507,6 +1540,11 @@ __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, R
   int b = blockIdx.x;
   if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
   if (b == 0 && threadIdx.x == 2) g.acc[ACC_DETBAD] = 0.0;
+  if (b == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + kAccParts) {  // ... and their partial sums
+    double* p = g.acc + ACC_N + (threadIdx.x - 64) * kAccPartStride;
+    p[0] = 0.0;
+    p[1] = 0.0;
+  }
   // (the cuboid workgroup first: one thread per cuboid walks a 9x9 Cholesky + inverse, the longest chain of the launch)
   if (b < rp.nb_cubprep) { cub_prep_body(g, lambda, b); return; }
   b -= rp.nb_cubprep;
@@ -1605,7 +1643,7 @@ __device__ __forceinline__ void update_reduced_body(const Graph& g, const State&
     }
   }
   sc = wave_sum(sc);
-  if ((lane & 63) == 0 && sc != 0.0) acc_add(g, &g.acc[ACC_SCALE], sc);
+  if ((lane & 63) == 0 && sc != 0.0) acc_add(g, acc_part(g, ACC_SCALE, threadIdx.x >> 6), sc);
 }
 
 // landmarks: x_l = Dinv (b_l - W' x_p) (block_solver.hpp:461-481), trial = cur [+] x_l, scale term.
@@ -1718,7 +1756,7 @@ __device__ __forceinline__ void backsub_body(const Graph& g, const State& cur, c
       trial.plane[4 * j] = p.nx; trial.plane[4 * j + 1] = p.ny; trial.plane[4 * j + 2] = p.nz; trial.plane[4 * j + 3] = p.d;
     }
   }
-  block_atomic_add(g, sc, &g.acc[ACC_SCALE], s_red);
+  block_atomic_add(g, sc, ACC_SCALE, s_red);
 }
 template <bool USE_LDS, int LPP>
 __global__ __launch_bounds__(256) void k_backsub(Graph g, State cur, State trial, double lambda) {

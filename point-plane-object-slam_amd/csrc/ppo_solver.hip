@@ -365,7 +365,7 @@ int launch_linearize_kernel(ppo_ba_solver* s, const State& st);
 ZeroPlan linearize_zero_plan(ppo_ba_solver* s, bool with_acc) {
   double* A = s->d_arena.p;
   ZeroPlan zp{};
-  zp.p[0] = A; zp.n[0] = with_acc ? s->zero_head : s->zero_head - ACC_N;  // HB | HC | acc
+  zp.p[0] = A; zp.n[0] = with_acc ? s->zero_head : s->zero_head - ACC_TOTAL;  // HB | HC | acc (+ its partial sums)
   zp.p[1] = A + s->zD_off; zp.n[1] = s->zD_n;
   zp.p[2] = A + s->zbl_off; zp.n[2] = s->zbl_n;
   zp.p[3] = s->d_W.p + s->zW_off; zp.n[3] = s->zW_n;
@@ -537,6 +537,8 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 // bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
 // can be queued behind the copy before the host blocks on it.
 int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false) {
+  if ((s->g.det && s->acc_fixed) || s->comm.active())  // the workgroups' partial sums into acc[0..1] (otherwise k_publish does it itself)
+    hipLaunchKernelGGL(k_fold_acc, dim3(1), dim3(64), 0, s->stream, s->g.acc, (s->g.det && s->acc_fixed) ? 1 : 0);
   if (s->g.det && s->acc_fixed) {  // chi2 and scale -> doubles (before they are summed over ranks / published)
     ZeroPlan zp{};
     zp.p[0] = s->g.acc; zp.n[0] = 2;
@@ -1239,7 +1241,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   g.n_pt_slots = slot_off[Npt];
   const size_t nF = (size_t)g.n_pt_slots * 4, nLinR = (size_t)(ld / 6 + 2) * 12, nWpl = (size_t)(g.n_slots - g.n_pt_slots) * 18;
   const size_t nHB = (size_t)nfree * 27, nHC = (size_t)Nc * 54, nD = (size_t)g.n_lm * 6, nbl = (size_t)g.n_lm * 3, nW = nF + nLinR + nWpl;
-  ok = ok && s->d_arena.alloc(nHB + nHC + ACC_N + nD + nbl) && s->d_W.alloc(nW);
+  ok = ok && s->d_arena.alloc(nHB + nHC + ACC_TOTAL + nD + nbl) && s->d_W.alloc(nW);
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
   ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
@@ -1284,8 +1286,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     double* a = s->d_arena.p;
     g.HB = a; a += nHB;
     g.HC = a; a += nHC;
-    g.acc = a; a += ACC_N;
-    s->zero_head = nHB + nHC + ACC_N;
+    g.acc = a; a += ACC_TOTAL;
+    s->zero_head = nHB + nHC + ACC_TOTAL;
     g.D = a; s->zD_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 6; s->zD_n = (size_t)Npl * 6; a += nD;
     g.bl = a; s->zbl_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 3; s->zbl_n = (size_t)Npl * 3; a += nbl;
     g.F = s->d_W.p; g.linR = g.F + nF; g.W = g.linR + nLinR; s->zW_off = nF + nLinR; s->zW_n = nWpl;

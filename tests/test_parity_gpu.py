@@ -701,7 +701,8 @@ def test_the_order_of_the_callers_edge_list_does_not_matter(hip):
     assert abs(a["iters"][-1]["chi2_after"] - b["iters"][-1]["chi2_after"]) <= 1e-7 * a["iters"][-1]["chi2_after"]
     np.testing.assert_allclose(rp.pose_qt, rq.pose_qt, atol=2e-6)
     np.testing.assert_allclose(rp.point_xyz, rq.point_xyz, atol=1e-5)
-    np.testing.assert_allclose(rp.mono_chi2[pm], rq.mono_chi2, rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose(rp.stereo_chi2[ps], rq.stereo_chi2, rtol=1e-5, atol=1e-7)
+    # (the estimates differ by the round-off above, and a residual of 0.1 px moves by 1e-3 relative when its point moves by 1e-6 m)
+    np.testing.assert_allclose(rp.mono_chi2[pm], rq.mono_chi2, rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(rp.stereo_chi2[ps], rq.stereo_chi2, rtol=2e-3, atol=1e-4)
     assert np.mean(rp.mono_level[pm] != rq.mono_level) < 1e-4 and np.mean(rp.stereo_level[ps] != rq.stereo_level) < 1e-4
     sp.close(); sq.close()
