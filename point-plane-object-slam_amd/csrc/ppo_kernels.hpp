@@ -223,7 +223,7 @@ __device__ __forceinline__ void block_atomic_add(const Graph& g, double v, int w
 #endif
     if (t != 0.0) acc_add(g, dst, t);
   }
-  __syncthreads();
+  // (no barrier behind it: every caller ends with this call, nothing reuses s_red)
 }
 __device__ __forceinline__ void atomic_max_pos(double* dst, double v) {  // v >= 0: IEEE order == integer order
   atomicMax(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v));
@@ -707,9 +707,8 @@ struct NumericShape {
   static constexpr int EPB = 4 * EPW;               // edges per 256-thread workgroup
 };
 // (a, c) of the packed lower-triangle index k = a (a + 1) / 2 + c
-__device__ __forceinline__ void unpack_lower(int k, int& a, int& c) {
-  a = 0;
-  while ((a + 1) * (a + 2) / 2 <= k) ++a;
+__device__ __forceinline__ void unpack_lower(int k, int& a, int& c) {  // (closed form: no data-dependent loop, the lanes of a wave stay together)
+  a = (int)((__fsqrt_rn(8.0f * (float)k + 1.0f) - 1.0f) * 0.5f);  // exact for the k < 64 used here: 8k + 1 is a perfect square exactly at the row starts
   c = k - a * (a + 1) / 2;
 }
 // element (row, col) of J' (rho1 Omega) J and element row of -J' (rho1 Omega e) from the Jacobian staged in LDS ([r][column], 16 per row)
@@ -793,25 +792,31 @@ __device__ __forceinline__ void lin_plane_body(const Graph& g, const State& st, 
 #endif
   if (act) {
     // 54 entries per edge: D_l (6, packed upper) | b_l (3) | pose block (21 packed lower + 6) | W (6 x 3)
+    // (written without branches on o: the 19 lanes of an edge sit in up to four of the segments at once)
     const PlaneEdge& ed = g.pl[i];
     const int l = g.n_points + ed.plane, fid = g.pose_free_id[ed.pose];
-    for (int o = lane; o < 54; o += LPE) {
-      if (o < 9) {
-        double* dst = o < 6 ? &g.D[(size_t)l * 6 + o] : &g.bl[(size_t)l * 3 + (o - 6)];
-        const int c = o < 3 ? 0 : (o < 5 ? 1 : 2), c2 = o < 3 ? o : (o < 5 ? o - 2 : 2);
-        acc_add(g, dst, o < 6 ? quad_H<DM>(sJ[grp], sW[grp], dim, c, c2) : quad_b<DM>(sJ[grp], sG[grp], dim, o - 6));
-      } else if (fid >= 0) {
-        if (o < 36) {
-          const int q = o - 9;
-          double v;
-          if (q < 21) { int a, c2; unpack_lower(q, a, c2); v = quad_H<DM>(sJ[grp], sW[grp], dim, 3 + a, 3 + c2); }
-          else v = quad_b<DM>(sJ[grp], sG[grp], dim, 3 + (q - 21));
-          acc_add(g, &g.HB[(size_t)fid * 27 + q], v);
-        } else if (ed.slot >= 0) {
-          const int q = o - 36;
-          acc_add(g, &g.W[(size_t)(ed.slot - g.n_pt_slots) * 18 + q], quad_H<DM>(sJ[grp], sW[grp], dim, 3 + q / 3, q % 3));
-        }
+    double* const pD = &g.D[(size_t)l * 6];
+    double* const pb = &g.bl[(size_t)l * 3];
+    double* const pH = &g.HB[(size_t)(fid >= 0 ? fid : 0) * 27];
+    double* const pW = &g.W[(size_t)(ed.slot >= 0 ? ed.slot - g.n_pt_slots : 0) * 18];
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+      const int o = lane + rd * LPE;
+      int qa, qc;
+      unpack_lower(o >= 9 && o < 30 ? o - 9 : 0, qa, qc);
+      // row / column of J' (rho1 Omega) J this entry is; isb: an entry of -J' (rho1 Omega e) instead
+      const int row = o < 3 ? 0 : o < 5 ? 1 : o < 6 ? 2 : o < 9 ? o - 6 : o < 30 ? 3 + qa : o < 36 ? 3 + (o - 30) : 3 + (o - 36) / 3;
+      const int col = o < 3 ? o : o < 5 ? o - 2 : o < 6 ? 2 : o < 9 ? 0 : o < 30 ? 3 + qc : o < 36 ? 0 : (o - 36) % 3;
+      const bool isb = (o >= 6 && o < 9) || (o >= 30 && o < 36);
+      double* const dst = o < 6 ? pD + o : o < 9 ? pb + (o - 6) : o < 36 ? pH + (o - 9) : pW + (o - 36);
+      const bool valid = o < 54 && (o < 9 || (fid >= 0 && (o < 36 || ed.slot >= 0)));
+      double h = 0;
+#pragma unroll
+      for (int r = 0; r < DM; ++r) {
+        const double x = sJ[grp][r][row], y = isb ? sG[grp][r] : sW[grp][r], z = isb ? 1.0 : sJ[grp][r][col];
+        if (r < dim) h += x * y * z;
       }
+      if (valid) acc_add(g, dst, h);
     }
   }
   LIN_STAMP(g, 3);
@@ -1823,6 +1828,25 @@ __global__ __launch_bounds__(256) void k_update_all(Graph g, State cur, State tr
   }
   if (b == up.nb_zero - 1)
     for (int i = threadIdx.x; i < up.ld; i += 256) up.bs[i] = 0.0;
+}
+
+// Pose-major static copies of the reprojection edges, expanded ON THE DEVICE from the landmark-major records and the index list the
+// host's bucket pass produced (ppo_ba_create): 4 bytes per edge cross the bus instead of a second 48 / 64-byte record.
+__global__ __launch_bounds__(256) void k_expand_pose_major(const MonoEdge* __restrict__ mono, const int32_t* __restrict__ mono_src, MonoEdgeP* __restrict__ monoP, int n_mono,
+                                                           const StereoEdge* __restrict__ stereo, const int32_t* __restrict__ stereo_src, StereoEdgeP* __restrict__ stereoP, int n_stereo) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_mono; q += stride) {
+    const int k = mono_src[q];
+    const MonoEdge m = mono[k];
+    monoP[q] = MonoEdgeP{m.u, m.v, m.info, m.huber, m.point, k, m.slot, 0};
+  }
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_stereo; q += stride) {
+    const int k = stereo_src[q];
+    const StereoEdge m = stereo[k];
+    StereoEdgeP e{};
+    e.u = m.u; e.v = m.v; e.ur = m.ur; e.info = m.info; e.huber = m.huber; e.point = m.point; e.eid = k; e.slot = m.slot;
+    stereoP[q] = e;
+  }
 }
 
 __global__ void k_pose_rt(State st, int n_poses) {  // derive rotation matrices after an upload

@@ -324,7 +324,8 @@ class HostTeam {
   }
 
  private:
-  static constexpr int kSpin = 4000;  // x ~40 ns
+  static constexpr int kSpin = 600;  // x ~40 ns.  (Kept short: a container with a CPU quota pays for every spinning thread, and long spins
+                                     // of 15 workers were measured as multi-millisecond throttling stalls inside ppo_ba_create.)
   static void relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
@@ -340,7 +341,7 @@ class HostTeam {
   };
   HostTeam() {
     unsigned hw = std::thread::hardware_concurrency();
-    int n = hw > 1 ? (int)std::min(hw - 1, 15u) : 0;  // (two jobs of 8 slices run side by side: edge records next to the pair plan)
+    int n = hw > 1 ? (int)std::min(hw - 1, 7u) : 0;
     if (const char* e = std::getenv("PPO_BA_HOST_THREADS")) n = std::max(0, std::min(atoi(e) - 1, 31));  // total threads a create may use
     for (int i = 0; i < n; ++i) workers_.emplace_back([this]() { loop(); });
   }

@@ -76,6 +76,7 @@ struct ppo_ba_solver {
   DevBuf<uint32_t> d_mono_flags, d_stereo_flags, d_mono_flags0, d_stereo_flags0;
   DevBuf<MonoEdgeP> d_monoP;
   DevBuf<StereoEdgeP> d_stereoP;
+  DevBuf<int32_t> d_monoP_src, d_stereoP_src;  // index lists the pose-major copies were expanded from (kept until destroy: the block cache is shared between streams)
   DevBuf<uint8_t> d_point_fixed, d_cub_flags;
   DevBuf<MonoEdge> d_mono;
   DevBuf<StereoEdge> d_stereo;
@@ -256,7 +257,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_pose_cam.release(); s->d_cub_fixedscale.release(); s->d_ptcub_pts.release();
   s->d_pose_col.release(); s->d_pose_free_id.release(); s->d_cub_col.release(); s->d_mo_off.release(); s->d_st_off.release();
   s->d_slot_col.release(); s->d_slot_lm.release(); s->d_pl_slot_off.release(); s->d_pl_slots.release();
-  s->d_mono_flags.release(); s->d_stereo_flags.release(); s->d_mono_flags0.release(); s->d_stereo_flags0.release(); s->d_monoP.release(); s->d_stereoP.release(); s->d_point_fixed.release(); s->d_cub_flags.release();
+  s->d_mono_flags.release(); s->d_stereo_flags.release(); s->d_mono_flags0.release(); s->d_stereo_flags0.release(); s->d_monoP.release(); s->d_stereoP.release(); s->d_monoP_src.release(); s->d_stereoP_src.release(); s->d_point_fixed.release(); s->d_cub_flags.release();
   s->d_mono.release(); s->d_stereo.release(); s->d_pl.release(); s->d_bbox.release(); s->d_corner.release(); s->d_ptcub.release();
   s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
@@ -812,8 +813,17 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // ---- which vertices enter the reduced system: non-fixed and touched by at least one edge -----------
   SVec<uint8_t> pose_used(Np, 0), cub_used(Nc, 0), point_fixed(Npt, 0);
   if (p->point_fixed) std::copy(p->point_fixed, p->point_fixed + Npt, point_fixed.begin());
-  for (int e = 0; e < p->n_mono; ++e) pose_used[p->mono_pose[e]] = 1;
-  for (int e = 0; e < p->n_stereo; ++e) pose_used[p->stereo_pose[e]] = 1;
+  {  // (the reprojection edges in slices on the host team, one private mark array per slice)
+    auto mark_poses = [&](const int32_t* pose, int n) {
+      HostTeam& tm = HostTeam::get();
+      const int nt = n >= (1 << 16) ? std::min(tm.size(), 8) : 1;
+      std::vector<std::vector<uint8_t>> local(nt, std::vector<uint8_t>(Np, 0));
+      tm.run(nt, [&](int t) { uint8_t* u = local[t].data(); for (int e = (int)((long)n * t / nt); e < (int)((long)n * (t + 1) / nt); ++e) u[pose[e]] = 1; });
+      for (int t = 0; t < nt; ++t) for (int i = 0; i < Np; ++i) pose_used[i] |= local[t][i];
+    };
+    mark_poses(p->mono_pose, p->n_mono);
+    mark_poses(p->stereo_pose, p->n_stereo);
+  }
   for (int e = 0; e < p->n_plane_edges; ++e) pose_used[p->pl_pose[e]] = 1;
   for (int e = 0; e < p->n_bbox; ++e) { pose_used[p->bbox_pose[e]] = 1; cub_used[p->bbox_cuboid[e]] = 1; }
   for (int e = 0; e < p->n_corner; ++e) { pose_used[p->corner_pose[e]] = 1; cub_used[p->corner_cuboid[e]] = 1; }
@@ -1128,34 +1138,24 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   bool ok = s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream);
   // ---- pose-major static copies of the owned reprojection edges + chunks (pose side of the linearisation) -----------
   SVec<int32_t> po_start, po_end, po_pose;
-  SVec<MonoEdgeP> h_monoP;
-  SVec<StereoEdgeP> h_stereoP;
+  SVec<int32_t> monoP_src, stereoP_src;  // position in the landmark-major array of the pose-major copy's q-th edge (expanded on the device)
   {
     const int chunk = []() { const char* e = PPO_DEV_ENV("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     auto build = [&](int type) {
       SVec<int32_t> cnt;
       const SVec<int32_t>& off = type == 0 ? mo_off : st_off;
+      SVec<int32_t>& src = type == 0 ? monoP_src : stereoP_src;
       auto pose_of = [&](int k) { return type == 0 ? s->h_mono[k].pose : s->h_stereo[k].pose; };
       bucket_by_key(g.pt_last - g.pt_first, Np, cnt,
                     [&](int u0, int u1, int32_t* h) {
                       for (int k = off[g.pt_first + u0]; k < off[g.pt_first + u1]; ++k)
                         if (pose_free_id[pose_of(k)] >= 0) h[pose_of(k)]++;
                     },
-                    [&](int32_t total) { if (type == 0) h_monoP.resize(total); else h_stereoP.resize(total); },
+                    [&](int32_t total) { src.resize(total); },
                     [&](int u0, int u1, int32_t* c) {
                       for (int k = off[g.pt_first + u0]; k < off[g.pt_first + u1]; ++k) {
                         const int pose = pose_of(k);
-                        if (pose_free_id[pose] < 0) continue;
-                        const int q = c[pose]++;
-                        if (type == 0) {
-                          const MonoEdge& m = s->h_mono[k];
-                          h_monoP[q] = MonoEdgeP{m.u, m.v, m.info, m.huber, m.point, k, m.slot, 0};
-                        } else {
-                          const StereoEdge& m = s->h_stereo[k];
-                          StereoEdgeP e{};
-                          e.u = m.u; e.v = m.v; e.ur = m.ur; e.info = m.info; e.huber = m.huber; e.point = m.point; e.eid = k; e.slot = m.slot;
-                          h_stereoP[q] = e;
-                        }
+                        if (pose_free_id[pose] >= 0) src[c[pose]++] = k;
                       }
                     });
       for (int i = 0; i < Np; ++i)
@@ -1168,7 +1168,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     build(0);
     build(1);
   }
-  ok = ok && s->d_monoP.upload(h_monoP, s->stream) && s->d_stereoP.upload(h_stereoP, s->stream);
+  ok = ok && s->d_monoP_src.upload(monoP_src, s->stream) && s->d_stereoP_src.upload(stereoP_src, s->stream);
+  ok = ok && s->d_monoP.alloc(monoP_src.size()) && s->d_stereoP.alloc(stereoP_src.size());
+  if (ok && monoP_src.size() + stereoP_src.size() > 0)
+    hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(monoP_src.size(), stereoP_src.size()), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
+                       s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)monoP_src.size(), s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)stereoP_src.size());
   SVec<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
   parallel_for(p->n_mono, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) h_mono_flags[k] = s->h_mono[k].flags; });
   parallel_for(p->n_stereo, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) h_stereo_flags[k] = s->h_stereo[k].flags; });
