@@ -69,8 +69,18 @@ def cpu_baseline_openmp(P, B, seconds_budget=6.0):
     path = os.path.join(REPO, "oracle", "libppo_oracle_omp.so")
     if not os.path.exists(path):
         return None
-    threads = max(1, min(32, os.cpu_count() or 1))
+    # (a container's CPU quota, not the number of logical CPUs it can see, is what the threads share: 32 spinning OpenMP threads
+    #  under a 16-CPU quota ran this oracle seven times SLOWER than one thread)
+    quota = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    threads = max(1, min(8, os.cpu_count() or 1, quota))
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     be = B._Backend(C.CDLL(path), "oracle_ba_")
     s = be.create(P, B.default_options())
     iters = calls = 0

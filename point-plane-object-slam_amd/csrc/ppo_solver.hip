@@ -947,6 +947,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       seg_cnt[l] = (int32_t)(std::unique(b0, q) - b0);
     }
   });
+  mark("  slots: gather + sort + unique");
   SVec<int32_t>& slot_off = s->h_slot_off;
   slot_off.assign(g.n_lm + 1, 0);
   for (int l = 0; l < g.n_lm; ++l) slot_off[l + 1] = slot_off[l] + seg_cnt[l];
@@ -957,6 +958,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     for (int l = l0; l < l1; ++l)
       for (int k = 0; k < seg_cnt[l]; ++k) { slot_col[slot_off[l] + k] = seg_col[seg_off[l] + k]; slot_lm[slot_off[l] + k] = l; }
   });
+  mark("  slots: compact");
   // device numbering is POSE-MAJOR: point slots ordered by (pose column, point), then plane slots by (pose column, plane),
   // so that everything a keyframe touches is contiguous (the pose side of the linearisation and the Schur pair kernel stream it)
   const int n_point_slots = slot_off[Npt];
@@ -1168,6 +1170,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     build(0);
     build(1);
   }
+  mark("  pose-major index lists");
   ok = ok && s->d_monoP_src.upload(monoP_src, s->stream) && s->d_stereoP_src.upload(stereoP_src, s->stream);
   ok = ok && s->d_monoP.alloc(monoP_src.size()) && s->d_stereoP.alloc(stereoP_src.size());
   if (ok && monoP_src.size() + stereoP_src.size() > 0)
@@ -1177,6 +1180,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   parallel_for(p->n_mono, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) h_mono_flags[k] = s->h_mono[k].flags; });
   parallel_for(p->n_stereo, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) h_stereo_flags[k] = s->h_stereo[k].flags; });
 
+  mark("  flags");
   // ---- cuboid elimination plan: edges per cuboid and all (a >= b) pairs of them -----------------------------------------
   SVec<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cp_cub, cp_a, cp_b;
   {
