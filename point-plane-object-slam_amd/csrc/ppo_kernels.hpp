@@ -209,6 +209,19 @@ __device__ __forceinline__ void fold_acc_parts(double* acc, int det) {
   p[0] = 0.0;
   p[1] = 0.0;
 }
+__device__ __forceinline__ void lds_wave_fence() {  // make this wave's LDS writes visible to its own other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// one atomic per WAVE, no barrier: waves that are done leave (their slots free up for the workgroups still queued)
+__device__ __forceinline__ void wave_atomic_add(const Graph& g, double v, int which) {
+  v = wave_sum(v);
+#ifdef PPO_BA_TEST_HOOKS
+  if (g.dbg & 4) v = 0.0;
+#endif
+  if ((threadIdx.x & 63) == 0 && v != 0.0) acc_add(g, acc_part(g, which, 17u * (threadIdx.x >> 6)), v);
+}
 __device__ __forceinline__ void block_atomic_add(const Graph& g, double v, int which, double* s_red) {
   double* const dst = acc_part(g, which, 0);
   v = wave_sum(v);
@@ -347,7 +360,8 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
       for (int k = 0; k < 3; ++k) g.bl[(size_t)p * 3 + k] = bl[k];
     }
   }
-  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
+  (void)s_red;
+  wave_atomic_add(g, chi_local, ACC_CHI2);
 }
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
@@ -785,7 +799,9 @@ __device__ __forceinline__ void lin_plane_body(const Graph& g, const State& st, 
         if (r < dim) { sW[grp][r] = rho1 * m.info(i, r); sG[grp][r] = -(m.info(i, r) * eo[r]) * rho1; }
     }
   }
-  __syncthreads();
+  // (the three edges of a wave stage their Jacobians for lanes of the SAME wave: a wave-local fence, no workgroup barrier -- the
+  //  waves of a plane workgroup finish their residual chains up to 4 us apart, tools/lin_stamps.py)
+  lds_wave_fence();
   LIN_STAMP(g, 2);
 #ifdef PPO_BA_TEST_HOOKS
   if (!(g.dbg & 1))
@@ -820,7 +836,8 @@ __device__ __forceinline__ void lin_plane_body(const Graph& g, const State& st, 
     }
   }
   LIN_STAMP(g, 3);
-  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
+  (void)s_red;
+  wave_atomic_add(g, chi_local, ACC_CHI2);
   LIN_STAMP(g, 4);
 }
 

@@ -1011,9 +1011,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     t_stage = s->stage;
     const int chunk = []() { const char* e = PPO_DEV_ENV("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
     const long nkeys = (long)nfree * (nfree + 1) / 2;
-    SVec<int32_t> slot_pose(g.n_slots);
-    for (int i = 0; i < g.n_slots; ++i) slot_pose[i] = slot_col[i] / 6;
-    auto key_of = [&](int a, int b) { const long pj = slot_pose[a], pi = slot_pose[b]; return pj * (pj + 1) / 2 + pi; };
+    // (slot_col is a multiple of 6: pose = col / 6; the row base pj (pj + 1) / 2 of a pair key is looked up per a, not per pair)
+    SVec<int32_t> row_base(nfree + 1);
+    for (long pj = 0; pj <= nfree; ++pj) row_base[pj] = (int32_t)(pj * (pj + 1) / 2);
     // owned landmarks as one unit range: points [pt_first, pt_last) then planes [plane_first, plane_last)
     const int n_own_pt = g.pt_last - g.pt_first, n_own = n_own_pt + (g.plane_last - g.plane_first);
     auto lm_of = [&](int u) { return u < n_own_pt ? g.pt_first + u : Npt + g.plane_first + (u - n_own_pt); };
@@ -1022,21 +1022,26 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                   [&](int u0, int u1, int32_t* h) {
                     for (int u = u0; u < u1; ++u) {
                       const int l = lm_of(u);
-                      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
-                        for (int b = slot_off[l]; b <= a; ++b) h[key_of(a, b)]++;
+                      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a) {
+                        int32_t* const hr = h + row_base[slot_col[a] / 6];
+                        for (int b = slot_off[l]; b <= a; ++b) hr[slot_col[b] / 6]++;
+                      }
                     }
                   },
                   [&](int32_t total) { pc_sj.resize(total); pc_si.resize(total); pc_lm.resize(total); },
                   [&](int u0, int u1, int32_t* c) {
                     for (int u = u0; u < u1; ++u) {
                       const int l = lm_of(u);
-                      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a)
+                      for (int a = slot_off[l]; a < slot_off[l + 1]; ++a) {
+                        int32_t* const cr = c + row_base[slot_col[a] / 6];
+                        const int32_t ida = new_id[a];
                         for (int b = slot_off[l]; b <= a; ++b) {
-                          const int32_t pos = c[key_of(a, b)]++;
-                          pc_sj[pos] = new_id[a];
+                          const int32_t pos = cr[slot_col[b] / 6]++;
+                          pc_sj[pos] = ida;
                           pc_si[pos] = new_id[b];
                           pc_lm[pos] = l;
                         }
+                      }
                     }
                   });
     pc_start.push_back(0);
@@ -1056,6 +1061,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     team.run(nt, [&](int t) { body((int)((long)n * t / nt), (int)((long)n * (t + 1) / nt)); });
   };
   s->h_mono.resize(p->n_mono);
+  SVec<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
+  SVec<int32_t> mono_pose_k(p->n_mono), stereo_pose_k(p->n_stereo);  // pose of the k-th record, compact (the pose-major bucket passes below read it)
   parallel_for(p->n_mono, [&](int k0, int k1) {
   for (int k = k0; k < k1; ++k) {
     const int e = s->mono_perm[k];
@@ -1066,6 +1073,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     const bool all_fixed = point_fixed[p->mono_point[e]] && pose_col[m.pose] < 0;
     m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
     m.point = p->mono_point[e];
+    h_mono_flags[k] = m.flags;
+    mono_pose_k[k] = m.pose;
   }
   });
   s->h_stereo.resize(p->n_stereo);
@@ -1081,6 +1090,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     m.slot = point_fixed[p->stereo_point[e]] ? -1 : find_slot(p->stereo_point[e], pose_col[m.pose]);
     const bool all_fixed = point_fixed[p->stereo_point[e]] && pose_col[m.pose] < 0;
     m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
+    h_stereo_flags[k] = m.flags;
+    stereo_pose_k[k] = m.pose;
   }
   });
   mark("reprojection edge records");
@@ -1147,7 +1158,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       SVec<int32_t> cnt;
       const SVec<int32_t>& off = type == 0 ? mo_off : st_off;
       SVec<int32_t>& src = type == 0 ? monoP_src : stereoP_src;
-      auto pose_of = [&](int k) { return type == 0 ? s->h_mono[k].pose : s->h_stereo[k].pose; };
+      const int32_t* const pose_k = type == 0 ? mono_pose_k.data() : stereo_pose_k.data();
+      auto pose_of = [&](int k) { return pose_k[k]; };
       bucket_by_key(g.pt_last - g.pt_first, Np, cnt,
                     [&](int u0, int u1, int32_t* h) {
                       for (int k = off[g.pt_first + u0]; k < off[g.pt_first + u1]; ++k)
@@ -1176,9 +1188,6 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (ok && monoP_src.size() + stereoP_src.size() > 0)
     hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(monoP_src.size(), stereoP_src.size()), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
                        s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)monoP_src.size(), s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)stereoP_src.size());
-  SVec<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
-  parallel_for(p->n_mono, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) h_mono_flags[k] = s->h_mono[k].flags; });
-  parallel_for(p->n_stereo, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) h_stereo_flags[k] = s->h_stereo[k].flags; });
 
   mark("  flags");
   // ---- cuboid elimination plan: edges per cuboid and all (a >= b) pairs of them -----------------------------------------
