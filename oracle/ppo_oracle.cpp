@@ -99,7 +99,10 @@ struct Oracle {
   std::vector<double> S, bs, x, coeff, Dinv;  // Schur workspace; x is n_red + 3 n_lm
   std::vector<double> diag_backup_p, diag_backup_l;
   bool do_schur = false;
-  int variant = 0;  // test aid (oracle_ba_set_variant): 1 = edges and landmarks summed in REVERSE order (nothing else changes)
+  int variant = 0;  // test aid (oracle_ba_set_variant): 1 = edges and landmarks summed in REVERSE order (nothing else changes);
+                    // 2 = the long sums (pose blocks of Hpp, b, the Schur complement S and its right-hand side) accumulated with a
+                    // compensation term each (Neumaier's two-sum: the result a wider accumulator would give, rounded once at the end)
+  std::vector<double> Hpp_c, b_c, S_c, coeff_c;  // compensation terms of variant 2
   bool only_pose = false;  // the unary Edge*SE3ProjectXYZOnlyPose flavour of the reprojection edges (pose-only optimisation)
   // ---- LM ----
   double lambda = -1, ni = 2;
@@ -509,6 +512,13 @@ double active_robust_chi2(const Oracle& o) {
 }
 
 inline double& HPP(Oracle& o, int r, int c) { return o.Hpp[(size_t)c * o.n_red + r]; }
+// s += v, with the rounding error collected in c when the compensated variant is on
+inline void acc_comp(bool on, double& s, double& c, double v) {
+  if (!on) { s += v; return; }
+  const double t = s + v;
+  c += (std::fabs(s) >= std::fabs(v)) ? (s - t) + v : (v - t) + s;
+  s = t;
+}
 
 // BlockSolver::buildSystem, block_solver.hpp:502-560 with constructQuadraticForm of
 // base_binary_edge.hpp:55-120 / base_unary_edge.hpp:43-72.
@@ -517,6 +527,9 @@ void build_system(Oracle& o) {
   std::fill(o.Hll.begin(), o.Hll.end(), 0.0);
   std::fill(o.hpl.begin(), o.hpl.end(), 0.0);
   std::fill(o.b.begin(), o.b.end(), 0.0);
+  const bool comp = o.variant == 2;
+  if (comp) { o.Hpp_c.assign(o.Hpp.size(), 0.0); o.b_c.assign(o.b.size(), 0.0); }
+  double dummy = 0.0;
   double J0[kMaxDim * 9], J1[kMaxDim * 9];
   const size_t na = o.active.size();
   for (size_t k = 0; k < na; ++k) {
@@ -563,11 +576,11 @@ void build_system(Oracle& o) {
         for (int a = 0; a < d; ++a) {
           double sb = 0;
           for (int r = 0; r < dim; ++r) sb += J[r * d + a] * omega_r[r];
-          o.b[c0 + a] += sb;
+          acc_comp(comp, o.b[c0 + a], comp ? o.b_c[c0 + a] : dummy, sb);
           for (int c = 0; c < d; ++c) {
             double s = 0;
             for (int r = 0; r < dim; ++r) s += J[r * d + a] * w[r] * J[r * d + c];
-            HPP(o, c0 + a, c0 + c) += s;
+            acc_comp(comp, HPP(o, c0 + a, c0 + c), comp ? o.Hpp_c[(size_t)(c0 + c) * o.n_red + c0 + a] : dummy, s);
           }
         }
       }
@@ -596,6 +609,10 @@ void build_system(Oracle& o) {
       // E_CUBPL: cuboid x plane block exists structurally in g2o but its Jacobians are identically zero
       // (constant error differentiated numerically), so nothing is accumulated.
     }
+  }
+  if (comp) {
+    for (size_t i = 0; i < o.Hpp.size(); ++i) o.Hpp[i] += o.Hpp_c[i];
+    for (size_t i = 0; i < o.b.size(); ++i) o.b[i] += o.b_c[i];
   }
 }
 
@@ -765,6 +782,9 @@ bool block_solve(Oracle& o) {
   if (!o.do_schur) return dense_solve(o, o.Hpp, o.b.data(), o.x.data());
   o.S = o.Hpp;
   std::fill(o.coeff.begin(), o.coeff.begin() + n, 0.0);
+  const bool comp = o.variant == 2;
+  if (comp) { o.S_c.assign(o.S.size(), 0.0); o.coeff_c.assign(o.coeff.size(), 0.0); }
+  double dummy = 0.0;
   for (int lk = 0; lk < o.n_lm; ++lk) {
     const int l = o.variant == 1 ? o.n_lm - 1 - lk : lk;
     double* Dinv = &o.Dinv[(size_t)9 * l];
@@ -779,15 +799,20 @@ bool block_solve(Oracle& o) {
       for (int a = 0; a < 6; ++a)
         for (int c = 0; c < 3; ++c)
           BDinv[a * 3 + c] = Bi[a * 3] * Dinv[c] + Bi[a * 3 + 1] * Dinv[3 + c] + Bi[a * 3 + 2] * Dinv[6 + c];
-      for (int a = 0; a < 6; ++a) o.coeff[r0 + a] += Bi[a * 3] * db[0] + Bi[a * 3 + 1] * db[1] + Bi[a * 3 + 2] * db[2];
+      for (int a = 0; a < 6; ++a) acc_comp(comp, o.coeff[r0 + a], comp ? o.coeff_c[r0 + a] : dummy, Bi[a * 3] * db[0] + Bi[a * 3 + 1] * db[1] + Bi[a * 3 + 2] * db[2]);
       for (int s2 = s1; s2 < o.hpl_start[l + 1]; ++s2) {
         const double* Bj = &o.hpl[(size_t)18 * s2];
         const int c0 = o.red_col0[o.hpl_rb[s2]];
         for (int a = 0; a < 6; ++a)
           for (int c = 0; c < 6; ++c)
-            o.S[(size_t)(c0 + c) * n + r0 + a] -= BDinv[a * 3] * Bj[c * 3] + BDinv[a * 3 + 1] * Bj[c * 3 + 1] + BDinv[a * 3 + 2] * Bj[c * 3 + 2];
+            acc_comp(comp, o.S[(size_t)(c0 + c) * n + r0 + a], comp ? o.S_c[(size_t)(c0 + c) * n + r0 + a] : dummy,
+                     -(BDinv[a * 3] * Bj[c * 3] + BDinv[a * 3 + 1] * Bj[c * 3 + 1] + BDinv[a * 3 + 2] * Bj[c * 3 + 2]));
       }
     }
+  }
+  if (comp) {
+    for (size_t i = 0; i < o.S.size(); ++i) o.S[i] += o.S_c[i];
+    for (int i = 0; i < n; ++i) o.coeff[i] += o.coeff_c[i];
   }
   for (int i = 0; i < n; ++i) o.bs[i] = o.b[i] - o.coeff[i];
   if (!dense_solve(o, o.S, o.bs.data(), o.x.data())) return false;
@@ -1093,7 +1118,7 @@ void oracle_ba_destroy(oracle_handle o) { delete o; }
 // order.  The algorithm, every formula and every input are unchanged; only the order of the floating-point additions differs --
 // the freedom g2o itself has (std::map<KeyFrame*, ...> pointer order, Optimizer.cc:2350).
 int oracle_ba_set_variant(oracle_handle o, int variant) {
-  if (!o || variant < 0 || variant > 1) return PPO_BA_ERR_ARG;
+  if (!o || variant < 0 || variant > 2) return PPO_BA_ERR_ARG;
   o->variant = variant;
   return PPO_BA_OK;
 }

@@ -5,6 +5,8 @@ Three re-runs of the oracle on the same graph:
                 g2o itself has that freedom (edge order follows std::map<KeyFrame*, ...> pointer order, Optimizer.cc:2350)
   fma           the same source compiled with floating-point contraction allowed (oracle/libppo_oracle_fma.so)
   fma+reversed  both
+  compensated   the long sums (pose blocks of Hpp, b, the Schur complement and its right-hand side) carried with a compensation
+                term each -- oracle_ba_set_variant(2): what accumulation in a wider type (long double) would give
 The spread between those runs is the accuracy to which the reference's result is DEFINED on that graph; a parity bar below
 it cannot be met by any second implementation, the reference compiled with another compiler included.
 """
@@ -43,7 +45,7 @@ def oracle_runs(oracle, P, opt, variants=("reversed", "fma", "fma+reversed")):
     out = [run(oracle, P, opt)]
     for v in variants:
         be = fma_backend() if v.startswith("fma") else oracle
-        out.append(run(be, P, opt, 1 if v.endswith("reversed") else 0))
+        out.append(run(be, P, opt, 2 if v == "compensated" else (1 if v.endswith("reversed") else 0)))
     return out
 
 

@@ -67,11 +67,33 @@ def test_oracle_self_sensitivity_on_the_windows_outside_the_bar(oracle):
     assert chatter <= 8
 
 
+def test_wider_accumulation_moves_the_sensitive_windows_like_a_change_of_summation_order(oracle):
+    """The other half of the question "summation order or arithmetic?": the oracle with its long sums carried in (effectively)
+    twice the precision -- oracle_ba_set_variant(2), Neumaier-compensated accumulation of Hpp, b, S and the Schur right-hand side
+    -- against the plain oracle, on the first flagged windows.  The exact-sum result is as far from the plain run as the reversed-
+    order run is: the plain double-precision result carries that much rounding, whichever order it is summed in."""
+    rs = _random_sweep()
+    ratios = []
+    for c in FLAGGED[:10]:
+        cfg, kw, elim = rs.random_case(c["seed"])
+        P = synth.make_problem(cfg, **kw)
+        runs = S.oracle_runs(oracle, P, B.default_options(eliminate_cuboids=elim), variants=("reversed", "compensated"))
+        if any(S.schedule(st) != S.schedule(runs[0][0]) for st, _ in runs[1:]):
+            continue  # an accept / reject decision flipped: the runs are not comparable quantity by quantity
+        rev, comp = S.metrics(runs[0][1], runs[1][1]), S.metrics(runs[0][1], runs[2][1])
+        for k in S.BARS:
+            if max(rev[k], comp[k]) > 1e-9:
+                ratios.append(comp[k] / max(rev[k], 1e-300))
+    r = np.array(ratios)
+    assert len(r) >= 10
+    assert 0.02 < np.median(r) < 50, np.sort(r)  # the same order of magnitude, not zero and not dominant
+
+
 def test_points_only_windows_repeat_to_rounding(oracle):
     """Control: with analytic Jacobians only (BASELINE config 2 shape) the same re-runs agree to 1e-10 -- the summation order is
     not what moves the windows above; the delta = 1e-9 differencing of the plane / cuboid edges amplifies it."""
     P = synth.make_problem(dict(n_kf=12, n_points=400, n_planes=0, n_cuboids=0), seed=6)
-    runs = S.oracle_runs(oracle, P, B.default_options())
+    runs = S.oracle_runs(oracle, P, B.default_options(), variants=("reversed", "fma", "fma+reversed", "compensated"))
     m, _, _ = S.spread(runs)
     assert max(m.values()) < 1e-10, m
     assert all(S.schedule(st) == S.schedule(runs[0][0]) for st, _ in runs)
