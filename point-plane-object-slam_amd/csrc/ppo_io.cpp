@@ -115,15 +115,19 @@ int ppo_ba_problem_load(const char* path, ppo_ba_problem** out) {
   Loaded* L = new Loaded();
   std::memset(&L->p, 0, sizeof(L->p));
   auto fail = [&](int code) {
-    std::fclose(f);
+    if (f) std::fclose(f);
+    f = nullptr;
     for (void* b : L->blocks) std::free(b);
     delete L;
     return code;
   };
+  // a record can never be larger than what is left of the file: a corrupt count must not turn into a multi-gigabyte allocation
+  long file_bytes = 0;
+  if (std::fseek(f, 0, SEEK_END) != 0 || (file_bytes = std::ftell(f)) < 0 || std::fseek(f, 0, SEEK_SET) != 0) return fail(PPO_BA_ERR_ARG);
   std::vector<std::pair<std::string, uint64_t>> loaded_counts;
   char magic[8];
   uint32_t n_rec = 0;
-  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "PPOBA001", 8) != 0 || std::fread(&n_rec, 4, 1, f) != 1) return fail(PPO_BA_ERR_ARG);
+  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "PPOBA001", 8) != 0 || std::fread(&n_rec, 4, 1, f) != 1 || n_rec > 4096) return fail(PPO_BA_ERR_ARG);
   for (uint32_t r = 0; r < n_rec; ++r) {
     uint32_t len = 0, dtype = 0;
     uint64_t count = 0;
@@ -132,6 +136,8 @@ int ppo_ba_problem_load(const char* path, ppo_ba_problem** out) {
     if (len && std::fread(&name[0], 1, len, f) != len) return fail(PPO_BA_ERR_ARG);
     if (std::fread(&dtype, 4, 1, f) != 1 || dtype > 2 || std::fread(&count, 8, 1, f) != 1 || count > (1ull << 33)) return fail(PPO_BA_ERR_ARG);
     const size_t bytes = (size_t)count * kElem[dtype];
+    const long here = std::ftell(f);
+    if (here < 0 || bytes > (size_t)(file_bytes - here)) return fail(PPO_BA_ERR_ARG);
     void* block = std::malloc(bytes ? bytes : 1);
     if (!block) return fail(PPO_BA_ERR_NOMEM);
     L->blocks.push_back(block);
@@ -151,20 +157,21 @@ int ppo_ba_problem_load(const char* path, ppo_ba_problem** out) {
     (void)used;  // unknown records are kept allocated and ignored
   }
   std::fclose(f);
+  f = nullptr;
   // consistency: every present array must have exactly the length its count implies (a truncated or foreign file must not
   // turn into out-of-bounds reads inside ppo_ba_create)
   for (const Count& c : kCounts)
-    if (count_of(&L->p, c.off) < 0) { f = std::fopen(path, "rb"); return fail(PPO_BA_ERR_ARG); }
+    if (count_of(&L->p, c.off) < 0) return fail(PPO_BA_ERR_ARG);
   for (const Field& fd : kFields) {
     if (!ptr_of(&L->p, fd.ptr_off)) continue;
     uint64_t have = 0;
     for (const auto& lc : loaded_counts)
       if (lc.first == fd.name) have = lc.second;
-    if (have != field_count(&L->p, fd)) { f = std::fopen(path, "rb"); return fail(PPO_BA_ERR_ARG); }
+    if (have != field_count(&L->p, fd)) return fail(PPO_BA_ERR_ARG);
   }
   if (L->p.n_ptcub == 0 && !L->p.ptcub_offsets) {  // the ABI wants a valid offsets array even when it is empty
     int32_t* z = static_cast<int32_t*>(std::calloc(1, sizeof(int32_t)));
-    if (!z) return PPO_BA_ERR_NOMEM;
+    if (!z) return fail(PPO_BA_ERR_NOMEM);
     L->blocks.push_back(z);
     L->p.ptcub_offsets = z;
   }

@@ -748,6 +748,8 @@ int optimize(ppo_ba_solver* s, int pass, int iterations, const volatile uint8_t*
 }  // namespace
 
 // ================================================================================================
+static thread_local ppo_ba_solver* t_creating = nullptr;  // the solver ppo_ba_create is building on this thread
+
 extern "C" {
 
 int ppo_ba_version(void) { return PPO_BA_ABI_VERSION; }
@@ -771,11 +773,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (o->device_id < 0 || o->device_id >= ndev) return PPO_BA_ERR_ARG;
   ppo_ba_solver* s = new (std::nothrow) ppo_ba_solver();
   if (!s) return PPO_BA_ERR_NOMEM;
+  t_creating = s;  // (the handler of this function's try block tears it down if a staging vector throws)
   s->opt = *o;
   s->device = o->device_id;
   s->stage = new Stage();
   StageScope stage_scope(s->stage, false);  // what create builds stays until destroy: the uploads below read it asynchronously
-  auto fail = [&](int code) { free_all(s); delete s; return code; };
+  auto fail = [&](int code) { t_creating = nullptr; free_all(s); delete s; return code; };
   if (hipSetDevice(s->device) != hipSuccess) return fail(PPO_BA_ERR_HIP);
   {
     int ncu = 0;  // (hipGetDeviceProperties fills a large structure and costs more than a millisecond)
@@ -1007,7 +1010,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // ---- Schur accumulation plan: (slot_j, slot_i) pairs of every owned landmark filed by pose pair, then chunked -----
   // (built on a helper thread while this one fills the edge records: both are ~3 ms of host work at the BASELINE size)
   SVec<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si, pc_lm;
-  std::thread pair_plan_thread([&]()   {
+  std::atomic<bool> pair_plan_failed{false};
+  std::thread pair_plan_thread([&]() { try {
     t_stage = s->stage;
     const int chunk = []() { const char* e = PPO_DEV_ENV("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
     const long nkeys = (long)nfree * (nfree + 1) / 2;
@@ -1052,7 +1056,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
           pc_coli.push_back((int32_t)(6 * pi));
           pc_start.push_back(std::min<int32_t>(e + chunk, cnt[k + 1]));
         }
-  });
+  } catch (...) { pair_plan_failed.store(true); } });
+  struct JoinGuard {  // an exception on this thread (std::bad_alloc from a staging vector) must not meet a joinable std::thread
+    std::thread& t;
+    ~JoinGuard() { if (t.joinable()) t.join(); }
+  } pair_plan_guard{pair_plan_thread};
 
   // ---- edge records -----------------------------------------------------------------------------------------
   // (independent per edge: large blocks are filled by a few host threads; this was the longest phase of create)
@@ -1230,6 +1238,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   mark("pose-major copies, cuboid plan, state");
   pair_plan_thread.join();
+  if (pair_plan_failed.load()) return fail(PPO_BA_ERR_NOMEM);
   mark("pair plan join");
   // ---- uploads (the two big record arrays are already on their way) -----------------------------------------------------
   SVec<double> v_cam(p->pose_cam, p->pose_cam + (size_t)5 * Np);
@@ -1350,10 +1359,17 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     s->lin_bytes = 176L * p->n_mono + 184L * p->n_stereo + 208L * (p->n_plane_edges - n_vp) + 200L * n_vp + 576L * p->n_bbox + 768L * p->n_corner +
                    96L * Npt + 104L * Npl + 512L * Nc + 272L * nfree + 56L * n_fixed;
   }
+  t_creating = nullptr;
   *out = s;
   return PPO_BA_OK;
-} catch (const std::bad_alloc&) {  // (the half-built solver is leaked rather than torn down under an unknown state)
+} catch (const std::bad_alloc&) {  // (helper threads have been joined by their guards; device blocks, stream and staging go back to the caches)
   std::fprintf(stderr, "[ppo_ba] ppo_ba_create: out of host memory\n");
+  if (ppo_ba_solver* s = t_creating) {
+    t_creating = nullptr;
+    t_stage = nullptr;
+    free_all(s);
+    delete s;
+  }
   return PPO_BA_ERR_NOMEM;
 }
 

@@ -52,6 +52,12 @@ def test_truncated_and_foreign_files_are_rejected(tmp_path):
     open(bad, "wb").write(patched)
     with pytest.raises(IOError):
         B.Problem.load(bad)
+    # a record that claims more elements than the file has bytes left is refused BEFORE anything is allocated for it
+    j = raw.index(b"pose_qt") + len(b"pose_qt") + 4
+    huge = raw[:j] + np.uint64(1 << 32).tobytes() + raw[j + 8:]
+    open(bad, "wb").write(huge)
+    with pytest.raises(IOError):
+        B.Problem.load(bad)
     with pytest.raises(IOError):
         B.Problem.load(tmp_path / "does_not_exist.ppoba")
 
