@@ -145,7 +145,9 @@ template <int J, int C>
 struct ColUpdate {
   static __device__ __forceinline__ void run(double (&a)[SB], double (&e)[SB], double l, double le) {
     fmac_bcast<C, C == J + 1>(a[C], l, l);
+#ifndef PPO_CHOL_EXPERIMENT_NO_E  // (timing experiment of tools/run_chol_experiments.sh: wrong results, the sweep without its extra rows)
     fmac_bcast<C, false>(e[C], l, le);
+#endif
     if constexpr (C + 1 < SB) ColUpdate<J, C + 1>::run(a, e, l, le);
   }
 };

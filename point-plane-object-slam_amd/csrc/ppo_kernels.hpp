@@ -1555,10 +1555,10 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
 // (there is no stage 2 any more: it streamed Z = W L^-T to memory)
 // The cuboid parts are tiny; as separate kernels on a side stream their fork/join events cost more than they hid.
 struct ReducePlan {
-  int nb_asm, nb_prep, nb_cubprep;
+  int nb_asm, nb_prep, nb_cubprep, nb_zero;
   int nb_pairs, nb_cubschur;
 };
-__global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp) {
+__global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp, ZeroPlan zother) {
   int b = blockIdx.x;
   if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
   if (b == 0 && threadIdx.x == 2) g.acc[ACC_DETBAD] = 0.0;
@@ -1571,7 +1571,11 @@ __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, R
   if (b < rp.nb_cubprep) { cub_prep_body(g, lambda, b); return; }
   b -= rp.nb_cubprep;
   if (b < rp.nb_asm) { assemble_body(g, lambda, b); return; }
-  schur_prep_body(g, lambda, b - rp.nb_asm);
+  b -= rp.nb_asm;
+  if (b < rp.nb_prep) { schur_prep_body(g, lambda, b); return; }
+  b -= rp.nb_prep;
+  // the linearisation buffer that is NOT current (ppo_solver.hip, LinBuf): cleared here for the linearisation of the trial state
+  zero_ranges_body(zother, (size_t)b * 256 + threadIdx.x, (size_t)rp.nb_zero * 256);
 }
 __global__ __launch_bounds__(256) void k_reduce_stage3(Graph g, PairChunks pc, ReducePlan rp) {
   __shared__ double s_buf[4][21][65];

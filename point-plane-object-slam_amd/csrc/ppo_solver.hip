@@ -118,8 +118,17 @@ struct ppo_ba_solver {
   bool use_lds = true;
   int n_cu = 256;
   // memset plan for a linearisation: [HB|HC|acc] always, and the plane part of D/bl/W (accumulated with atomics)
-  size_t zero_head = 0;
-  size_t zD_off = 0, zD_n = 0, zbl_off = 0, zbl_n = 0, zW_off = 0, zW_n = 0;
+  // The accumulation targets of a linearisation (H_pp | H_cc, D_l, b_l, the planes' W) exist TWICE.  A linearisation always writes the
+  // buffer that is not current; the reduction of the next solve attempt clears the other one in its first launch.  That removes the
+  // clearing launch from between the update and the (speculated) linearisation of the trial state, and a rejected trial leaves the
+  // kept state's system untouched: switching back costs nothing (it used to cost a re-linearisation).
+  // (Everything a linearisation WRITES belongs to its buffer: besides the accumulation targets, the factor records of the point slots,
+  // the linearisation-point rotations and the pose-cuboid blocks of the cuboid projections, which are plain stores.)
+  struct LinBuf { double *HB, *HC, *D, *bl, *W, *F, *linR, *Wpc_bbox, *Wpc_corner; };
+  LinBuf lb[2] = {};
+  int lin_buf = 0;                       // the buffer s->g points at: the linearisation of the current estimate
+  bool lin_clean[2] = {false, false};    // all-zero accumulation ranges (ready to be linearised into)
+  size_t nHBC = 0, zD_n = 0, zbl_n = 0, zW_n = 0;  // doubles: H_pp | H_cc, the planes' part of D / b_l, the planes' W
   // LM state (levenberg.cpp:43-55)
   double lambda = -1, ni = 2;
   int nBad = 0;
@@ -327,6 +336,7 @@ State make_state(double* base, int np, int npt, int npl, int nc) {
 
 inline int nblk(long n, int b) { return (int)std::max<long>(1, (n + b - 1) / b); }
 
+void use_lin_buffer(ppo_ba_solver* s, int buf);
 int reset_device(ppo_ba_solver* s) {
   // edge flags back to "level 0, kernel on", estimates back to the inputs
   // (device-to-device from the pristine copies made at create: a reset never crosses PCIe)
@@ -351,7 +361,10 @@ int reset_device(ppo_ba_solver* s) {
   ZeroPlan zp{};
   zp.p[0] = s->d_chi2_all.p; zp.n[0] = s->d_chi2_all.n;
   zp.p[1] = s->d_arena.p; zp.n[1] = s->d_arena.n;
-  const size_t work = words + 2 * (zp.n[0] + zp.n[1]);
+  zp.p[2] = s->lb[0].W; zp.n[2] = 2 * s->zW_n;  // both copies of the planes' W
+  s->lin_clean[0] = s->lin_clean[1] = true;
+  use_lin_buffer(s, 0);
+  const size_t work = words + 2 * (zp.n[0] + zp.n[1] + zp.n[2]);
   hipLaunchKernelGGL(k_reset, dim3(std::min(nblk((long)work / 4, 256), 4 * s->n_cu)), dim3(256), 0, s->stream, cp, zp);
   HIP_TRY(hipGetLastError());
   s->cur = 0;
@@ -362,40 +375,53 @@ int reset_device(ppo_ba_solver* s) {
 }
 
 // ---- one linearisation of the current state: fills HB/HC/D/bl/W, per-edge chi2, acc[ACC_CHI2] ------------
-int launch_linearize_kernel(ppo_ba_solver* s, const State& st);
-ZeroPlan linearize_zero_plan(ppo_ba_solver* s, bool with_acc) {
-  double* A = s->d_arena.p;
+int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st);
+ZeroPlan linearize_zero_plan(ppo_ba_solver* s, int buf, bool with_acc) {
+  const ppo_ba_solver::LinBuf& b = s->lb[buf];
   ZeroPlan zp{};
-  zp.p[0] = A; zp.n[0] = with_acc ? s->zero_head : s->zero_head - ACC_TOTAL;  // HB | HC | acc (+ its partial sums)
-  zp.p[1] = A + s->zD_off; zp.n[1] = s->zD_n;
-  zp.p[2] = A + s->zbl_off; zp.n[2] = s->zbl_n;
-  zp.p[3] = s->d_W.p + s->zW_off; zp.n[3] = s->zW_n;
+  zp.p[0] = b.HB; zp.n[0] = s->nHBC;  // H_pp | H_cc
+  zp.p[1] = b.D + (size_t)s->g.n_points * 6; zp.n[1] = s->zD_n;
+  zp.p[2] = b.bl + (size_t)s->g.n_points * 3; zp.n[2] = s->zbl_n;
+  zp.p[3] = b.W; zp.n[3] = s->zW_n;
+  if (with_acc) { zp.p[4] = s->g.acc; zp.n[4] = ACC_TOTAL; }
   return zp;
 }
-
-int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool already_zeroed = false) {
-  const Graph& g = s->g;
+size_t zero_plan_doubles(const ZeroPlan& zp) { return zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3] + zp.n[4] + zp.n[5]; }
+void point_graph_at(Graph& g, const ppo_ba_solver::LinBuf& b) {
+  g.HB = b.HB; g.HC = b.HC; g.D = b.D; g.bl = b.bl; g.W = b.W;
+  g.F = b.F; g.linR = b.linR; g.Wpc_bbox = b.Wpc_bbox; g.Wpc_corner = b.Wpc_corner;
+}
+void use_lin_buffer(ppo_ba_solver* s, int buf) {
+  point_graph_at(s->g, s->lb[buf]);
+  s->lin_buf = buf;
+}
+// Linearise state `which_state` (default: the current estimate) into the buffer that is not current.  commit: that buffer becomes the
+// current one right away (the linearisation of the kept / initial state); otherwise the caller switches once the trial is accepted.
+// zero_acc: the chi2 / scale accumulators start from zero too (not for the speculated linearisation: the scale of the update is in there).
+int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool commit = true, bool zero_acc = true) {
   const State& st = s->st[which_state < 0 ? s->cur : which_state];
-  if (!already_zeroed) {
-    const ZeroPlan zp = linearize_zero_plan(s, true);
-    const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
-    hipLaunchKernelGGL(k_zero_ranges, dim3(std::min(nblk((long)tot / 2, 256), 2 * s->n_cu)), dim3(256), 0, s->stream, zp);
+  const int target = s->lin_buf ^ 1;
+  if (!s->lin_clean[target] || zero_acc) {
+    ZeroPlan zp = linearize_zero_plan(s, target, zero_acc);
+    if (s->lin_clean[target]) { zp.n[0] = zp.n[1] = zp.n[2] = zp.n[3] = 0; }  // only the accumulator block
+    hipLaunchKernelGGL(k_zero_ranges, dim3(std::max(1, std::min(nblk((long)zero_plan_doubles(zp) / 2, 256), 2 * s->n_cu))), dim3(256), 0, s->stream, zp);
   }
-  (void)g;
-  RC_TRY(launch_linearize_kernel(s, st));
+  Graph g = s->g;
+  point_graph_at(g, s->lb[target]);
+  RC_TRY(launch_linearize_kernel(s, g, st));
+  s->lin_clean[target] = false;
   if (g.det) {  // the ranges the launch summed into (H_pp | H_cc, the planes' D / b_l / W) back to doubles
-    const ZeroPlan zp = linearize_zero_plan(s, false);
-    const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
-    hipLaunchKernelGGL(k_fix_to_double, dim3(std::max(1, std::min(nblk((long)tot, 256), 2 * s->n_cu))), dim3(256), 0, s->stream, zp);
+    const ZeroPlan zp = linearize_zero_plan(s, target, false);
+    hipLaunchKernelGGL(k_fix_to_double, dim3(std::max(1, std::min(nblk((long)zero_plan_doubles(zp), 256), 2 * s->n_cu))), dim3(256), 0, s->stream, zp);
     s->acc_fixed = true;
   }
+  if (commit) use_lin_buffer(s, target);
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
 }
 
 // the fused linearisation launch alone (no zeroing): numeric edge classes | pose-major chunks | landmark-major points
-int launch_linearize_kernel(ppo_ba_solver* s, const State& st) {
-  const Graph& g = s->g;
+int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st) {
   LinPlan lp{};
   lp.nb[LIN_PLANE] = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, NumericShape<PlaneModel>::EPB) : 0;
   if (g.owns_reduced) {
@@ -481,7 +507,16 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
   rp.nb_cubprep = cub_stage ? nblk(g.n_cuboids, 256) : 0;
   rp.nb_pairs = (nl > 0 && s->pc.n_chunks > 0) ? (nblk(s->pc.n_chunks, 4) + 7) / 8 * 8 : 0;
   rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? (nblk((long)g.n_cub_pairs * 8, 256) + 7) / 8 * 8 : 0;  // (multiple of 8: see k_reduce_stage3)
-  hipLaunchKernelGGL(k_reduce_stage1, dim3(rp.nb_asm + rp.nb_prep + rp.nb_cubprep), dim3(256), 0, s->stream, g, lambda, rp);
+  // ... and, in the same launch, clears the linearisation buffer that is not current: the (speculated) linearisation of the trial
+  // state this reduction leads to is written there
+  ZeroPlan zother{};
+  rp.nb_zero = 0;
+  if (!s->lin_clean[s->lin_buf ^ 1]) {
+    zother = linearize_zero_plan(s, s->lin_buf ^ 1, false);
+    rp.nb_zero = std::max(1, std::min(nblk((long)zero_plan_doubles(zother) / 2, 256), s->n_cu));
+    s->lin_clean[s->lin_buf ^ 1] = true;
+  }
+  hipLaunchKernelGGL(k_reduce_stage1, dim3(rp.nb_asm + rp.nb_prep + rp.nb_cubprep + rp.nb_zero), dim3(256), 0, s->stream, g, lambda, rp, zother);
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
   if (g.det) {  // S and b were summed as fixed-point integers (assembly, pair chunks, cuboid terms): back to doubles before anybody factors them
     ZeroPlan zp{};
@@ -554,14 +589,9 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linea
     if (s->comm.sum(s->g.acc, 3, s->stream)) return PPO_BA_ERR_COMM;
     if (with_maxdiag && s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
   }
+  (void)zero_for_next_linearize;  // (the linearisation targets are double-buffered: nothing to clear behind the hand-over any more)
   ZeroPlan zp{};
-  int grid = 1;
-  if (zero_for_next_linearize) {
-    zp = linearize_zero_plan(s, false);
-    const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
-    grid = 1 + (int)std::min<size_t>(std::max<size_t>(1, tot / 2 / 64), (size_t)2 * s->n_cu);
-  }
-  hipLaunchKernelGGL(k_publish, dim3(grid), dim3(64), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, zp);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, zp);
   // (no event behind it: a hipEventRecord costs a 6-8 us bubble in the queue in front of the next kernel -- measured with
   //  tools/gap_report.py as idle time before k_reduce_stage1 in every iteration; the host's spin is backed up by the stream itself)
   return PPO_BA_OK;
@@ -664,18 +694,15 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     static const bool chi2_pass = []() { const char* e = PPO_DEV_ENV("PPO_BA_CHI2_PASS"); return e && e[0] == '1'; }();
     if (speculated && !chi2_pass) {
       phase_mark(s, PH_LIN);
-      const ZeroPlan zp = linearize_zero_plan(s, false);
-      const size_t tot = zp.n[0] + zp.n[1] + zp.n[2] + zp.n[3];
-      hipLaunchKernelGGL(k_zero_ranges, dim3(std::min(nblk((long)tot / 2, 256), 2 * s->n_cu)), dim3(256), 0, s->stream, zp);
-      RC_TRY(launch_linearize(s, s->cur ^ 1, true));
-      RC_TRY(fetch_acc_enqueue(s, true, false, false));
+      RC_TRY(launch_linearize(s, s->cur ^ 1, false, false));  // (into the other buffer, which the reduction above has cleared)
+      RC_TRY(fetch_acc_enqueue(s, true, false));
     } else {
       phase_mark(s, PH_CHI2);
       RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
-      RC_TRY(fetch_acc_enqueue(s, true, speculated, false));
+      RC_TRY(fetch_acc_enqueue(s, true, false));
       if (speculated) {
         phase_mark(s, PH_LIN);
-        RC_TRY(launch_linearize(s, s->cur ^ 1, true));
+        RC_TRY(launch_linearize(s, s->cur ^ 1, false, true));
       }
     }
     phase_mark(s, PH_OTHER);
@@ -700,6 +727,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
       currentChi = tempChi;
       s->cur ^= 1;  // discardTop(): the trial state becomes the estimate
       it.accepted = 1;
+      if (speculated) use_lin_buffer(s, s->lin_buf ^ 1);  // ... and its (speculated) linearisation the current system
       s->lin_valid = speculated;
       s->chi_cur = tempChi;
     } else {
@@ -707,12 +735,8 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
       s->ni *= 2;
       it.accepted = 0;  // pop(): keep the current state
       if (!(rho < 0)) rho = (info != 0) ? -1.0 : rho;
-      if (speculated && rho < 0 && qmax + 1 < s->opt.lm_max_trials && !stop_now(s)) {
-        // the buffers hold the rejected state's linearisation: restore the kept state's before the retry
-        phase_mark(s, PH_LIN);
-        RC_TRY(launch_linearize(s));
-        phase_mark(s, PH_OTHER);
-      }
+      // (the rejected state's linearisation sits in the OTHER buffer: the kept state's system is intact, the retry reduces it again
+      //  with the larger lambda and clears the other buffer on the way)
     }
     qmax++;
     s->stats.n_trials++;
@@ -1266,11 +1290,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // arena: HB | HC | acc | D | bl;  d_W: factor records of the point slots | linearisation-point rotations | W of the plane slots
   g.n_pt_slots = slot_off[Npt];
   const size_t nF = (size_t)g.n_pt_slots * 4, nLinR = (size_t)(ld / 6 + 2) * 12, nWpl = (size_t)(g.n_slots - g.n_pt_slots) * 18;
-  const size_t nHB = (size_t)nfree * 27, nHC = (size_t)Nc * 54, nD = (size_t)g.n_lm * 6, nbl = (size_t)g.n_lm * 3, nW = nF + nLinR + nWpl;
-  ok = ok && s->d_arena.alloc(nHB + nHC + ACC_TOTAL + nD + nbl) && s->d_W.alloc(nW);
+  const size_t nHB = (size_t)nfree * 27, nHC = (size_t)Nc * 54, nD = (size_t)g.n_lm * 6, nbl = (size_t)g.n_lm * 3, nW = 2 * (nF + nLinR + nWpl);
+  ok = ok && s->d_arena.alloc(2 * (nHB + nHC + nD + nbl) + ACC_TOTAL) && s->d_W.alloc(nW);
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
-  ok = ok && s->d_Wpc.alloc((size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
+  ok = ok && s->d_Wpc.alloc(2 * (size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
   ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
   if (s->comm.active()) ok = ok && s->d_pack.alloc((size_t)(ld / 64) * (ld / 64 + 1) / 2 * 4096 + ld);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
@@ -1309,17 +1333,25 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     g.ptcub_chi2 = c;
   }
   {
-    double* a = s->d_arena.p;
-    g.HB = a; a += nHB;
-    g.HC = a; a += nHC;
+    double* a = s->d_arena.p;  // [H_pp | H_cc | D | b_l] x 2, then the accumulator block
+    for (int b = 0; b < 2; ++b) {
+      s->lb[b].HB = a; a += nHB;
+      s->lb[b].HC = a; a += nHC;
+      s->lb[b].D = a; a += nD;
+      s->lb[b].bl = a; a += nbl;
+    }
     g.acc = a; a += ACC_TOTAL;
-    s->zero_head = nHB + nHC + ACC_TOTAL;
-    g.D = a; s->zD_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 6; s->zD_n = (size_t)Npl * 6; a += nD;
-    g.bl = a; s->zbl_off = (size_t)(a - s->d_arena.p) + (size_t)Npt * 3; s->zbl_n = (size_t)Npl * 3; a += nbl;
-    g.F = s->d_W.p; g.linR = g.F + nF; g.W = g.linR + nLinR; s->zW_off = nF + nLinR; s->zW_n = nWpl;
+    s->nHBC = nHB + nHC; s->zD_n = (size_t)Npl * 6; s->zbl_n = (size_t)Npl * 3; s->zW_n = nWpl;
+    {  // d_W: [the planes' W | the planes' W] (cleared together), then [factor records | linearisation-point rotations] x 2
+      double* w = s->d_W.p;
+      s->lb[0].W = w; s->lb[1].W = w + nWpl; w += 2 * nWpl;
+      for (int b = 0; b < 2; ++b) { s->lb[b].F = w; w += nF; s->lb[b].linR = w; w += nLinR; }
+      double* c = s->d_Wpc.p;
+      for (int b = 0; b < 2; ++b) { s->lb[b].Wpc_bbox = c; c += (size_t)p->n_bbox * 54; s->lb[b].Wpc_corner = c; c += (size_t)p->n_corner * 54; }
+    }
+    use_lin_buffer(s, 0);
     if (nW) (void)hipMemsetAsync(s->d_W.p, 0, nW * sizeof(double), s->stream);
   }
-  g.Wpc_bbox = s->d_Wpc.p; g.Wpc_corner = s->d_Wpc.p + (size_t)p->n_bbox * 54;
   g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p;
   g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_Dinv = s->d_cub_Dinv.p; g.xc = s->d_xc.p;
   g.Dinv = s->d_Dinv.p; g.ul = s->d_ul.p; s->d_bs_p = s->d_S.p + (size_t)ld * ld; g.S = s->d_S.p; g.bs = s->d_bs_p; g.xr = s->d_xr.p;
@@ -1651,9 +1683,7 @@ int ppo_ba_time_kernel(ppo_ba_handle s, int which, int reps, double* ms_out, int
         else hipLaunchKernelGGL((k_backsub<false, 4>), dim3(nblk(4L * nl, 256)), dim3(256), 0, s->stream, g, st, tr, s->lambda);
         return true;
       case PPO_BA_KERNEL_LINEARIZE_ALL: {
-        const size_t zh = s->zero_head;
-        (void)zh;
-        return launch_linearize_kernel(s, st) == PPO_BA_OK;
+        return launch_linearize_kernel(s, g, st) == PPO_BA_OK;
       }
       case PPO_BA_KERNEL_CHI2_POINTS:
         if (npts <= 0) return false;
