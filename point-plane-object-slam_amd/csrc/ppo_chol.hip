@@ -513,6 +513,9 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
     if (wave == 0) {  // diagonal 16x16 block + the sub-diagonal tiles of this block column
       const int bad = potf2_16(sL, sT[kk], sId, o, true);
       if (lane == 0 && bad && sBad == 0) sBad = o + bad;
+#ifdef PPO_CHOL_EXPERIMENT_NO_SIDE  // (timing experiment: wrong results, the register factorisations without the MFMA jobs in their shadow)
+    } else if (true) {
+#endif
     } else if (kk == 0) {
       if (upd) tile_update1(sL, wave, 1, wave == 1, sQ, sQ);  // D(1,1) D(2,1) D(3,1): what the next factorisation needs
       if (uo) tile_update1(sB, r0t, wave - 1, false, sP, sQ);
