@@ -237,7 +237,9 @@ const char* ppo_ba_strerror(int code);
 /* fills *o with the reference's constants (the comments on ppo_ba_options) */
 void ppo_ba_default_options(ppo_ba_options* o);
 
-/* validate + copy + upload once.  Fails with PPO_BA_ERR_HIP when no gfx950 device is usable. */
+/* validate + copy + upload once.  Fails with PPO_BA_ERR_HIP when no gfx950 device is usable.
+ * Host threads: the flattening passes run on a process-wide worker team of min(hardware threads - 1, 7) threads, started on first
+ * use and asleep between calls; the environment variable PPO_BA_HOST_THREADS=n caps the total (1: the calling thread only). */
 int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handle* out);
 
 /* pass 1, outlier classification, pass 2.  stop_flag (may be NULL) is polled before the start,
