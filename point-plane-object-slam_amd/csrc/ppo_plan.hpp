@@ -1,0 +1,210 @@
+// ppo_plan.hpp -- the per-window plans of ppo_ba_create that are built ON THE DEVICE (included by ppo_solver.hip only).
+//
+// ppo_ba_create flattens a window into edge records, (landmark, pose) slots, a pose-major copy of the reprojection edges and the Schur
+// pair plan.  The slot numbering stays on the host (a sort + unique per landmark over ~8 entries); everything that is per EDGE or per
+// landmark-pose PAIR -- 2.5e5 records, 2.5e5 pose-major indices, 9e5 pairs bucketed by pose pair -- is built here from the caller's raw
+// arrays and the slot tables, when the reprojection edge lists arrive sorted by point (the reference's own loop and
+// include/ppo_flatten.hpp produce them that way; any other order takes the host builder in ppo_solver.hip, which produces the same
+// device state -- tests/test_parity_gpu.py runs both on the same window).  Orders are the host builder's: edges of a keyframe in
+// landmark order, pairs of a pose pair in (landmark, a, b) order -- both come out of STABLE radix sorts (rocPRIM), so the layout does
+// not depend on how the device schedules anything.
+#pragma once
+#include <cstring>  // (rocPRIM's texture iterator calls memset from host code)
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "ppo_kernels.hpp"
+#include "ppo_pool.hpp"
+
+namespace ppo {
+
+// slot of (landmark l, reduced pose column pc) in the landmark-major slot table, as its device (pose-major) number; -1 if none
+__device__ __forceinline__ int32_t plan_find_slot(const int32_t* __restrict__ slot_off, const int32_t* __restrict__ slot_col_lm, const int32_t* __restrict__ new_id, int l, int pc) {
+  if (pc < 0) return -1;
+  int lo = slot_off[l], hi = slot_off[l + 1];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (slot_col_lm[mid] < pc) lo = mid + 1;
+    else hi = mid;
+  }
+  return (lo < slot_off[l + 1] && slot_col_lm[lo] == pc) ? new_id[lo] : -1;
+}
+
+struct ReprojRaw {  // the caller's arrays of one reprojection edge class, staged and uploaded as they are
+  const double* obs;   // [n][2] or [n][3]
+  const double* info;  // [n]
+  const double* huber; // [n]
+  const int32_t* pose; // [n]
+  const int32_t* point;// [n]
+  int n;
+};
+struct SlotTables {
+  const int32_t* slot_off;     // [n_lm + 1]
+  const int32_t* slot_col_lm;  // [n_slots] reduced pose column, landmark-major
+  const int32_t* new_id;       // [n_slots] landmark-major index -> device slot number
+  const int32_t* pose_col;     // [Np]
+  const uint8_t* point_fixed;  // [Npt]
+};
+
+// edge records + flags of the reprojection edges (the edge lists are sorted by point: record k is caller edge k)
+__global__ __launch_bounds__(256) void k_plan_records(ReprojRaw mo, ReprojRaw st, SlotTables t, MonoEdge* __restrict__ mono, StereoEdge* __restrict__ stereo,
+                                                      uint32_t* __restrict__ mono_flags, uint32_t* __restrict__ mono_flags0, uint32_t* __restrict__ stereo_flags,
+                                                      uint32_t* __restrict__ stereo_flags0) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < mo.n; k += stride) {
+    MonoEdge m;
+    m.u = mo.obs[2 * (size_t)k]; m.v = mo.obs[2 * (size_t)k + 1]; m.info = mo.info[k]; m.huber = mo.huber[k];
+    m.pose = mo.pose[k]; m.point = mo.point[k];
+    const int pc = t.pose_col[m.pose];
+    const bool pf = t.point_fixed[m.point];
+    m.slot = pf ? -1 : plan_find_slot(t.slot_off, t.slot_col_lm, t.new_id, m.point, pc);
+    m.flags = ((pf && pc < 0) ? 0u : F_ACTIVE) | F_ROBUST;
+    mono[k] = m;
+    mono_flags[k] = m.flags;
+    mono_flags0[k] = m.flags;
+  }
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < st.n; k += stride) {
+    StereoEdge m{};
+    m.u = st.obs[3 * (size_t)k]; m.v = st.obs[3 * (size_t)k + 1]; m.ur = st.obs[3 * (size_t)k + 2]; m.info = st.info[k]; m.huber = st.huber[k];
+    m.pose = st.pose[k]; m.point = st.point[k];
+    const int pc = t.pose_col[m.pose];
+    const bool pf = t.point_fixed[m.point];
+    m.slot = pf ? -1 : plan_find_slot(t.slot_off, t.slot_col_lm, t.new_id, m.point, pc);
+    m.flags = ((pf && pc < 0) ? 0u : F_ACTIVE) | F_ROBUST;
+    stereo[k] = m;
+    stereo_flags[k] = m.flags;
+    stereo_flags0[k] = m.flags;
+  }
+}
+
+// sort key of edge k for the pose-major copy: its pose if the edge belongs there (owned point, free pose), a sentinel above every pose otherwise
+__global__ __launch_bounds__(256) void k_plan_pose_keys(const int32_t* __restrict__ pose, const int32_t* __restrict__ point, int n, const int32_t* __restrict__ pose_free_id,
+                                                        int pt_first, int pt_last, uint32_t sentinel, uint32_t* __restrict__ key) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int pt = point[k];
+  key[k] = (pt >= pt_first && pt < pt_last && pose_free_id[pose[k]] >= 0) ? (uint32_t)pose[k] : sentinel;
+}
+
+// ---- Schur pair plan ---------------------------------------------------------------------------------------------------------------
+struct OwnedLandmarks {  // points [pt_first, pt_last) then planes [plane_first, plane_last): one unit range, like the host builder's
+  int n_points, pt_first, n_own_pt, plane_first, n_own;
+  __host__ __device__ int lm_of(int u) const { return u < n_own_pt ? pt_first + u : n_points + plane_first + (u - n_own_pt); }
+  __host__ __device__ int unit_of(int l) const {  // -1: not owned
+    if (l < n_points) return (l >= pt_first && l < pt_first + n_own_pt) ? l - pt_first : -1;
+    const int j = l - n_points - plane_first;
+    return (j >= 0 && j < n_own - n_own_pt) ? n_own_pt + j : -1;
+  }
+};
+__global__ __launch_bounds__(256) void k_plan_pair_counts(OwnedLandmarks own, const int32_t* __restrict__ slot_off, int32_t* __restrict__ npairs) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u > own.n_own) return;
+  if (u == own.n_own) { npairs[u] = 0; return; }  // (the scan wants n_own + 1 entries: the last offset is the total)
+  const int l = own.lm_of(u), k = slot_off[l + 1] - slot_off[l];
+  npairs[u] = k * (k + 1) / 2;
+}
+// (a, c) of the packed lower-triangle index t = a (a + 1) / 2 + c for large t
+__device__ __forceinline__ void unpack_lower_big(long long t, int& a, int& c) {
+  long long r = (long long)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (r * (r + 1) / 2 > t) --r;
+  while ((r + 1) * (r + 2) / 2 <= t) ++r;
+  a = (int)r;
+  c = (int)(t - r * (r + 1) / 2);
+}
+// one thread per landmark-major slot a: the keys of its pairs (a, b <= a), key = pose_a (pose_a + 1) / 2 + pose_b, at the position the
+// host builder's (landmark, a, b) loop would visit them; a histogram of the keys next to it
+__global__ __launch_bounds__(256) void k_plan_pair_keys(OwnedLandmarks own, const int32_t* __restrict__ slot_off, const int32_t* __restrict__ slot_col_lm,
+                                                        const int32_t* __restrict__ slot_lm_lm, int n_slots, const int32_t* __restrict__ pair_off, uint32_t* __restrict__ key,
+                                                        int32_t* __restrict__ key_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  const int l = slot_lm_lm[i], u = own.unit_of(l);
+  if (u < 0) return;
+  const int s0 = slot_off[l], a = i - s0;
+  const uint32_t pa = (uint32_t)(slot_col_lm[i] / 6), base_key = pa * (pa + 1) / 2;
+  const int base = pair_off[u] + a * (a + 1) / 2;
+  for (int b = 0; b <= a; ++b) {
+    const uint32_t k = base_key + (uint32_t)(slot_col_lm[s0 + b] / 6);
+    key[base + b] = k;
+    atomicAdd(&key_count[k], 1);
+  }
+}
+// the plan entries in sorted order: perm[i] = position in the (landmark, a, b) enumeration of the i-th pair by key
+__global__ __launch_bounds__(256) void k_plan_pair_fill(OwnedLandmarks own, const int32_t* __restrict__ slot_off, const int32_t* __restrict__ new_id,
+                                                        const int32_t* __restrict__ pair_off, const uint32_t* __restrict__ perm, int n_pairs, int32_t* __restrict__ pc_sj,
+                                                        int32_t* __restrict__ pc_si, int32_t* __restrict__ pc_lm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int pos = (int)perm[i];
+  int lo = 0, hi = own.n_own;  // largest u with pair_off[u] <= pos
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pair_off[mid] <= pos) lo = mid;
+    else hi = mid;
+  }
+  int a, b;
+  unpack_lower_big(pos - pair_off[lo], a, b);
+  const int l = own.lm_of(lo), s0 = slot_off[l];
+  pc_sj[i] = new_id[s0 + a];
+  pc_si[i] = new_id[s0 + b];
+  pc_lm[i] = l;
+}
+__global__ __launch_bounds__(256) void k_plan_chunk_counts(const int32_t* __restrict__ key_count, int n_keys, int chunk, int32_t* __restrict__ n_chunks) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n_keys) return;
+  n_chunks[k] = k < n_keys ? (key_count[k] + chunk - 1) / chunk : 0;
+}
+// chunk headers: key k = pj (pj + 1) / 2 + pi owns the pairs [key_start[k], key_start[k + 1]), cut into chunks of `chunk`
+__global__ __launch_bounds__(256) void k_plan_chunk_fill(const int32_t* __restrict__ key_start, const int32_t* __restrict__ chunk_off, int n_keys, int chunk,
+                                                         int32_t* __restrict__ pc_colj, int32_t* __restrict__ pc_coli, int32_t* __restrict__ pc_start, int32_t* __restrict__ n_chunks_out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n_keys) return;
+  if (k == n_keys) {
+    pc_start[chunk_off[n_keys]] = key_start[n_keys];
+    *n_chunks_out = chunk_off[n_keys];
+    return;
+  }
+  int pj, pi;
+  unpack_lower_big(k, pj, pi);
+  const int c0 = chunk_off[k], c1 = chunk_off[k + 1];
+  for (int c = c0; c < c1; ++c) {
+    pc_colj[c] = 6 * pj;
+    pc_coli[c] = 6 * pi;
+    pc_start[c] = key_start[k] + (c - c0) * chunk;
+  }
+}
+
+// device-wide helpers over rocPRIM (temporary storage from the block cache; everything on the caller's stream)
+struct PlanScratch {
+  std::vector<DevBuf<unsigned char>> tmp;  // released by the caller after its final synchronisation
+  void* take(size_t bytes) {
+    tmp.emplace_back();
+    if (!tmp.back().alloc(bytes ? bytes : 1)) return nullptr;
+    return tmp.back().p;
+  }
+  void release() {
+    for (auto& b : tmp) b.release();
+    tmp.clear();
+  }
+};
+inline bool plan_exclusive_scan(PlanScratch& sc, const int32_t* in, int32_t* out, size_t n, hipStream_t s) {
+  size_t bytes = 0;
+  if (rocprim::exclusive_scan(nullptr, bytes, in, out, (int32_t)0, n, rocprim::plus<int32_t>(), s) != hipSuccess) return false;
+  void* t = sc.take(bytes);
+  return t && rocprim::exclusive_scan(t, bytes, in, out, (int32_t)0, n, rocprim::plus<int32_t>(), s) == hipSuccess;
+}
+// stable sort of (key, position) by key; perm_out[i] = position of the i-th smallest
+inline bool plan_sort_positions(PlanScratch& sc, const uint32_t* key_in, uint32_t* key_out, uint32_t* perm_out, size_t n, int bits, hipStream_t s) {
+  rocprim::counting_iterator<uint32_t> pos(0);
+  size_t bytes = 0;
+  if (rocprim::radix_sort_pairs(nullptr, bytes, key_in, key_out, pos, perm_out, n, 0, bits, s) != hipSuccess) return false;
+  void* t = sc.take(bytes);
+  return t && rocprim::radix_sort_pairs(t, bytes, key_in, key_out, pos, perm_out, n, 0, bits, s) == hipSuccess;
+}
+inline int plan_bits(unsigned long long max_value) {
+  int b = 1;
+  while (b < 32 && (max_value >> b)) ++b;
+  return b;
+}
+
+}  // namespace ppo

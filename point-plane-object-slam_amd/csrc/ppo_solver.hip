@@ -26,6 +26,7 @@
 #include "ppo_chol.hpp"
 #include "ppo_comm.hpp"
 #include "ppo_kernels.hpp"
+#include "ppo_plan.hpp"
 #include "ppo_pool.hpp"
 
 using namespace ppo;
@@ -62,8 +63,9 @@ struct ppo_ba_solver {
   // host copies kept after create
   Stage* stage = nullptr;  // page-locked host arena: every SVec below and in create / read lives here until destroy
   SVec<int32_t> mono_perm, stereo_perm;  // sorted position -> caller index
-  SVec<MonoEdge> h_mono;
+  SVec<MonoEdge> h_mono;      // (host builder only; the device builder of ppo_plan.hpp writes the records in place)
   SVec<StereoEdge> h_stereo;
+  SVec<int32_t> hk_mono_pose, hk_mono_point, hk_stereo_pose, hk_stereo_point;  // pose / point of the k-th record, kept for ppo_ba_read
   SVec<PlaneEdge> h_pl;
   SVec<CubEdge> h_bbox, h_corner;
   SVec<PtCubEdge> h_ptcub;
@@ -885,13 +887,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   s->stats.n_reduced = 6 * nfree + 9 * n_cub_used;  // the reference's reduced dimension (cuboids are not marginalised there)
 
   // ---- reprojection edges sorted by point (stable counting sort), CSR offsets -------------------------
-  auto csr_sort = [&](int n, const int32_t* key, SVec<int32_t>& off, SVec<int32_t>& perm) {
+  auto csr_sort = [&](int n, const int32_t* key, SVec<int32_t>& off, SVec<int32_t>& perm) -> bool {
     // the reference adds the observations point by point (Optimizer.cc:2350-2422), so the edges normally ARRIVE sorted: then the
     // permutation is the identity and the offsets are the positions where the key changes (both filled in slices by the team)
-    if (n >= (1 << 16) && all_slices((size_t)n - 1, [&](size_t a, size_t b) { int32_t bad = 0; for (size_t e = a; e < b; ++e) bad |= (int32_t)(key[e] > key[e + 1]); return bad == 0; })) {
+    if (n >= 4096 && all_slices((size_t)n - 1, [&](size_t a, size_t b) { int32_t bad = 0; for (size_t e = a; e < b; ++e) bad |= (int32_t)(key[e] > key[e + 1]); return bad == 0; })) {
       off.resize(Npt + 1);
       perm.resize(n);
-      const int nt = std::min(HostTeam::get().size(), 8);
+      const int nt = n >= (1 << 16) ? std::min(HostTeam::get().size(), 8) : 1;
       HostTeam::get().run(nt, [&](int t) {
         const int e0 = (int)((long)n * t / nt), e1 = (int)((long)n * (t + 1) / nt);
         for (int e = e0; e < e1; ++e) perm[e] = e;
@@ -901,7 +903,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
           for (; k <= key[e]; ++k) off[k] = e;
         if (e1 == n) for (; k <= Npt; ++k) off[k] = n;
       });
-      return;
+      return true;
     }
     off.assign(Npt + 1, 0);
     for (int e = 0; e < n; ++e) off[key[e] + 1]++;
@@ -909,10 +911,15 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     perm.resize(n);
     SVec<int32_t> cursor(off.begin(), off.end() - 1);
     for (int e = 0; e < n; ++e) perm[cursor[key[e]]++] = e;
+    return n == 0;
   };
   SVec<int32_t> mo_off, st_off;
-  csr_sort(p->n_mono, p->mono_point, mo_off, s->mono_perm);
-  csr_sort(p->n_stereo, p->stereo_point, st_off, s->stereo_perm);
+  const bool mono_sorted = csr_sort(p->n_mono, p->mono_point, mo_off, s->mono_perm);
+  const bool stereo_sorted = csr_sort(p->n_stereo, p->stereo_point, st_off, s->stereo_perm);
+  // Edge lists that arrive sorted by point (the reference's loop, include/ppo_flatten.hpp) have their records, pose-major copy and
+  // Schur pair plan built ON THE DEVICE (ppo_plan.hpp); anything else, and small windows, take the host builder below.  Both produce
+  // the same device state.
+  const bool dev_plan = mono_sorted && stereo_sorted && (long)p->n_mono + p->n_stereo >= 40000 && !PPO_DEV_ENV("PPO_BA_HOST_PLAN");
 
   mark("csr sort");
   // ---- host threads for the plans below -------------------------------------------------------------------------------
@@ -970,6 +977,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       } else {
         for (int k = pl_off[l - Npt]; k < pl_off[l - Npt + 1]; ++k) { const int pc = pose_col[p->pl_pose[pl_perm[k]]]; if (pc >= 0) *q++ = pc; }
       }
+      bool ascending = true;  // (observations usually arrive in keyframe order: then there is nothing to sort or to merge)
+      for (int32_t* x = b0 + 1; x < q; ++x) ascending &= x[-1] < x[0];
+      if (ascending) { seg_cnt[l] = (int32_t)(q - b0); continue; }
       std::sort(b0, q);
       seg_cnt[l] = (int32_t)(std::unique(b0, q) - b0);
     }
@@ -1035,9 +1045,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // (built on a helper thread while this one fills the edge records: both are ~3 ms of host work at the BASELINE size)
   SVec<int32_t> pc_start, pc_colj, pc_coli, pc_sj, pc_si, pc_lm;
   std::atomic<bool> pair_plan_failed{false};
-  std::thread pair_plan_thread([&]() { try {
+  const int pair_chunk = []() { const char* e = PPO_DEV_ENV("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+  std::thread pair_plan_thread;
+  if (!dev_plan) pair_plan_thread = std::thread([&]() { try {
     t_stage = s->stage;
-    const int chunk = []() { const char* e = PPO_DEV_ENV("PPO_BA_SCHUR_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    const int chunk = pair_chunk;
     const long nkeys = (long)nfree * (nfree + 1) / 2;
     // (slot_col is a multiple of 6: pose = col / 6; the row base pj (pj + 1) / 2 of a pair key is looked up per a, not per pair)
     SVec<int32_t> row_base(nfree + 1);
@@ -1092,9 +1104,33 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     const int nt = n >= 40000 ? n_host_threads : 1;
     team.run(nt, [&](int t) { body((int)((long)n * t / nt), (int)((long)n * (t + 1) / nt)); });
   };
+  SVec<uint32_t> h_mono_flags, h_stereo_flags;
+  SVec<int32_t>& mono_pose_k = s->hk_mono_pose;  // pose of the k-th record, compact (the pose-major bucket passes below and ppo_ba_read use it)
+  SVec<int32_t>& stereo_pose_k = s->hk_stereo_pose;
+  mono_pose_k.resize(p->n_mono); stereo_pose_k.resize(p->n_stereo);
+  s->hk_mono_point.resize(p->n_mono); s->hk_stereo_point.resize(p->n_stereo);
+  // device builder: the caller's arrays are staged as they are (page-locked copies, made in slices) and start their upload now
+  SVec<double> raw_mono_obs, raw_mono_info, raw_mono_huber, raw_stereo_obs, raw_stereo_info, raw_stereo_huber;
+  DevBuf<double> d_raw_mono_obs, d_raw_mono_info, d_raw_mono_huber, d_raw_stereo_obs, d_raw_stereo_info, d_raw_stereo_huber;
+  DevBuf<int32_t> d_raw_mono_pose, d_raw_mono_point, d_raw_stereo_pose, d_raw_stereo_point;
+  bool ok = true;
+  if (dev_plan) {
+    auto stage_copy = [&](SVec<double>& dst, const double* src, size_t n) {
+      dst.resize(n);
+      parallel_for((int)(n / 2), [&](int a, int b) { std::memcpy(dst.data() + 2 * (size_t)a, src + 2 * (size_t)a, 2 * (size_t)(b - a) * sizeof(double)); });
+      if (n & 1) dst[n - 1] = src[n - 1];
+    };
+    stage_copy(raw_mono_obs, p->mono_obs, 2 * (size_t)p->n_mono); stage_copy(raw_mono_info, p->mono_info, p->n_mono); stage_copy(raw_mono_huber, p->mono_huber, p->n_mono);
+    stage_copy(raw_stereo_obs, p->stereo_obs, 3 * (size_t)p->n_stereo); stage_copy(raw_stereo_info, p->stereo_info, p->n_stereo); stage_copy(raw_stereo_huber, p->stereo_huber, p->n_stereo);
+    parallel_for(p->n_mono, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) { mono_pose_k[k] = p->mono_pose[k]; s->hk_mono_point[k] = p->mono_point[k]; } });
+    parallel_for(p->n_stereo, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) { stereo_pose_k[k] = p->stereo_pose[k]; s->hk_stereo_point[k] = p->stereo_point[k]; } });
+    ok = d_raw_mono_obs.upload(raw_mono_obs, s->stream) && d_raw_mono_info.upload(raw_mono_info, s->stream) && d_raw_mono_huber.upload(raw_mono_huber, s->stream) &&
+         d_raw_stereo_obs.upload(raw_stereo_obs, s->stream) && d_raw_stereo_info.upload(raw_stereo_info, s->stream) && d_raw_stereo_huber.upload(raw_stereo_huber, s->stream) &&
+         d_raw_mono_pose.upload(mono_pose_k, s->stream) && d_raw_mono_point.upload(s->hk_mono_point, s->stream) &&
+         d_raw_stereo_pose.upload(stereo_pose_k, s->stream) && d_raw_stereo_point.upload(s->hk_stereo_point, s->stream);
+  } else {
   s->h_mono.resize(p->n_mono);
-  SVec<uint32_t> h_mono_flags(p->n_mono), h_stereo_flags(p->n_stereo);
-  SVec<int32_t> mono_pose_k(p->n_mono), stereo_pose_k(p->n_stereo);  // pose of the k-th record, compact (the pose-major bucket passes below read it)
+  h_mono_flags.resize(p->n_mono); h_stereo_flags.resize(p->n_stereo);
   parallel_for(p->n_mono, [&](int k0, int k1) {
   for (int k = k0; k < k1; ++k) {
     const int e = s->mono_perm[k];
@@ -1107,6 +1143,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     m.point = p->mono_point[e];
     h_mono_flags[k] = m.flags;
     mono_pose_k[k] = m.pose;
+    s->hk_mono_point[k] = m.point;
   }
   });
   s->h_stereo.resize(p->n_stereo);
@@ -1124,8 +1161,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     m.flags = (all_fixed ? 0u : F_ACTIVE) | F_ROBUST;
     h_stereo_flags[k] = m.flags;
     stereo_pose_k[k] = m.pose;
+    s->hk_stereo_point[k] = m.point;
   }
   });
+  }  // (host builder)
   mark("reprojection edge records");
   s->h_pl.resize(p->n_plane_edges);
   for (int e = 0; e < p->n_plane_edges; ++e) {
@@ -1180,10 +1219,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   mark("other edge records");
   // the copy engine moves the landmark-major records (19 MB at the BASELINE size) while the host builds the rest
-  bool ok = s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream);
+  if (dev_plan) ok = ok && s->d_mono.alloc(p->n_mono) && s->d_stereo.alloc(p->n_stereo);
+  else ok = ok && s->d_mono.upload(s->h_mono, s->stream) && s->d_stereo.upload(s->h_stereo, s->stream);
   // ---- pose-major static copies of the owned reprojection edges + chunks (pose side of the linearisation) -----------
   SVec<int32_t> po_start, po_end, po_pose;
   SVec<int32_t> monoP_src, stereoP_src;  // position in the landmark-major array of the pose-major copy's q-th edge (expanded on the device)
+  int32_t n_monoP = 0, n_stereoP = 0;
   {
     const int chunk = []() { const char* e = PPO_DEV_ENV("PPO_BA_POSE_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     auto build = [&](int type) {
@@ -1197,8 +1238,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                       for (int k = off[g.pt_first + u0]; k < off[g.pt_first + u1]; ++k)
                         if (pose_free_id[pose_of(k)] >= 0) h[pose_of(k)]++;
                     },
-                    [&](int32_t total) { src.resize(total); },
+                    [&](int32_t total) { if (!dev_plan) src.resize(total); (type == 0 ? n_monoP : n_stereoP) = total; },
                     [&](int u0, int u1, int32_t* c) {
+                      if (dev_plan) return;  // (the device sorts the edge positions by pose itself: only the counts are needed here)
                       for (int k = off[g.pt_first + u0]; k < off[g.pt_first + u1]; ++k) {
                         const int pose = pose_of(k);
                         if (pose_free_id[pose] >= 0) src[c[pose]++] = k;
@@ -1215,11 +1257,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     build(1);
   }
   mark("  pose-major index lists");
-  ok = ok && s->d_monoP_src.upload(monoP_src, s->stream) && s->d_stereoP_src.upload(stereoP_src, s->stream);
-  ok = ok && s->d_monoP.alloc(monoP_src.size()) && s->d_stereoP.alloc(stereoP_src.size());
-  if (ok && monoP_src.size() + stereoP_src.size() > 0)
-    hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(monoP_src.size(), stereoP_src.size()), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
-                       s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)monoP_src.size(), s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)stereoP_src.size());
+  ok = ok && s->d_monoP.alloc(n_monoP) && s->d_stereoP.alloc(n_stereoP);
+  if (!dev_plan) {
+    ok = ok && s->d_monoP_src.upload(monoP_src, s->stream) && s->d_stereoP_src.upload(stereoP_src, s->stream);
+    if (ok && n_monoP + n_stereoP > 0)
+      hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(n_monoP, n_stereoP), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
+                         s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)n_monoP, s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)n_stereoP);
+  }
 
   mark("  flags");
   // ---- cuboid elimination plan: edges per cuboid and all (a >= b) pairs of them -----------------------------------------
@@ -1261,7 +1305,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
 
   mark("pose-major copies, cuboid plan, state");
-  pair_plan_thread.join();
+  if (pair_plan_thread.joinable()) pair_plan_thread.join();
   if (pair_plan_failed.load()) return fail(PPO_BA_ERR_NOMEM);
   mark("pair plan join");
   // ---- uploads (the two big record arrays are already on their way) -----------------------------------------------------
@@ -1277,8 +1321,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_mo_off.upload(mo_off, s->stream) && s->d_st_off.upload(st_off, s->stream);
   ok = ok && s->d_slot_col.upload(d_slot_col_v, s->stream) && s->d_slot_lm.upload(d_slot_lm_v, s->stream);
   ok = ok && s->d_pl_slot_off.upload(pl_slot_off, s->stream) && s->d_pl_slots.upload(pl_slots, s->stream);
-  ok = ok && s->d_mono_flags.upload(h_mono_flags, s->stream) && s->d_mono_flags0.upload(h_mono_flags, s->stream);
-  ok = ok && s->d_stereo_flags.upload(h_stereo_flags, s->stream) && s->d_stereo_flags0.upload(h_stereo_flags, s->stream);
+  if (dev_plan) {
+    ok = ok && s->d_mono_flags.alloc(p->n_mono) && s->d_mono_flags0.alloc(p->n_mono) && s->d_stereo_flags.alloc(p->n_stereo) && s->d_stereo_flags0.alloc(p->n_stereo);
+  } else {
+    ok = ok && s->d_mono_flags.upload(h_mono_flags, s->stream) && s->d_mono_flags0.upload(h_mono_flags, s->stream);
+    ok = ok && s->d_stereo_flags.upload(h_stereo_flags, s->stream) && s->d_stereo_flags0.upload(h_stereo_flags, s->stream);
+  }
   ok = ok && s->d_point_fixed.upload(point_fixed, s->stream) && s->d_cub_flags.upload(v_cf, s->stream);
   ok = ok && s->d_pl.upload(s->h_pl, s->stream);
   ok = ok && s->d_bbox.upload(s->h_bbox, s->stream) && s->d_corner.upload(s->h_corner, s->stream) && s->d_ptcub.upload(s->h_ptcub, s->stream);
@@ -1301,9 +1349,77 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream);
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
   ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_Dinv.alloc((size_t)Nc * 81) && s->d_xc.alloc((size_t)Nc * 9);
-  ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
-  ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream) && s->d_pc_lm.upload(pc_lm, s->stream);
-  s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, (int)pc_colj.size()};
+  PlanScratch plan_scratch;
+  DevBuf<int32_t> d_slot_off_lm, d_slot_col_lm, d_new_id, d_slot_lm_lm, d_pair_off, d_npairs, d_key_count, d_key_start, d_nchunks, d_chunk_off, d_n_chunks_out;
+  DevBuf<uint32_t> d_pose_key, d_pose_key_out, d_pair_key, d_pair_key_out, d_pair_perm;
+  int32_t* h_n_chunks = nullptr;  // (page-locked: the device's chunk count comes back with the final synchronisation)
+  if (!dev_plan) {
+    ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
+    ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream) && s->d_pc_lm.upload(pc_lm, s->stream);
+    s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, (int)pc_colj.size()};
+  } else {
+    // ---- device builder (ppo_plan.hpp): records + flags, pose-major index lists, Schur pair plan ------------------------------------
+    ok = ok && d_slot_off_lm.upload(slot_off, s->stream) && d_slot_col_lm.upload(slot_col, s->stream) && d_new_id.upload(new_id, s->stream) && d_slot_lm_lm.upload(slot_lm, s->stream);
+    if (!ok) return fail(PPO_BA_ERR_NOMEM);
+    const SlotTables tabs{d_slot_off_lm.p, d_slot_col_lm.p, d_new_id.p, s->d_pose_col.p, s->d_point_fixed.p};
+    const ReprojRaw rm{d_raw_mono_obs.p, d_raw_mono_info.p, d_raw_mono_huber.p, d_raw_mono_pose.p, d_raw_mono_point.p, p->n_mono};
+    const ReprojRaw rs{d_raw_stereo_obs.p, d_raw_stereo_info.p, d_raw_stereo_huber.p, d_raw_stereo_pose.p, d_raw_stereo_point.p, p->n_stereo};
+    hipLaunchKernelGGL(k_plan_records, dim3(std::min(nblk((long)std::max(p->n_mono, p->n_stereo), 256), 4 * s->n_cu)), dim3(256), 0, s->stream, rm, rs, tabs, s->d_mono.p,
+                       s->d_stereo.p, s->d_mono_flags.p, s->d_mono_flags0.p, s->d_stereo_flags.p, s->d_stereo_flags0.p);
+    // pose-major copies: edge positions sorted by pose (stable: landmark order inside a keyframe), edges that do not belong at the end
+    const size_t n_key = (size_t)std::max(p->n_mono, p->n_stereo);
+    ok = ok && d_pose_key.alloc(n_key) && d_pose_key_out.alloc(n_key) && s->d_monoP_src.alloc(p->n_mono) && s->d_stereoP_src.alloc(p->n_stereo);
+    if (!ok) return fail(PPO_BA_ERR_NOMEM);
+    const int pose_bits = plan_bits((unsigned long long)Np);
+    for (int type = 0; type < 2; ++type) {
+      const int n = type == 0 ? p->n_mono : p->n_stereo;
+      if (n == 0) continue;
+      hipLaunchKernelGGL(k_plan_pose_keys, dim3(nblk(n, 256)), dim3(256), 0, s->stream, type == 0 ? d_raw_mono_pose.p : d_raw_stereo_pose.p,
+                         type == 0 ? d_raw_mono_point.p : d_raw_stereo_point.p, n, s->d_pose_free_id.p, g.pt_first, g.pt_last, (uint32_t)Np, d_pose_key.p);
+      if (!plan_sort_positions(plan_scratch, d_pose_key.p, d_pose_key_out.p, reinterpret_cast<uint32_t*>(type == 0 ? s->d_monoP_src.p : s->d_stereoP_src.p), (size_t)n, pose_bits, s->stream))
+        return fail(PPO_BA_ERR_NOMEM);
+    }
+    if (n_monoP + n_stereoP > 0)
+      hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(n_monoP, n_stereoP), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
+                         s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)n_monoP, s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)n_stereoP);
+    // Schur pair plan
+    OwnedLandmarks own{Npt, g.pt_first, g.pt_last - g.pt_first, g.plane_first, (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first)};
+    long n_pairs = 0;
+    for (int u = 0; u < own.n_own; ++u) { const long k = seg_cnt[own.lm_of(u)]; n_pairs += k * (k + 1) / 2; }
+    const long nkeys = (long)nfree * (nfree + 1) / 2;
+    const long max_chunks = nkeys + n_pairs / pair_chunk + 1;
+    if (n_pairs >= (1L << 31) || nkeys >= (1L << 31)) return fail(PPO_BA_ERR_ARG);
+    ok = ok && d_npairs.alloc(own.n_own + 1) && d_pair_off.alloc(own.n_own + 1) && d_key_count.alloc(nkeys + 1) && d_key_start.alloc(nkeys + 1) && d_nchunks.alloc(nkeys + 1) &&
+         d_chunk_off.alloc(nkeys + 1) && d_n_chunks_out.alloc(1) && d_pair_key.alloc(n_pairs) && d_pair_key_out.alloc(n_pairs) && d_pair_perm.alloc(n_pairs);
+    ok = ok && s->d_pc_sj.alloc(n_pairs) && s->d_pc_si.alloc(n_pairs) && s->d_pc_lm.alloc(n_pairs) && s->d_pc_colj.alloc(max_chunks) && s->d_pc_coli.alloc(max_chunks) &&
+         s->d_pc_start.alloc(max_chunks + 1);
+    if (!ok) return fail(PPO_BA_ERR_NOMEM);
+    (void)hipMemsetAsync(d_key_count.p, 0, (size_t)(nkeys + 1) * sizeof(int32_t), s->stream);
+    (void)hipMemsetAsync(d_n_chunks_out.p, 0, sizeof(int32_t), s->stream);
+    if (own.n_own > 0 && nkeys > 0) {
+      hipLaunchKernelGGL(k_plan_pair_counts, dim3(nblk(own.n_own + 1, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_npairs.p);
+      if (!plan_exclusive_scan(plan_scratch, d_npairs.p, d_pair_off.p, (size_t)own.n_own + 1, s->stream)) return fail(PPO_BA_ERR_NOMEM);
+      if (g.n_slots > 0)
+        hipLaunchKernelGGL(k_plan_pair_keys, dim3(nblk(g.n_slots, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_slot_col_lm.p, d_slot_lm_lm.p, g.n_slots, d_pair_off.p,
+                           d_pair_key.p, d_key_count.p);
+      if (n_pairs > 0) {
+        if (!plan_sort_positions(plan_scratch, d_pair_key.p, d_pair_key_out.p, d_pair_perm.p, (size_t)n_pairs, plan_bits((unsigned long long)nkeys), s->stream)) return fail(PPO_BA_ERR_NOMEM);
+        hipLaunchKernelGGL(k_plan_pair_fill, dim3(nblk(n_pairs, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_new_id.p, d_pair_off.p, d_pair_perm.p, (int)n_pairs, s->d_pc_sj.p,
+                           s->d_pc_si.p, s->d_pc_lm.p);
+      }
+      hipLaunchKernelGGL(k_plan_chunk_counts, dim3(nblk(nkeys + 1, 256)), dim3(256), 0, s->stream, d_key_count.p, (int)nkeys, pair_chunk, d_nchunks.p);
+      if (!plan_exclusive_scan(plan_scratch, d_key_count.p, d_key_start.p, (size_t)nkeys + 1, s->stream) ||
+          !plan_exclusive_scan(plan_scratch, d_nchunks.p, d_chunk_off.p, (size_t)nkeys + 1, s->stream))
+        return fail(PPO_BA_ERR_NOMEM);
+      hipLaunchKernelGGL(k_plan_chunk_fill, dim3(nblk(nkeys + 1, 256)), dim3(256), 0, s->stream, d_key_start.p, d_chunk_off.p, (int)nkeys, pair_chunk, s->d_pc_colj.p, s->d_pc_coli.p,
+                         s->d_pc_start.p, d_n_chunks_out.p);
+    }
+    h_n_chunks = static_cast<int32_t*>(s->stage->take(sizeof(int32_t)));
+    if (!h_n_chunks) return fail(PPO_BA_ERR_NOMEM);
+    *h_n_chunks = 0;
+    HIP_TRY(hipMemcpyAsync(h_n_chunks, d_n_chunks_out.p, sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, 0};  // (n_chunks: after the synchronisation below)
+  }
   mark("hipMalloc + H2D enqueue");
   if (!ok) return fail(PPO_BA_ERR_NOMEM);
   {  // blocks come from the cache with stale contents: the work arrays that are only partially written start from zero
@@ -1375,6 +1491,14 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (Np) hipLaunchKernelGGL(k_pose_rt, dim3(nblk(Np, 256)), dim3(256), 0, s->stream, is, Np);
   }
   if (reset_device(s) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
+  if (dev_plan) {  // (reset_device has synchronised the stream: the plan is complete, its temporaries can go back to the block cache)
+    s->pc.n_chunks = *h_n_chunks;
+    plan_scratch.release();
+    for (DevBuf<int32_t>* b : {&d_slot_off_lm, &d_slot_col_lm, &d_new_id, &d_slot_lm_lm, &d_pair_off, &d_npairs, &d_key_count, &d_key_start, &d_nchunks, &d_chunk_off, &d_n_chunks_out,
+                               &d_raw_mono_pose, &d_raw_mono_point, &d_raw_stereo_pose, &d_raw_stereo_point}) b->release();
+    for (DevBuf<uint32_t>* b : {&d_pose_key, &d_pose_key_out, &d_pair_key, &d_pair_key_out, &d_pair_perm}) b->release();
+    for (DevBuf<double>* b : {&d_raw_mono_obs, &d_raw_mono_info, &d_raw_mono_huber, &d_raw_stereo_obs, &d_raw_stereo_info, &d_raw_stereo_huber}) b->release();
+  }
   mark("reset + sync");
   if (o->verbose) {
     size_t cap = 0, used = 0;
@@ -1538,7 +1662,7 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
       const int e = s->mono_perm[k];
       if (r->mono_chi2) r->mono_chi2[e] = c_mono[k];
       if (r->mono_level) r->mono_level[e] = (hmf[k] & F_ACTIVE) ? 0 : 1;
-      if (r->mono_depth_positive) r->mono_depth_positive[e] = depth(s->h_mono[k].pose, s->h_mono[k].point);
+      if (r->mono_depth_positive) r->mono_depth_positive[e] = depth(s->hk_mono_pose[k], s->hk_mono_point[k]);
     }
   });
   in_slices(g.n_stereo, [&](int k0, int k1) {
@@ -1546,7 +1670,7 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
       const int e = s->stereo_perm[k];
       if (r->stereo_chi2) r->stereo_chi2[e] = c_st[k];
       if (r->stereo_level) r->stereo_level[e] = (hsf[k] & F_ACTIVE) ? 0 : 1;
-      if (r->stereo_depth_positive) r->stereo_depth_positive[e] = depth(s->h_stereo[k].pose, s->h_stereo[k].point);
+      if (r->stereo_depth_positive) r->stereo_depth_positive[e] = depth(s->hk_stereo_pose[k], s->hk_stereo_point[k]);
     }
   });
   for (int e = 0; e < g.n_pl; ++e) {
@@ -1577,8 +1701,8 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
         {r->corner_chi2, nullptr, (size_t)g.n_corner, 3}, {r->corner_errnorm, nullptr, (size_t)g.n_corner, 3}, {nullptr, r->corner_level, (size_t)g.n_corner, 3},
         {r->ptcub_chi2, nullptr, (size_t)g.n_ptcub, 3}};
     SVec<uint8_t> own_mono(g.n_mono, 0), own_stereo(g.n_stereo, 0), own_pl(g.n_pl, 0);
-    for (int k = 0; k < g.n_mono; ++k) own_mono[s->mono_perm[k]] = s->h_mono[k].point >= g.pt_first && s->h_mono[k].point < g.pt_last;
-    for (int k = 0; k < g.n_stereo; ++k) own_stereo[s->stereo_perm[k]] = s->h_stereo[k].point >= g.pt_first && s->h_stereo[k].point < g.pt_last;
+    for (int k = 0; k < g.n_mono; ++k) own_mono[s->mono_perm[k]] = s->hk_mono_point[k] >= g.pt_first && s->hk_mono_point[k] < g.pt_last;
+    for (int k = 0; k < g.n_stereo; ++k) own_stereo[s->stereo_perm[k]] = s->hk_stereo_point[k] >= g.pt_first && s->hk_stereo_point[k] < g.pt_last;
     for (int e = 0; e < g.n_pl; ++e) own_pl[e] = hp[e].plane >= g.plane_first && hp[e].plane < g.plane_last;
     size_t total = 0;
     for (const Item& it : items) total += it.n;

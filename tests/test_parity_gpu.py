@@ -707,3 +707,33 @@ def test_the_order_of_the_callers_edge_list_does_not_matter(hip):
     np.testing.assert_allclose(rp.stereo_chi2[ps], rq.stereo_chi2, rtol=2e-3, atol=1e-4)
     assert np.mean(rp.mono_level[pm] != rq.mono_level) < 1e-4 and np.mean(rp.stereo_level[ps] != rq.stereo_level) < 1e-4
     sp.close(); sq.close()
+
+
+def test_device_built_plans_equal_the_host_built_ones(hip_hooks, monkeypatch):
+    """ppo_ba_create builds the reprojection edge records, the pose-major copy and the Schur pair plan on the device when the edge
+    lists arrive sorted by point (csrc/ppo_plan.hpp), on the host otherwise.  Same window through both builders (the test-hooks
+    library takes PPO_BA_HOST_PLAN=1), deterministic mode -- every cross-wave sum is an exact integer sum there, so the two runs are
+    BIT-IDENTICAL exactly when both builders produced the same records, slots and pairs -- and once more in the default mode, where
+    the order inside a chunk may show as round-off."""
+    P = synth.make_problem("cfg3", seed=3, stereo_frac=0.25, with_corners=True, fixed_observer_frac=0.1)
+    assert P.count("n_mono") + P.count("n_stereo") >= 40000
+    for det in (1, 0):
+        res = []
+        for host in ("", "1"):
+            if host:
+                monkeypatch.setenv("PPO_BA_HOST_PLAN", host)
+            else:
+                monkeypatch.delenv("PPO_BA_HOST_PLAN", raising=False)
+            s = hip_hooks.create(P, B.default_options(deterministic=det))
+            st = s.run()
+            res.append((st, s.read()))
+            s.close()
+        (sa, ra), (sb, rb) = res
+        assert [(i["trials"], i["accepted"]) for i in sa["iters"]] == [(i["trials"], i["accepted"]) for i in sb["iters"]]
+        if det:
+            assert [i["chi2_after"] for i in sa["iters"]] == [i["chi2_after"] for i in sb["iters"]]
+            for name in ("pose_qt", "point_xyz", "plane_coef", "cuboid_qt", "cuboid_scale", "mono_chi2", "stereo_chi2", "mono_level", "stereo_level"):
+                assert np.array_equal(getattr(ra, name), getattr(rb, name)), name
+        else:
+            np.testing.assert_allclose(ra.pose_qt, rb.pose_qt, atol=2e-6)
+            assert abs(sa["iters"][-1]["chi2_after"] - sb["iters"][-1]["chi2_after"]) <= 1e-7 * sa["iters"][-1]["chi2_after"]
