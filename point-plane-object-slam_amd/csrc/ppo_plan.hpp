@@ -1,9 +1,9 @@
 // ppo_plan.hpp -- the per-window plans of ppo_ba_create that are built ON THE DEVICE (included by ppo_solver.hip only).
 //
 // ppo_ba_create flattens a window into edge records, (landmark, pose) slots, a pose-major copy of the reprojection edges and the Schur
-// pair plan.  The slot numbering stays on the host (a sort + unique per landmark over ~8 entries); everything that is per EDGE or per
-// landmark-pose PAIR -- 2.5e5 records, 2.5e5 pose-major indices, 9e5 pairs bucketed by pose pair -- is built here from the caller's raw
-// arrays and the slot tables, when the reprojection edge lists arrive sorted by point (the reference's own loop and
+// pair plan.  All of it -- 4e5 slots (a sort + unique per landmark, then a pose-major renumbering), 2.5e5 records, 2.5e5 pose-major
+// indices, 9e5 pairs bucketed by pose pair -- is built here from the caller's raw arrays when the reprojection edge lists arrive
+// sorted by point (the reference's own loop and
 // include/ppo_flatten.hpp produce them that way; any other order takes the host builder in ppo_solver.hip, which produces the same
 // device state -- tests/test_parity_gpu.py runs both on the same window).  Orders are the host builder's: edges of a keyframe in
 // landmark order, pairs of a pose pair in (landmark, a, b) order -- both come out of STABLE radix sorts (rocPRIM), so the layout does
@@ -86,6 +86,93 @@ __global__ __launch_bounds__(256) void k_plan_pose_keys(const int32_t* __restric
   key[k] = (pt >= pt_first && pt < pt_last && pose_free_id[pose[k]] >= 0) ? (uint32_t)pose[k] : sentinel;
 }
 
+// ---- (landmark, pose) slots --------------------------------------------------------------------------------------------------------
+// One thread per landmark: the reduced columns of the free poses that observe it, gathered from its edges (points: the mono and stereo
+// ranges of the sorted lists; planes: a small CSR the host builds), sorted and made unique in place.  A landmark has ~8 observers at the
+// BASELINE size (a few hundred at most): an insertion sort by its own thread.  seg is addressed by the landmark's EDGE offset, so it needs
+// no scan; a fixed point gets no slots.
+struct SlotInputs {
+  const int32_t* mo_off; const int32_t* st_off;      // [Npt + 1]
+  const int32_t* mono_pose; const int32_t* stereo_pose;
+  const int32_t* pl_off; const int32_t* pl_perm; const int32_t* pl_pose;  // planes: CSR over the plane edges
+  const int32_t* pose_col; const uint8_t* point_fixed;
+  int n_points, n_planes, n_mono, n_stereo;
+};
+__global__ __launch_bounds__(256) void k_plan_slot_gather(SlotInputs in, int32_t* __restrict__ seg, int32_t* __restrict__ seg_cnt) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x, n_lm = in.n_points + in.n_planes;
+  if (l > n_lm) return;
+  if (l == n_lm) { seg_cnt[l] = 0; return; }  // (the scan wants n_lm + 1 entries)
+  int32_t* b0;
+  int q = 0;
+  if (l < in.n_points) {
+    if (in.point_fixed[l]) { seg_cnt[l] = 0; return; }
+    b0 = seg + in.mo_off[l] + in.st_off[l];
+    for (int k = in.mo_off[l]; k < in.mo_off[l + 1]; ++k) { const int pc = in.pose_col[in.mono_pose[k]]; if (pc >= 0) b0[q++] = pc; }
+    for (int k = in.st_off[l]; k < in.st_off[l + 1]; ++k) { const int pc = in.pose_col[in.stereo_pose[k]]; if (pc >= 0) b0[q++] = pc; }
+  } else {
+    const int j = l - in.n_points;
+    b0 = seg + in.n_mono + in.n_stereo + in.pl_off[j];
+    for (int k = in.pl_off[j]; k < in.pl_off[j + 1]; ++k) { const int pc = in.pose_col[in.pl_pose[in.pl_perm[k]]]; if (pc >= 0) b0[q++] = pc; }
+  }
+  for (int i = 1; i < q; ++i) {  // insertion sort (observations usually arrive in keyframe order: one comparison per entry)
+    const int32_t v = b0[i];
+    int j = i - 1;
+    while (j >= 0 && b0[j] > v) { b0[j + 1] = b0[j]; --j; }
+    b0[j + 1] = v;
+  }
+  int u = 0;
+  for (int i = 0; i < q; ++i)
+    if (u == 0 || b0[i] != b0[u - 1]) b0[u++] = b0[i];
+  seg_cnt[l] = u;
+}
+// slots in landmark-major order: column and landmark of each; counts[0] = n_slots, counts[1] = n_pt_slots
+__global__ __launch_bounds__(256) void k_plan_slot_compact(SlotInputs in, const int32_t* __restrict__ seg, const int32_t* __restrict__ slot_off, int32_t* __restrict__ slot_col_lm,
+                                                           int32_t* __restrict__ slot_lm_lm, int32_t* __restrict__ counts) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x, n_lm = in.n_points + in.n_planes;
+  if (l == 0) { counts[0] = slot_off[n_lm]; counts[1] = slot_off[in.n_points]; }
+  if (l >= n_lm) return;
+  const int32_t* b0 = l < in.n_points ? seg + in.mo_off[l] + in.st_off[l] : seg + in.n_mono + in.n_stereo + in.pl_off[l - in.n_points];
+  const int s0 = slot_off[l], k = slot_off[l + 1] - s0;
+  for (int i = 0; i < k; ++i) { slot_col_lm[s0 + i] = b0[i]; slot_lm_lm[s0 + i] = l; }
+}
+// device numbering is POSE-MAJOR: point slots by (pose column, point), then plane slots by (pose column, plane).  Sort key of the
+// landmark-major slot i; positions past the last slot (the arrays are sized by an upper bound) get a sentinel above every key.
+__global__ __launch_bounds__(256) void k_plan_slot_keys(const int32_t* __restrict__ slot_col_lm, const int32_t* __restrict__ slot_lm_lm, const int32_t* __restrict__ counts, int n_bound,
+                                                        int n_points, int pose_bits, uint32_t* __restrict__ key) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_bound) return;
+  key[i] = i < counts[0] ? (((uint32_t)(slot_lm_lm[i] >= n_points) << pose_bits) | (uint32_t)(slot_col_lm[i] / 6)) : (2u << pose_bits);
+}
+__global__ __launch_bounds__(256) void k_plan_slot_number(const uint32_t* __restrict__ order, const int32_t* __restrict__ slot_col_lm, const int32_t* __restrict__ slot_lm_lm,
+                                                          const int32_t* __restrict__ counts, int32_t* __restrict__ slot_col, int32_t* __restrict__ slot_lm, int32_t* __restrict__ new_id) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= counts[0]) return;
+  const int src = (int)order[i];
+  slot_col[i] = slot_col_lm[src];
+  slot_lm[i] = slot_lm_lm[src];
+  new_id[src] = i;
+}
+// planes: their slots as a CSR over device slot numbers; plane edges: the slot of (plane, observing pose)
+__global__ __launch_bounds__(256) void k_plan_plane_lists(const int32_t* __restrict__ slot_off, const int32_t* __restrict__ new_id, const int32_t* __restrict__ counts, int n_points,
+                                                          int n_planes, int32_t* __restrict__ pl_slot_off, int32_t* __restrict__ pl_slots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_pt_slots = counts[1], n_pl_slots = counts[0] - counts[1];
+  if (i <= n_planes) pl_slot_off[i] = slot_off[n_points + i] - n_pt_slots;
+  if (i < n_pl_slots) pl_slots[i] = new_id[n_pt_slots + i];
+}
+__global__ __launch_bounds__(256) void k_plan_plane_edge_slots(PlaneEdge* __restrict__ pl, PlaneEdge* __restrict__ pl0, int n, const int32_t* __restrict__ slot_off,
+                                                               const int32_t* __restrict__ slot_col_lm, const int32_t* __restrict__ new_id, const int32_t* __restrict__ pose_col, int n_points) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int32_t sl = plan_find_slot(slot_off, slot_col_lm, new_id, n_points + pl[e].plane, pose_col[pl[e].pose]);
+  pl[e].slot = sl;
+  pl0[e].slot = sl;
+}
+__global__ __launch_bounds__(256) void k_plan_fill_u32(uint32_t* __restrict__ p, const int32_t* __restrict__ first, int n_bound, uint32_t v) {  // p[*first .. n_bound) = v
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *first && i < n_bound) p[i] = v;
+}
+
 // ---- Schur pair plan ---------------------------------------------------------------------------------------------------------------
 struct OwnedLandmarks {  // points [pt_first, pt_last) then planes [plane_first, plane_last): one unit range, like the host builder's
   int n_points, pt_first, n_own_pt, plane_first, n_own;
@@ -114,10 +201,10 @@ __device__ __forceinline__ void unpack_lower_big(long long t, int& a, int& c) {
 // one thread per landmark-major slot a: the keys of its pairs (a, b <= a), key = pose_a (pose_a + 1) / 2 + pose_b, at the position the
 // host builder's (landmark, a, b) loop would visit them; a histogram of the keys next to it
 __global__ __launch_bounds__(256) void k_plan_pair_keys(OwnedLandmarks own, const int32_t* __restrict__ slot_off, const int32_t* __restrict__ slot_col_lm,
-                                                        const int32_t* __restrict__ slot_lm_lm, int n_slots, const int32_t* __restrict__ pair_off, uint32_t* __restrict__ key,
-                                                        int32_t* __restrict__ key_count) {
+                                                        const int32_t* __restrict__ slot_lm_lm, const int32_t* __restrict__ counts, const int32_t* __restrict__ pair_off,
+                                                        uint32_t* __restrict__ key, int32_t* __restrict__ key_count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_slots) return;
+  if (i >= counts[0]) return;
   const int l = slot_lm_lm[i], u = own.unit_of(l);
   if (u < 0) return;
   const int s0 = slot_off[l], a = i - s0;
@@ -131,10 +218,10 @@ __global__ __launch_bounds__(256) void k_plan_pair_keys(OwnedLandmarks own, cons
 }
 // the plan entries in sorted order: perm[i] = position in the (landmark, a, b) enumeration of the i-th pair by key
 __global__ __launch_bounds__(256) void k_plan_pair_fill(OwnedLandmarks own, const int32_t* __restrict__ slot_off, const int32_t* __restrict__ new_id,
-                                                        const int32_t* __restrict__ pair_off, const uint32_t* __restrict__ perm, int n_pairs, int32_t* __restrict__ pc_sj,
+                                                        const int32_t* __restrict__ pair_off, const uint32_t* __restrict__ perm, int32_t* __restrict__ pc_sj,
                                                         int32_t* __restrict__ pc_si, int32_t* __restrict__ pc_lm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pairs) return;
+  if (i >= pair_off[own.n_own]) return;  // (the grid is sized by an upper bound of the pair count)
   const int pos = (int)perm[i];
   int lo = 0, hi = own.n_own;  // largest u with pair_off[u] <= pos
   while (hi - lo > 1) {

@@ -961,7 +961,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     SVec<int32_t> cursor(pl_off.begin(), pl_off.end() - 1);
     for (int e = 0; e < p->n_plane_edges; ++e) pl_perm[cursor[p->pl_plane[e]]++] = e;
   }
-  SVec<int32_t> seg_off(g.n_lm + 1, 0), seg_col, seg_cnt(g.n_lm, 0);
+  // (device builder: all of this happens in k_plan_slot_* of ppo_plan.hpp; the host only sizes the arrays by upper bounds)
+  SVec<int32_t> seg_off, seg_col, seg_cnt, slot_col, slot_lm, new_id, d_slot_col_v, d_slot_lm_v, pl_slot_off, pl_slots;
+  SVec<int32_t>& slot_off = s->h_slot_off;
+  int n_point_slots = p->n_mono + p->n_stereo;
+  g.n_slots = n_point_slots + p->n_plane_edges;
+  if (!dev_plan) {
+  seg_off.assign(g.n_lm + 1, 0); seg_cnt.assign(g.n_lm, 0);
   for (int pt = 0; pt < Npt; ++pt) seg_off[pt + 1] = seg_off[pt] + (mo_off[pt + 1] - mo_off[pt]) + (st_off[pt + 1] - st_off[pt]);
   for (int j = 0; j < Npl; ++j) seg_off[Npt + j + 1] = seg_off[Npt + j] + (pl_off[j + 1] - pl_off[j]);
   seg_col.resize(seg_off[g.n_lm]);
@@ -985,11 +991,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     }
   });
   mark("  slots: gather + sort + unique");
-  SVec<int32_t>& slot_off = s->h_slot_off;
   slot_off.assign(g.n_lm + 1, 0);
   for (int l = 0; l < g.n_lm; ++l) slot_off[l + 1] = slot_off[l] + seg_cnt[l];
   g.n_slots = slot_off[g.n_lm];
-  SVec<int32_t> slot_col(g.n_slots), slot_lm(g.n_slots);
+  slot_col.resize(g.n_slots); slot_lm.resize(g.n_slots);
   run_threads(n_host_threads, [&](int t) {
     const int l0 = (int)((long)g.n_lm * t / n_host_threads), l1 = (int)((long)g.n_lm * (t + 1) / n_host_threads);
     for (int l = l0; l < l1; ++l)
@@ -998,8 +1003,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   mark("  slots: compact");
   // device numbering is POSE-MAJOR: point slots ordered by (pose column, point), then plane slots by (pose column, plane),
   // so that everything a keyframe touches is contiguous (the pose side of the linearisation and the Schur pair kernel stream it)
-  const int n_point_slots = slot_off[Npt];
-  SVec<int32_t> new_id(g.n_slots), d_slot_col_v(g.n_slots), d_slot_lm_v(g.n_slots);
+  n_point_slots = slot_off[Npt];
+  new_id.resize(g.n_slots); d_slot_col_v.resize(g.n_slots); d_slot_lm_v.resize(g.n_slots);
   {
     auto renumber = [&](int first, int last, int base) {
       SVec<int32_t> start;
@@ -1014,9 +1019,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       for (int i = i0; i < i1; ++i) { d_slot_col_v[new_id[i]] = slot_col[i]; d_slot_lm_v[new_id[i]] = slot_lm[i]; }
     });
   }
-  SVec<int32_t> pl_slot_off(Npl + 1, 0), pl_slots(g.n_slots - n_point_slots);
+  pl_slot_off.assign(Npl + 1, 0); pl_slots.resize(g.n_slots - n_point_slots);
   for (int j = 0; j <= Npl; ++j) pl_slot_off[j] = slot_off[Npt + j] - n_point_slots;
   for (int i = n_point_slots; i < g.n_slots; ++i) pl_slots[i - n_point_slots] = new_id[i];
+  }  // (host builder)
   auto find_slot = [&](int l, int pc) -> int32_t {
     if (pc < 0) return -1;
     const int32_t* b = slot_col.data() + slot_off[l];
@@ -1174,7 +1180,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     for (int i = 0; i < 3; ++i) m.info[i] = p->pl_info[3 * e + i];
     m.huber = p->pl_huber[e];
     m.plane = p->pl_plane[e]; m.pose = p->pl_pose[e];
-    m.slot = find_slot(Npt + m.plane, pose_col[m.pose]);
+    m.slot = dev_plan ? -1 : find_slot(Npt + m.plane, pose_col[m.pose]);  // (device builder: k_plan_plane_edge_slots)
     m.flags = F_ACTIVE | F_ROBUST | ((uint32_t)(p->pl_kind ? p->pl_kind[e] : 0) << 8);
   }
   auto fill_cub = [&](SVec<CubEdge>& v, int n, const int32_t* pose, const int32_t* cub, const double* meas, const double* info,
@@ -1319,8 +1325,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_pose_cam.upload(v_cam, s->stream) && s->d_cub_fixedscale.upload(v_fs, s->stream) && s->d_ptcub_pts.upload(v_pts, s->stream);
   ok = ok && s->d_pose_col.upload(pose_col, s->stream) && s->d_pose_free_id.upload(pose_free_id, s->stream) && s->d_cub_col.upload(cub_col, s->stream);
   ok = ok && s->d_mo_off.upload(mo_off, s->stream) && s->d_st_off.upload(st_off, s->stream);
-  ok = ok && s->d_slot_col.upload(d_slot_col_v, s->stream) && s->d_slot_lm.upload(d_slot_lm_v, s->stream);
-  ok = ok && s->d_pl_slot_off.upload(pl_slot_off, s->stream) && s->d_pl_slots.upload(pl_slots, s->stream);
+  if (dev_plan) {
+    ok = ok && s->d_slot_col.alloc(g.n_slots) && s->d_slot_lm.alloc(g.n_slots) && s->d_pl_slot_off.alloc(Npl + 1) && s->d_pl_slots.alloc(p->n_plane_edges);
+  } else {
+    ok = ok && s->d_slot_col.upload(d_slot_col_v, s->stream) && s->d_slot_lm.upload(d_slot_lm_v, s->stream);
+    ok = ok && s->d_pl_slot_off.upload(pl_slot_off, s->stream) && s->d_pl_slots.upload(pl_slots, s->stream);
+  }
   if (dev_plan) {
     ok = ok && s->d_mono_flags.alloc(p->n_mono) && s->d_mono_flags0.alloc(p->n_mono) && s->d_stereo_flags.alloc(p->n_stereo) && s->d_stereo_flags0.alloc(p->n_stereo);
   } else {
@@ -1336,7 +1346,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   const size_t n_chi = (size_t)p->n_mono + p->n_stereo + p->n_plane_edges + 2 * (size_t)p->n_bbox + 2 * (size_t)p->n_corner + p->n_ptcub;
   ok = ok && s->d_chi2_all.alloc(n_chi);
   // arena: HB | HC | acc | D | bl;  d_W: factor records of the point slots | linearisation-point rotations | W of the plane slots
-  g.n_pt_slots = slot_off[Npt];
+  g.n_pt_slots = n_point_slots;  // (device builder: upper bounds here, the exact counts come back with the final synchronisation)
   const size_t nF = (size_t)g.n_pt_slots * 4, nLinR = (size_t)(ld / 6 + 2) * 12, nWpl = (size_t)(g.n_slots - g.n_pt_slots) * 18;
   const size_t nHB = (size_t)nfree * 27, nHC = (size_t)Nc * 54, nD = (size_t)g.n_lm * 6, nbl = (size_t)g.n_lm * 3, nW = 2 * (nF + nLinR + nWpl);
   ok = ok && s->d_arena.alloc(2 * (nHB + nHC + nD + nbl) + ACC_TOTAL) && s->d_W.alloc(nW);
@@ -1351,7 +1361,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_Dinv.alloc((size_t)Nc * 81) && s->d_xc.alloc((size_t)Nc * 9);
   PlanScratch plan_scratch;
   DevBuf<int32_t> d_slot_off_lm, d_slot_col_lm, d_new_id, d_slot_lm_lm, d_pair_off, d_npairs, d_key_count, d_key_start, d_nchunks, d_chunk_off, d_n_chunks_out;
-  DevBuf<uint32_t> d_pose_key, d_pose_key_out, d_pair_key, d_pair_key_out, d_pair_perm;
+  DevBuf<int32_t> d_pl_off, d_pl_perm, d_pl_pose, d_seg, d_seg_cnt, d_counts;
+  DevBuf<uint32_t> d_pose_key, d_pose_key_out, d_pair_key, d_pair_key_out, d_pair_perm, d_slot_key, d_slot_key_out, d_slot_order;
   int32_t* h_n_chunks = nullptr;  // (page-locked: the device's chunk count comes back with the final synchronisation)
   if (!dev_plan) {
     ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
@@ -1359,8 +1370,32 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, (int)pc_colj.size()};
   } else {
     // ---- device builder (ppo_plan.hpp): records + flags, pose-major index lists, Schur pair plan ------------------------------------
-    ok = ok && d_slot_off_lm.upload(slot_off, s->stream) && d_slot_col_lm.upload(slot_col, s->stream) && d_new_id.upload(new_id, s->stream) && d_slot_lm_lm.upload(slot_lm, s->stream);
+    // (landmark, pose) slots: gather + sort + unique per landmark, scan, compact, pose-major numbering by a stable sort
+    const int n_slot_bound = g.n_slots, pose_bits = plan_bits((unsigned long long)Np);
+    ok = ok && d_pl_off.upload(pl_off, s->stream) && d_pl_perm.upload(pl_perm, s->stream);
+    {
+      SVec<int32_t> pl_pose_v(p->pl_pose, p->pl_pose + p->n_plane_edges);
+      ok = ok && d_pl_pose.upload(pl_pose_v, s->stream);
+    }
+    ok = ok && d_seg.alloc(n_slot_bound) && d_seg_cnt.alloc(g.n_lm + 1) && d_slot_off_lm.alloc(g.n_lm + 1) && d_slot_col_lm.alloc(n_slot_bound) && d_slot_lm_lm.alloc(n_slot_bound) &&
+         d_new_id.alloc(n_slot_bound) && d_counts.alloc(4) && d_slot_key.alloc(n_slot_bound) && d_slot_key_out.alloc(n_slot_bound) && d_slot_order.alloc(n_slot_bound);
     if (!ok) return fail(PPO_BA_ERR_NOMEM);
+    const SlotInputs sin{s->d_mo_off.p, s->d_st_off.p, d_raw_mono_pose.p, d_raw_stereo_pose.p, d_pl_off.p, d_pl_perm.p, d_pl_pose.p, s->d_pose_col.p, s->d_point_fixed.p,
+                         Npt, Npl, p->n_mono, p->n_stereo};
+    hipLaunchKernelGGL(k_plan_slot_gather, dim3(nblk(g.n_lm + 1, 256)), dim3(256), 0, s->stream, sin, d_seg.p, d_seg_cnt.p);
+    if (!plan_exclusive_scan(plan_scratch, d_seg_cnt.p, d_slot_off_lm.p, (size_t)g.n_lm + 1, s->stream)) return fail(PPO_BA_ERR_NOMEM);
+    hipLaunchKernelGGL(k_plan_slot_compact, dim3(nblk(std::max(g.n_lm, 1), 256)), dim3(256), 0, s->stream, sin, d_seg.p, d_slot_off_lm.p, d_slot_col_lm.p, d_slot_lm_lm.p, d_counts.p);
+    if (n_slot_bound > 0) {
+      hipLaunchKernelGGL(k_plan_slot_keys, dim3(nblk(n_slot_bound, 256)), dim3(256), 0, s->stream, d_slot_col_lm.p, d_slot_lm_lm.p, d_counts.p, n_slot_bound, Npt, pose_bits, d_slot_key.p);
+      if (!plan_sort_positions(plan_scratch, d_slot_key.p, d_slot_key_out.p, d_slot_order.p, (size_t)n_slot_bound, pose_bits + 2, s->stream)) return fail(PPO_BA_ERR_NOMEM);
+      hipLaunchKernelGGL(k_plan_slot_number, dim3(nblk(n_slot_bound, 256)), dim3(256), 0, s->stream, d_slot_order.p, d_slot_col_lm.p, d_slot_lm_lm.p, d_counts.p, s->d_slot_col.p,
+                         s->d_slot_lm.p, d_new_id.p);
+    }
+    hipLaunchKernelGGL(k_plan_plane_lists, dim3(nblk(std::max(Npl + 1, p->n_plane_edges), 256)), dim3(256), 0, s->stream, d_slot_off_lm.p, d_new_id.p, d_counts.p, Npt, Npl,
+                       s->d_pl_slot_off.p, s->d_pl_slots.p);
+    if (p->n_plane_edges > 0)
+      hipLaunchKernelGGL(k_plan_plane_edge_slots, dim3(nblk(p->n_plane_edges, 256)), dim3(256), 0, s->stream, s->d_pl.p, s->d_pl0.p, p->n_plane_edges, d_slot_off_lm.p, d_slot_col_lm.p,
+                         d_new_id.p, s->d_pose_col.p, Npt);
     const SlotTables tabs{d_slot_off_lm.p, d_slot_col_lm.p, d_new_id.p, s->d_pose_col.p, s->d_point_fixed.p};
     const ReprojRaw rm{d_raw_mono_obs.p, d_raw_mono_info.p, d_raw_mono_huber.p, d_raw_mono_pose.p, d_raw_mono_point.p, p->n_mono};
     const ReprojRaw rs{d_raw_stereo_obs.p, d_raw_stereo_info.p, d_raw_stereo_huber.p, d_raw_stereo_pose.p, d_raw_stereo_point.p, p->n_stereo};
@@ -1370,7 +1405,6 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     const size_t n_key = (size_t)std::max(p->n_mono, p->n_stereo);
     ok = ok && d_pose_key.alloc(n_key) && d_pose_key_out.alloc(n_key) && s->d_monoP_src.alloc(p->n_mono) && s->d_stereoP_src.alloc(p->n_stereo);
     if (!ok) return fail(PPO_BA_ERR_NOMEM);
-    const int pose_bits = plan_bits((unsigned long long)Np);
     for (int type = 0; type < 2; ++type) {
       const int n = type == 0 ? p->n_mono : p->n_stereo;
       if (n == 0) continue;
@@ -1384,8 +1418,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                          s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)n_monoP, s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)n_stereoP);
     // Schur pair plan
     OwnedLandmarks own{Npt, g.pt_first, g.pt_last - g.pt_first, g.plane_first, (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first)};
-    long n_pairs = 0;
-    for (int u = 0; u < own.n_own; ++u) { const long k = seg_cnt[own.lm_of(u)]; n_pairs += k * (k + 1) / 2; }
+    long n_pairs = 0;  // (upper bound: every edge of a landmark a slot; the device knows the exact number, positions past it sort to the end)
+    for (int u = 0; u < own.n_own; ++u) {
+      const int l = own.lm_of(u);
+      const long k = l < Npt ? (long)(mo_off[l + 1] - mo_off[l]) + (st_off[l + 1] - st_off[l]) : (long)(pl_off[l - Npt + 1] - pl_off[l - Npt]);
+      n_pairs += k * (k + 1) / 2;
+    }
     const long nkeys = (long)nfree * (nfree + 1) / 2;
     const long max_chunks = nkeys + n_pairs / pair_chunk + 1;
     if (n_pairs >= (1L << 31) || nkeys >= (1L << 31)) return fail(PPO_BA_ERR_ARG);
@@ -1399,12 +1437,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (own.n_own > 0 && nkeys > 0) {
       hipLaunchKernelGGL(k_plan_pair_counts, dim3(nblk(own.n_own + 1, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_npairs.p);
       if (!plan_exclusive_scan(plan_scratch, d_npairs.p, d_pair_off.p, (size_t)own.n_own + 1, s->stream)) return fail(PPO_BA_ERR_NOMEM);
-      if (g.n_slots > 0)
-        hipLaunchKernelGGL(k_plan_pair_keys, dim3(nblk(g.n_slots, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_slot_col_lm.p, d_slot_lm_lm.p, g.n_slots, d_pair_off.p,
+      if (n_slot_bound > 0)
+        hipLaunchKernelGGL(k_plan_pair_keys, dim3(nblk(n_slot_bound, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_slot_col_lm.p, d_slot_lm_lm.p, d_counts.p, d_pair_off.p,
                            d_pair_key.p, d_key_count.p);
       if (n_pairs > 0) {
+        hipLaunchKernelGGL(k_plan_fill_u32, dim3(nblk(n_pairs, 256)), dim3(256), 0, s->stream, d_pair_key.p, d_pair_off.p + own.n_own, (int)n_pairs, (uint32_t)nkeys);
         if (!plan_sort_positions(plan_scratch, d_pair_key.p, d_pair_key_out.p, d_pair_perm.p, (size_t)n_pairs, plan_bits((unsigned long long)nkeys), s->stream)) return fail(PPO_BA_ERR_NOMEM);
-        hipLaunchKernelGGL(k_plan_pair_fill, dim3(nblk(n_pairs, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_new_id.p, d_pair_off.p, d_pair_perm.p, (int)n_pairs, s->d_pc_sj.p,
+        hipLaunchKernelGGL(k_plan_pair_fill, dim3(nblk(n_pairs, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_new_id.p, d_pair_off.p, d_pair_perm.p, s->d_pc_sj.p,
                            s->d_pc_si.p, s->d_pc_lm.p);
       }
       hipLaunchKernelGGL(k_plan_chunk_counts, dim3(nblk(nkeys + 1, 256)), dim3(256), 0, s->stream, d_key_count.p, (int)nkeys, pair_chunk, d_nchunks.p);
@@ -1414,10 +1453,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       hipLaunchKernelGGL(k_plan_chunk_fill, dim3(nblk(nkeys + 1, 256)), dim3(256), 0, s->stream, d_key_start.p, d_chunk_off.p, (int)nkeys, pair_chunk, s->d_pc_colj.p, s->d_pc_coli.p,
                          s->d_pc_start.p, d_n_chunks_out.p);
     }
-    h_n_chunks = static_cast<int32_t*>(s->stage->take(sizeof(int32_t)));
+    h_n_chunks = static_cast<int32_t*>(s->stage->take(4 * sizeof(int32_t)));  // [0] chunks, [1] slots, [2] point slots
     if (!h_n_chunks) return fail(PPO_BA_ERR_NOMEM);
-    *h_n_chunks = 0;
+    h_n_chunks[0] = h_n_chunks[1] = h_n_chunks[2] = 0;
     HIP_TRY(hipMemcpyAsync(h_n_chunks, d_n_chunks_out.p, sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(h_n_chunks + 1, d_counts.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
     s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, 0};  // (n_chunks: after the synchronisation below)
   }
   mark("hipMalloc + H2D enqueue");
@@ -1492,11 +1532,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   if (reset_device(s) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
   if (dev_plan) {  // (reset_device has synchronised the stream: the plan is complete, its temporaries can go back to the block cache)
-    s->pc.n_chunks = *h_n_chunks;
+    s->pc.n_chunks = h_n_chunks[0];
+    s->g.n_slots = h_n_chunks[1];
+    s->g.n_pt_slots = h_n_chunks[2];
     plan_scratch.release();
     for (DevBuf<int32_t>* b : {&d_slot_off_lm, &d_slot_col_lm, &d_new_id, &d_slot_lm_lm, &d_pair_off, &d_npairs, &d_key_count, &d_key_start, &d_nchunks, &d_chunk_off, &d_n_chunks_out,
-                               &d_raw_mono_pose, &d_raw_mono_point, &d_raw_stereo_pose, &d_raw_stereo_point}) b->release();
-    for (DevBuf<uint32_t>* b : {&d_pose_key, &d_pose_key_out, &d_pair_key, &d_pair_key_out, &d_pair_perm}) b->release();
+                               &d_raw_mono_pose, &d_raw_mono_point, &d_raw_stereo_pose, &d_raw_stereo_point, &d_pl_off, &d_pl_perm, &d_pl_pose, &d_seg, &d_seg_cnt, &d_counts}) b->release();
+    for (DevBuf<uint32_t>* b : {&d_pose_key, &d_pose_key_out, &d_pair_key, &d_pair_key_out, &d_pair_perm, &d_slot_key, &d_slot_key_out, &d_slot_order}) b->release();
     for (DevBuf<double>* b : {&d_raw_mono_obs, &d_raw_mono_info, &d_raw_mono_huber, &d_raw_stereo_obs, &d_raw_stereo_info, &d_raw_stereo_huber}) b->release();
   }
   mark("reset + sync");
