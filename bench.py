@@ -246,15 +246,20 @@ def main():
     # the library's block cache warm as in a running SLAM process; never part of `value`
     call_ms = {}
     if world == 1:
-        solver.close()
-        t_a = time.perf_counter()
-        solver = B.hip_backend().create(P, opt)
-        t_b = time.perf_counter()
-        solver.run()
-        t_c2 = time.perf_counter()
-        solver.read()
-        t_d = time.perf_counter()
-        call_ms = {"create": 1e3 * (t_b - t_a), "run": 1e3 * (t_c2 - t_b), "read": 1e3 * (t_d - t_c2), "total": 1e3 * (t_d - t_a)}
+        samples = []
+        for _ in range(5):  # (median of five: a single call is at the mercy of the container's CPU quota)
+            solver.close()
+            t_a = time.perf_counter()
+            solver = B.hip_backend().create(P, opt)
+            t_b = time.perf_counter()
+            solver.run()
+            t_c2 = time.perf_counter()
+            solver.read()
+            t_d = time.perf_counter()
+            samples.append((1e3 * (t_b - t_a), 1e3 * (t_c2 - t_b), 1e3 * (t_d - t_c2), 1e3 * (t_d - t_a)))
+        med = [sorted(x[i] for x in samples)[len(samples) // 2] for i in range(4)]
+        call_ms = {"create": med[0], "run": med[1], "read": med[2], "total": med[3],
+                   "note": "median of 5 calls through the Python harness (read includes allocating the result arrays); examples/replay.cpp measures the C++ caller"}
 
     extras = world == 1 and not a.no_extras
     pose_only = pose_only_figures(B, not a.no_cpu_baseline) if extras else {}

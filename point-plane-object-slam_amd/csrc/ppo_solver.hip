@@ -890,7 +890,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   auto csr_sort = [&](int n, const int32_t* key, SVec<int32_t>& off, SVec<int32_t>& perm) -> bool {
     // the reference adds the observations point by point (Optimizer.cc:2350-2422), so the edges normally ARRIVE sorted: then the
     // permutation is the identity and the offsets are the positions where the key changes (both filled in slices by the team)
-    if (n >= 4096 && all_slices((size_t)n - 1, [&](size_t a, size_t b) { int32_t bad = 0; for (size_t e = a; e < b; ++e) bad |= (int32_t)(key[e] > key[e + 1]); return bad == 0; })) {
+    if (n >= 1 && all_slices((size_t)n - 1, [&](size_t a, size_t b) { int32_t bad = 0; for (size_t e = a; e < b; ++e) bad |= (int32_t)(key[e] > key[e + 1]); return bad == 0; })) {
       off.resize(Npt + 1);
       perm.resize(n);
       const int nt = n >= (1 << 16) ? std::min(HostTeam::get().size(), 8) : 1;
@@ -919,7 +919,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // Edge lists that arrive sorted by point (the reference's loop, include/ppo_flatten.hpp) have their records, pose-major copy and
   // Schur pair plan built ON THE DEVICE (ppo_plan.hpp); anything else, and small windows, take the host builder below.  Both produce
   // the same device state.
-  const bool dev_plan = mono_sorted && stereo_sorted && (long)p->n_mono + p->n_stereo >= 40000 && !PPO_DEV_ENV("PPO_BA_HOST_PLAN");
+  const long dev_plan_min = PPO_DEV_ENV("PPO_BA_DEV_PLAN_MIN") ? atol(PPO_DEV_ENV("PPO_BA_DEV_PLAN_MIN")) : 40000;  // (small windows: the host builder is faster than ~40 launches)
+  const bool dev_plan = mono_sorted && stereo_sorted && (long)p->n_mono + p->n_stereo >= dev_plan_min && !PPO_DEV_ENV("PPO_BA_HOST_PLAN");
 
   mark("csr sort");
   // ---- host threads for the plans below -------------------------------------------------------------------------------

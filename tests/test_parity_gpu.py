@@ -737,3 +737,33 @@ def test_device_built_plans_equal_the_host_built_ones(hip_hooks, monkeypatch):
         else:
             np.testing.assert_allclose(ra.pose_qt, rb.pose_qt, atol=2e-6)
             assert abs(sa["iters"][-1]["chi2_after"] - sb["iters"][-1]["chi2_after"]) <= 1e-7 * sa["iters"][-1]["chi2_after"]
+
+
+def test_device_builder_on_randomly_structured_windows(hip_hooks, monkeypatch):
+    """The device-side builder of slots, records and plans (csrc/ppo_plan.hpp) normally takes only large windows; the test-hooks library
+    lets it take everything (PPO_BA_DEV_PLAN_MIN=0).  40 windows of random size and composition -- fixed points, fixed observers,
+    stereo share, planes with vertical / parallel edges, cuboids with corners, empty classes, both elimination modes
+    (tools/random_sweep.py) -- through both builders in deterministic mode: BIT-identical iteration histories and estimates, i.e. the
+    same slots, records and pairs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("random_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "random_sweep.py"))
+    rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rs)
+    for seed in range(5000, 5040):
+        cfg, kw, elim = rs.random_case(seed)
+        P = synth.make_problem(cfg, **kw)
+        out = []
+        for host in (False, True):
+            monkeypatch.setenv("PPO_BA_DEV_PLAN_MIN", "0")
+            if host:
+                monkeypatch.setenv("PPO_BA_HOST_PLAN", "1")
+            else:
+                monkeypatch.delenv("PPO_BA_HOST_PLAN", raising=False)
+            s = hip_hooks.create(P, B.default_options(deterministic=1, eliminate_cuboids=elim))
+            st = s.run()
+            out.append((st, s.read()))
+            s.close()
+        (sa, ra), (sb, rb) = out
+        assert [(i["trials"], i["accepted"], i["chi2_after"]) for i in sa["iters"]] == [(i["trials"], i["accepted"], i["chi2_after"]) for i in sb["iters"]], (seed, cfg, kw)
+        for name in ("pose_qt", "point_xyz", "plane_coef", "cuboid_qt", "cuboid_scale", "mono_chi2", "stereo_chi2", "pl_chi2", "mono_level", "stereo_level", "pl_level"):
+            assert np.array_equal(getattr(ra, name), getattr(rb, name)), (seed, name, cfg, kw)
