@@ -415,6 +415,12 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     const int bj = t - bi * (bi + 1) / 2;
     const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
+#ifdef PPO_CHOL_TRAIL_DELAY_TICKS  // (experiment: trailing tiles start late, the column workgroups' prologue has the memory system to itself)
+    {
+      const unsigned long long t_in = wall_clock64();
+      while (wall_clock64() - t_in < PPO_CHOL_TRAIL_DELAY_TICKS) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     double2 tp[NI], tq[NI];
     load_tile_nt<NT>(&A[(size_t)kp * ld + r0], ld, tp);
     load_tile_nt<NT>(&A[(size_t)kp * ld + c0], ld, tq);
