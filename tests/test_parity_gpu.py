@@ -767,3 +767,27 @@ def test_device_builder_on_randomly_structured_windows(hip_hooks, monkeypatch):
         assert [(i["trials"], i["accepted"], i["chi2_after"]) for i in sa["iters"]] == [(i["trials"], i["accepted"], i["chi2_after"]) for i in sb["iters"]], (seed, cfg, kw)
         for name in ("pose_qt", "point_xyz", "plane_coef", "cuboid_qt", "cuboid_scale", "mono_chi2", "stereo_chi2", "pl_chi2", "mono_level", "stereo_level", "pl_level"):
             assert np.array_equal(getattr(ra, name), getattr(rb, name)), (seed, name, cfg, kw)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_landmark_sharding_with_the_device_builder(hip_hooks, monkeypatch, world):
+    """Sharded ranks whose plans come from the device-side builder (csrc/ppo_plan.hpp: pose-major copies and pair plan of the OWNED
+    landmark range only, slots of all landmarks): same answer as one rank, and as the host builder, on a window with planes, cuboids,
+    stereo edges and fixed observers."""
+    monkeypatch.setenv("PPO_BA_DEV_PLAN_MIN", "0")
+    P = synth.make_problem(dict(n_kf=14, n_points=500, n_planes=5, n_cuboids=3), seed=9, stereo_frac=0.3, fixed_observer_frac=0.2)
+    s = hip_hooks.create(P, B.default_options())
+    st1, r1 = s.run(), s.read()
+    s.close()
+    res = _run_sharded_in_process(hip_hooks, P, world, key=4000 + world)
+    for st, r in res:
+        assert [(i["trials"], i["accepted"], i["result"]) for i in st["iters"]] == [(i["trials"], i["accepted"], i["result"]) for i in st1["iters"]]
+        compare_states(r1, r)
+        assert np.array_equal(r.mono_level, r1.mono_level) and np.array_equal(r.stereo_level, r1.stereo_level) and np.array_equal(r.pl_level, r1.pl_level)
+    monkeypatch.setenv("PPO_BA_HOST_PLAN", "1")
+    res_h = _run_sharded_in_process(hip_hooks, P, world, key=4100 + world, deterministic=1)
+    monkeypatch.delenv("PPO_BA_HOST_PLAN")
+    res_d = _run_sharded_in_process(hip_hooks, P, world, key=4200 + world, deterministic=1)
+    for (sa, ra), (sb, rb) in zip(res_h, res_d):  # deterministic mode: the two builders give bit-identical sharded runs
+        assert [i["chi2_after"] for i in sa["iters"]] == [i["chi2_after"] for i in sb["iters"]]
+        assert np.array_equal(ra.pose_qt, rb.pose_qt) and np.array_equal(ra.point_xyz, rb.point_xyz) and np.array_equal(ra.mono_chi2, rb.mono_chi2)
