@@ -749,6 +749,9 @@ __device__ __forceinline__ double quad_b(const double (*sJ)[16], const double* s
 // 4 000 plane edges alone issued 216 000 line operations, 135-180 of them per hot line (a plane's D_l, a keyframe's pose block): the
 // accumulation phase took 6 us of a 14 us workgroup (tools/lin_stamps.py), against 2 us now.
 
+// entry o (= lane + 19 * round) of the 54 a plane edge adds: row | col << 4 | is_b << 8 | segment (0 D_l, 1 b_l, 2 pose block, 3 W) << 9 | offset << 11
+__device__ const uint16_t kPlaneEmit[57] = {0x0000, 0x0810, 0x1020, 0x1811, 0x2021, 0x2822, 0x0300, 0x0b01, 0x1302, 0x0433, 0x0c34, 0x1444, 0x1c35, 0x2445, 0x2c55, 0x3436, 0x3c46, 0x4456, 0x4c66, 0x5437, 0x5c47, 0x6457, 0x6c67, 0x7477, 0x7c38, 0x8448, 0x8c58, 0x9468, 0x9c78, 0xa488, 0xad03, 0xb504, 0xbd05, 0xc506, 0xcd07, 0xd508, 0x0603, 0x0e13, 0x1623, 0x1e04, 0x2614, 0x2e24, 0x3605, 0x3e15, 0x4625, 0x4e06, 0x5616, 0x5e26, 0x6607, 0x6e17, 0x7627, 0x7e08, 0x8618, 0x8e28, 0xffff, 0xffff, 0xffff};
+
 // ---- plane edges: 19 lanes per edge (the two signs of a column in neighbouring lanes + the base residual), 3 edges per wave ----------
 __device__ __forceinline__ void lin_plane_body(const Graph& g, const State& st, int n_edges, double delta, int vblock, double* smem) {
   using Model = PlaneModel;
@@ -818,14 +821,11 @@ __device__ __forceinline__ void lin_plane_body(const Graph& g, const State& st, 
 #pragma unroll
     for (int rd = 0; rd < 3; ++rd) {
       const int o = lane + rd * LPE;
-      int qa, qc;
-      unpack_lower(o >= 9 && o < 30 ? o - 9 : 0, qa, qc);
-      // row / column of J' (rho1 Omega) J this entry is; isb: an entry of -J' (rho1 Omega e) instead
-      const int row = o < 3 ? 0 : o < 5 ? 1 : o < 6 ? 2 : o < 9 ? o - 6 : o < 30 ? 3 + qa : o < 36 ? 3 + (o - 30) : 3 + (o - 36) / 3;
-      const int col = o < 3 ? o : o < 5 ? o - 2 : o < 6 ? 2 : o < 9 ? 0 : o < 30 ? 3 + qc : o < 36 ? 0 : (o - 36) % 3;
-      const bool isb = (o >= 6 && o < 9) || (o >= 30 && o < 36);
-      double* const dst = o < 6 ? pD + o : o < 9 ? pb + (o - 6) : o < 36 ? pH + (o - 9) : pW + (o - 36);
-      const bool valid = o < 54 && (o < 9 || (fid >= 0 && (o < 36 || ed.slot >= 0)));
+      const unsigned en = kPlaneEmit[o];  // (a table: decoding o arithmetically was a third of this phase)
+      const int row = en & 15, col = (en >> 4) & 15, seg = (en >> 9) & 3, off = en >> 11;
+      const bool isb = (en >> 8) & 1;
+      double* const dst = (seg == 0 ? pD : seg == 1 ? pb : seg == 2 ? pH : pW) + off;
+      const bool valid = o < 54 && (seg < 2 || (fid >= 0 && (seg == 2 || ed.slot >= 0)));
       double h = 0;
 #pragma unroll
       for (int r = 0; r < DM; ++r) {
