@@ -784,7 +784,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---- role ----
   int bi, slot;
   {
+#ifdef PPO_CHOL_FWD_ONE_XCD  // (experiment: every eighth workgroup works, so that all hand-offs stay behind ONE L2)
+    if (blockIdx.x & 7) return;
+    const int b = blockIdx.x >> 3;
+#else
     const int b = blockIdx.x;
+#endif
     if (b < 2) { bi = b; slot = b == 0 ? 0 : 0; }
     else {
       bi = 2;
@@ -1146,7 +1151,11 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
       hipLaunchKernelGGL(chol_step, dim3(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(kStepThreads), 0, s, A, ld, k0, b, w.y, x, info);
     }
   } else {
+#ifdef PPO_CHOL_FWD_ONE_XCD
+    hipLaunchKernelGGL(chol_fwd_all, dim3(8 * (nb < 2 ? 1 : 1 + nb * (nb - 1) / 2)), dim3(256), 0, s, A, ld, b, x, info, w);
+#else
     hipLaunchKernelGGL(chol_fwd_all, dim3(nb < 2 ? 1 : 1 + nb * (nb - 1) / 2), dim3(256), 0, s, A, ld, b, x, info, w);
+#endif
   }
   hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(256), 0, s, (const double*)A, ld, (const double*)w.y, x, info, w.tile, (int)ws_flag_ints(nb));
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;

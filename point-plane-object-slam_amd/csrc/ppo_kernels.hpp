@@ -1087,6 +1087,9 @@ __global__ __launch_bounds__(256, PPO_LIN_WAVES) void k_linearize_all(Graph g, S
       else b -= n;
     }
   }
+#ifdef PPO_LIN_ONLY
+  if (part != PPO_LIN_ONLY) return;
+#endif
   switch (part) {
     case LIN_PLANE: lin_plane_body(g, st, g.n_pl, delta, b, smem); break;
     case LIN_BBOX: lin_cubproj_body<false>(g, st, b, delta, smem); break;
