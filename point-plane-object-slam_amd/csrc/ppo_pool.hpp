@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <pthread.h>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -275,15 +276,16 @@ using SVec = std::vector<T, StageAlloc<T>>;
 class HostTeam {
  public:
   static HostTeam& get() {
-    static HostTeam t;
-    return t;
+    // (never destroyed: the workers end with the process; a child made by fork() has no workers -- it runs every job on the caller)
+    static HostTeam* const t = new HostTeam();
+    return *t;
   }
   int size() const { return (int)workers_.size() + 1; }
   // fn(t) for t in [0, nt): t = 0 on the caller, the rest on whoever is free (the caller included).  std::bad_alloc thrown by a
   // task is rethrown here once the whole job has ended.
   template <class F>
   void run(int nt, F&& fn) {
-    if (nt <= 1 || workers_.empty()) {
+    if (nt <= 1 || workers_.empty() || forked().load(std::memory_order_relaxed)) {
       for (int t = 0; t < nt; ++t) fn(t);
       return;
     }
@@ -344,6 +346,11 @@ class HostTeam {
     int n = hw > 1 ? (int)std::min(hw - 1, 7u) : 0;
     if (const char* e = std::getenv("PPO_BA_HOST_THREADS")) n = std::max(0, std::min(atoi(e) - 1, 31));  // total threads a create may use
     for (int i = 0; i < n; ++i) workers_.emplace_back([this]() { loop(); });
+    if (n > 0) (void)pthread_atfork(nullptr, nullptr, []() { forked().store(true); });
+  }
+  static std::atomic<bool>& forked() {
+    static std::atomic<bool> f{false};
+    return f;
   }
   ~HostTeam() {
     {

@@ -6,6 +6,8 @@
 #include <numeric>
 #include <thread>
 #include <vector>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "ppo_pool.hpp"
 
@@ -42,6 +44,18 @@ int main() {
   std::atomic<int> inner{0};
   team.run(4, [&](int) { team.run(3, [&](int) { inner++; }); });
   if (inner.load() != 12) bad++;
+  // a child made by fork() has no worker threads: jobs must run on the caller instead of waiting for workers that do not exist
+  {
+    fflush(stdout);
+    const pid_t pid = fork();
+    if (pid == 0) {
+      std::atomic<int> c{0};
+      team.run(5, [&](int) { c++; });
+      _exit(c.load() == 5 ? 0 : 3);
+    }
+    int status = 0;
+    if (pid < 0 || waitpid(pid, &status, 0) != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) bad++;
+  }
   std::printf("%s\n", bad.load() == 0 ? "OK" : "FAILED");
   return bad.load() == 0 ? 0 : 1;
 }
