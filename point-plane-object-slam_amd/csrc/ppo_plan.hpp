@@ -273,6 +273,7 @@ struct PlanScratch {
     for (auto& b : tmp) b.release();
     tmp.clear();
   }
+  ~PlanScratch() { release(); }
 };
 inline bool plan_exclusive_scan(PlanScratch& sc, const int32_t* in, int32_t* out, size_t n, hipStream_t s) {
   size_t bytes = 0;

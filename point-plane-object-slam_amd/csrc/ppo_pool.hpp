@@ -430,4 +430,14 @@ struct DevBuf {
 };
 
 
+// a DevBuf that hands its block back when it goes out of scope (temporaries of ppo_ba_create: every early return releases them; the
+// owner has synchronised the stream by then -- free_all on the failure paths, reset_device on the way out)
+template <class T>
+struct ScopedDevBuf : DevBuf<T> {
+  ScopedDevBuf() = default;
+  ScopedDevBuf(const ScopedDevBuf&) = delete;
+  ScopedDevBuf& operator=(const ScopedDevBuf&) = delete;
+  ~ScopedDevBuf() { this->release(); }
+};
+
 }  // namespace ppo

@@ -1118,8 +1118,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   s->hk_mono_point.resize(p->n_mono); s->hk_stereo_point.resize(p->n_stereo);
   // device builder: the caller's arrays are staged as they are (page-locked copies, made in slices) and start their upload now
   SVec<double> raw_mono_obs, raw_mono_info, raw_mono_huber, raw_stereo_obs, raw_stereo_info, raw_stereo_huber;
-  DevBuf<double> d_raw_mono_obs, d_raw_mono_info, d_raw_mono_huber, d_raw_stereo_obs, d_raw_stereo_info, d_raw_stereo_huber;
-  DevBuf<int32_t> d_raw_mono_pose, d_raw_mono_point, d_raw_stereo_pose, d_raw_stereo_point;
+  ScopedDevBuf<double> d_raw_mono_obs, d_raw_mono_info, d_raw_mono_huber, d_raw_stereo_obs, d_raw_stereo_info, d_raw_stereo_huber;
+  ScopedDevBuf<int32_t> d_raw_mono_pose, d_raw_mono_point, d_raw_stereo_pose, d_raw_stereo_point;
   bool ok = true;
   if (dev_plan) {
     auto stage_copy = [&](SVec<double>& dst, const double* src, size_t n) {
@@ -1361,9 +1361,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
   ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_Dinv.alloc((size_t)Nc * 81) && s->d_xc.alloc((size_t)Nc * 9);
   PlanScratch plan_scratch;
-  DevBuf<int32_t> d_slot_off_lm, d_slot_col_lm, d_new_id, d_slot_lm_lm, d_pair_off, d_npairs, d_key_count, d_key_start, d_nchunks, d_chunk_off, d_n_chunks_out;
-  DevBuf<int32_t> d_pl_off, d_pl_perm, d_pl_pose, d_seg, d_seg_cnt, d_counts;
-  DevBuf<uint32_t> d_pose_key, d_pose_key_out, d_pair_key, d_pair_key_out, d_pair_perm, d_slot_key, d_slot_key_out, d_slot_order;
+  ScopedDevBuf<int32_t> d_slot_off_lm, d_slot_col_lm, d_new_id, d_slot_lm_lm, d_pair_off, d_npairs, d_key_count, d_key_start, d_nchunks, d_chunk_off, d_n_chunks_out;
+  ScopedDevBuf<int32_t> d_pl_off, d_pl_perm, d_pl_pose, d_seg, d_seg_cnt, d_counts;
+  ScopedDevBuf<uint32_t> d_pose_key, d_pose_key_out, d_pair_key, d_pair_key_out, d_pair_perm, d_slot_key, d_slot_key_out, d_slot_order;
   int32_t* h_n_chunks = nullptr;  // (page-locked: the device's chunk count comes back with the final synchronisation)
   if (!dev_plan) {
     ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
