@@ -38,7 +38,7 @@ enum {
   PPO_BA_OK = 0,
   PPO_BA_ABORTED = 1,        /* *stop_flag became non-zero (Optimizer.cc:2723-2725, 2732-2734) */
   PPO_BA_ERR_ARG = -1,       /* null pointer, negative size, index out of range */
-  PPO_BA_ERR_NONFINITE = -2, /* NaN/Inf in the inputs */
+  PPO_BA_ERR_NONFINITE = -2, /* NaN/Inf in the inputs; deterministic mode: a term of the first linearisation outside the fixed-point range */
   PPO_BA_ERR_NOMEM = -3,
   PPO_BA_ERR_HIP = -4,       /* no device, kernel or runtime failure */
   PPO_BA_ERR_SOLVER = -5,    /* dense factorisation backend failure (not "matrix not positive") */

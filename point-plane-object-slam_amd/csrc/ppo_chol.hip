@@ -145,7 +145,7 @@ template <int J, int C>
 struct ColUpdate {
   static __device__ __forceinline__ void run(double (&a)[SB], double (&e)[SB], double l, double le) {
     fmac_bcast<C, C == J + 1>(a[C], l, l);
-#ifndef PPO_CHOL_EXPERIMENT_NO_E  // (timing experiment of tools/run_chol_experiments.sh: wrong results, the sweep without its extra rows)
+#if !(defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_NO_E))  // (timing experiment of tools/run_chol_experiments.sh: wrong results, the sweep without its extra rows)
     fmac_bcast<C, false>(e[C], l, le);
 #endif
     if constexpr (C + 1 < SB) ColUpdate<J, C + 1>::run(a, e, l, le);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     const int bj = t - bi * (bi + 1) / 2;
     const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
-#ifdef PPO_CHOL_TRAIL_DELAY_TICKS  // (experiment: trailing tiles start late, the column workgroups' prologue has the memory system to itself)
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_TRAIL_DELAY_TICKS)  // (experiment: trailing tiles start late, the column workgroups' prologue has the memory system to itself)
     {
       const unsigned long long t_in = wall_clock64();
       while (wall_clock64() - t_in < PPO_CHOL_TRAIL_DELAY_TICKS) __builtin_amdgcn_s_sleep(8);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
     if (wave == 0) {  // diagonal 16x16 block + the sub-diagonal tiles of this block column
       const int bad = potf2_16(sL, sT[kk], sId, o, true);
       if (lane == 0 && bad && sBad == 0) sBad = o + bad;
-#ifdef PPO_CHOL_EXPERIMENT_NO_SIDE  // (timing experiment: wrong results, the register factorisations without the MFMA jobs in their shadow)
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_NO_SIDE)  // (timing experiment: wrong results, the register factorisations without the MFMA jobs in their shadow)
     } else if (true) {
 #endif
     } else if (kk == 0) {
@@ -607,401 +607,9 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
   STAMP(4);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// chol_fwd_all: the WHOLE forward factorisation (and the forward substitution) in ONE launch.
-//
-// One workgroup per task, numbered row by row (row i of 64-blocks: the "generic" workgroups of the tiles (i, 0) .. (i, i-2),
-// then the row's "head"):
-//   * generic (i, j), j <= i - 2: keeps its tile in MFMA accumulators, subtracts L_ik L_jk' for k = 0 .. j-1 as those tiles are
-//     published, then solves against the diagonal block j as its four 16-column pieces arrive (block substitution with the
-//     16x16 inverses, as in chol_step), publishes L_ij and its share L_ij y_j of the forward substitution, and exits;
-//   * head i: owns the sub-diagonal tile (i, i-1) AND the diagonal tile (i, i).  Same updates for k <= i-2; then the
-//     substitution of (i, i-1) and the rank-16 updates of the diagonal tile piece by piece while head i-1 is still factoring;
-//     then the 64x64 factorisation itself (four 16x16 register factorisations on wave 0, potf2_16), publishing after each one
-//     the 16x16 inverse and the 16 columns of L that the rows below need.
-// The critical path -- nb diagonal factorisations in a row -- therefore crosses workgroups ONCE per panel, by a 2 KB piece,
-// and everything else is look-ahead.  Against one launch per panel (chol_step) this removes, per panel, the launch boundary,
-// the cold 96 KB prologue of the column workgroups and the store/reload of the block between panels.
-//
-// Hand-off (MI355X_MICROARCH.md, R1): the producer writes its payload with write-through (sc1) stores, drains them
-// (s_waitcnt vmcnt(0)) and then stores a flag with sc1; a consumer polls the flag with ONE lane (sc1 loads, s_sleep
-// back-off), barriers, and reads the payload with sc1 loads (which bypass its L1).  No fences, no grid barrier.
-// Progress: every workgroup waits only for workgroups with a SMALLER index (tiles of the same row to its left, rows above), and
-// workgroups start in index order, so whatever is resident can always run to completion -- also when the launch does not fit
-// the chip at once (n > 1472) or shares it with another stream.  Every spin is bounded all the same: a time-out marks the
-// solve as failed (info bit 30) instead of hanging the device.
-// Flags are zero at entry (allocation / the idle workgroups of chol_back_all clear them after every solve).
-// ------------------------------------------------------------------------------------------------------------------
-typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int kAuxSc1 = 16;            // cache-policy bit of the raw buffer intrinsics on gfx940+: sc1
-constexpr int kPiece = 256 + 16 * NB;  // doubles per published piece: T (16 x 16, [k][j]) then the 16 L columns ([c][row])
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
-}
-__device__ __forceinline__ double2 ld16_sc1(__amdgpu_buffer_rsrc_t r, size_t elem) {  // two consecutive doubles, L1 bypassed
-  const v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(elem * 8), 0, kAuxSc1);
-  return make_double2(__hiloint2double(v.y, v.x), __hiloint2double(v.w, v.z));
-}
-__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, size_t elem, double a, double b) {  // write-through
-  const v4i v = {__double2loint(a), __double2hiint(a), __double2loint(b), __double2hiint(b)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(elem * 8), 0, kAuxSc1);
-}
-__device__ __forceinline__ int load_flag(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void store_flag(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// this thread's write-through stores have left (inline assembly: the compiler may not drop the wait, see the guide's note)
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// One lane spins until *f >= want (bounded); the workgroup meets at the barrier that follows in the caller.
-__device__ __forceinline__ void spin_until(const int* f, int want, int nap, int* timed_out) {
-  int spins = 0;
-  while (load_flag(f) < want) {
-    if (++spins > kSpinCap) { *timed_out = 1; break; }
-    __builtin_amdgcn_s_sleep(1);
-    for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(8);
-  }
-}
-
-struct FwdWs {
-  double* y;       // [ld] forward-substituted right-hand side (input of chol_back_all)
-  double* pieces;  // [nb][4][kPiece]
-  double* P;       // [nb][nb][NB]: P[i][j] = L_ij y_j
-  int* tile;       // [nb][nb] 1 = L_ij published
-  int* piece;      // [nb][4]  1 = piece published
-  int* yflag;      // [nb]     1 = y_j published (in y)
-  int* pcnt;       // [nb]     number of P[i][.] rows published
-};
-
-// 64x64 tile of A (column-major, leading dimension ld) -> k-major LDS operand array (sX[m][row] = tile(row, m)), L1 bypassed
-__device__ __forceinline__ void fetch_tile_sc1(__amdgpu_buffer_rsrc_t rA, size_t base, int ld, double2 (&t)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = threadIdx.x + 256 * i;
-    t[i] = ld16_sc1(rA, base + (size_t)(p >> 5) * ld + 2 * (p & 31));
-  }
-}
-__device__ __forceinline__ void stash_tile(double (*sX)[UP], const double2 (&t)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = threadIdx.x + 256 * i;
-    *reinterpret_cast<double2*>(&sX[p >> 5][2 * (p & 31)]) = t[i];
-  }
-}
-// own tile of A -> the wave's 32x32 quadrant in MFMA accumulator layout (see quadrant_product)
-__device__ __forceinline__ void load_quadrant(const double* __restrict__ A, int ld, int r0, int c0, double (&q)[2][2][4]) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-#pragma unroll
-  for (int jc = 0; jc < 2; ++jc)
-#pragma unroll
-    for (int ir = 0; ir < 2; ++ir)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) q[jc][ir][reg] = A[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li];
-}
-// (cold - acc) of the quadrant -> rows x columns LDS array; lower_only: strict upper triangle zeroed (diagonal block)
-__device__ __forceinline__ void spill_quadrant(double (*M)[LP], const double (&cold)[2][2][4], const v4d (&acc)[2][2], bool lower_only) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-#pragma unroll
-  for (int jc = 0; jc < 2; ++jc)
-#pragma unroll
-    for (int ir = 0; ir < 2; ++ir)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int r = wr + 16 * ir + li, c = wc + 16 * jc + lk + 4 * reg;
-        const double v = cold[jc][ir][reg] - acc[jc][ir][reg];
-        M[r][c] = (!lower_only || r >= c) ? v : 0.0;
-      }
-}
-// piece (j, kk) -> sT[kk] and columns [16 kk, 16 kk + 16) of sLd (all 256 threads)
-__device__ __forceinline__ void fetch_piece(__amdgpu_buffer_rsrc_t rP, size_t base, int kk, double (*sLd)[LP], double (*sT)[SB][17]) {
-  const int t = threadIdx.x, o = kk * SB;
-  const double2 tv = ld16_sc1(rP, base + 2 * (t & 127));  // T: 256 doubles, threads 0..127
-  double2 lv[2] = {};
-  if (kk + 1 < NB / SB) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) lv[q] = ld16_sc1(rP, base + 256 + 2 * (t + 256 * q));
-  }
-  if (t < 128) {
-    const int idx = 2 * t;
-    sT[kk][idx >> 4][idx & 15] = tv.x;
-    sT[kk][idx >> 4][(idx & 15) + 1] = tv.y;
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int idx = 2 * (t + 256 * q), c = idx >> 6, r = idx & 63;
-    sLd[r][o + c] = lv[q].x;
-    sLd[r + 1][o + c] = lv[q].y;
-  }
-}
-// the opposite direction, by ONE wave: sT[kk] and columns [16 kk, 16 kk + 16) of sD -> piece, drained, then the flag
-__device__ __forceinline__ void publish_piece(__amdgpu_buffer_rsrc_t rP, size_t base, int kk, const double (*sD)[LP], const double (*sT)[SB][17], int* flag) {
-  const int lane = threadIdx.x & 63, o = kk * SB;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int idx = 2 * (lane + 64 * q);
-    st16_sc1(rP, base + idx, sT[kk][idx >> 4][idx & 15], sT[kk][idx >> 4][(idx & 15) + 1]);
-  }
-  if (kk + 1 < NB / SB) {  // (nothing lies below the last diagonal tile)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = 2 * (lane + 64 * q), c = idx >> 6, r = idx & 63;
-      st16_sc1(rP, base + 256 + idx, sD[r][o + c], sD[r + 1][o + c]);
-    }
-  }
-  drain_stores();
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) store_flag(flag, 1);
-}
-
-template <int KK>
-__device__ __forceinline__ void solve_step(double (*sB)[LP], int rt, const double (*sLd)[LP], const double (*sT)[SB][17]) { solve_rows<KK>(sB, rt, sLd, sT); }
-__device__ __forceinline__ void solve_step_dyn(int kk, double (*sB)[LP], int rt, const double (*sLd)[LP], const double (*sT)[SB][17]) {
-  if (kk == 0) solve_rows<0>(sB, rt, sLd, sT);
-  else if (kk == 1) solve_rows<1>(sB, rt, sLd, sT);
-  else if (kk == 2) solve_rows<2>(sB, rt, sLd, sT);
-  else solve_rows<3>(sB, rt, sLd, sT);
-}
-
-struct FwdLds {
-  double sD[NB][LP];       // head: own diagonal tile
-  double sB[NB + 1][LP];   // own off-diagonal tile, rows x columns; row NB of a head carries the right-hand side
-  union {
-    struct { double sP[NB][UP], sQ[NB][UP]; } upd;           // update phase: operand tiles, k-major
-    struct { double sLd[NB][LP]; double sT[NB / SB][SB][17]; } trs;  // substitution phase: diagonal block j and its 16x16 inverses
-  } u;
-  double sT2[NB / SB][SB][17];  // head: inverses of its own factorisation
-  double sId[SB + 1][SB];
-  double sY[NB], sY2[NB];
-  int sBad, sTimeout, sAvail;
-};
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void chol_fwd_all(double* __restrict__ A, int ld, const double* __restrict__ rhs_in, double* xout,
-                                                                                              int* __restrict__ info, FwdWs ws) {
-  __shared__ FwdLds S;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nb = ld / NB;
-  // ---- role ----
-  int bi, slot;
-  {
-#ifdef PPO_CHOL_FWD_ONE_XCD  // (experiment: every eighth workgroup works, so that all hand-offs stay behind ONE L2)
-    if (blockIdx.x & 7) return;
-    const int b = blockIdx.x >> 3;
-#else
-    const int b = blockIdx.x;
+#ifdef PPO_BA_TEST_HOOKS
+#include "ppo_chol_fwd.inc"  // chol_fwd_all: the one-launch forward factorisation (measured, not adopted)
 #endif
-    if (b < 2) { bi = b; slot = b == 0 ? 0 : 0; }
-    else {
-      bi = 2;
-      while (1 + (bi + 1) * bi / 2 <= b) ++bi;
-      slot = b - (1 + bi * (bi - 1) / 2);
-    }
-  }
-  const bool head = (bi < 2) || (slot == bi - 1);
-  const int bj = head ? bi - 1 : slot;  // column of the off-diagonal tile this workgroup owns (-1: head 0 has none)
-  const int r0 = bi * NB;
-  const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (size_t)ld * ld * 8);
-  const __amdgpu_buffer_rsrc_t rP = make_rsrc(ws.pieces, (size_t)nb * 4 * kPiece * 8);
-  if (tid == 0) { S.sBad = 0; S.sTimeout = 0; }
-  STAMPF(0);
-  STAMPG(0);
-  for (int i = tid; i < (SB + 1) * SB; i += 256) S.sId[i / SB][i % SB] = (i / SB == i % SB) ? 1.0 : 0.0;
-  // ---- own tiles -> registers ----
-  double coldB[2][2][4], coldD[2][2][4];
-  if (bj >= 0) load_quadrant(A, ld, r0, bj * NB, coldB);
-  if (head) load_quadrant(A, ld, r0, r0, coldD);
-  v4d accB[2][2] = {}, accD[2][2] = {};
-  double psum = 0.0;  // head, threads 0..63: sum_k (L_ik y_k)[tid] over the generic tiles of the row, taken as their flags are seen
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32, li = lane & 15, lk = lane >> 4;
-  // ---- updates by the panels to the left of the own column ----
-  // Software-pipelined by one panel: when the tiles of panel k + 1 are already published their loads are issued before the
-  // matrix instructions of panel k, so a workgroup that has fallen behind catches up at the MFMA rate, not at the rate of
-  // one memory round trip plus one product per panel.
-  {
-    const int nupd = bj > 0 ? bj : 0;
-    double2 tp[8], tq[8];
-    double pk = 0.0;  // head, threads 0..63: (L_ik y_k)[tid] of the generic tile (i, k); stored and drained before that tile's flag
-    bool have = false;
-    for (int k = 0; k < nupd; ++k) {
-      if (!have) {
-        if (tid == 0) {
-          spin_until(&ws.tile[bi * nb + k], 1, (k + 3 >= bi) ? 0 : min(bi - k - 2, 8), &S.sTimeout);
-          spin_until(&ws.tile[bj * nb + k], 1, 0, &S.sTimeout);
-        }
-        __syncthreads();  // (also: every wave is done with the operand tiles of the previous panel)
-        fetch_tile_sc1(rA, (size_t)k * NB * ld + r0, ld, tp);
-        fetch_tile_sc1(rA, (size_t)k * NB * ld + bj * NB, ld, tq);
-        if (head && tid < NB) pk = __hip_atomic_load(&ws.P[((size_t)bi * nb + k) * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        __syncthreads();
-      }
-      stash_tile(S.u.upd.sP, tp);
-      stash_tile(S.u.upd.sQ, tq);
-      psum += pk;
-      if (tid == 0) S.sAvail = (k + 1 < nupd) && load_flag(&ws.tile[bi * nb + k + 1]) >= 1 && load_flag(&ws.tile[bj * nb + k + 1]) >= 1;
-      __syncthreads();
-      have = S.sAvail != 0;
-      if (have) {
-        fetch_tile_sc1(rA, (size_t)(k + 1) * NB * ld + r0, ld, tp);
-        fetch_tile_sc1(rA, (size_t)(k + 1) * NB * ld + bj * NB, ld, tq);
-        if (head && tid < NB) pk = __hip_atomic_load(&ws.P[((size_t)bi * nb + k + 1) * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      quadrant_product(S.u.upd.sP, S.u.upd.sQ, wr, wc, li, lk, accB);
-      if (head) quadrant_product(S.u.upd.sP, S.u.upd.sP, wr, wc, li, lk, accD);
-    }
-  }
-  STAMPG(1);
-  if (head && tid < NB) S.sY2[tid] = psum;
-  __syncthreads();
-  STAMPF(1);
-  if (bj >= 0) spill_quadrant(S.sB, coldB, accB, false);
-  if (head) spill_quadrant(S.sD, coldD, accD, true);
-  // ---- substitution against the diagonal block bj, piece by piece ----
-  if (bj >= 0) {
-    // (whatever has been published is taken in one go: a workgroup that arrives late must not pay a hand-off per piece)
-    int done = 0;
-#pragma unroll 1
-    while (done < NB / SB) {
-      if (tid == 0) {
-        spin_until(&ws.piece[bj * 4 + done], 1, 0, &S.sTimeout);
-        int n = done + 1;
-        while (n < NB / SB && load_flag(&ws.piece[bj * 4 + n]) >= 1) ++n;  // (pieces are published in order)
-        S.sAvail = n;
-      }
-      STAMPF(2 + done);
-      __syncthreads();
-      const int upto = S.sAvail;
-      for (int kk = done; kk < upto; ++kk) fetch_piece(rP, (size_t)(bj * 4 + kk) * kPiece, kk, S.u.trs.sLd, S.u.trs.sT);
-      __syncthreads();
-      for (int kk = done; kk < upto; ++kk) solve_step_dyn(kk, S.sB, wave, S.u.trs.sLd, S.u.trs.sT);  // wave w: rows [16 w, 16 w + 16) of the tile
-      if (head) {  // the diagonal tile takes the rank-16 updates of the columns that have just become final
-        __syncthreads();
-        for (int kk = done; kk < upto; ++kk) {
-          int t = 0;
-#pragma unroll
-          for (int ti = 0; ti < NB / SB; ++ti)
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj, ++t)
-              if ((t & 3) == wave) mfma_sub_16(S.sD, ti * SB, tj * SB, S.sB, ti * SB, S.sB, tj * SB, kk * SB);
-        }
-      }
-      for (int kk = done + 1; kk < upto; ++kk) STAMPF(2 + kk);
-      done = upto;
-    }
-    __syncthreads();
-    STAMPG(2);
-    if (!head) {
-      // L_ij -> A (write-through), its share of the forward substitution -> P, then the flags
-      const size_t base = (size_t)bj * NB * ld + r0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
-        st16_sc1(rA, base + (size_t)c * ld + r, S.sB[r][c], S.sB[r + 1][c]);
-      }
-      if (tid == 0) spin_until(&ws.yflag[bj], 1, 0, &S.sTimeout);
-      __syncthreads();
-      if (tid < NB) S.sY[tid] = __hip_atomic_load(&ws.y[bj * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (tid < NB) {
-        double sacc = 0.0;
-#pragma unroll 16
-        for (int m = 0; m < NB; ++m) sacc = __builtin_fma(S.sB[tid][m], S.sY[m], sacc);
-        __hip_atomic_store(&ws.P[((size_t)bi * nb + bj) * NB + tid], sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      drain_stores();
-      __syncthreads();
-      if (tid == 0) {
-        store_flag(&ws.tile[bi * nb + bj], 1);
-        STAMPG(3);
-        if (S.sTimeout) atomicOr(info, 1 << 30);
-      }
-      return;
-    }
-  }
-  // ---- head: the 64x64 factorisation, published piece by piece ----
-  // Wave 0 factors; in its shadow wave 1 publishes the pieces, waves 0, 2, 3 update the trailing 16x16 tiles of the block between
-  // the steps, and in phase 0 waves 1 and 2 store the finished sub-diagonal tile while wave 3 assembles the right-hand side
-  // r_i = b_i - sum_j L_ij y_j (its own share from the tile in LDS, the others from P) -- none of it on the chain of
-  // factorisations.
-  STAMPF(6);
-  if (bi == 0 && tid == 0) { store_flag(info, 0); drain_stores(); }  // (every other write to info follows a hand-off from this workgroup)
-#pragma unroll
-  for (int kk = 0; kk < NB / SB; ++kk) {
-    const int o = kk * SB;
-    if (wave == 0) {
-      const int bad = potf2_16(S.sD, S.sT2[kk], S.sId, o, true);
-      if (lane == 0 && bad && S.sBad == 0) S.sBad = o + bad;
-    } else if (wave == 1) {
-      if (kk == 0) {
-        if (bj >= 0) {  // L_(i, i-1) -> A, drained, then its flag: the head of the next row needs it for its last update
-          const size_t base = (size_t)bj * NB * ld + r0;
-#pragma unroll
-          for (int q = 0; q < 32; ++q) {
-            const int p = lane + 64 * q, c = p >> 5, r = 2 * (p & 31);
-            st16_sc1(rA, base + (size_t)c * ld + r, S.sB[r][c], S.sB[r + 1][c]);
-          }
-          drain_stores();
-          __builtin_amdgcn_wave_barrier();
-          if (lane == 0) store_flag(&ws.tile[bi * nb + bj], 1);
-          if (lane == 0) { STAMPG(3); }
-        }
-      } else {  // the piece of the previous step, in the shadow of this one
-        publish_piece(rP, (size_t)(bi * 4 + kk - 1) * kPiece, kk - 1, S.sD, S.sT2, &ws.piece[bi * 4 + kk - 1]);
-      }
-    } else if (wave == 3) {
-      if (kk == 0) {
-        double r = rhs_in[r0 + lane] - S.sY2[lane];
-        if (bj >= 0) {
-          if (lane == 0) spin_until(&ws.yflag[bj], 1, 0, &S.sTimeout);
-          __builtin_amdgcn_wave_barrier();
-          S.sY[lane] = __hip_atomic_load(&ws.y[bj * NB + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          wave_lds_fence();
-          double sacc = 0.0;
-#pragma unroll 16
-          for (int m = 0; m < NB; ++m) sacc = __builtin_fma(S.sB[lane][m], S.sY[m], sacc);
-          r -= sacc;
-        }
-        S.sB[NB][lane] = r;
-      } else {
-        solve_rhs_row(S.sB, kk - 1, S.sD, S.sT2);
-      }
-    }
-    __syncthreads();
-    STAMPF(7 + kk);
-    if (kk + 1 < NB / SB) {  // trailing 16x16 tiles inside the block, dealt to the four waves
-      int t = 0;
-#pragma unroll
-      for (int ti = kk + 1; ti < NB / SB; ++ti)
-#pragma unroll
-        for (int tj = kk + 1; tj <= ti; ++tj, ++t)
-          if ((t & 3) == wave) mfma_sub_16(S.sD, ti * SB, tj * SB, S.sD, ti * SB, S.sD, tj * SB, o);
-      __syncthreads();
-    }
-  }
-  if (wave == 1) publish_piece(rP, (size_t)(bi * 4 + 3) * kPiece, 3, S.sD, S.sT2, &ws.piece[bi * 4 + 3]);  // the one piece the next head waits for
-  if (wave == 3) {
-    solve_rhs_row(S.sB, NB / SB - 1, S.sD, S.sT2);
-    // y_i: to the workspace (chol_back_all reads it) and, by its flag, to the tiles of column i
-    __hip_atomic_store(&ws.y[r0 + lane], S.sB[NB][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    drain_stores();
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) store_flag(&ws.yflag[bi], 1);
-  }
-  // the factor itself, for the backward substitution (a later launch: plain stores)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
-    if (r + 1 >= c) *reinterpret_cast<double2*>(&A[(size_t)(r0 + c) * ld + r0 + r]) = make_double2(S.sD[r][c], S.sD[r + 1][c]);
-  }
-  STAMPF(11);
-  if (bi == 0)  // arm the hand-off granules of the backward substitution (chol_back_all)
-    for (int i = tid; i < ld; i += 256) xout[i] = __longlong_as_double((long long)kSentinel);
-  if (tid == 0) {
-    const int bad = S.sBad;
-    if (bad) atomicCAS(info, 0, r0 + bad);
-    if (S.sTimeout) atomicOr(info, 1 << 30);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // chol_back_all: the whole backward substitution L^T x = y in ONE launch, one workgroup per 64-block, pipelined through
@@ -1023,7 +631,8 @@ __global__ __launch_bounds__(256) void chol_back_all(const double* __restrict__ 
   __shared__ double sV[NB];
   // every eighth workgroup works: workgroups are dealt to the 8 XCDs round-robin, so the whole pipeline sits behind ONE L2
   if (blockIdx.x & 7) {
-    // the others re-arm the hand-off flags of chol_fwd_all for the next solve (its launch is over: nobody reads them any more)
+    // the others have nothing to do in the product build (nflags = 0); in the test-hooks build they re-arm the hand-off flags of
+    // the one-launch experiment for the next solve
     const int w = (blockIdx.x >> 3) * 7 + (blockIdx.x & 7) - 1, nw = (gridDim.x >> 3) * 7;
     for (int i = w * 256 + threadIdx.x; i < nflags; i += nw * 256) flags[i] = 0;
     return;
@@ -1122,6 +731,7 @@ struct GraphKey {
 std::mutex g_mu;
 std::map<GraphKey, hipGraphExec_t> g_graphs;
 
+#ifdef PPO_BA_TEST_HOOKS
 // workspace: y [ld] | pieces [nb][4][kPiece] | P [nb][nb][NB] | flags (ints): tile [nb][nb], piece [nb][4], yflag [nb], pcnt [nb]
 size_t ws_flag_ints(int nb) { return (size_t)nb * nb + 6 * (size_t)nb; }
 FwdWs carve(double* ws, int ld) {
@@ -1136,28 +746,36 @@ FwdWs carve(double* ws, int ld) {
   w.pcnt = w.yflag + nb;
   return w;
 }
+#endif
 
+// One launch per panel + one for the backward substitution.  (The one-launch factorisation, ppo_chol_fwd.inc, exists only in the
+// test-hooks build: PPO_BA_CHOL_ONELAUNCH=1 selects it there; DESIGN.md 4.1 has the measurement.)
 int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s) {
   const int nb = ld / NB;
+  double* y = ws;  // [ld] forward-substituted right-hand side
+  int* flags = nullptr;
+  int nflags = 0;
+#ifdef PPO_BA_TEST_HOOKS
   const FwdWs w = carve(ws, ld);
-  // One launch per panel is the product path.  The one-launch factorisation (chol_fwd_all) is kept as a measured experiment
-  // (365 us against 290 us at n = 1216 -- every dependent hop between workgroups costs 2-3 us with its payload,
-  // and a tile's update by panel k hangs on three of them); PPO_BA_CHOL_ONELAUNCH=1 selects it in the test-hooks build.
+  flags = w.tile;
+  nflags = (int)ws_flag_ints(nb);
   static const bool one_launch = []() { const char* e = PPO_DEV_ENV("PPO_BA_CHOL_ONELAUNCH"); return e && e[0] == '1'; }();
-  if (!one_launch) {
-    for (int k = 0; k < nb; ++k) {
-      const int k0 = k * NB;
-      const int m = nb - k;  // column workgroups: 1 (diagonal) + 2 per block row below (row halves); then the trailing tiles
-      hipLaunchKernelGGL(chol_step, dim3(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(kStepThreads), 0, s, A, ld, k0, b, w.y, x, info);
-    }
-  } else {
+  if (one_launch) {
 #ifdef PPO_CHOL_FWD_ONE_XCD
     hipLaunchKernelGGL(chol_fwd_all, dim3(8 * (nb < 2 ? 1 : 1 + nb * (nb - 1) / 2)), dim3(256), 0, s, A, ld, b, x, info, w);
 #else
     hipLaunchKernelGGL(chol_fwd_all, dim3(nb < 2 ? 1 : 1 + nb * (nb - 1) / 2), dim3(256), 0, s, A, ld, b, x, info, w);
 #endif
+  } else
+#endif
+  {
+    for (int k = 0; k < nb; ++k) {
+      const int k0 = k * NB;
+      const int m = nb - k;  // column workgroups: 1 (diagonal) + 2 per block row below (row halves); then the trailing tiles
+      hipLaunchKernelGGL(chol_step, dim3(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(kStepThreads), 0, s, A, ld, k0, b, y, x, info);
+    }
   }
-  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(256), 0, s, (const double*)A, ld, (const double*)w.y, x, info, w.tile, (int)ws_flag_ints(nb));
+  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(256), 0, s, (const double*)A, ld, (const double*)y, x, info, flags, nflags);
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
 }
 
@@ -1206,7 +824,12 @@ void chol_release(double* A) {
 
 size_t chol_workspace_doubles(int n) {  // must be ZERO when first used (the hand-off flags live in it)
   const int ld = chol_padded_ld(n), nb = ld / NB;
+#ifdef PPO_BA_TEST_HOOKS
   return (size_t)ld + (size_t)nb * 4 * kPiece + (size_t)nb * nb * NB + (ws_flag_ints(nb) + 1) / 2 + 8;
+#else
+  (void)nb;
+  return (size_t)ld + 8;
+#endif
 }
 int chol_padded_ld(int n) { return (n + NB - 1) / NB * NB; }
 int chol_default_backend() { return PPO_SOLVER_NATIVE; }

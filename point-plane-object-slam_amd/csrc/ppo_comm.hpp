@@ -31,6 +31,7 @@ namespace ppo {
 // small kernel and copies the result back.  It exists so that the sharded arithmetic of the N > 1 path (partial systems,
 // landmark ownership, the gather in ppo_ba_read) can be tested for real on a single-GPU box, where RCCL cannot put two
 // ranks on one device.
+#ifdef PPO_BA_TEST_HOOKS
 __global__ void k_loop_reduce(double* __restrict__ a, const double* __restrict__ b, size_t n, int op) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     a[i] = op == 0 ? a[i] + b[i] : (a[i] > b[i] ? a[i] : b[i]);
@@ -55,6 +56,7 @@ inline std::shared_ptr<LoopGroup> loop_group(unsigned long long key, int world) 
   }
   return g;
 }
+#endif  // PPO_BA_TEST_HOOKS
 
 struct Comm {
   // minimal RCCL surface (ABI of rccl.h: ncclUniqueId is 128 opaque bytes; enums ncclFloat64 = 8, ncclSum = 0, ncclMax = 2)
@@ -70,7 +72,9 @@ struct Comm {
   fn_allreduce allreduce = nullptr;
   fn_destroy comm_destroy = nullptr;
   int rank = 0, world = 1;
+#ifdef PPO_BA_TEST_HOOKS
   std::shared_ptr<LoopGroup> loop;  // non-null: loopback mode
+#endif
   bool forced = false;  // PPO_BA_COMM_SELFTEST: a one-rank communicator, so that the whole N > 1 code path runs on a single GPU
 
   bool load() {
@@ -114,8 +118,8 @@ struct Comm {
     rank = rank_;
     world = world_;
     forced = false;
-    loop.reset();
 #ifdef PPO_BA_TEST_HOOKS
+    loop.reset();
     if (world > 1 && std::memcmp(id_bytes, "PPOLOOP0", 8) == 0) {
       unsigned long long key = 0;
       std::memcpy(&key, id_bytes + 8, 8);
@@ -138,6 +142,7 @@ struct Comm {
     return init_rank(&comm, world, id, rank) == 0 ? 0 : -1;
   }
   bool active() const { return world > 1 || forced; }
+#ifdef PPO_BA_TEST_HOOKS
   int loop_reduce(double* buf, size_t n, int op, hipStream_t s) {
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     LoopGroup& g = *loop;
@@ -158,21 +163,28 @@ struct Comm {
     }
     return g.failed ? -1 : 0;
   }
+#endif
   int sum(double* buf, size_t n, hipStream_t s) {
     if (!active() || n == 0) return 0;
+#ifdef PPO_BA_TEST_HOOKS
     if (loop) return loop_reduce(buf, n, 0, s);
+#endif
     return allreduce(buf, buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, s) == 0 ? 0 : -1;
   }
   int max(double* buf, size_t n, hipStream_t s) {
     if (!active() || n == 0) return 0;
+#ifdef PPO_BA_TEST_HOOKS
     if (loop) return loop_reduce(buf, n, 1, s);
+#endif
     return allreduce(buf, buf, n, 8, /*ncclMax*/ 2, comm, s) == 0 ? 0 : -1;
   }
   void destroy() {
     if (comm && comm_destroy) comm_destroy(comm);
     comm = nullptr;
     forced = false;
+#ifdef PPO_BA_TEST_HOOKS
     loop.reset();
+#endif
   }
 };
 

@@ -1150,6 +1150,7 @@ __global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restri
   __syncthreads();
   double v = 0.0;
   if (t < ACC_N) { v = acc[t]; host[t] = v; }
+  if (t == ACC_DETBAD) acc[t] = 0.0;  // deterministic mode: "an addend did not fit" has been handed over; armed again for the next launches
   if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
   __threadfence_system();
   __syncthreads();
@@ -1593,7 +1594,7 @@ struct ReducePlan {
 __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp, ZeroPlan zother) {
   int b = blockIdx.x;
   if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
-  if (b == 0 && threadIdx.x == 2) g.acc[ACC_DETBAD] = 0.0;
+  // (acc[ACC_DETBAD] is NOT cleared here: assemble_body of this very launch may raise it -- k_publish clears it once it is copied out)
   if (b == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + kAccParts) {  // ... and their partial sums
     double* p = g.acc + ACC_N + (threadIdx.x - 64) * kAccPartStride;
     p[0] = 0.0;

@@ -9,6 +9,7 @@
 // landmark order, pairs of a pose pair in (landmark, a, b) order -- both come out of STABLE radix sorts (rocPRIM), so the layout does
 // not depend on how the device schedules anything.
 #pragma once
+#include <exception>
 #include <cstring>  // (rocPRIM's texture iterator calls memset from host code)
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -273,7 +274,10 @@ struct PlanScratch {
     for (auto& b : tmp) b.release();
     tmp.clear();
   }
-  ~PlanScratch() { release(); }
+  ~PlanScratch() {
+    if (!tmp.empty() && std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();  // unwinding: the sorts / scans may still be running
+    release();
+  }
 };
 inline bool plan_exclusive_scan(PlanScratch& sc, const int32_t* in, int32_t* out, size_t n, hipStream_t s) {
   size_t bytes = 0;

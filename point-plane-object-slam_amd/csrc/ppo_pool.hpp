@@ -2,6 +2,7 @@
 // page-locked host staging memory (and the arena + vector type built on it).
 #pragma once
 #include "ppo_dev.hpp"
+#include <exception>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -344,7 +345,7 @@ class HostTeam {
   HostTeam() {
     unsigned hw = std::thread::hardware_concurrency();
     int n = hw > 1 ? (int)std::min(hw - 1, 7u) : 0;
-    if (const char* e = std::getenv("PPO_BA_HOST_THREADS")) n = std::max(0, std::min(atoi(e) - 1, 31));  // total threads a create may use
+    if (const char* e = PPO_DEV_ENV("PPO_BA_HOST_THREADS")) n = std::max(0, std::min(atoi(e) - 1, 31));  // total threads a create may use
     for (int i = 0; i < n; ++i) workers_.emplace_back([this]() { loop(); });
     if (n > 0) (void)pthread_atfork(nullptr, nullptr, []() { forked().store(true); });
   }
@@ -437,7 +438,13 @@ struct ScopedDevBuf : DevBuf<T> {
   ScopedDevBuf() = default;
   ScopedDevBuf(const ScopedDevBuf&) = delete;
   ScopedDevBuf& operator=(const ScopedDevBuf&) = delete;
-  ~ScopedDevBuf() { this->release(); }
+  ~ScopedDevBuf() {
+    // stack unwinding (std::bad_alloc from a staging vector) reaches this destructor BEFORE the handler's free_all has synchronised
+    // the stream: uploads or plan kernels may still be using the block, and a block handed back now could be taken by a concurrent
+    // ppo_ba_create on another stream.  Rare path: wait for the whole device.
+    if (this->p && std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();
+    this->release();
+  }
 };
 
 }  // namespace ppo

@@ -590,6 +590,7 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linea
     HIP_TRY(hipMemcpyAsync(s->g.acc + ACC_STOP, s->h_pinned + ACC_N + 2, sizeof(double), hipMemcpyHostToDevice, s->stream));
     if (s->comm.sum(s->g.acc, 3, s->stream)) return PPO_BA_ERR_COMM;
     if (with_maxdiag && s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
+    if (s->g.det && s->comm.sum(s->g.acc + ACC_DETBAD, 1, s->stream)) return PPO_BA_ERR_COMM;  // every rank must see every rank's flag
   }
   (void)zero_for_next_linearize;  // (the linearisation targets are double-buffered: nothing to clear behind the hand-over any more)
   ZeroPlan zp{};
@@ -663,6 +664,9 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
   double currentChi;
   if (fresh || iteration == 0) {
     RC_TRY(fetch_acc(s, false, iteration == 0));
+    // deterministic mode: an addend of THIS linearisation (the committed state) did not fit the fixed-point range -- its system is
+    // incomplete and there is no earlier state to fall back to
+    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) return PPO_BA_ERR_NONFINITE;
     currentChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
   } else {
     currentChi = s->chi_cur;  // computeActiveErrors of the state the previous trial produced (levenberg.cpp:72-75)
@@ -1457,8 +1461,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     h_n_chunks = static_cast<int32_t*>(s->stage->take(4 * sizeof(int32_t)));  // [0] chunks, [1] slots, [2] point slots
     if (!h_n_chunks) return fail(PPO_BA_ERR_NOMEM);
     h_n_chunks[0] = h_n_chunks[1] = h_n_chunks[2] = 0;
-    HIP_TRY(hipMemcpyAsync(h_n_chunks, d_n_chunks_out.p, sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(h_n_chunks + 1, d_counts.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    // (never HIP_TRY / RC_TRY once `s` exists: a plain return would leak the half-built solver and leave t_creating dangling)
+    if (hipMemcpyAsync(h_n_chunks, d_n_chunks_out.p, sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(PPO_BA_ERR_HIP);
+    if (hipMemcpyAsync(h_n_chunks + 1, d_counts.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(PPO_BA_ERR_HIP);
     s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, 0};  // (n_chunks: after the synchronisation below)
   }
   mark("hipMalloc + H2D enqueue");

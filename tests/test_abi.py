@@ -113,3 +113,17 @@ def test_no_cpu_fallback():
         lib.ppo_ba_destroy(h)
     else:
         assert rc == -4 and not h.value
+
+
+def test_product_library_carries_no_experiment_code():
+    """The one-launch Cholesky experiment, the timing-only macros and the loopback communicator exist only in the
+    test-hooks build (csrc/libppo_ba_test.so): neither symbol tables nor device code objects of libppo_ba.so name them."""
+    import subprocess
+    so = os.path.join(REPO, "point-plane-object-slam_amd", "csrc", "libppo_ba.so")
+    sym = subprocess.run(["nm", "-C", so], capture_output=True, text=True).stdout
+    blob = open(so, "rb").read()
+    for name in ("chol_fwd_all", "k_loop_reduce", "LoopGroup", "loop_reduce"):
+        assert name not in sym, name
+        assert name.encode() not in blob, name
+    for env in (b"PPO_BA_CHOL_ONELAUNCH", b"PPO_BA_CHOL_GRAPH", b"PPO_BA_COMM_SELFTEST", b"PPO_BA_LIN_PARTS"):
+        assert env not in blob, env
