@@ -17,6 +17,17 @@ assumed from headers that could not be compiled):
                                                      map's data pointer at +0xe0 / +0x118, Xw at +0xf0 / +0x128, fx fy cx cy
                                                      (bf) at +0x108 / +0x140; the vertex keeps q at +0xb0 and t at +0xd0
                                                      (all read off the disassembly of the four functions)
+  g2o::BaseUnaryEdge<2|3, ..., VertexSE3Expmap>::linearizeOplus(JacobianWorkspace&) / ::constructQuadraticForm()
+                                                     (base_unary_edge.hpp:43-80) on the two OnlyPose edge classes with a
+                                                     RobustKernelHuber attached.  NOTE what the binary holds: the exported
+                                                     linearizeOplus(JacobianWorkspace&) is five instructions -- it stores
+                                                     workspaceForVertex(0) into the Jacobian map (this+0xe0 / +0x118) and tail-calls
+                                                     the VIRTUAL linearizeOplus() (vtable slot 0xe0), which both instantiations
+                                                     override with their analytic form.  The NUMERIC body of
+                                                     BaseUnaryEdge::linearizeOplus() (base_unary_edge.hpp:82-123) was never emitted
+                                                     into libg2o.so (no symbol, no caller: `nm -C` lists every BaseUnaryEdge member
+                                                     there is), so it cannot be pinned; it is line by line the Xi half of
+                                                     BaseBinaryEdge::linearizeOplusXi, which IS pinned bit for bit below.
 The custom plane / cuboid types live in lib/libORB_SLAM2.so, which does not load in this container (OpenCV 3.3, PCL 1.8,
 Pangolin, VTK missing): they stay unpinned.
 
@@ -173,6 +184,7 @@ def generate():
     out["cases"]["onlypose_stereo"] = only["stereo"]
 
     out["cases"].update(generate_binary_edges(lib))
+    out["cases"].update(generate_unary_edges(lib))
 
     os.makedirs(os.path.dirname(GOLD), exist_ok=True)
     with open(GOLD, "w") as fh:
@@ -313,6 +325,150 @@ def generate_binary_edges(lib):
     return out
 
 
+# ---- unary OnlyPose edges through BaseUnaryEdge::linearizeOplus(JacobianWorkspace&) and ::constructQuadraticForm() ------------
+# The OnlyPose edge classes export no constructor (inline in the header), so the object is laid out by hand on top of the exported
+# OptimizableGraph::Edge::Edge(): vtable pointer (exported vtable + 16), _vertices = one slot, _dimension (+0x24) = D, the robust
+# kernel at +0x30, measurement / information / error / Jacobian map / Xw / intrinsics at the offsets listed in the module docstring
+# (information: +0xb0 for D = 2, +0xb8 for D = 3, the BaseEdge<D> layout of the binary edges above).  The pose vertex is built by
+# its exported constructor; Hessian map pointer +0x70, _b +0x80, _fixed +0x54.
+_BU = {2: "_ZN3g2o13BaseUnaryEdgeILi2EN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEENS_15VertexSE3ExpmapEE",
+       3: "_ZN3g2o13BaseUnaryEdgeILi3EN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEENS_15VertexSE3ExpmapEE"}
+_UNARY = {
+    "mono": dict(D=2, vt="_ZTVN3g2o25EdgeSE3ProjectXYZOnlyPoseE", err_fn="_ZN3g2o25EdgeSE3ProjectXYZOnlyPose12computeErrorEv",
+                 chi2="_ZNK3g2o8BaseEdgeILi2EN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEEE4chi2Ev", meas=0xa0, info=0xb0, err=0xd0, jac=0xe0, xw=0xf0, cam=0x108, ncam=4),
+    "stereo": dict(D=3, vt="_ZTVN3g2o31EdgeStereoSE3ProjectXYZOnlyPoseE", err_fn="_ZN3g2o31EdgeStereoSE3ProjectXYZOnlyPose12computeErrorEv",
+                   chi2="_ZNK3g2o8BaseEdgeILi3EN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEEE4chi2Ev", meas=0xa0, info=0xb8, err=0x100, jac=0x118, xw=0x128, cam=0x140, ncam=5),
+}
+
+
+def make_unary_edge(lib, kind, vertex, xw, cam, obs, w, delta, keep):
+    """A hand-laid-out OnlyPose edge attached to `vertex`; returns (edge buffer, Jacobian buffer)."""
+    vp = C.c_void_p
+    K = _UNARY[kind]
+    D = K["D"]
+    e = _aligned(0x200)
+    f = lib._ZN3g2o16OptimizableGraph4EdgeC1Ev
+    f.argtypes = [vp]
+    f.restype = None
+    f(e.ctypes.data)
+    u64 = e.view(np.uint64)
+    u64[0] = C.addressof(C.c_void_p.in_dll(lib, K["vt"])) + 16
+    slots = np.array([vertex.ctypes.data], dtype=np.uint64)  # _vertices: begin / end / end of storage
+    u64[1], u64[2], u64[3] = slots.ctypes.data, slots.ctypes.data + 8, slots.ctypes.data + 8
+    e.view(np.int32)[0x24 // 4] = D
+    e[K["meas"] // 8:K["meas"] // 8 + D] = obs[:D]
+    e[K["info"] // 8:K["info"] // 8 + D * D] = (np.eye(D) * w).reshape(-1)
+    e[K["xw"] // 8:K["xw"] // 8 + 3] = xw
+    e[K["cam"] // 8:K["cam"] // 8 + K["ncam"]] = cam[:K["ncam"]]
+    kern = None
+    if delta > 0:
+        kern = _aligned(64)
+        kern.view(np.uint64)[0] = C.addressof(C.c_void_p.in_dll(lib, "_ZTVN3g2o17RobustKernelHuberE")) + 16
+        sd = lib._ZN3g2o17RobustKernelHuber8setDeltaEd
+        sd.argtypes = [vp, C.c_double]
+        sd(kern.ctypes.data, delta)
+        u64[0x30 // 8] = kern.ctypes.data
+    J = _aligned(8 * 6 * D + 64)
+    keep.extend([e, slots, kern, J])
+    return e, J
+
+
+def fake_jacobian_workspace(J, keep):
+    """What linearizeOplus(JacobianWorkspace&) dereferences: _workspace.begin() -> VectorXd{data, size} -> data."""
+    vec0 = np.array([J.ctypes.data, J.size], dtype=np.uint64)
+    ws = np.array([vec0.ctypes.data, vec0.ctypes.data + 16, vec0.ctypes.data + 16, 0], dtype=np.uint64)
+    keep.extend([vec0, ws])
+    return ws
+
+
+def drive_unary_edge(lib, kind, q, t, xw, cam, obs, w, delta, fix_pose):
+    vp = C.c_void_p
+    K = _UNARY[kind]
+    D = K["D"]
+    keep = []
+
+    def fn(name, *argtypes, restype=None):
+        f = getattr(lib, name)
+        f.argtypes = list(argtypes)
+        f.restype = restype
+        return f
+    ps = _aligned(0x200)
+    fn("_ZN3g2o15VertexSE3ExpmapC1Ev", vp)(ps.ctypes.data)
+    ps[0xb0 // 8:0xb0 // 8 + 4] = q
+    ps[0xd0 // 8:0xd0 // 8 + 3] = t
+    ps.view(np.uint8)[0x54] = fix_pose
+    e, J = make_unary_edge(lib, kind, ps, xw, cam, obs, w, delta, keep)
+    fn(K["err_fn"], vp)(e.ctypes.data)
+    err = e[K["err"] // 8:K["err"] // 8 + D].copy()
+    chi2 = float(fn(K["chi2"], vp, restype=C.c_double)(e.ctypes.data))
+    ws = fake_jacobian_workspace(J, keep)
+    fn(_BU[D] + "14linearizeOplusERNS_17JacobianWorkspaceE", vp, vp)(e.ctypes.data, ws.ctypes.data)
+    assert int(e.view(np.uint64)[K["jac"] // 8]) == J.ctypes.data  # the wrapper mapped the workspace
+    Jm = J[:6 * D].reshape(6, D).T.copy()
+    H = _aligned(8 * 36 + 64)
+    ps.view(np.uint64)[0x70 // 8] = H.ctypes.data
+    fn(_BU[D] + "22constructQuadraticFormEv", vp)(e.ctypes.data)
+    b = ps[0x80 // 8:0x80 // 8 + 6].copy()
+    Hm = H[:36].reshape(6, 6).T.copy()
+    flat = lambda m: np.asarray(m).reshape(-1).tolist()  # noqa: E731
+    return {"error": err.tolist(), "chi2": chi2, "J": flat(Jm), "H_pose": flat(Hm), "b_pose": b.tolist()}
+
+
+def generate_unary_edges(lib):
+    rng = np.random.default_rng(20261001)  # its own stream: every vector above stays bit-identical
+    out = {"unary_mono": [], "unary_stereo": []}
+    for kind in ("mono", "stereo"):
+        for k in range(32):
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            if q[3] < 0:
+                q = -q
+            t = rng.normal(size=3)
+            pc = np.array([rng.normal() * 1.2, rng.normal() * 0.9, rng.uniform(0.4, 9.0)])
+            Xw = (_rot(q).T @ (pc - t)).astype(np.float32).astype(np.float64)  # Optimizer.cc:318-320: Xw.at<float>
+            pc = _rot(q) @ Xw + t
+            cam = [rng.uniform(300, 700), rng.uniform(300, 700), rng.uniform(300, 340), rng.uniform(220, 260), float(np.float32(rng.uniform(20, 60)))]
+            proj = np.array([cam[0] * pc[0] / pc[2] + cam[2], cam[1] * pc[1] / pc[2] + cam[3], 0.0])
+            proj[2] = proj[0] - cam[4] / pc[2]
+            delta = 0.0 if k % 4 == 3 else float(np.float32(np.sqrt(5.991 if kind == "mono" else 7.815)))  # Optimizer.cc:282-283 (const float)
+            w = float(np.float32(1.2 ** (-2 * int(rng.integers(0, 8)))))  # Optimizer.cc:308: const float invSigma2
+            at_knee = k % 8 == 4 and delta > 0
+            mag = [0.3, 1.0, 2.0, 4.0, 30.0, 300.0][k % 6]  # below the Huber knee, around it, far above it
+            obs = proj + rng.normal(size=3) * (1.0 if at_knee else mag)
+            if kind == "stereo" and obs[2] < 0:
+                obs[2] = abs(obs[2])  # a negative right coordinate MEANS "monocular" to the caller (Optimizer.cc:294)
+            if at_knee:
+                # AT the knee: take the residual the library itself computes for this observation and rescale it so that
+                # chi2 = e' (w I) e lands within a few ulps of delta^2 (the projection does not depend on the observation)
+                e0 = np.array(drive_unary_edge(lib, kind, q, t, Xw, cam, obs, w, delta, 0)["error"])
+                scale = delta / np.sqrt(w * float(e0 @ e0))
+                obs[:len(e0)] = obs[:len(e0)] - e0 + e0 * scale
+            fix_pose = 1 if k % 16 == 9 else 0
+            res = drive_unary_edge(lib, kind, q, t, Xw, cam, obs, w, delta, fix_pose)
+            res.update({"qt": q.tolist() + t.tolist(), "cam": cam, "xw": Xw.tolist(), "obs": obs.tolist(), "info": w, "huber_delta": delta, "fix_pose": fix_pose})
+            out["unary_" + kind].append(res)
+    return out
+
+
+def check_unary_edges(lib, gold, worst):
+    """Oracle (oracle_unary_edge_pin) against the unary-edge vectors; the same comparison tests/test_golden.py makes."""
+    c_dp = C.POINTER(C.c_double)
+    lib.oracle_unary_edge_pin.argtypes = [c_dp] * 4 + [C.c_int, C.c_double, C.c_double, C.c_int] + [c_dp] * 5
+    lib.oracle_unary_edge_pin.restype = C.c_int
+    for kind in ("mono", "stereo"):
+        for c in gold.get("unary_" + kind, []):
+            D = len(c["error"])
+            o = {"error": np.zeros(3), "chi2": np.zeros(1), "J": np.zeros(18), "H_pose": np.zeros(36), "b_pose": np.zeros(6)}
+            lib.oracle_unary_edge_pin(dptr(np.array(c["qt"])), dptr(np.array(c["cam"])), dptr(np.array(c["xw"])), dptr(np.array(c["obs"])),
+                                      int(kind == "stereo"), c["info"], c["huber_delta"], c["fix_pose"], *[dptr(o[k]) for k in ("error", "chi2", "J", "H_pose", "b_pose")])
+            for k, n in (("error", D), ("chi2", 1), ("J", 6 * D), ("H_pose", 36), ("b_pose", 6)):
+                ref = np.atleast_1d(np.array(c[k], dtype=float))
+                dev = float((np.abs(o[k][:n] - ref) / np.maximum(1.0, np.abs(ref))).max())
+                key = "unary_%s_%s" % (kind, k)
+                worst[key] = max(worst.get(key, 0.0), dev)
+    return worst
+
+
 def check_binary_edges(lib, gold, worst):
     """Oracle (oracle_binary_edge_pin) against the binary-edge vectors; the same comparison tests/test_golden.py makes."""
     c_dp = C.POINTER(C.c_double)
@@ -390,6 +546,7 @@ def check():
             ref = np.array(c["J"])
             worst["onlypose_" + kind + "_J"] = max(worst.get("onlypose_" + kind + "_J", 0), float((np.abs(J[:6 * d] - ref) / np.maximum(1.0, np.abs(ref))).max()))
     check_binary_edges(lib, gold, worst)
+    check_unary_edges(lib, gold, worst)
     print("max abs deviation oracle vs prebuilt g2o:", worst)
     return worst
 

@@ -573,9 +573,18 @@ void build_system(Oracle& o) {
         }
       } else {
         const int c0 = o.col0[t][i];
+        // A unary edge groups its right-hand side differently (base_unary_edge.hpp:62,65): b -= ((rho1 A') Omega) e, the 6 x D
+        // product formed first -- against b += B' ((-Omega e) rho1) of a binary edge (base_binary_edge.hpp:74,99-111).  Same
+        // value, different rounding; the golden vectors of the prebuilt libg2o.so pin both.
+        const bool unary = t1 == V_NONE || o.only_pose;
         for (int a = 0; a < d; ++a) {
           double sb = 0;
-          for (int r = 0; r < dim; ++r) sb += J[r * d + a] * omega_r[r];
+          if (unary) {
+            for (int r = 0; r < dim; ++r) sb += e[r] * ((rho1 * J[r * d + a]) * info_at(o, er.type, er.idx, r));
+            sb = -sb;
+          } else {
+            for (int r = 0; r < dim; ++r) sb += J[r * d + a] * omega_r[r];
+          }
           acc_comp(comp, o.b[c0 + a], comp ? o.b_c[c0 + a] : dummy, sb);
           for (int c = 0; c < d; ++c) {
             double s = 0;
@@ -1248,6 +1257,7 @@ void oracle_huber(double e, double delta, double rho[3]) { huber_robustify(e, de
 // One free pose, fixed map points, unary reprojection edges; four rounds of optimize(10) from the same initial pose with a
 // re-classification of every observation after each round.  Runs on the engine above: a fixed point vertex contributes no
 // block, which is what the unary edges amount to; `only_pose` selects their residual / Jacobian flavour.
+static thread_local ppo_ba_stats* t_pose_trace = nullptr;  // oracle_pose_optimize_trace: LM statistics of the LAST frame of the call
 int oracle_pose_optimize(const ppo_pose_problem* p, const ppo_pose_options* po, ppo_pose_result* r) {
   if (!p || !po || !r || !r->pose_qt) return PPO_BA_ERR_ARG;
   if (po->rounds < 0 || po->rounds > PPO_POSE_MAX_ROUNDS) return PPO_BA_ERR_ARG;
@@ -1337,9 +1347,20 @@ int oracle_pose_optimize(const ppo_pose_problem* p, const ppo_pose_options* po, 
     q[0] = T.r.x; q[1] = T.r.y; q[2] = T.r.z; q[3] = T.r.w; q[4] = T.t[0]; q[5] = T.t[1]; q[6] = T.t[2];
     if (r->n_inliers) r->n_inliers[f] = n - nBad;  // OPT:458
     if (r->stats) r->stats[f] = st;
+    if (t_pose_trace) *t_pose_trace = o->stats;
     oracle_ba_destroy(o);
   }
   return PPO_BA_OK;
+}
+// The same call, additionally returning the per-iteration LM statistics (pass = round, trials, lambda of the last trial, chi2
+// before / after) of the last frame: the pose-only result struct has no room for them, tests/test_g2o_pose_pin.py holds them
+// against the reference's own run.
+int oracle_pose_optimize_trace(const ppo_pose_problem* p, const ppo_pose_options* po, ppo_pose_result* r, ppo_ba_stats* trace) {
+  if (trace) std::memset(trace, 0, sizeof(*trace));
+  t_pose_trace = trace;
+  const int rc = oracle_pose_optimize(p, po, r);
+  t_pose_trace = nullptr;
+  return rc;
 }
 
 // residual and Jacobian of one unary OnlyPose edge (for the golden vectors of the prebuilt libg2o.so)
@@ -1406,6 +1427,49 @@ int oracle_binary_edge_pin(const double qt[7], const double cam[5], const double
     for (int c = 0; c < 3; ++c) Hlp[c * 6 + a] = (o.n_lm && o.n_red) ? o.hpl[a * 3 + c] : 0.0;
   for (int i = 0; i < 3; ++i) bl[i] = o.n_lm ? o.b[(size_t)o.n_red + i] : 0.0;
   for (int i = 0; i < 6; ++i) bp[i] = o.n_red ? o.b[i] : 0.0;
+  return dim;
+}
+
+// One unary OnlyPose edge (Optimizer::PoseOptimization, OPT:247-459; the same driver EdgePointCuboidOnlyObject runs through) taken
+// through computeError, BaseEdge::chi2, linearizeOplus and BaseUnaryEdge::constructQuadraticForm (base_unary_edge.hpp:43-72) with a
+// RobustKernelHuber, for the golden vectors oracle/pin_g2o_prebuilt.py produced by calling exactly those functions in the prebuilt
+// libg2o.so.  The oracle models the unary edge as a reprojection edge whose point vertex is fixed (`only_pose` selects the OnlyPose
+// residual / Jacobian flavour): a fixed vertex contributes no block, which is what a unary edge amounts to.
+// Outputs (row-major): e[dim], chi2, J[dim x 6], H[6 x 6], b[6] (H and b zero when the pose is fixed: nothing is written, :52).
+int oracle_unary_edge_pin(const double qt[7], const double cam[5], const double xw[3], const double obs[3], int stereo, double info_w,
+                          double huber_delta, int fix_pose, double* e, double* chi2, double* J, double* H, double* b) {
+  Oracle o;
+  ppo_ba_options O{};
+  O.numeric_delta = 1e-9;
+  o.opt = O;
+  o.only_pose = true;
+  o.n_poses = 1; o.n_points = 1;
+  SE3 T;  // q and t are written straight into the vertex by the pinning script (no normalisation)
+  T.r = Quat{qt[0], qt[1], qt[2], qt[3]};
+  T.t = mk(qt[4], qt[5], qt[6]);
+  o.pose0.assign(1, T);
+  o.point0.assign(1, mk(xw[0], xw[1], xw[2]));
+  o.pose_cam.assign(cam, cam + 5);
+  o.pose_fixed.assign(1, (uint8_t)0);  // (the fixed case is evaluated on a free pose and its blocks dropped below)
+  o.point_fixed.assign(1, (uint8_t)1);
+  const int type = stereo ? E_STEREO : E_MONO, dim = stereo ? 3 : 2;
+  o.n_edges[type] = 1;
+  o.e_v0[type].assign(1, 0); o.e_v1[type].assign(1, 0);
+  o.e_meas[type].assign(obs, obs + dim);
+  o.e_info[type].assign(1, info_w);
+  o.e_huber[type].assign(1, huber_delta);
+  reset_state(o);
+  initialize_optimization(o, 0);
+  compute_active_errors(o);
+  std::copy(&o.err[type][0], &o.err[type][0] + dim, e);
+  *chi2 = edge_chi2(o, type, 0);
+  double J0[kMaxDim * 9] = {0}, J1[kMaxDim * 9] = {0};
+  linearize(o, type, 0, J0, J1);
+  std::copy(J1, J1 + dim * 6, J);
+  build_system(o);
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) H[r * 6 + c] = (o.n_red && !fix_pose) ? o.Hpp[(size_t)c * o.n_red + r] : 0.0;
+  for (int i = 0; i < 6; ++i) b[i] = (o.n_red && !fix_pose) ? o.b[i] : 0.0;
   return dim;
 }
 

@@ -2,6 +2,7 @@
 // the CPU test-suite can check them against the golden vectors of the reference's prebuilt libg2o.so and against the
 // oracle.  Not linked into libppo_ba.so and never used by the product path.
 #include "ppo_math.hpp"
+#include "ppo_pose_math.hpp"
 
 using namespace ppo;
 
@@ -99,5 +100,19 @@ void hc_quadform(const double* qt, const double* X, const double* cam, const dou
   factor_M(f, cam[0], cam[1], cam[4], stereo != 0, M);
   for (int a = 0; a < 6; ++a)
     for (int c = 0; c < 3; ++c) W[3 * a + c] = M[3 * a] * R.a[c] + M[3 * a + 1] * R.a[3 + c] + M[3 * a + 2] * R.a[6 + c];
+}
+// One OnlyPose observation through exactly the per-observation arithmetic of k_pose_only (ppo_pose_math.hpp): residual, chi2, and
+// its contribution acc[28] (21 packed lower H | 6 b | rho0) to the 6x6 normal equations.  obs[2] < 0 marks a monocular observation.
+double hc_pose_obs(const double* qt, const double* cam, const double* xw, const double* obs, double invs, double huber_delta, double* e, double* acc) {
+  const Pose T{Quat{qt[0], qt[1], qt[2], qt[3]}, Vec3{qt[4], qt[5], qt[6]}};
+  PoseEdge E;
+  E.X = v3(xw[0], xw[1], xw[2]);
+  E.u = obs[0]; E.v = obs[1]; E.ur = obs[2];
+  E.invs = invs;
+  E.stereo = !(E.ur < 0);
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  Vec3 pc;
+  (void)pose_edge_chi2(T, cam, E, e, pc);
+  return pose_obs_accumulate(T, cam, E, huber_delta, acc);
 }
 }

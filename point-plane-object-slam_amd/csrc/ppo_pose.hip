@@ -24,6 +24,7 @@
 
 #include "../../include/ppo_pose.h"
 #include "ppo_math.hpp"
+#include "ppo_pose_math.hpp"
 #include "ppo_pool.hpp"
 
 namespace ppo {
@@ -93,11 +94,6 @@ __device__ __forceinline__ void block_sum_acc(double (&v)[kAccN], double* sP, do
   for (int k = 0; k < kAccN; ++k) v[k] = sR[k];
 }
 
-struct PoseEdge {
-  Vec3 X;
-  double u, v, ur, invs;
-  bool stereo;
-};
 __device__ __forceinline__ PoseEdge load_pose_edge(const PoseOnlyArgs& a, int e) {
   PoseEdge E;
   E.X = v3(a.xw[3 * (size_t)e], a.xw[3 * (size_t)e + 1], a.xw[3 * (size_t)e + 2]);
@@ -108,25 +104,6 @@ __device__ __forceinline__ PoseEdge load_pose_edge(const PoseOnlyArgs& a, int e)
   E.stereo = !(E.ur < 0);  // Optimizer.cc:294 `if(pFrame->mvuRight[i]<0)` is the monocular branch
   return E;
 }
-// computeError + chi2 (base_edge.h:58-61 with Omega = invSigma2 * I); pc = Tcw * Xw
-__device__ __forceinline__ double pose_edge_chi2(const Pose& T, const double* cam, const PoseEdge& E, double* e, Vec3& pc) {
-  pc = qrot(T.q, E.X) + T.t;
-  if (!E.stereo) {
-    e[0] = E.u - (pc.x / pc.z * cam[0] + cam[2]);
-    e[1] = E.v - (pc.y / pc.z * cam[1] + cam[3]);
-    e[2] = 0.0;
-    return e[0] * (E.invs * e[0]) + e[1] * (E.invs * e[1]);
-  }
-  const float invz = (float)(1.0 / pc.z);  // `const float invz = 1.0f/trans_xyz[2]`: a double division rounded to float
-  const double r0 = pc.x * invz * cam[0] + cam[2];
-  const double r1 = pc.y * invz * cam[1] + cam[3];
-  const double r2 = r0 - cam[4] * invz;    // bf is a double member of the OnlyPose edge
-  e[0] = E.u - r0;
-  e[1] = E.v - r1;
-  e[2] = E.ur - r2;
-  return e[0] * (E.invs * e[0]) + e[1] * (E.invs * e[1]) + e[2] * (E.invs * e[2]);
-}
-
 // (H + lambda I) x = b with H packed lower (row r, column c <= r at r(r+1)/2 + c); false when a pivot is not positive.
 // Every thread walks this chain alone, so it is written for latency: one reciprocal square root per pivot, no division.
 __device__ __forceinline__ bool solve6(const double* H, double lambda, const double* b, double* x) {
@@ -247,36 +224,7 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
         for (int e = e0 + tid; e < e1; e += kPoseThreads) {
           if (a.level[e]) continue;
           const PoseEdge E = load_pose_edge(a, e);
-          double er[3];
-          Vec3 pc;
-          const double chi2 = pose_edge_chi2(T, cam, E, er, pc);
-          a.stored[e] = chi2;
-          double rho0, rho1;
-          huber(chi2, robust ? (E.stereo ? a.hub_stereo : a.hub_mono) : 0.0, rho0, rho1);
-          acc[27] += rho0;
-          // types_six_dof_expmap.cpp:298-320, 367-398
-          const double xx = pc.x, yy = pc.y, invz = 1.0 / pc.z, invz_2 = invz * invz;
-          double J[18];
-          J[0] = xx * yy * invz_2 * cam[0]; J[1] = -(1 + (xx * xx * invz_2)) * cam[0]; J[2] = yy * invz * cam[0];
-          J[3] = -invz * cam[0];            J[4] = 0;                                  J[5] = xx * invz_2 * cam[0];
-          J[6] = (1 + yy * yy * invz_2) * cam[1]; J[7] = -xx * yy * invz_2 * cam[1];   J[8] = -xx * invz * cam[1];
-          J[9] = 0;                         J[10] = -invz * cam[1];                    J[11] = yy * invz_2 * cam[1];
-          J[12] = J[0] - cam[4] * yy * invz_2; J[13] = J[1] + cam[4] * xx * invz_2;    J[14] = J[2];
-          J[15] = J[3];                     J[16] = 0;                                 J[17] = J[5] - cam[4] * invz_2;
-          const int dim = E.stereo ? 3 : 2;
-          const double w = rho1 * E.invs;  // robustInformation(rho) = rho[1] * Omega (base_edge.h:96-102)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            if (r < dim) {
-              const double we = rho1 * (E.invs * er[r]);
-#pragma unroll
-              for (int c = 0; c < 6; ++c) {
-                acc[21 + c] -= J[6 * r + c] * we;
-#pragma unroll
-                for (int c2 = 0; c2 <= c; ++c2) acc[c * (c + 1) / 2 + c2] += J[6 * r + c] * w * J[6 * r + c2];
-              }
-            }
-          }
+          a.stored[e] = pose_obs_accumulate(T, cam, E, robust ? (E.stereo ? a.hub_stereo : a.hub_mono) : 0.0, acc);
         }
         block_sum_acc<NT>(acc, sP, sQ, sR);
         double currentChi = acc[27];

@@ -40,7 +40,8 @@ def hc():
 
 def test_vector_counts():
     assert {k: len(v) for k, v in GOLD.items()} == {"se3_exp": 39, "pose_oplus": 24, "huber": 28, "mono_project": 32, "stereo_project": 32,
-                                                    "onlypose_mono": 24, "onlypose_stereo": 24, "binary_mono": 32, "binary_stereo": 32}
+                                                    "onlypose_mono": 24, "onlypose_stereo": 24, "binary_mono": 32, "binary_stereo": 32,
+                                                    "unary_mono": 32, "unary_stereo": 32}
 
 
 def test_oracle_se3_exp_matches_prebuilt_g2o(oracle_lib):
@@ -137,6 +138,41 @@ def test_oracle_binary_edges_match_prebuilt_g2o(oracle_lib, kind):
     assert n_fixed >= 6 and n_knee >= 8
 
 
+_UN_KEYS = ("error", "chi2", "J", "H_pose", "b_pose")
+
+
+@pytest.mark.parametrize("kind", ["mono", "stereo"])
+def test_oracle_unary_edges_match_prebuilt_g2o_bit_for_bit(oracle_lib, kind):
+    """Edge(Stereo)SE3ProjectXYZOnlyPose -- the edges of Optimizer::PoseOptimization (OPT:247-459), and the driver every unary edge
+    of the path (EdgePointCuboidOnlyObject, A13) runs through -- taken IN THE REFERENCE'S PREBUILT libg2o.so through computeError,
+    BaseEdge::chi2, BaseUnaryEdge<2|3,...,VertexSE3Expmap>::linearizeOplus(JacobianWorkspace&) and ::constructQuadraticForm()
+    (base_unary_edge.hpp:43-80) with a RobustKernelHuber attached: 32 cases each, residuals below, AT (chi2 within an ulp of
+    delta^2) and far above the knee, no-kernel cases, fixed-pose cases.  The oracle reproduces every output bit for bit --
+    including b, whose grouping differs from the binary edges' ((rho1 A' Omega) e, not A' ((-Omega e) rho1)).
+    The exported linearizeOplus(JacobianWorkspace&) maps the workspace and tail-calls the virtual linearizeOplus(), which both
+    classes override analytically; the numeric body (base_unary_edge.hpp:82-123) does not exist in the binary (see the pinning
+    script's docstring) -- it is the Xi half of BaseBinaryEdge::linearizeOplusXi, pinned in the test above."""
+    c_dp = C.POINTER(C.c_double)
+    oracle_lib.oracle_unary_edge_pin.argtypes = [c_dp] * 4 + [C.c_int, C.c_double, C.c_double, C.c_int] + [c_dp] * 5
+    oracle_lib.oracle_unary_edge_pin.restype = C.c_int
+    n_fixed = n_above = n_at = n_plain = 0
+    for c in GOLD["unary_" + kind]:
+        D = len(c["error"])
+        o = {"error": np.zeros(3), "chi2": np.zeros(1), "J": np.zeros(18), "H_pose": np.zeros(36), "b_pose": np.zeros(6)}
+        oracle_lib.oracle_unary_edge_pin(dptr(np.array(c["qt"])), dptr(np.array(c["cam"])), dptr(np.array(c["xw"])), dptr(np.array(c["obs"])),
+                                         int(kind == "stereo"), c["info"], c["huber_delta"], c["fix_pose"], *[dptr(o[k]) for k in _UN_KEYS])
+        for k, n in (("error", D), ("chi2", 1), ("J", 6 * D), ("H_pose", 36), ("b_pose", 6)):
+            assert o[k][:n].tolist() == np.atleast_1d(np.array(c[k], dtype=float)).tolist(), (kind, k, c)
+        d2 = c["huber_delta"] ** 2
+        n_fixed += c["fix_pose"]
+        n_plain += int(c["huber_delta"] == 0)
+        n_above += int(c["huber_delta"] > 0 and c["chi2"] > 1.5 * d2)
+        n_at += int(c["huber_delta"] > 0 and abs(c["chi2"] - d2) <= 1e-12 * d2)
+        if c["fix_pose"]:
+            assert not np.any(c["H_pose"]) and not np.any(c["b_pose"])
+    assert n_fixed >= 2 and n_above >= 6 and n_at >= 3 and n_plain >= 6
+
+
 def test_reference_numeric_jacobian_noise_floor():
     """What delta = 1e-9 central differences are worth, measured on the reference's own binary: its numeric Jacobian of the mono
     edge differs from its analytic one by up to ~1e-4 relative (pixel-scale residuals carry ~1e-13 of rounding, divided by
@@ -216,6 +252,34 @@ def test_device_math_binary_edges_match_prebuilt_g2o(hc, kind):
         # b = J' (rho1 w e) sums terms of both signs: 1e-11 of the largest entry
         np.testing.assert_allclose(bl, c["b_point"], rtol=0, atol=1e-11 * max(1.0, np.abs(c["b_point"]).max()))
         np.testing.assert_allclose(A[21:27], c["b_pose"], rtol=0, atol=1e-11 * max(1.0, np.abs(c["b_pose"]).max()))
+
+
+@pytest.mark.parametrize("kind", ["mono", "stereo"])
+def test_device_math_unary_edges_match_prebuilt_g2o(hc, kind):
+    """The per-observation arithmetic of the pose-only kernel (csrc/ppo_pose_math.hpp: residual with the OnlyPose stereo flavour --
+    `bf` is a DOUBLE member there, a float argument in the binary edge --, chi2, Huber, 6x6 block and right-hand side) against
+    computeError / chi2 / BaseUnaryEdge::constructQuadraticForm of the reference's prebuilt libg2o.so on the same 32 + 32 cases:
+    to rounding (1e-12 relative), the kernel regroups."""
+    hc.hc_pose_obs.argtypes = [B.c_dp] * 4 + [C.c_double, C.c_double] + [B.c_dp] * 2
+    hc.hc_pose_obs.restype = C.c_double
+    for c in GOLD["unary_" + kind]:
+        D = len(c["error"])
+        obs = np.array(c["obs"], dtype=float)
+        if kind == "mono":
+            obs[2] = -1.0
+        e, acc = np.zeros(3), np.zeros(28)
+        chi2 = hc.hc_pose_obs(dptr(np.array(c["qt"])), dptr(np.array(c["cam"])), dptr(np.array(c["xw"])), dptr(obs), c["info"], c["huber_delta"], dptr(e), dptr(acc))
+        np.testing.assert_allclose(e[:D], c["error"], rtol=0, atol=2e-12)  # residuals of up to ~1e3 px
+        assert abs(chi2 - c["chi2"]) <= 1e-12 * max(1.0, c["chi2"])
+        if c["fix_pose"]:
+            continue  # a fixed pose has no system at all in the kernel
+        Hpp = np.array(c["H_pose"]).reshape(6, 6)
+        got = np.zeros((6, 6))
+        for r in range(6):
+            for cc in range(r + 1):
+                got[r, cc] = got[cc, r] = acc[r * (r + 1) // 2 + cc]
+        np.testing.assert_allclose(got, Hpp, rtol=0, atol=1e-12 * max(1.0, np.abs(Hpp).max()))
+        np.testing.assert_allclose(acc[21:27], c["b_pose"], rtol=0, atol=1e-11 * max(1.0, np.abs(c["b_pose"]).max()))
 
 
 def test_device_math_matches_oracle_on_plane_and_cuboid_functions(hc, oracle_lib):
