@@ -1121,6 +1121,33 @@ int oracle_ba_read(oracle_handle o, ppo_ba_result* r) {
   return PPO_BA_OK;
 }
 
+// Test aid: the oracle's CURRENT objective -- the active edge set, levels and robust kernels as its last
+// initializeOptimization / classification left them (after oracle_ba_run: the pass-2 cost) -- evaluated at a FOREIGN state (any
+// pointer may be NULL: that vertex class keeps the oracle's own state).  computeActiveErrors + activeRobustChi2
+// (sparse_optimizer.cpp:61-76, 100-114) on a copy: the oracle's state and stored errors are untouched.
+// tests/test_parity_gpu.py: "the device's final state is an equally good minimiser of the REFERENCE cost".
+int oracle_ba_chi2_at(oracle_handle o, const double* pose_qt, const double* point_xyz, const double* plane_coef, const double* cuboid_qt,
+                      const double* cuboid_scale, double* chi2) {
+  if (!o || !chi2) return PPO_BA_ERR_ARG;
+  const std::vector<SE3> pose = o->pose;
+  const std::vector<V3> point = o->point;
+  const std::vector<Plane> plane = o->plane;
+  const std::vector<Cuboid> cuboid = o->cuboid;
+  std::vector<double> err[E_NTYPES];
+  for (int t = 0; t < E_NTYPES; ++t) err[t] = o->err[t];
+  auto get_se3 = [](const double* q) { SE3 T; T.r = Quat{q[0], q[1], q[2], q[3]}; T.t = mk(q[4], q[5], q[6]); return T; };
+  if (pose_qt) for (int i = 0; i < o->n_poses; ++i) o->pose[i] = get_se3(&pose_qt[7 * i]);
+  if (point_xyz) for (int i = 0; i < o->n_points; ++i) o->point[i] = mk(point_xyz[3 * i], point_xyz[3 * i + 1], point_xyz[3 * i + 2]);
+  if (plane_coef) for (int i = 0; i < o->n_planes; ++i) for (int a = 0; a < 4; ++a) o->plane[i].c[a] = plane_coef[4 * i + a];
+  if (cuboid_qt) for (int i = 0; i < o->n_cuboids; ++i) o->cuboid[i].pose = get_se3(&cuboid_qt[7 * i]);
+  if (cuboid_scale) for (int i = 0; i < o->n_cuboids; ++i) o->cuboid[i].scale = mk(cuboid_scale[3 * i], cuboid_scale[3 * i + 1], cuboid_scale[3 * i + 2]);
+  compute_active_errors(*o);
+  *chi2 = active_robust_chi2(*o);
+  o->pose = pose; o->point = point; o->plane = plane; o->cuboid = cuboid;
+  for (int t = 0; t < E_NTYPES; ++t) o->err[t] = err[t];
+  return PPO_BA_OK;
+}
+
 void oracle_ba_destroy(oracle_handle o) { delete o; }
 
 // Test aid for tests/test_oracle_sensitivity.py: 1 = sum the edges (chi2, H, b) and the landmarks (Schur complement) in reverse

@@ -97,3 +97,27 @@ def schedule(st):
 
 
 BARS = {"t": 1e-5, "r": 1e-6, "p": 1e-5, "pl": 1e-6, "cb": 1e-5}
+
+
+def oracle_cost_at(oracle, so, r):
+    """The oracle's CURRENT objective (after so.run(): the pass-2 cost -- its own active set, levels and kernels) evaluated at the
+    state of result `r` (oracle_ba_chi2_at).  With r = so.read() it returns the oracle's own final robust chi2."""
+    f = oracle.lib.oracle_ba_chi2_at
+    f.argtypes = [C.c_void_p] + [B.c_dp] * 5 + [B.c_dp]
+    f.restype = C.c_int
+    chi = C.c_double()
+
+    def p(a):
+        a = np.ascontiguousarray(a, np.float64)
+        return a, (a.ctypes.data_as(B.c_dp) if a.size else None)
+    keep = [p(r.pose_qt), p(r.point_xyz), p(r.plane_coef), p(r.cuboid_qt), p(r.cuboid_scale)]
+    assert f(so.h, *[k[1] for k in keep], C.cast(C.byref(chi), B.c_dp)) == 0
+    return chi.value
+
+
+def optimality_gap(oracle, so, ro, r_other):
+    """|cost_ref(x_other) - cost_ref(x_oracle)| / cost_ref(x_oracle): how much worse (or better) a minimiser of the REFERENCE cost the
+    other implementation's final state is."""
+    c0 = oracle_cost_at(oracle, so, ro)
+    c1 = oracle_cost_at(oracle, so, r_other)
+    return abs(c1 - c0) / max(1.0, abs(c0)), c0, c1

@@ -26,3 +26,30 @@ def test_window_through_flatten_and_the_library():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "flatten_demo ok" in out.stdout
+
+
+def _build_from_reference(tmp_path):
+    exe = tmp_path / "from_reference_test"
+    csrc = os.path.join(REPO, "point-plane-object-slam_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(REPO, "include"), "-o", str(exe),
+                           os.path.join(HERE, "from_reference_test.cpp"), "-L", csrc, "-lppo_ba", "-Wl,-rpath," + csrc])
+    return exe
+
+
+def test_reference_side_adapter_on_mock_classes(tmp_path):
+    """include/ppo_from_reference.hpp -- the window gather (Optimizer.cc:1997-2105), the copy loops over KeyFrame / MapPoint / MapPlane /
+    MapCuboid and the write-back under Map::mMutexMapUpdate (Optimizer.cc:2892-2966) as templates over the reference's member names --
+    instantiated on mock classes carrying exactly those names: gathered sets, markers, field-by-field copies, lock order, erase calls.
+    Here (no GPU) the last stage also shows the product failing loudly with the map untouched."""
+    exe = _build_from_reference(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "from_reference_test ok" in out.stdout, out.stdout + out.stderr
+    assert ("no GPU" in out.stdout) != os.path.exists("/dev/kfd")
+
+
+@pytest.mark.gpu
+def test_reference_side_adapter_through_the_library(tmp_path):
+    """The same test program on the GPU box: its last stage takes the mock window through ppo_ba_create / run / read / destroy."""
+    exe = _build_from_reference(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "from_reference_test ok" in out.stdout and "went through libppo_ba.so" in out.stdout, out.stdout + out.stderr
