@@ -50,7 +50,14 @@ enum {
 enum { PPO_CUBOID_FIX_ROLLPITCH = 1, PPO_CUBOID_FIX_HEIGHT = 2, PPO_CUBOID_FIX_ROTATION = 4 };
 
 /* Jacobian mode for the edges g2o differentiates numerically */
-enum { PPO_JAC_NUMERIC = 0 /* central differences, delta = numeric_delta, as the reference */ };
+enum {
+  PPO_JAC_NUMERIC = 0, /* central differences, delta = numeric_delta, as the reference (base_binary_edge.hpp:217-320): the default */
+  PPO_JAC_ANALYTIC = 1 /* opt-in: exact derivatives of the same composite maps for the plane edges (EdgePlane / EdgeVerticalPlane /
+                        * EdgeParallelPlane, G2O_Plane3D.h:176-310) and the cuboid projections (EdgeSE3CuboidProj / CornerProj,
+                        * g2o_cuboid.cc:70-120); they agree with the central differences to the 1e-7 round-off those carry.  The
+                        * point-cuboid edge stays numeric.  Cuboids with PPO_CUBOID_FIX_ROTATION are refused in this mode
+                        * (their box-plus resets the rotation: a zero update is not the identity) -> PPO_BA_ERR_ARG */
+};
 
 /* dense reduced-system backend */
 enum { PPO_SOLVER_AUTO = 0, PPO_SOLVER_ROCSOLVER = 1, PPO_SOLVER_NATIVE = 2 };
@@ -157,7 +164,7 @@ typedef struct ppo_ba_options {
   double lm_lower;          /* 1/3 :49 */
   double lm_upper;          /* 2/3 :48 */
   double numeric_delta;     /* 1e-9 base_binary_edge.hpp:232 */
-  int32_t jacobian_mode;    /* PPO_JAC_NUMERIC (the only mode: what the reference does); anything else -> PPO_BA_ERR_ARG */
+  int32_t jacobian_mode;    /* PPO_JAC_NUMERIC (default: what the reference does) or PPO_JAC_ANALYTIC; anything else -> PPO_BA_ERR_ARG */
   /* outlier thresholds of the between-pass classification, Optimizer.cc:2739-2833 */
   double chi2_mono;         /* 5.991 */
   double chi2_stereo;       /* 7.815 */

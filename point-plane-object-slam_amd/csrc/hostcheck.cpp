@@ -115,4 +115,15 @@ double hc_pose_obs(const double* qt, const double* cam, const double* xw, const 
   (void)pose_edge_chi2(T, cam, E, e, pc);
   return pose_obs_accumulate(T, cam, E, huber_delta, acc);
 }
+// analytic Jacobians (jacobian_mode = PPO_JAC_ANALYTIC) for tests/test_analytic_jacobians.py
+void hc_plane_analytic(const double* qt, const double* plane, const double* meas, int kind, double* e, double* J27) {
+  const Pose T{Quat{qt[0], qt[1], qt[2], qt[3]}, Vec3{qt[4], qt[5], qt[6]}};
+  plane_edge_analytic(T, plane_canon(plane[0], plane[1], plane[2], plane[3]), plane_canon(meas[0], meas[1], meas[2], meas[3]), kind, e, J27);
+}
+void hc_cubproj_analytic(const double* pose_qt, const double* c10, const double* K, const double* meas, unsigned flags, int scale_fixed, int corner, double* e, double* J) {
+  const Pose T{Quat{pose_qt[0], pose_qt[1], pose_qt[2], pose_qt[3]}, Vec3{pose_qt[4], pose_qt[5], pose_qt[6]}};
+  const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};
+  if (corner) corner_edge_analytic(T, c, flags, scale_fixed != 0, K, meas, e, J);
+  else bbox_edge_analytic(T, c, flags, scale_fixed != 0, K, meas, e, J);
+}
 }

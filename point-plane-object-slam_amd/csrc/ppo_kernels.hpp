@@ -147,6 +147,8 @@ struct Graph {
   double* xc;                   // [Nc][9]  cuboid update
   int pt_first, pt_last, plane_first, plane_last;
   int owns_reduced;  // 1 on the rank that adds Hcc / lambda / cuboid terms
+  int jac;           // options.jacobian_mode: 0 numeric (central differences, what the reference does), 1 analytic for the plane and the
+                     // cuboid-projection edges (ppo_math.hpp: plane_edge_analytic, cuboid_corner_analytic); the point-cuboid edge stays numeric
   int det;           // options.deterministic: every cross-wave accumulation is an INTEGER atomic on a 2^-24 fixed-point image of the
                      // addend (exact, hence independent of the order the atomics arrive in); k_fix_to_double turns the ranges back into doubles
   const double* hb_diag;  // sharded runs, first iteration: diagonal of Hpp summed over ranks (NULL: read it from HB)
@@ -956,6 +958,195 @@ __device__ __forceinline__ void lin_cubproj_body(const Graph& g, const State& st
   LIN_STAMP(g, 4);
 }
 
+// ---- analytic mode (options.jacobian_mode = PPO_JAC_ANALYTIC) ------------------------------------------------------------------------
+// The numeric classes above spend 19 (planes) or 248 (cuboid projections) lanes per edge on the 2 x columns + 1 residual evaluations of a
+// central difference.  With the exact derivative an edge needs ONE evaluation: 8 lanes per edge -- for a cuboid projection one lane
+// per corner -- , 32 edges per workgroup: 4 000 plane edges are 125 workgroups instead of 334, 500 bbox edges 16 instead of 500, and
+// the fused launch is back to one round of workgroups.  The accumulation (entries, order inside an edge, lane-contiguous atomics) is
+// the numeric classes': sJ / sW / sG in LDS, then consecutive lanes add consecutive entries.
+constexpr int kAnaLanes = 8, kAnaPlaneEPB = 32, kAnaBboxEPB = 32, kAnaCornerEPB = 12;
+__device__ __forceinline__ void lin_plane_body_analytic(const Graph& g, const State& st, int n_edges, int vblock, double* smem) {
+  constexpr int DM = 3, EPB = kAnaPlaneEPB;
+  double (*sJ)[DM][16] = reinterpret_cast<double (*)[DM][16]>(smem);  // [edge of the workgroup][row][col]
+  double (*sW)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16);
+  double (*sG)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16 + EPB * DM);
+  const PlaneModel m{g, false};
+  const int grp = threadIdx.x >> 3, lane = threadIdx.x & 7;
+  const int i = vblock * EPB + grp;
+  LIN_STAMP(g, 0);
+  const bool act = i < n_edges && m.active(i);
+  const int dim = act ? m.dim(i) : 0;
+  double chi_local = 0.0;
+  if (act) {
+    const PlaneEdge& ed = g.pl[i];
+    double e[3] = {0.0, 0.0, 0.0}, J[27];
+    plane_edge_analytic(load_pose(&st.pose_qt[7 * ed.pose]), load_plane(&st.plane[4 * ed.plane]), PlaneC{ed.meas[0], ed.meas[1], ed.meas[2], ed.meas[3]},
+                        (ed.flags >> 8) & 3, e, J);
+    const bool pose_free = g.pose_col[ed.pose] >= 0;  // nothing is differentiated for a fixed vertex (base_binary_edge.hpp:275-278)
+#pragma unroll
+    for (int r = 0; r < DM; ++r)
+      if (r < dim) {
+        // (every lane holds the whole Jacobian; lane q stages column q, lane 0 also column 8 -- selected without a run-time register index)
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v = (c == lane) ? J[r * 9 + c] : v;
+        sJ[grp][r][lane] = (lane < 3 || pose_free) ? v : 0.0;
+        if (lane == 0) sJ[grp][r][8] = pose_free ? J[r * 9 + 8] : 0.0;
+      }
+    if (lane == 0) {
+      double chi2 = 0, nrm = 0;
+#pragma unroll
+      for (int r = 0; r < DM; ++r)
+        if (r < dim) { chi2 += e[r] * (ed.info[r] * e[r]); nrm += e[r] * e[r]; }
+      m.store_chi2(i, chi2, sqrt(nrm));
+      double rho0, rho1;
+      huber(chi2, m.huber_delta(i), rho0, rho1);
+      chi_local = rho0;
+#pragma unroll
+      for (int r = 0; r < DM; ++r)
+        if (r < dim) { sW[grp][r] = rho1 * ed.info[r]; sG[grp][r] = -(ed.info[r] * e[r]) * rho1; }
+    }
+  }
+  LIN_STAMP(g, 1);
+  lds_wave_fence();  // (the eight lanes of an edge sit in one wave)
+  LIN_STAMP(g, 2);
+  if (act) {
+    const PlaneEdge& ed = g.pl[i];
+    const int l = g.n_points + ed.plane, fid = g.pose_free_id[ed.pose];
+    double* const pD = &g.D[(size_t)l * 6];
+    double* const pb = &g.bl[(size_t)l * 3];
+    double* const pH = &g.HB[(size_t)(fid >= 0 ? fid : 0) * 27];
+    double* const pW = &g.W[(size_t)(ed.slot >= 0 ? ed.slot - g.n_pt_slots : 0) * 18];
+#pragma unroll
+    for (int rd = 0; rd < 7; ++rd) {  // 54 entries per edge (kPlaneEmit), eight per round
+      const int o = lane + rd * kAnaLanes;
+      const unsigned en = kPlaneEmit[o < 54 ? o : 54];
+      const int row = en & 15, col = (en >> 4) & 15, seg = (en >> 9) & 3, off = en >> 11;
+      const bool isb = (en >> 8) & 1;
+      double* const dst = (seg == 0 ? pD : seg == 1 ? pb : seg == 2 ? pH : pW) + off;
+      const bool valid = o < 54 && (seg < 2 || (fid >= 0 && (seg == 2 || ed.slot >= 0)));
+      double h = 0;
+#pragma unroll
+      for (int r = 0; r < DM; ++r) {
+        const double x = sJ[grp][r][row], y = isb ? sG[grp][r] : sW[grp][r], z = isb ? 1.0 : sJ[grp][r][col];
+        if (r < dim) h += x * y * z;
+      }
+      if (valid) acc_add(g, dst, h);
+    }
+  }
+  LIN_STAMP(g, 3);
+  wave_atomic_add(g, chi_local, ACC_CHI2);
+  LIN_STAMP(g, 4);
+}
+
+template <bool CORNER>
+__device__ __forceinline__ void lin_cubproj_body_analytic(const Graph& g, const State& st, int n_edges, int vblock, double* smem) {
+  constexpr int DM = CORNER ? 16 : 4, EPB = CORNER ? kAnaCornerEPB : kAnaBboxEPB;
+  double (*sJ)[DM][16] = reinterpret_cast<double (*)[DM][16]>(smem);  // [edge of the workgroup][row][col]
+  double (*sW)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16);
+  double (*sG)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16 + EPB * DM);
+  const int grp = threadIdx.x >> 3, k = threadIdx.x & 7;  // lane k = cuboid corner k
+  const int i = vblock * EPB + grp;
+  const bool in = grp < EPB && i < n_edges;
+  const CubEdge& ed = (CORNER ? g.corner : g.bbox)[in ? i : 0];
+  const bool act = in && (ed.flags & F_ACTIVE);
+  const int fid = g.pose_free_id[ed.pose];
+  LIN_STAMP(g, 0);
+  double chi_local = 0.0;
+  if (act) {
+    const Pose T = load_pose(&st.pose_qt[7 * ed.pose]);
+    const Cub cb = load_cub(&st.cub[10 * ed.cuboid]);
+    const Mat3 Rwo = rotmat(cb.T.q), Rcw = rotmat(T.q);
+    double u, v, Ju[15], Jv[15];
+    cuboid_corner_analytic(cb, Rwo, Rcw, T.t, ed.K, g.cub_flags[ed.cuboid], g.cub_fixedscale[3 * ed.cuboid] > 0, k, u, v, Ju, Jv);
+    if (g.pose_col[ed.pose] < 0) {  // fixed pose: its columns are not differentiated
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { Ju[c] = 0.0; Jv[c] = 0.0; }
+    }
+    const int lane0 = (threadIdx.x & 63) & ~7;
+    double e0, e1 = 0.0;
+    if (CORNER) {
+      e0 = u - ed.meas[2 * k];
+      e1 = v - ed.meas[2 * k + 1];
+#pragma unroll
+      for (int c = 0; c < 15; ++c) { sJ[grp][2 * k][c] = Ju[c]; sJ[grp][2 * k + 1][c] = Jv[c]; }
+    } else {
+      // the hull and the corners attaining it (the lowest corner index on a tie, like the sequential scan of bbox_edge_analytic)
+      double ulo = u, uhi = u, vlo = v, vhi = v;
+#pragma unroll
+      for (int sft = 1; sft < 8; sft <<= 1) {
+        ulo = fmin(ulo, __shfl_xor(ulo, sft, 64)); uhi = fmax(uhi, __shfl_xor(uhi, sft, 64));
+        vlo = fmin(vlo, __shfl_xor(vlo, sft, 64)); vhi = fmax(vhi, __shfl_xor(vhi, sft, 64));
+      }
+      int kulo = (u == ulo) ? k : 8, kuhi = (u == uhi) ? k : 8, kvlo = (v == vlo) ? k : 8, kvhi = (v == vhi) ? k : 8;
+#pragma unroll
+      for (int sft = 1; sft < 8; sft <<= 1) {
+        kulo = min(kulo, __shfl_xor(kulo, sft, 64)); kuhi = min(kuhi, __shfl_xor(kuhi, sft, 64));
+        kvlo = min(kvlo, __shfl_xor(kvlo, sft, 64)); kvhi = min(kvhi, __shfl_xor(kvhi, sft, 64));
+      }
+      e0 = k == 0 ? (uhi + ulo) / 2 - ed.meas[0] : (k == 1 ? (vhi + vlo) / 2 - ed.meas[1] : (k == 2 ? (uhi - ulo) - ed.meas[2] : (vhi - vlo) - ed.meas[3]));
+#pragma unroll
+      for (int c = 0; c < 15; ++c) {
+        const double a = __shfl(Ju[c], lane0 + kuhi, 64), b = __shfl(Ju[c], lane0 + kulo, 64);
+        const double p = __shfl(Jv[c], lane0 + kvhi, 64), q = __shfl(Jv[c], lane0 + kvlo, 64);
+        if ((c & 7) == k) { sJ[grp][0][c] = (a + b) / 2; sJ[grp][1][c] = (p + q) / 2; sJ[grp][2][c] = a - b; sJ[grp][3][c] = p - q; }
+      }
+    }
+    // rows gathered in order: chi2 is summed exactly like the residual-only pass does
+    double chi2 = 0, nrm = 0;
+#pragma unroll
+    for (int row = 0; row < DM; ++row) {
+      const double er = CORNER ? __shfl((row & 1) ? e1 : e0, lane0 + (row >> 1), 64) : __shfl(e0, lane0 + row, 64);
+      chi2 += er * (ed.info[row] * er);
+      nrm += er * er;
+    }
+    double rho0, rho1;
+    huber(chi2, (ed.flags & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+    if (k == 0) {
+      if (CORNER) { g.corner_chi2[i] = chi2; g.corner_norm[i] = sqrt(nrm); } else { g.bbox_chi2[i] = chi2; g.bbox_norm[i] = sqrt(nrm); }
+      chi_local = rho0;
+    }
+    if (CORNER) {
+      sW[grp][2 * k] = rho1 * ed.info[2 * k]; sG[grp][2 * k] = -(ed.info[2 * k] * e0) * rho1;
+      sW[grp][2 * k + 1] = rho1 * ed.info[2 * k + 1]; sG[grp][2 * k + 1] = -(ed.info[2 * k + 1] * e1) * rho1;
+    } else if (k < 4) {
+      sW[grp][k] = rho1 * ed.info[k]; sG[grp][k] = -(ed.info[k] * e0) * rho1;
+    }
+  }
+  LIN_STAMP(g, 1);
+  lds_wave_fence();  // (the eight lanes of an edge sit in one wave)
+  LIN_STAMP(g, 2);
+  if (act) {
+    // 135 entries: pose block (21 packed lower + 6) | cuboid block (45 packed lower + 9) | W pose rows x cuboid cols (6 x 9), eight per round
+    const double (*J)[16] = sJ[grp];
+#pragma unroll 1
+    for (int o = k; o < 135; o += kAnaLanes) {
+      if (o < 27) {
+        if (fid >= 0) {
+          double val;
+          if (o < 21) { int a, c2; unpack_lower(o, a, c2); val = quad_H<DM>(J, sW[grp], DM, a, c2); }
+          else val = quad_b<DM>(J, sG[grp], DM, o - 21);
+          acc_add(g, &g.HB[(size_t)fid * 27 + o], val);
+        }
+      } else if (o < 81) {
+        const int q = o - 27;
+        double val;
+        if (q < 45) { int a, c2; unpack_lower(q, a, c2); val = quad_H<DM>(J, sW[grp], DM, 6 + a, 6 + c2); }
+        else val = quad_b<DM>(J, sG[grp], DM, 6 + (q - 45));
+        acc_add(g, &g.HC[(size_t)ed.cuboid * 54 + q], val);
+      } else if (fid >= 0) {
+        const int q = o - 81;
+        ((CORNER ? g.Wpc_corner : g.Wpc_bbox) + (size_t)i * 54)[q] = quad_H<DM>(J, sW[grp], DM, q / 9, 6 + q % 9);
+      }
+    }
+  }
+  LIN_STAMP(g, 3);
+  wave_atomic_add(g, chi_local, ACC_CHI2);
+  LIN_STAMP(g, 4);
+}
+constexpr int kAnalyticLdsDoubles = kAnaCornerEPB * 16 * 18 > kAnaPlaneEPB * 3 * 18 ? (kAnaCornerEPB * 16 * 18 > kAnaBboxEPB * 4 * 18 ? kAnaCornerEPB * 16 * 18 : kAnaBboxEPB * 4 * 18)
+                                                                                   : kAnaPlaneEPB * 3 * 18;
+
 // ---- point-cuboid edges: ONE edge per workgroup, 8 lanes per residual, each summing every eighth point -----------------------------------
 // (19 residuals x 8 = 152 lanes.  The residual is a mean over the cuboid's points, ~13 us as one chain for the 30-40 points of a
 //  BASELINE cuboid; the eight partial sums are combined by a fixed exchange tree, so the result does not depend on anything but the edge.)
@@ -1075,7 +1266,7 @@ struct LinPlan {
   int nb[LIN_PARTS];     // workgroups per part
   int order[LIN_PARTS];  // grid order of the parts
 };
-template <bool USE_LDS, bool WITH_CORNERS>
+template <bool USE_LDS, bool WITH_CORNERS, bool ANALYTIC = false>
 __global__ __launch_bounds__(256, PPO_LIN_WAVES) void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
   extern __shared__ double smem[];
   int b = blockIdx.x, part = -1;
@@ -1091,10 +1282,19 @@ __global__ __launch_bounds__(256, PPO_LIN_WAVES) void k_linearize_all(Graph g, S
   if (part != PPO_LIN_ONLY) return;
 #endif
   switch (part) {
-    case LIN_PLANE: lin_plane_body(g, st, g.n_pl, delta, b, smem); break;
-    case LIN_BBOX: lin_cubproj_body<false>(g, st, b, delta, smem); break;
+    case LIN_PLANE:
+      if (ANALYTIC) lin_plane_body_analytic(g, st, g.n_pl, b, smem);
+      else lin_plane_body(g, st, g.n_pl, delta, b, smem);
+      break;
+    case LIN_BBOX:
+      if (ANALYTIC) lin_cubproj_body_analytic<false>(g, st, g.n_bbox, b, smem);
+      else lin_cubproj_body<false>(g, st, b, delta, smem);
+      break;
     case LIN_CORNER:
-      if (WITH_CORNERS) lin_cubproj_body<true>(g, st, b, delta, smem);  // compiled in only for windows that have corner edges
+      if (WITH_CORNERS) {  // compiled in only for windows that have corner edges
+        if (ANALYTIC) lin_cubproj_body_analytic<true>(g, st, g.n_corner, b, smem);
+        else lin_cubproj_body<true>(g, st, b, delta, smem);
+      }
       break;
     case LIN_PTCUB: lin_ptcub_body(g, st, b, delta, smem); break;
     case LIN_POSE: LIN_STAMP(g, 0); lin_poses_body(g, st, pc, b, smem); LIN_STAMP(g, 4); break;

@@ -319,6 +319,150 @@ PPO_HD void corner_residual(const Pose& Tcw, const Cub& c, const double* K, cons
     e[2 * k + 1] = v - meas[2 * k + 1];
   }
 }
+// ---- analytic Jacobians (options.jacobian_mode = PPO_JAC_ANALYTIC; SURVEY.md section 7 H1: "numeric first, analytic later") ------------
+// The reference differentiates these edges numerically (base_binary_edge.hpp:217-320, delta = 1e-9).  The functions below are the exact
+// derivatives of the same composite maps -- vertex box-plus, transform, residual -- at a zero update; they agree with the central
+// differences to the 1e-7 relative round-off those carry (tests/test_analytic_jacobians.py, csrc/hostcheck.cpp).
+//
+// EdgePlane / EdgeVerticalPlane / EdgeParallelPlane (include/G2O_Plane3D.h:176-310).  With n~ = sigma R n the camera-frame normal
+// (sigma = -1 when the transformed offset is negative, :136-137) and c~ its offset, a zero-centred update moves them by
+//   plane  (azimuth a, elevation b, distance dd; :74-87):  dn~ = sigma R (a Yw + b Zw),  dc~ = sigma (-dd - t . R (a Yw + b Zw)),
+//          Yw, Zw = second and third column of rotation(n) (:66-72);
+//   pose   (omega, upsilon; exp(delta) T):                 dn~ = sigma (omega x R n),     dc~ = -sigma (R n) . upsilon.
+// The angular residual is (azimuth, elevation) of F(a)' n_m with F = rotation(a) and a = n~ (ominus, :89-95), +-n~ (ominus_par, :108-117)
+// or the unit projection of n_m onto the plane perpendicular to n~ (ominus_ver, :97-106: a quarter turn of n~ about n~ x n_m).  Its
+// derivative with respect to the axis is a pair of tangent vectors g0, g1 (below), chained through da = dn~ (ominus), +-dn~ (par),
+// (dp - a (a . dp)) / |p| with dp = -(dn~ . n_m) n~ - (n~ . n_m) dn~ (ver).  J is row-major [3][9]: columns 0-2 plane, 3-8 pose;
+// e as plane_residual.  (The d >= 0 flips of :120-125, :136-137 are constant in a neighbourhood, as the central difference sees them.)
+PPO_HD void plane_edge_analytic(const Pose& Tcw, const PlaneC& p, const PlaneC& m, int kind, double* e, double* J) {
+  const Mat3 R = rotmat(Tcw.q);
+  const Vec3 nw = v3(p.nx, p.ny, p.nz), u = v3(m.nx, m.ny, m.nz);
+  const Vec3 nc = matvec(R, nw);
+  const double d2 = p.d - dot3(Tcw.t, nc);
+  const double sg = d2 < 0.0 ? -1.0 : 1.0;
+  const PlaneC loc = plane_canon(sg * nc.x, sg * nc.y, sg * nc.z, sg * d2);
+  const Vec3 nt = v3(loc.nx, loc.ny, loc.nz);
+  // axis of the residual frame and the linear map dn~ -> (de0, de1) as two gradient vectors G0, G1
+  Vec3 a = nt;
+  double s2 = 1.0, gdot = 0.0, ipn = 1.0;
+  if (kind == 1) {
+    gdot = dot3(nt, u);
+    const Vec3 pr = u - nt * gdot;
+    ipn = 1.0 / sqrt(dot3(pr, pr));
+    a = pr * ipn;
+  } else if (kind == 2) {
+    if (dot3(u, nt) < 0) { s2 = -1.0; a = nt * -1.0; }
+  }
+  const Mat3 F = plane_frame(a);
+  const Vec3 yh = v3(F.a[1], F.a[4], F.a[7]), zh = v3(F.a[2], F.a[5], F.a[8]);
+  const double ce = F.a[8], se = F.a[6];  // cos / sin of the axis' elevation
+  const Vec3 mm = matTvec(F, u);
+  e[0] = az_of(mm);
+  e[1] = el_of(mm);
+  if (kind == 0) e[2] = (-loc.d) - (-m.d);
+  const double rho2 = mm.x * mm.x + mm.y * mm.y, irho = 1.0 / sqrt(rho2);
+  const double A0 = (-mm.x * (ce * mm.x - se * mm.z) - ce * mm.y * mm.y) / rho2, B0 = -mm.y * mm.z / rho2;
+  const double A1 = -se * mm.y * irho, B1 = -mm.x * irho;
+  const double ice = 1.0 / ce;
+  Vec3 g0 = yh * (A0 * ice) + zh * B0, g1 = yh * (A1 * ice) + zh * B1;
+  if (kind == 1) {  // g . da = (g . dp) / |p| (g is perpendicular to a): fold the projection into the gradients
+    g0 = (u * dot3(g0, nt) + g0 * gdot) * -ipn;
+    g1 = (u * dot3(g1, nt) + g1 * gdot) * -ipn;
+  } else if (kind == 2) {
+    g0 = g0 * s2;
+    g1 = g1 * s2;
+  }
+  const Mat3 Fw = plane_frame(nw);
+  const Vec3 ry = matvec(R, v3(Fw.a[1], Fw.a[4], Fw.a[7])) * sg, rz = matvec(R, v3(Fw.a[2], Fw.a[5], Fw.a[8])) * sg;  // dn~ of the plane's two angles
+  const Vec3 snc = nc * sg;
+  const Vec3 w0 = cross3(snc, g0), w1 = cross3(snc, g1);  // g . (e_k x s nc) = e_k . (s nc x g)
+  J[0] = dot3(g0, ry); J[1] = dot3(g0, rz); J[2] = 0.0; J[3] = w0.x; J[4] = w0.y; J[5] = w0.z; J[6] = 0.0; J[7] = 0.0; J[8] = 0.0;
+  J[9] = dot3(g1, ry); J[10] = dot3(g1, rz); J[11] = 0.0; J[12] = w1.x; J[13] = w1.y; J[14] = w1.z; J[15] = 0.0; J[16] = 0.0; J[17] = 0.0;
+  if (kind == 0) {  // e2 = -c~ + c_m: -dc~
+    J[18] = dot3(Tcw.t, ry); J[19] = dot3(Tcw.t, rz); J[20] = sg; J[21] = 0.0; J[22] = 0.0; J[23] = 0.0; J[24] = snc.x; J[25] = snc.y; J[26] = snc.z;
+  } else {
+    for (int k = 18; k < 27; ++k) J[k] = 0.0;
+  }
+}
+
+// One projected cuboid corner (include/g2o_cuboid.h:198-225) with its derivatives: Ju / Jv [15] = d(u, v) / d(pose omega, upsilon |
+// cuboid update 9).  Pose: exp(delta) Tcw moves the camera-frame corner by omega x pc + upsilon.  Cuboid (src/g2o_cuboid.cc:39-67):
+// fix-roll/pitch (flags bit 0): pose . (Rz(yaw), V upsilon) -> the corner moves by Rwo (z x b) dyaw + Rwo upsilon, columns 0, 1 are
+// zero; otherwise pose . exp(delta): Rwo (omega x b) + Rwo upsilon; fix-height (bit 1) restores the WORLD y of the translation:
+// the upsilon columns lose their y row; scale: Rwo e_j sign_j unless a fixed scale is set.  (b = scale * corner signs.)
+// whether_fixrotation (bit 2) resets the rotation in its box-plus (a zero update is not the identity there): not supported, the
+// library refuses the analytic mode for such a cuboid.
+PPO_HD void cuboid_corner_analytic(const Cub& c, const Mat3& Rwo, const Mat3& Rcw, Vec3 tcw, const double* K, unsigned flags, bool scale_fixed, int k, double& u,
+                                   double& v, double* Ju, double* Jv) {
+  double sx, sy, sz;
+  corner_sign(k, sx, sy, sz);
+  const Vec3 b = v3(c.s.x * sx, c.s.y * sy, c.s.z * sz);
+  Vec3 pw;
+  pw.x = (Rwo.a[0] * c.s.x) * sx + (Rwo.a[1] * c.s.y) * sy + (Rwo.a[2] * c.s.z) * sz + c.T.t.x;
+  pw.y = (Rwo.a[3] * c.s.x) * sx + (Rwo.a[4] * c.s.y) * sy + (Rwo.a[5] * c.s.z) * sz + c.T.t.y;
+  pw.z = (Rwo.a[6] * c.s.x) * sx + (Rwo.a[7] * c.s.y) * sy + (Rwo.a[8] * c.s.z) * sz + c.T.t.z;
+  const Vec3 pc = matvec(Rcw, pw) + tcw;
+  const double hx = K[0] * pc.x + K[1] * pc.y + K[2] * pc.z;
+  const double hy = K[3] * pc.x + K[4] * pc.y + K[5] * pc.z;
+  const double hz = K[6] * pc.x + K[7] * pc.y + K[8] * pc.z;
+  const double ihz = 1.0 / hz;
+  u = hx / hz;
+  v = hy / hz;
+  const Vec3 gu = v3((K[0] - u * K[6]) * ihz, (K[1] - u * K[7]) * ihz, (K[2] - u * K[8]) * ihz);  // du / dpc
+  const Vec3 gv = v3((K[3] - v * K[6]) * ihz, (K[4] - v * K[7]) * ihz, (K[5] - v * K[8]) * ihz);
+  const Vec3 wu = cross3(pc, gu), wv = cross3(pc, gv);  // g . (e_j x pc) = e_j . (pc x g)
+  Ju[0] = wu.x; Ju[1] = wu.y; Ju[2] = wu.z; Ju[3] = gu.x; Ju[4] = gu.y; Ju[5] = gu.z;
+  Jv[0] = wv.x; Jv[1] = wv.y; Jv[2] = wv.z; Jv[3] = gv.x; Jv[4] = gv.y; Jv[5] = gv.z;
+  const Vec3 hu = matTvec(Rcw, gu), hv = matTvec(Rcw, gv);  // du / dpw
+  const Vec3 bu = matTvec(Rwo, hu), bv = matTvec(Rwo, hv);  // du / d(body-frame displacement)
+  // rotation columns: omega x b in the body frame
+  const Vec3 ru = cross3(b, bu), rv = cross3(b, bv);      // bu . (e_j x b) = e_j . (b x bu)
+  if (flags & 1u) { Ju[6] = 0.0; Ju[7] = 0.0; Jv[6] = 0.0; Jv[7] = 0.0; }
+  else { Ju[6] = ru.x; Ju[7] = ru.y; Jv[6] = rv.x; Jv[7] = rv.y; }
+  Ju[8] = ru.z; Jv[8] = rv.z;
+  // translation columns: Rwo e_j in the world, y row dropped when the height is fixed
+  const bool fh = (flags & 2u) != 0;
+  const Vec3 hu2 = fh ? v3(hu.x, 0.0, hu.z) : hu, hv2 = fh ? v3(hv.x, 0.0, hv.z) : hv;
+  const Vec3 tu = matTvec(Rwo, hu2), tv = matTvec(Rwo, hv2);
+  Ju[9] = tu.x; Ju[10] = tu.y; Ju[11] = tu.z; Jv[9] = tv.x; Jv[10] = tv.y; Jv[11] = tv.z;
+  if (scale_fixed) { Ju[12] = Ju[13] = Ju[14] = 0.0; Jv[12] = Jv[13] = Jv[14] = 0.0; }
+  else { Ju[12] = bu.x * sx; Ju[13] = bu.y * sy; Ju[14] = bu.z * sz; Jv[12] = bv.x * sx; Jv[13] = bv.y * sy; Jv[14] = bv.z * sz; }
+}
+// bbox edge (EdgeSE3CuboidProj, src/g2o_cuboid.cc:70-91): e[4] and J[4][15]; the hull's derivative is that of the corners attaining it
+PPO_HD void bbox_edge_analytic(const Pose& Tcw, const Cub& c, unsigned flags, bool scale_fixed, const double* K, const double* meas, double* e, double* J) {
+  const Mat3 Rwo = rotmat(c.T.q), Rcw = rotmat(Tcw.q);
+  double ulo = 0, uhi = 0, vlo = 0, vhi = 0;
+  double Julo[15], Juhi[15], Jvlo[15], Jvhi[15];
+  for (int k = 0; k < 8; ++k) {
+    double u, v, Ju[15], Jv[15];
+    cuboid_corner_analytic(c, Rwo, Rcw, Tcw.t, K, flags, scale_fixed, k, u, v, Ju, Jv);
+    if (k == 0 || u < ulo) { ulo = u; for (int q = 0; q < 15; ++q) Julo[q] = Ju[q]; }
+    if (k == 0 || u > uhi) { uhi = u; for (int q = 0; q < 15; ++q) Juhi[q] = Ju[q]; }
+    if (k == 0 || v < vlo) { vlo = v; for (int q = 0; q < 15; ++q) Jvlo[q] = Jv[q]; }
+    if (k == 0 || v > vhi) { vhi = v; for (int q = 0; q < 15; ++q) Jvhi[q] = Jv[q]; }
+  }
+  e[0] = (uhi + ulo) / 2 - meas[0];
+  e[1] = (vhi + vlo) / 2 - meas[1];
+  e[2] = (uhi - ulo) - meas[2];
+  e[3] = (vhi - vlo) - meas[3];
+  for (int q = 0; q < 15; ++q) {
+    J[q] = (Juhi[q] + Julo[q]) / 2;
+    J[15 + q] = (Jvhi[q] + Jvlo[q]) / 2;
+    J[30 + q] = Juhi[q] - Julo[q];
+    J[45 + q] = Jvhi[q] - Jvlo[q];
+  }
+}
+// corner edge (EdgeSE3CuboidCornerProj, src/g2o_cuboid.cc:103-120): e[16] and J[16][15]
+PPO_HD void corner_edge_analytic(const Pose& Tcw, const Cub& c, unsigned flags, bool scale_fixed, const double* K, const double* meas, double* e, double* J) {
+  const Mat3 Rwo = rotmat(c.T.q), Rcw = rotmat(Tcw.q);
+  for (int k = 0; k < 8; ++k) {
+    double u, v;
+    cuboid_corner_analytic(c, Rwo, Rcw, Tcw.t, K, flags, scale_fixed, k, u, v, &J[(2 * k) * 15], &J[(2 * k + 1) * 15]);
+    e[2 * k] = u - meas[2 * k];
+    e[2 * k + 1] = v - meas[2 * k + 1];
+  }
+}
+
 // EdgePointCuboidOnlyObject::computeError, src/g2o_cuboid.cc:132-160, in two steps: the sum over the points first + k stride, k = 0, 1, ...
 // (the whole list with first = 0, stride = 1; one of several interleaved partial sums otherwise), then the mean and the prior terms
 PPO_HD void ptcub_partial(const Cub& c, const double* pts, int npts, int first, int stride, double margin, double* acc) {

@@ -425,10 +425,11 @@ int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool commit = true,
 // the fused linearisation launch alone (no zeroing): numeric edge classes | pose-major chunks | landmark-major points
 int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st) {
   LinPlan lp{};
-  lp.nb[LIN_PLANE] = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, NumericShape<PlaneModel>::EPB) : 0;
+  const bool ana = g.jac != 0;  // analytic Jacobians: 8 lanes per plane / cuboid-projection edge instead of 19 / 248
+  lp.nb[LIN_PLANE] = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, ana ? kAnaPlaneEPB : NumericShape<PlaneModel>::EPB) : 0;
   if (g.owns_reduced) {
-    lp.nb[LIN_BBOX] = g.n_bbox;
-    lp.nb[LIN_CORNER] = g.n_corner;
+    lp.nb[LIN_BBOX] = ana ? (g.n_bbox ? nblk(g.n_bbox, kAnaBboxEPB) : 0) : g.n_bbox;
+    lp.nb[LIN_CORNER] = ana ? (g.n_corner ? nblk(g.n_corner, kAnaCornerEPB) : 0) : g.n_corner;
     lp.nb[LIN_PTCUB] = g.n_ptcub;
   }
   const int npts = g.pt_last - g.pt_first;
@@ -462,6 +463,14 @@ int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st) {
 #endif
   if (grid > 0) {
     const bool cor = lp.nb[LIN_CORNER] > 0;
+    const dim3 gd(grid), bd(256);
+    const double dl = s->opt.numeric_delta;
+    if (ana) {  // (the point-cuboid edges stay numeric in this mode)
+      if (s->use_lds_lin && cor) hipLaunchKernelGGL((k_linearize_all<true, true, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl);
+      else if (s->use_lds_lin) hipLaunchKernelGGL((k_linearize_all<true, false, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl);
+      else if (cor) hipLaunchKernelGGL((k_linearize_all<false, true, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl);
+      else hipLaunchKernelGGL((k_linearize_all<false, false, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl);
+    } else
     if (s->use_lds_lin && cor) hipLaunchKernelGGL((k_linearize_all<true, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
     else if (s->use_lds_lin) hipLaunchKernelGGL((k_linearize_all<true, false>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
     else if (cor) hipLaunchKernelGGL((k_linearize_all<false, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
@@ -788,8 +797,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (!p || !o || !out) return PPO_BA_ERR_ARG;
   *out = nullptr;
   if (o->abi_version != PPO_BA_ABI_VERSION) return PPO_BA_ERR_ARG;
-  if ((o->deterministic != 0 && o->deterministic != 1) || o->jacobian_mode != PPO_JAC_NUMERIC) {
-    std::fprintf(stderr, "[ppo_ba] options.deterministic must be 0 or 1, jacobian_mode PPO_JAC_NUMERIC (the only one implemented)\n");
+  if ((o->deterministic != 0 && o->deterministic != 1) || (o->jacobian_mode != PPO_JAC_NUMERIC && o->jacobian_mode != PPO_JAC_ANALYTIC)) {
+    std::fprintf(stderr, "[ppo_ba] options.deterministic must be 0 or 1, jacobian_mode PPO_JAC_NUMERIC or PPO_JAC_ANALYTIC\n");
     return PPO_BA_ERR_ARG;
   }
   if (o->world_size < 1 || o->rank < 0 || o->rank >= o->world_size) return PPO_BA_ERR_ARG;
@@ -923,7 +932,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // Edge lists that arrive sorted by point (the reference's loop, include/ppo_flatten.hpp) have their records, pose-major copy and
   // Schur pair plan built ON THE DEVICE (ppo_plan.hpp); anything else, and small windows, take the host builder below.  Both produce
   // the same device state.
-  const long dev_plan_min = PPO_DEV_ENV("PPO_BA_DEV_PLAN_MIN") ? atol(PPO_DEV_ENV("PPO_BA_DEV_PLAN_MIN")) : 40000;  // (small windows: the host builder is faster than ~40 launches)
+  // The device builder wins at every size measured (tools/small_window_times.py, profiles/r03_small_windows.txt: create 0.47 vs 0.51 ms at
+  // 15 keyframes / 2 900 edges, 0.59 vs 0.89 at 30 / 9 500 -- the ICL-sized windows the reference really runs --, 0.75 vs 1.40 at 50 / 24 800),
+  // so every window whose edge lists arrive sorted by point takes it; the host builder remains for unsorted input.
+  const long dev_plan_min = PPO_DEV_ENV("PPO_BA_DEV_PLAN_MIN") ? atol(PPO_DEV_ENV("PPO_BA_DEV_PLAN_MIN")) : 0;
   const bool dev_plan = mono_sorted && stereo_sorted && (long)p->n_mono + p->n_stereo >= dev_plan_min && !PPO_DEV_ENV("PPO_BA_HOST_PLAN");
 
   mark("csr sort");
@@ -1040,6 +1052,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // ---- landmark ownership (multi-GPU): contiguous edge-balanced ranges; rank 0 owns the reduced-only terms ----
   g.pt_first = 0; g.pt_last = Npt; g.plane_first = 0; g.plane_last = Npl; g.owns_reduced = 1;
   g.det = o->deterministic ? 1 : 0;
+  g.jac = o->jacobian_mode == PPO_JAC_ANALYTIC ? 1 : 0;
 #ifdef PPO_BA_TEST_HOOKS
   g.dbg = PPO_DEV_ENV("PPO_BA_LIN_DBG") ? atoi(PPO_DEV_ENV("PPO_BA_LIN_DBG")) : 0;
   g.stamps = nullptr;
@@ -1325,6 +1338,12 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (p->cuboid_fixedscale) std::copy(p->cuboid_fixedscale, p->cuboid_fixedscale + (size_t)3 * Nc, v_fs.begin());
   SVec<uint8_t> v_cf(Nc, (uint8_t)(PPO_CUBOID_FIX_ROLLPITCH | PPO_CUBOID_FIX_HEIGHT));
   if (p->cuboid_flags) std::copy(p->cuboid_flags, p->cuboid_flags + Nc, v_cf.begin());
+  if (o->jacobian_mode == PPO_JAC_ANALYTIC)
+    for (int i = 0; i < Nc; ++i)
+      if (v_cf[i] & PPO_CUBOID_FIX_ROTATION) {
+        std::fprintf(stderr, "[ppo_ba] PPO_JAC_ANALYTIC does not support cuboids with PPO_CUBOID_FIX_ROTATION (cuboid %d)\n", i);
+        return fail(PPO_BA_ERR_ARG);
+      }
   SVec<double> v_pts;
   if (p->n_ptcub && p->ptcub_offsets[p->n_ptcub] > 0) v_pts.assign(p->ptcub_points, p->ptcub_points + (size_t)3 * p->ptcub_offsets[p->n_ptcub]);
   ok = ok && s->d_pose_cam.upload(v_cam, s->stream) && s->d_cub_fixedscale.upload(v_fs, s->stream) && s->d_ptcub_pts.upload(v_pts, s->stream);
@@ -1529,7 +1548,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
         hipFuncSetAttribute((const void*)k_update_all<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess) s->use_lds = false;
   }
   s->use_lds_lin = s->use_lds && s->lds_bytes <= 40 * 1024;
-  s->lin_lds_bytes = std::max({(int)(4 * kPoseWaveLds * sizeof(double)), (int)(kNumericLdsDoubles * sizeof(double)),
+  s->lin_lds_bytes = std::max({(int)(4 * kPoseWaveLds * sizeof(double)), (int)((g.jac ? std::max(kNumericLdsDoubles, kAnalyticLdsDoubles) : kNumericLdsDoubles) * sizeof(double)),
                                s->use_lds_lin ? s->lds_bytes + 64 : 64});
   // derive the rotation matrices of the pristine state once
   {

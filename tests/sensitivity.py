@@ -96,6 +96,7 @@ def schedule(st):
     return [(a["pass_"], a["iteration"], a["trials"], a["accepted"], a["result"]) for a in st["iters"]]
 
 
+VARIANTS = ("reversed", "fma", "fma+reversed", "compensated")  # the four rounding-only re-runs of the oracle the parity tests use
 BARS = {"t": 1e-5, "r": 1e-6, "p": 1e-5, "pl": 1e-6, "cb": 1e-5}
 
 

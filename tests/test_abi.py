@@ -94,7 +94,7 @@ def test_bad_arguments_are_rejected_before_touching_the_device():
     assert lib.ppo_ba_create(C.byref(ps3), C.byref(o), C.byref(h)) == -2
     # options that exist in the struct but are not implemented fail loudly instead of being ignored
     assert lib.ppo_ba_create(C.byref(ps), C.byref(B.default_options(deterministic=2)), C.byref(h)) == -1
-    assert lib.ppo_ba_create(C.byref(ps), C.byref(B.default_options(jacobian_mode=1)), C.byref(h)) == -1
+    assert lib.ppo_ba_create(C.byref(ps), C.byref(B.default_options(jacobian_mode=2)), C.byref(h)) == -1  # 0 numeric, 1 analytic
     assert lib.ppo_ba_create(C.byref(ps), C.byref(B.default_options(rank=1, world_size=1)), C.byref(h)) == -1
     assert lib.ppo_ba_create(C.byref(ps), C.byref(B.default_options(rank=0, world_size=0)), C.byref(h)) == -1
     lib.ppo_ba_destroy(None)  # NULL-safe

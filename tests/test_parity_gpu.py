@@ -27,9 +27,10 @@ def hip_hooks():
     return B.hip_backend(test_hooks=True)
 
 
-def both(oracle, hip, P, **opt):
+def both(oracle, hip, P, hip_only=None, **opt):
+    """The same options on both sides; `hip_only` options (jacobian_mode: the oracle IS the numeric reference) go to the device only."""
     o = B.default_options(**opt)
-    return oracle.create(P, o), hip.create(P, o)
+    return oracle.create(P, o), hip.create(P, B.default_options(**dict(opt, **(hip_only or {}))))
 
 
 def compare_states(ro, rh, tol_scale=1.0):
@@ -111,13 +112,21 @@ def test_full_protocol_matches_oracle(oracle, hip, cfg, kw, elim):
     to, th = so.run(), sh.run()
     assert to["n_reduced"] == th["n_reduced"]
     assert len(to["iters"]) == len(th["iters"])
+    worst = 0.0
     for a, b in zip(to["iters"], th["iters"]):
         assert (a["pass_"], a["iteration"], a["trials"], a["accepted"], a["result"]) == (b["pass_"], b["iteration"], b["trials"], b["accepted"], b["result"])
-        # measured over 6400 runs (tools/parity_margins.py): worst 3.2e-7, driven by the 1e-7 noise of the delta = 1e-9 Jacobians;
-        # one excursion above 1e-6 was seen in ~100 suite runs, hence 3e-6 here (the final-state bar below is unchanged)
-        assert abs(a["chi2_before"] - b["chi2_before"]) <= 3e-6 * abs(a["chi2_before"])
-        assert abs(a["chi2_after"] - b["chi2_after"]) <= 3e-6 * abs(a["chi2_after"])
+        worst = max(worst, abs(a["chi2_before"] - b["chi2_before"]) / abs(a["chi2_before"]), abs(a["chi2_after"] - b["chi2_after"]) / abs(a["chi2_after"]))
         assert abs(a["lambda_"] - b["lambda_"]) <= 1e-3 * abs(a["lambda_"])  # lambda is a cubic function of the gain ratio
+    # BASELINE.md's bar: 1e-6 per iteration (measured: worst 3.0e-7 over 320 runs, tools/r3_diag.py; 3.2e-7 over 6400 in round 1, one
+    # excursion above 1e-6 in ~100 suite runs).  Above the bar only where the ORACLE's own trace moves as much when nothing but its
+    # rounding changes (the 1e-7 noise of the delta = 1e-9 Jacobians, amplified over the iterations).
+    if worst > 1e-6:
+        import sensitivity as S
+        own = 0.0
+        for st2, _ in S.oracle_runs(oracle, P, B.default_options(eliminate_cuboids=elim), variants=S.VARIANTS)[1:]:
+            for a, b in zip(to["iters"], st2["iters"]):
+                own = max(own, abs(a["chi2_after"] - b["chi2_after"]) / abs(a["chi2_after"]))
+        assert worst <= 5 * own, (worst, own)
     ro, rh = so.read(), sh.read()
     compare_states(ro, rh)
     o = B.default_options()
@@ -251,21 +260,148 @@ def test_full_size_properties(hip, cfg):
     assert np.sqrt(np.mean((r1.pose_qt[:, 4:] - r2.pose_qt[:, 4:]) ** 2)) < 1e-6
 
 
-def test_rejected_trials_follow_the_reference_schedule(oracle, hip):
-    """A badly initialised graph (20x the usual noise) makes LM reject trials: lambda grows by ni = 2, 4, 8 ..., the kept state is
-    re-linearised (the device speculatively linearised the rejected one) and the per-iteration trial counts must match the
-    oracle's.  Far from the optimum the 1e-7 noise of the numeric Jacobians (and the run-to-run order of the atomic sums)
-    is amplified from iteration to iteration, so only the first pass is run: it already holds three rejections."""
+@pytest.mark.parametrize("det", [0, 1])
+def test_rejected_trials_follow_the_reference_schedule(oracle, hip, det):
+    """A badly initialised graph (20x the usual noise) makes LM reject trials: lambda grows by ni = 2, 4, 8 ..., the kept state's
+    system is still in its buffer and the per-iteration trial counts must match the oracle's -- through BOTH passes (30 solve
+    attempts for 15 iterations), in the default and in the deterministic mode.  Far from the optimum the 1e-7 noise of the numeric
+    Jacobians is amplified from iteration to iteration: measured on MI355X (tools/r3_diag.py) chi2 per iteration agrees to 4e-5,
+    lambda to 6e-3, and the final states differ by t 8e-5 m / r 2e-5 rad / planes 7e-5 -- a QUARTER of what the ORACLE's own result
+    moves on this window when only its rounding changes (reversed summation, FMA contraction, compensated sums: t 3.5e-4, planes
+    3e-4).  So the states are held to "inside the reference algorithm's own spread", the cost reached to the direct check: the
+    oracle's objective evaluated at the device's final state equals its own minimum to 1e-6 (measured 3.5e-8)."""
+    import sensitivity as S
     P = synth.make_problem("small", seed=2, noise_scale=20.0)
-    so, sh = both(oracle, hip, P, iters_pass2=0)
+    so, sh = both(oracle, hip, P, deterministic=det)
     to, th = so.run(), sh.run()
-    assert sum(i["trials"] for i in to["iters"]) >= len(to["iters"]) + 3, "the case no longer exercises rejections"
+    assert sum(i["trials"] for i in to["iters"]) >= len(to["iters"]) + 10 and len(to["iters"]) == 15, "the case no longer exercises rejections in both passes"
     assert [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in to["iters"]] == \
            [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in th["iters"]]
     for a, b in zip(to["iters"], th["iters"]):
-        assert abs(a["chi2_after"] - b["chi2_after"]) <= 1e-4 * abs(a["chi2_after"])
-        assert abs(a["lambda_"] - b["lambda_"]) <= 1e-2 * abs(a["lambda_"])
-    compare_states(so.read(), sh.read(), tol_scale=1000.0)
+        assert abs(a["chi2_after"] - b["chi2_after"]) <= 2e-4 * abs(a["chi2_after"])
+        assert abs(a["lambda_"] - b["lambda_"]) <= 3e-2 * abs(a["lambda_"])
+    ro, rh = so.read(), sh.read()
+    gap, _, _ = S.optimality_gap(oracle, so, ro, rh)
+    assert gap <= 1e-6, gap
+    m = S.metrics(ro, rh)
+    oo, _, _ = S.spread(S.oracle_runs(oracle, P, B.default_options(), variants=S.VARIANTS))
+    for k, bar in S.BARS.items():
+        assert m[k] <= max(10 * bar, oo[k]), (k, m[k], oo[k])
+    compare_states(ro, rh, tol_scale=100.0)
+
+
+def _not_positive_window():
+    """The `small` window with ONE bbox observation carrying a NEGATIVE information weight (no robust kernel on it): the cuboid's
+    block, and with it the reduced system, is indefinite by a wide margin wherever the damping is small.  With lm_tau = 3.566e-4
+    and lm_max_trials = 2 the oracle (LDLT + `isPositive()`, linear_solver_dense.h:108-112) walks: iteration 0 -- lambda_0 = 1710,
+    smallest eigenvalue +383: solved, accepted; iteration 1 -- lambda_0 / 3 and 2 lambda_0 / 3, smallest eigenvalue -9e3: BOTH
+    factorisations fail, the trials are rejected, Terminate (found by scanning tau with the oracle; the pattern holds for a factor
+    1.8 of tau around this value)."""
+    P = synth.make_problem("small", seed=1)
+    info = P["bbox_info"].copy().reshape(-1, 4)
+    hub = P["bbox_huber"].copy()
+    info[0, :] = -0.5
+    hub[0] = 0.0
+    P.set("bbox_info", info)
+    P.set("bbox_huber", hub)
+    return P, dict(lm_tau=1e-5 * 1.1 ** 37.5, lm_max_trials=2)
+
+
+@pytest.mark.parametrize("elim", [1, 0])
+def test_failed_factorisation_is_a_rejected_trial(oracle, hip, elim):
+    """The not-positive path (linear_solver_dense.h:108-112 -> levenberg.cpp:110-127: `if (!ok2) tempChi = max` -> rho < 0 -> lambda *= ni,
+    pop) on the device: the native Cholesky reports the non-positive pivot (LAPACK-style info), the trial is rejected, lambda follows
+    the reference's schedule, the kept state is untouched, and after ten... here two failures the iteration Terminates.  Schedule,
+    lambda, chi2 against the oracle; then pass 2 runs on from the kept state."""
+    P, kw = _not_positive_window()
+    so, sh = both(oracle, hip, P, iters_pass2=0, eliminate_cuboids=elim, **kw)
+    to, th = so.run(), sh.run()
+    sched = [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in to["iters"]]
+    assert sched == [(0, 0, 1, 1, 0), (0, 1, 2, 0, 1)], "the case no longer produces: solved + accepted, then two failed factorisations"
+    assert sched == [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in th["iters"]]
+    for a, b in zip(to["iters"], th["iters"]):
+        assert abs(a["lambda_"] - b["lambda_"]) <= 1e-6 * a["lambda_"]
+        assert abs(a["chi2_before"] - b["chi2_before"]) <= 1e-6 * a["chi2_before"] and abs(a["chi2_after"] - b["chi2_after"]) <= 1e-6 * a["chi2_after"]
+    assert to["iters"][1]["chi2_after"] == to["iters"][1]["chi2_before"] and th["iters"][1]["chi2_after"] == th["iters"][1]["chi2_before"]  # nothing accepted
+    ro, rh = so.read(), sh.read()
+    compare_states(ro, rh)  # both kept the state iteration 0 produced
+    # the system really is indefinite there: the device's own reduced matrix has a negative eigenvalue at the lambda of the failed trials
+    hip.lib.ppo_ba_debug_set_lambda(sh.h, C.c_double(th["iters"][1]["lambda_"]))
+    n = C.c_int32()
+    hip.lib.ppo_ba_debug_reduced(sh.h, None, None, None, C.byref(n))
+    Sm = np.zeros((n.value, n.value))
+    assert hip.lib.ppo_ba_debug_reduced(sh.h, dptr(Sm), None, None, None) == 0
+    assert not np.isfinite(Sm).all() or np.linalg.eigvalsh(Sm).min() < -1.0
+    so.close(); sh.close()
+    # the complete protocol: pass 1 as above, then the classification and pass 2 from the kept state
+    so, sh = both(oracle, hip, P, eliminate_cuboids=elim, **kw)
+    to, th = so.run(), sh.run()
+    assert [(i["trials"], i["accepted"], i["result"]) for i in th["iters"][:2]] == [(1, 1, 0), (2, 0, 1)]
+    # (pass 2 may differ from the oracle's: whether the negative-weight observation is culled in between hangs on the stored errors of
+    #  the failed trials -- the one deliberate deviation, pinned by the next test; with it still active pass 2 fails and terminates at once)
+    assert len(th["iters"]) > 2 and all(np.isfinite(i["chi2_after"]) and i["chi2_after"] <= i["chi2_before"] for i in th["iters"])
+    so.close(); sh.close()
+
+
+def test_failed_factorisation_leaves_the_kept_states_errors_behind__the_one_deliberate_deviation(oracle, hip):
+    """DESIGN.md section 2 lists ONE deviation of the product from the reference's control flow, and this test pins it.  When a
+    factorisation fails the reference still applies `_solver->x()` -- the STALE solution of the last successful solve --, evaluates
+    every edge there, and only then pops the vertices (levenberg.cpp:110-146): the edges' stored `_error` (what `e->chi2()` returns
+    to the outlier classification, Optimizer.cc:2739-2814) are those of kept state (+) stale step.  The device rejects the trial
+    without touching anything: its stored errors are the kept state's.  Same estimates, different per-edge chi2 after a pass that
+    ENDS in failed factorisations -- which needs lm_max_trials consecutive failures right after a success, i.e. an indefinite
+    problem like this one; a positive semi-definite system (every real window: J' W J + lambda I) cannot get there."""
+    P, kw = _not_positive_window()
+    so, sh = both(oracle, hip, P, iters_pass2=0, **kw)
+    so.run(); sh.run()
+    ro, rh = so.read(), sh.read()
+    compare_states(ro, rh)
+    # per-edge chi2 AT the kept state, by the oracle, on a graph that starts there
+    Pk = synth.make_problem("small", seed=1)
+    for name in ("bbox_info", "bbox_huber"):
+        Pk.set(name, P[name])
+    Pk.set("pose_qt", ro.pose_qt); Pk.set("point_xyz", ro.point_xyz); Pk.set("plane_coef", ro.plane_coef)
+    Pk.set("cuboid_qt", ro.cuboid_qt); Pk.set("cuboid_scale", ro.cuboid_scale)
+    sk = oracle.create(Pk, B.default_options(**kw))
+    sk.linearize()
+    rk = sk.read()
+    dev = np.abs(rh.mono_chi2 - rk.mono_chi2).max() / max(1.0, np.abs(rk.mono_chi2).max())
+    ref = np.abs(ro.mono_chi2 - rk.mono_chi2).max() / max(1.0, np.abs(rk.mono_chi2).max())
+    assert dev <= 1e-5, dev   # the device: the kept state's errors
+    assert ref >= 1e-2, ref   # the reference algorithm: the errors of (kept state + stale step) -- a different set
+    so.close(); sh.close(); sk.close()
+
+
+def test_nan_residual_freezes_the_window_like_the_reference(oracle, hip):
+    """`ominus_ver` divides by |n x n_m| (G2O_Plane3D.h:97-106): a vertical-plane measurement whose normal is PARALLEL to the predicted one
+    gives a NaN residual.  In the reference chi2 is then NaN, every comparison on it is false: each LM iteration makes one solve
+    attempt, rejects it (`rho > 0` is false), leaves the loop (`rho < 0` is false too), never counts as bad -- 5 + 10 iterations that
+    change nothing.  The device must walk the same schedule, keep every estimate, report NaN for that edge and neither hang nor
+    fail (the parallel pair is made exact: identity keyframe pose, plane (0, 0, 1, 2), measurement (0, 0, 1, 3))."""
+    P = synth.make_problem("small", seed=4, with_vp_planes=2)
+    e = int(np.nonzero(P["pl_kind"] == 1)[0][0])
+    pl, ps = int(P["pl_plane"][e]), int(P["pl_pose"][e])
+    qt = P["pose_qt"].copy(); qt[ps] = [0, 0, 0, 1, 0, 0, 0]; P.set("pose_qt", qt)
+    fx = P["pose_fixed"].copy(); fx[ps] = 1; P.set("pose_fixed", fx)
+    pc = P["plane_coef"].copy(); pc[pl] = [0, 0, 1, 2]; P.set("plane_coef", pc)
+    m = P["pl_meas"].copy().reshape(-1, 4); m[e] = [0, 0, 1, 3]; P.set("pl_meas", m)
+    so, sh = both(oracle, hip, P)
+    to, th = so.run(), sh.run()
+    assert [(i["pass_"], i["trials"], i["accepted"], i["result"]) for i in to["iters"]] == [(0, 1, 0, 0)] * 5 + [(1, 1, 0, 0)] * 10
+    assert [(i["pass_"], i["trials"], i["accepted"], i["result"]) for i in th["iters"]] == [(0, 1, 0, 0)] * 5 + [(1, 1, 0, 0)] * 10
+    assert all(np.isnan(i["chi2_before"]) for i in th["iters"])
+    for a, b in zip(to["iters"][:5], th["iters"][:5]):  # lambda_0 and the ni = 2, 4, 8 ... growth (pass 2's lambda_0 is max(|NaN|, ...): unspecified)
+        assert abs(a["lambda_"] - b["lambda_"]) <= 1e-6 * a["lambda_"]
+    ro, rh = so.read(), sh.read()
+    assert np.isnan(ro.pl_chi2[e]) and np.isnan(rh.pl_chi2[e]) and rh.pl_level[e] == ro.pl_level[e] == 0
+    for name in ("pose_qt", "point_xyz", "plane_coef", "cuboid_qt", "cuboid_scale"):
+        np.testing.assert_allclose(getattr(rh, name), getattr(ro, name), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(rh.point_xyz, P["point_xyz"], rtol=0, atol=0)
+    # deterministic mode turns the same input into an error instead: a non-finite term cannot enter the fixed-point sums
+    sd = hip.create(P, B.default_options(deterministic=1))
+    with pytest.raises(RuntimeError):
+        sd.run()
+    sd.close(); so.close(); sh.close()
 
 
 def test_block_cache_survives_changing_shapes(oracle, hip):
@@ -334,41 +470,65 @@ def test_phase_times_are_collected_in_verbose_mode_and_do_not_change_the_result(
     assert np.abs(rl.pose_qt - rq.pose_qt).max() < 1e-5
 
 
+def _schedules_may_differ(to, th, runs):
+    """When the device and the oracle walk different accept / reject sequences: is that a property of the window?  Yes if the
+    oracle's own re-runs (summation order, FMA contraction, compensated sums) flip among themselves; or the FIRST iteration that
+    differs is a marginal one in the oracle's own trace -- it needed more than one solve attempt there (rejections: the gain
+    ratio's sign is being decided near zero) or moved chi2 by less than 1e-7 relative (convergence plateau)."""
+    import sensitivity as S
+    if any(S.schedule(st) != S.schedule(runs[0][0]) for st, _ in runs[1:]):
+        return True
+    so_, sh_ = S.schedule(to), S.schedule(th)
+    first = next((k for k, (x, y) in enumerate(zip(so_, sh_)) if x != y), min(len(so_), len(sh_)) - 1)
+    for k in (first, max(first - 1, 0)):
+        a = to["iters"][k]
+        if a["trials"] > 1 or abs(a["chi2_before"] - a["chi2_after"]) < 1e-7 * a["chi2_before"]:
+            return True
+    return th["iters"][first]["trials"] > 1
+
+
 def test_randomly_structured_windows_against_the_oracle(oracle, hip):
     """60 windows of random size and composition (3-23 keyframes, 30-700 points, 0-8 planes, 0-4 cuboids, stereo share, corner
     edges, vertical / parallel planes, fixed observers, 0-20 % gross outliers, both elimination modes; tools/random_sweep.py).
-    The cost reached must agree in EVERY case, and EVERY window must be either inside BASELINE.md's bar on every quantity or
-    demonstrably undefined to that accuracy in the reference algorithm itself: for each quantity outside the bar the oracle's
-    own spread under a change of summation order / FMA contraction (tests/sensitivity.py) must reach a twentieth of the
-    HIP-vs-oracle deviation, or -- when the accept / reject sequences differ -- the window must sit on a convergence plateau
-    where a trial's acceptance hangs on the last digits of chi2 (tests/test_oracle_sensitivity.py has the statistics over the
-    37 of 600 such windows of round 1: the oracle's own spread is the larger one for the median window)."""
+    Three requirements per window (numbers: tools/optimality_sweep.py over 200 windows, profiles/r03_optimality.txt):
+      1. DIRECT OPTIMALITY -- the oracle's objective (its pass-2 active set, levels and kernels) evaluated at the DEVICE's final
+         state equals the oracle's own minimum: relative gap <= max(1e-7, 5 x the gap the oracle's own four rounding-only re-runs
+         show on that window).  Measured: never above 2 x; the re-runs themselves reach 1.9e-6.
+      2. every quantity of BASELINE.md's bar is inside the bar, OR the reference algorithm does not define it to the bar on that
+         window: the oracle's own spread over the four re-runs reaches 0.3 of the deviation (measured minimum 0.57; it was 0.05
+         in round 2).  13 of 200 windows use this, 12 of them by the point RMSE alone (landmarks left with one observation).
+      3. the same accept / reject sequence, or a demonstrably marginal one (_schedules_may_differ; 2 of 200)."""
     import importlib.util
     import sensitivity as S
     spec = importlib.util.spec_from_file_location("random_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "random_sweep.py"))
     rs = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rs)
-    inside = 0
     n = 60
+    n_out = n_sched = 0
     for seed in range(3000, 3000 + n):
-        ok, sched, m, chi, cfg, kw, elim, iters = rs.run_case(hip, oracle, seed)
-        assert chi < 5e-4, (seed, cfg, kw, chi)
+        cfg, kw, elim = rs.random_case(seed)
+        P = synth.make_problem(cfg, **kw)
+        opt = B.default_options(eliminate_cuboids=elim)
+        so, sh = oracle.create(P, opt), hip.create(P, opt)
+        to, th = so.run(), sh.run()
+        ro, rh = so.read(), sh.read()
+        m = S.metrics(ro, rh)
         assert m["t"] < 1e-3 and m["r"] < 1e-3, (seed, cfg, kw, m)  # nothing diverges
-        inside += bool(ok)
-        if ok:
-            continue
-        runs = S.oracle_runs(oracle, synth.make_problem(cfg, **kw), B.default_options(eliminate_cuboids=elim))
+        runs = S.oracle_runs(oracle, P, opt, variants=S.VARIANTS)
+        own_gap = max(S.optimality_gap(oracle, so, ro, r)[0] for _, r in runs[1:])
+        gap, _, _ = S.optimality_gap(oracle, so, ro, rh)
+        assert gap <= max(1e-7, 5 * own_gap), (seed, gap, own_gap, cfg, kw)
         oo, _, _ = S.spread(runs)
-        flips = any(S.schedule(st) != S.schedule(runs[0][0]) for st, _ in runs[1:])
-        if not sched:
-            plateau = any(a["trials"] > 1 and abs(a["chi2_before"] - a["chi2_after"]) < 1e-7 * a["chi2_before"] for a in runs[0][0]["iters"])
-            assert flips or plateau, (seed, cfg, kw)
-            if not flips:
-                continue
-        for k, bar in S.BARS.items():
-            if m[k] >= bar:
-                assert oo[k] >= 0.05 * m[k], (seed, k, m[k], oo[k], cfg, kw)
-    assert inside >= int(0.85 * n), inside
+        out = [k for k, bar in S.BARS.items() if m[k] >= bar]
+        for k in out:
+            assert oo[k] >= 0.3 * m[k], (seed, k, m[k], oo[k], cfg, kw)
+        n_out += bool(out)
+        if S.schedule(to) != S.schedule(th):
+            n_sched += 1
+            assert _schedules_may_differ(to, th, runs), (seed, cfg, kw, S.schedule(to), S.schedule(th))
+        so.close(); sh.close()
+    # drift guard: measured 5 windows outside the bar and 1 differing schedule among these 60 (7 % / 1 % over 200)
+    assert n_out <= 9 and n_sched <= 3, (n_out, n_sched)
 
 
 def test_sharded_code_path_with_a_one_rank_rccl_communicator(hip_hooks, monkeypatch):
@@ -448,18 +608,20 @@ def test_landmark_sharding_gives_the_single_rank_answer(hip_hooks, cfg, kw, worl
         np.testing.assert_array_equal(r.pose_qt, res[0][1].pose_qt)
 
 
-def _full_size_against_oracle(oracle, hip, P):
-    """Complete 5 + 10 protocol on both sides: same accept / reject schedule, chi2 per iteration, final estimates at BASELINE.md's
-    bars, same outlier sets.  Cuboids and points: each one inside the bar, OR within thirty times that same cuboid's / point's spread
-    between re-runs of the ORACLE under reversed summation order and FMA contraction (tests/sensitivity.py) -- i.e. a deviation
-    is only accepted where the reference algorithm's own result is not defined to the bar
-    (tests/test_oracle_sensitivity.py::test_config4_cuboids_are_not_defined_to_1e5_by_the_reference_algorithm)."""
+def _full_size_against_oracle(oracle, hip, P, with_spread, hip_only=None):
+    """Complete 5 + 10 protocol on both sides: same accept / reject schedule, chi2 per iteration at 1e-6, final estimates at
+    BASELINE.md's bars, same outlier sets, and the DIRECT check: the oracle's objective evaluated at the device's final state equals
+    its own minimum (relative gap <= max(1e-7, 5 x the gap between the oracle's own four rounding-only re-runs; measured <= 2 x,
+    tools/optimality_sweep.py full).  Cuboids and points: each one inside the bar, OR within FIVE times that same cuboid's / point's
+    spread between those re-runs of the ORACLE (thirty in round 2; measured <= 1.5 x) -- a deviation is only accepted where the
+    reference algorithm's own result is not defined to the bar (tests/test_oracle_sensitivity.py) -- and the device's own spread
+    (default against deterministic mode) stays within the same five times."""
     import sensitivity as S
-    so, sh = both(oracle, hip, P)
+    so, sh = both(oracle, hip, P, hip_only=hip_only)
     to, th = so.run(), sh.run()
     assert [(i["pass_"], i["iteration"], i["trials"], i["accepted"]) for i in to["iters"]] == [(i["pass_"], i["iteration"], i["trials"], i["accepted"]) for i in th["iters"]]
     for a, b in zip(to["iters"], th["iters"]):
-        assert abs(a["chi2_after"] - b["chi2_after"]) <= 3e-6 * abs(a["chi2_after"])
+        assert abs(a["chi2_after"] - b["chi2_after"]) <= 1e-6 * abs(a["chi2_after"])
     ro, rh = so.read(), sh.read()
     n = ro.pose_qt.shape[0]
     assert np.sqrt(np.mean(np.sum((ro.pose_qt[:, 4:] - rh.pose_qt[:, 4:]) ** 2, axis=1))) < 1e-5
@@ -469,17 +631,26 @@ def _full_size_against_oracle(oracle, hip, P):
     d_pt = S.per_point(ro, rh)
     d_cb = S.per_cuboid(ro, rh)
     p_rmse = np.sqrt(np.mean(d_pt ** 2))
-    if p_rmse >= 1e-5 or (d_cb.size and d_cb.max() >= 1e-5):
-        # measured on MI355X (tools/fullsize_margins.py, config 4 and its five option sets): point RMSE 3e-8 .. 6.5e-6, one to four
-        # of the 50 cuboids beyond 1e-5 (worst 3.3e-4 where the oracle's own re-runs differ by 3.2e-5 .. 2.2e-4)
-        runs = S.oracle_runs(oracle, P, B.default_options())
+    gap, _, _ = S.optimality_gap(oracle, so, ro, rh)
+    need_spread = p_rmse >= 1e-5 or (d_cb.size and d_cb.max() >= 1e-5) or gap > 1e-7
+    if need_spread or with_spread:
+        # measured on MI355X (tools/optimality_sweep.py full, config 4 and its five option sets): point RMSE 3e-8 .. 1.4e-5, one to five
+        # of the 50 cuboids beyond 1e-5 (worst 2.6e-4 where the oracle's own re-runs differ by 4.1e-4), gap 1e-10 .. 1.6e-7
+        runs = S.oracle_runs(oracle, P, B.default_options(), variants=S.VARIANTS)
+        own_gap = max(S.optimality_gap(oracle, so, ro, r)[0] for _, r in runs[1:])
+        assert gap <= max(1e-7, 5 * own_gap), (gap, own_gap)
         _, s_cb, s_pt = S.spread(runs)
         if d_cb.size:
-            assert (d_cb < np.maximum(1e-5, 30 * s_cb)).all(), (np.sort(d_cb)[::-1][:5], np.sort(s_cb)[::-1][:5])
-            assert int((d_cb >= 1e-5).sum()) <= int((s_cb > 1e-6).sum())
+            assert (d_cb < np.maximum(1e-5, 5 * s_cb)).all(), (np.sort(d_cb)[::-1][:5], np.sort(s_cb)[::-1][:5])
+            assert int((d_cb >= 1e-5).sum()) <= int((s_cb > 2e-6).sum())
             assert np.mean(d_cb < 1e-5) >= 0.9
+            sd = hip.create(P, B.default_options(deterministic=1, **(hip_only or {})))
+            sd.run()
+            h_cb = S.per_cuboid(rh, sd.read())
+            sd.close()
+            assert (h_cb < np.maximum(1e-5, 5 * s_cb)).all(), (np.sort(h_cb)[::-1][:5], np.sort(s_cb)[::-1][:5])
         if p_rmse >= 1e-5:
-            assert (d_pt < np.maximum(1e-5, 30 * s_pt)).all()
+            assert (d_pt < np.maximum(1e-5, 5 * s_pt)).all()
             assert np.sqrt(np.mean(d_pt[s_pt < 1e-6] ** 2)) < 1e-5
     assert abs(to["iters"][-1]["chi2_after"] - th["iters"][-1]["chi2_after"]) <= 1e-6 * to["iters"][-1]["chi2_after"]
     o = B.default_options()
@@ -495,7 +666,7 @@ def _full_size_against_oracle(oracle, hip, P):
 def test_baseline_configurations_match_the_oracle_at_full_size(oracle, hip, cfg):
     """BASELINE.json configs 2-4 at their full sizes (50 KF / 10k points; 100 KF / 30k points / 100 planes; 200 KF / 50k points /
     200 planes / 50 cuboids).  (The single-threaded oracle needs ~2 s for config 4.)"""
-    _full_size_against_oracle(oracle, hip, synth.make_problem(cfg, seed=1))
+    _full_size_against_oracle(oracle, hip, synth.make_problem(cfg, seed=1), with_spread=(cfg == "cfg4"))
 
 
 @pytest.mark.parametrize("kw", [dict(stereo_frac=0.2), dict(with_corners=True), dict(with_vp_planes=1000), dict(fixed_observer_frac=0.1),
@@ -506,7 +677,58 @@ def test_config4_edge_class_options_match_the_oracle_at_full_size(oracle, hip, k
     observations (multi-chunk StereoEdgeP segments, Optimizer.cc:2393-2422), the 16-D corner edges on all 500 cuboid observations
     (the second kernel variant, Optimizer.cc:2493-2551), 1 000 vertical + 1 000 parallel plane edges (Optimizer.cc:2262-2307),
     10 % additional fixed observers, and all of them together."""
-    _full_size_against_oracle(oracle, hip, synth.make_problem("cfg4", seed=1, **kw))
+    _full_size_against_oracle(oracle, hip, synth.make_problem("cfg4", seed=1, **kw), with_spread=False)
+
+
+ANALYTIC = dict(jacobian_mode=1)  # PPO_JAC_ANALYTIC
+
+
+@pytest.mark.parametrize("cfg,kw", [c for c in CASES if c[0] != "tiny"][:6] + [("small", dict(seed=8, stereo_frac=0.2, with_corners=True, with_vp_planes=2))])
+def test_analytic_jacobians_give_the_reference_result(oracle, hip, cfg, kw):
+    """options.jacobian_mode = PPO_JAC_ANALYTIC (include/ppo_ba.h): exact derivatives for the plane and the
+    cuboid-projection edges instead of the reference's delta = 1e-9 central differences.  Against the NUMERIC oracle: the first
+    reduced system at the tolerance of the numeric Jacobians' own noise, then the whole protocol -- the same accept / reject sequence,
+    chi2 per iteration to 1e-6, final states at BASELINE.md's bars, identical outlier sets."""
+    P = synth.make_problem(cfg, **kw)
+    so, sh = both(oracle, hip, P, hip_only=ANALYTIC, eliminate_cuboids=0)
+    assert abs(so.linearize() - sh.linearize()) <= 1e-9 * max(1.0, abs(so.linearize()))
+    lam = 7.5
+    n = C.c_int32()
+    oracle.lib.oracle_ba_reduced(so.h, lam, 0, -1, 1, None, None, C.byref(n))
+    So, bo = np.zeros((n.value, n.value)), np.zeros(n.value)
+    oracle.lib.oracle_ba_reduced(so.h, lam, 0, -1, 1, dptr(So), dptr(bo), None)
+    hip.lib.ppo_ba_debug_set_lambda(sh.h, C.c_double(lam))
+    Sh, bh = np.zeros((n.value, n.value)), np.zeros(n.value)
+    assert hip.lib.ppo_ba_debug_reduced(sh.h, dptr(Sh), dptr(bh), None, None) == 0
+    assert np.abs(So - Sh).max() <= 2e-6 * np.abs(So).max() and np.abs(bo - bh).max() <= 2e-6 * np.abs(bo).max()
+    so.close(); sh.close()
+    so, sh = both(oracle, hip, P, hip_only=ANALYTIC)
+    to, th = so.run(), sh.run()
+    assert [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in to["iters"]] == \
+           [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in th["iters"]]
+    for a, b in zip(to["iters"], th["iters"]):
+        assert abs(a["chi2_after"] - b["chi2_after"]) <= 1e-6 * abs(a["chi2_after"])
+    ro, rh = so.read(), sh.read()
+    compare_states(ro, rh)
+    assert np.array_equal(ro.pl_level, rh.pl_level) and np.array_equal(ro.bbox_level, rh.bbox_level) and np.array_equal(ro.corner_level, rh.corner_level)
+    compare_levels(ro.mono_level, rh.mono_level, ro.mono_chi2, B.default_options().chi2_mono)
+    so.close(); sh.close()
+
+
+@pytest.mark.parametrize("cfg,kw", [("cfg3", {}), ("cfg4", {}), ("cfg4", dict(with_corners=True, with_vp_planes=1000))], ids=["cfg3", "cfg4", "cfg4-corners-vp"])
+def test_analytic_jacobians_at_full_size(oracle, hip, cfg, kw):
+    """The analytic mode at the full BASELINE sizes against the (numeric) oracle, by the same rules as the numeric mode."""
+    _full_size_against_oracle(oracle, hip, synth.make_problem(cfg, seed=1, **kw), with_spread=False, hip_only=ANALYTIC)
+
+
+def test_analytic_mode_refuses_a_fix_rotation_cuboid(hip):
+    P = synth.make_problem("small", seed=1)
+    f = P["cuboid_flags"].copy()
+    f[0] = 4 | 1
+    P.set("cuboid_flags", f)
+    with pytest.raises(RuntimeError):
+        hip.create(P, B.default_options(jacobian_mode=1))
+    hip.create(P, B.default_options()).close()  # the numeric mode takes it
 
 
 def test_product_library_ignores_the_development_switches(hip, monkeypatch):

@@ -34,9 +34,10 @@ def one(hip, orc, P, opt_kw, tag):
     sched = S.schedule(to) == S.schedule(th)
     sched_d = S.schedule(td) == S.schedule(th)
     out_of_bar = [k for k, bar in S.BARS.items() if m[k] >= bar]
-    line = "%s sched %s (hip det=default %s) gap %.1e (det %.1e) chi2 %.6g | " % (tag, sched, sched_d, gap, gapd, c0) + " ".join("%s %.1e" % kv for kv in m.items())
+    runs = S.oracle_runs(orc, P, o, variants=("reversed", "fma", "fma+reversed", "compensated"))
+    ogap = max(S.optimality_gap(orc, so, ro, r)[0] for _, r in runs[1:])
+    line = "%s sched %s (hip det=default %s) gap %.1e (det %.1e; oracle variants %.1e) chi2 %.6g | " % (tag, sched, sched_d, gap, gapd, ogap, c0) + " ".join("%s %.1e" % kv for kv in m.items())
     if out_of_bar or not sched:
-        runs = S.oracle_runs(orc, P, o)
         oo, s_cb, s_pt = S.spread(runs)
         flips = any(S.schedule(st) != S.schedule(runs[0][0]) for st, _ in runs[1:])
         line += " | OUT %s oracle-spread %s flips %s | hip-spread %s" % (out_of_bar, " ".join("%s %.1e" % (k, oo[k]) for k in out_of_bar), flips,
