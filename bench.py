@@ -63,9 +63,11 @@ TRAFFIC_FILES = ("r02_lin_traffic.json", "r01_lin_traffic.json")  # newest first
 
 
 def cpu_baseline_openmp(P, B, seconds_budget=6.0):
-    """Secondary, clearly labelled "best CPU" line: the same oracle built with OpenMP (dense LDLT column updates and
-    the residual pass on many cores).  NOT how the reference runs -- g2o's OpenMP is off (Thirdparty/g2o/config.h:4) and the whole
-    BA sits on the LocalMapping thread -- and not part of cpu_baseline."""
+    """Secondary, clearly labelled "best CPU" line: the oracle built with OpenMP -- edge loop of the linearisation with
+    per-thread accumulators, landmark loop of the Schur complement with per-thread copies of S, a blocked right-looking Cholesky
+    (64-wide panels, two fork-joins per panel) instead of the unblocked pivoted LDLT, residual pass over the edges.  NOT how the
+    reference runs -- g2o's OpenMP is off (Thirdparty/g2o/config.h:4) and the whole BA sits on the LocalMapping thread -- and not
+    part of cpu_baseline."""
     path = os.path.join(REPO, "oracle", "libppo_oracle_omp.so")
     if not os.path.exists(path):
         return None
@@ -94,8 +96,9 @@ def cpu_baseline_openmp(P, B, seconds_budget=6.0):
         calls += 1
     s.close()
     return dict(value=iters / dt, unit="LM iters/s", cores=int(os.environ["OMP_NUM_THREADS"]), kind="port+openmp", ms_per_call=1e3 * dt / calls,
-                sample="oracle/libppo_oracle_omp.so: %d complete 5+10 calls = %d LM iterations in %.1f s; OpenMP over the rows of the LDLT column "
-                       "updates and over the edges of the residual pass only (bit-identical results); the reference itself is single-threaded" % (calls, iters, dt))
+                sample="oracle/libppo_oracle_omp.so: %d complete 5+10 calls = %d LM iterations in %.1f s; OpenMP over the edges (linearisation, residuals), "
+                       "the landmarks (Schur complement) and the tiles of a blocked Cholesky; same schedule and results to rounding as the 1-thread "
+                       "port (tests/test_oracle_known_answers.py); the reference itself is single-threaded" % (calls, iters, dt))
 
 
 def committed_traffic(k_bytes):
@@ -284,6 +287,25 @@ def main():
             t_.join()
         concurrent = {"handles": 2, "lm_iters_per_s_aggregate": sum(counts) / (time.perf_counter() - t_c0)}
         hs[1].close()
+    # secondary figure, never `value`: the same window with options.jacobian_mode = PPO_JAC_ANALYTIC (exact derivatives for the plane and
+    # cuboid-projection edges instead of the reference's delta = 1e-9 central differences; opt-in, include/ppo_ba.h)
+    analytic = {}
+    if extras and (sizes["n_plane_edges"] or sizes["n_bbox"]):
+        ao = B.default_options(device_id=local_rank, solver=a.solver, jacobian_mode=1)
+        sa = B.hip_backend().create(P, ao)
+        sa.run()
+        n_it = 0
+        t_a0 = time.perf_counter()
+        for _ in range(10):
+            sa.reset()
+            n_it += sa.run()["n_iters"]
+        t_a1 = time.perf_counter()
+        sa.reset()
+        ka_ms, ka_b = C.c_double(), C.c_int64()
+        assert lib.ppo_ba_time_kernel(sa.h, 6, a.lin_reps, C.byref(ka_ms), C.byref(ka_b)) == 0
+        analytic = {"lm_iters_per_s": n_it / (t_a1 - t_a0), "k_linearize_all_us": 1e3 * ka_ms.value,
+                    "note": "opt-in mode; parity against the numeric oracle: tests/test_parity_gpu.py::test_analytic_jacobians_*"}
+        sa.close()
     # where the device time of one 5+10 call goes (ppo_ba_stats.ms_*, HIP events on the stream, outside the timed region)
     phases = {}
     if extras:
@@ -323,7 +345,7 @@ def main():
                 "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
                 "first_create_ms_incl_module_load": create_ms, "steady_state_call_ms": call_ms, "kernels": kernels,
                 "pose_only": pose_only, "device_ms_per_phase_of_one_call": phases,
-                "two_windows_concurrently": concurrent,
+                "two_windows_concurrently": concurrent, "analytic_jacobians": analytic,
             },
             "roofline": {"bound": "hbm", "kernel": "k_linearize_all", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -336,8 +358,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline(P, B)
             omp = cpu_baseline_openmp(P, B)
             if omp and omp["value"] <= out["cpu_baseline"]["value"]:
-                # (fork-join per LDLT column: under a container CPU quota the threaded build runs SLOWER than one thread -- 1.0 against
-                #  6.9 LM iterations/s on the GPU box -- and says nothing about what many cores could do)
                 omp = {"omitted": "the OpenMP build of the oracle ran slower than the single-threaded one on this host (%.2f vs %.2f LM iters/s, %d threads)"
                                   % (omp["value"], out["cpu_baseline"]["value"], omp["cores"])}
             if omp:

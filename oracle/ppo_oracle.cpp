@@ -32,6 +32,9 @@
 #include "../include/ppo_pose.h"
 #include "oracle_math.hpp"
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <algorithm>
 #include <chrono>
 #include <cfloat>
@@ -522,7 +525,120 @@ inline void acc_comp(bool on, double& s, double& c, double v) {
 
 // BlockSolver::buildSystem, block_solver.hpp:502-560 with constructQuadraticForm of
 // base_binary_edge.hpp:55-120 / base_unary_edge.hpp:43-72.
+#ifdef _OPENMP
+// libppo_oracle_omp.so ONLY (secondary "best CPU" line of bench.py): the same per-edge arithmetic as build_system below, the edge
+// loop split over the threads.  Reduced-variable blocks (pose / cuboid diagonal blocks, b) go to per-thread compact accumulators that
+// are summed at the end; landmark blocks are added with atomics (a landmark's edges are neighbours in the list: contention is rare);
+// the few pose-cuboid coupling blocks too.  The sums are taken in another order than the serial build: same values to rounding.
+void build_system_omp(Oracle& o) {
+  std::fill(o.Hpp.begin(), o.Hpp.end(), 0.0);
+  std::fill(o.Hll.begin(), o.Hll.end(), 0.0);
+  std::fill(o.hpl.begin(), o.hpl.end(), 0.0);
+  std::fill(o.b.begin(), o.b.end(), 0.0);
+  const int nb = o.n_red_blocks, n = o.n_red;
+  const size_t na = o.active.size();
+  const int nt = omp_get_max_threads();
+  std::vector<std::vector<double>> Hd(nt), bp(nt);
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num();
+    Hd[t].assign((size_t)nb * 81, 0.0);
+    bp[t].assign(n, 0.0);
+    double J0[kMaxDim * 9], J1[kMaxDim * 9];
+#pragma omp for schedule(static)
+    for (size_t k = 0; k < na; ++k) {
+      const EdgeRef& er = o.active[k];
+      int t0, i0, t1, i1;
+      edge_vertices(o, er.type, er.idx, t0, i0, t1, i1);
+      const int dim = edge_dim(o, er.type, er.idx);
+      linearize(o, er.type, er.idx, J0, J1);
+      const double* e = &o.err[er.type][(size_t)kMaxDim * er.idx];
+      double rho1 = 1.0;
+      const double hub = o.e_huber[er.type][er.idx];
+      if (o.robust[er.type][er.idx] && hub > 0) {
+        double rho[3];
+        huber_robustify(edge_chi2(o, er.type, er.idx), hub, rho);
+        rho1 = rho[1];
+      }
+      double w[kMaxDim], omega_r[kMaxDim];
+      for (int r = 0; r < dim; ++r) {
+        const double om = info_at(o, er.type, er.idx, r);
+        w[r] = rho1 * om;
+        omega_r[r] = -(om * e[r]) * rho1;
+      }
+      const bool free0 = !vertex_fixed(o, t0, i0) && o.hidx[t0][i0] >= 0;
+      const bool free1 = t1 != V_NONE && !vertex_fixed(o, t1, i1) && o.hidx[t1][i1] >= 0;
+      const int d0 = kVDim[t0], d1 = t1 == V_NONE ? 0 : kVDim[t1];
+      auto add_diag = [&](int vt, int vi, const double* J, int d) {
+        if (vt == V_POINT || vt == V_PLANE) {
+          double* D = &o.Hll[(size_t)9 * o.hidx[vt][vi]];
+          double* bl = &o.b[(size_t)o.n_red + o.col0[vt][vi]];
+          for (int a = 0; a < 3; ++a) {
+            double sb = 0;
+            for (int r = 0; r < dim; ++r) sb += J[r * d + a] * omega_r[r];
+#pragma omp atomic
+            bl[a] += sb;
+            for (int c = 0; c < 3; ++c) {
+              double sacc = 0;
+              for (int r = 0; r < dim; ++r) sacc += J[r * d + a] * w[r] * J[r * d + c];
+#pragma omp atomic
+              D[a * 3 + c] += sacc;
+            }
+          }
+        } else {
+          double* H = &Hd[t][(size_t)81 * o.hidx[vt][vi]];
+          double* bb = &bp[t][o.col0[vt][vi]];
+          for (int a = 0; a < d; ++a) {
+            double sb = 0;
+            for (int r = 0; r < dim; ++r) sb += J[r * d + a] * omega_r[r];
+            bb[a] += sb;
+            for (int c = 0; c < d; ++c) {
+              double sacc = 0;
+              for (int r = 0; r < dim; ++r) sacc += J[r * d + a] * w[r] * J[r * d + c];
+              H[a * 9 + c] += sacc;
+            }
+          }
+        }
+      };
+      if (free0) add_diag(t0, i0, J0, d0);
+      if (free1) add_diag(t1, i1, J1, d1);
+      if (free0 && free1) {
+        if (er.type == E_BBOX || er.type == E_CORNER) {
+          const int r0 = o.col0[t0][i0], c0 = o.col0[t1][i1];
+          for (int a = 0; a < d0; ++a)
+            for (int c = 0; c < d1; ++c) {
+              double sacc = 0;
+              for (int r = 0; r < dim; ++r) sacc += J0[r * d0 + a] * w[r] * J1[r * d1 + c];
+#pragma omp atomic
+              HPP(o, r0 + a, c0 + c) += sacc;
+            }
+        } else if (er.type == E_PLANE || er.type == E_MONO || er.type == E_STEREO) {
+          double* blk = &o.hpl[(size_t)18 * o.edge_slot[er.type][er.idx]];
+          for (int a = 0; a < 6; ++a)
+            for (int c = 0; c < 3; ++c) {
+              double sacc = 0;
+              for (int r = 0; r < dim; ++r) sacc += J1[r * 6 + a] * w[r] * J0[r * 3 + c];
+              blk[a * 3 + c] += sacc;
+            }
+        }
+      }
+    }
+  }
+  for (int t = 0; t < nt; ++t) {
+    for (int blk = 0; blk < nb; ++blk) {
+      const int c0 = o.red_col0[blk], d = o.red_dim[blk];
+      for (int a = 0; a < d; ++a)
+        for (int c = 0; c < d; ++c) HPP(o, c0 + a, c0 + c) += Hd[t][(size_t)81 * blk + a * 9 + c];
+    }
+    for (int i = 0; i < n; ++i) o.b[i] += bp[t][i];
+  }
+}
+#endif
+
 void build_system(Oracle& o) {
+#ifdef _OPENMP
+  if (o.variant == 0) { build_system_omp(o); return; }
+#endif
   std::fill(o.Hpp.begin(), o.Hpp.end(), 0.0);
   std::fill(o.Hll.begin(), o.Hll.end(), 0.0);
   std::fill(o.hpl.begin(), o.hpl.end(), 0.0);
@@ -692,23 +808,12 @@ bool ldlt_solve(std::vector<double>& A, int n, const double* rhs, double* xout) 
       M(k, k) -= s;
       if (rs > 0) {
         double* colk = &A[(size_t)k * n + k + 1];
-#ifdef _OPENMP
-        // (libppo_oracle_omp.so, bench.py's secondary "best CPU" line only: the rows of the column update are independent; every row
-        //  still sums over j in ascending order, so the result is bit-identical to the serial build)
-#pragma omp parallel for schedule(static) if (rs * (long)k > 20000)
-        for (int i = 0; i < rs; ++i) {
-          double v = colk[i];
-          for (int j = 0; j < k; ++j) v -= A[(size_t)j * n + k + 1 + i] * temp[j];
-          colk[i] = v;
-        }
-#else
         for (int j = 0; j < k; ++j) {
           const double tj = temp[j];
           if (tj == 0.0) continue;
           double* colj = &A[(size_t)j * n + k + 1];
           for (int i = 0; i < rs; ++i) colk[i] -= colj[i] * tj;
         }
-#endif
       }
     }
     const double akk = M(k, k);
@@ -757,12 +862,90 @@ bool ldlt_solve(std::vector<double>& A, int n, const double* rhs, double* xout) 
 }
 
 // LinearSolverDense::solve, linear_solver_dense.h:65-113: mirror the upper blocks, factor, gate on isPositive
+
+#ifdef _OPENMP
+// libppo_oracle_omp.so ONLY (bench.py's secondary "best CPU" line; never the checker): what a multi-core CPU implementation of this
+// path would do with the dense solve -- a right-looking blocked Cholesky, 64-wide panels, the panel solve and the trailing update
+// spread over the threads (two fork-joins per panel instead of one per column), column-major so that every inner loop is a
+// contiguous axpy.  Not Eigen's pivoted LDLT: same solution to rounding, "not positive" = a non-positive pivot.
+bool blocked_llt_solve_omp(std::vector<double>& A, int n, const double* rhs, double* xout) {
+  constexpr int NB = 64;
+  bool ok = true;
+  for (int k0 = 0; k0 < n && ok; k0 += NB) {
+    const int kb = std::min(NB, n - k0);
+    for (int k = k0; k < k0 + kb; ++k) {  // diagonal block, unblocked
+      double* colk = &A[(size_t)k * n];
+      const double d = colk[k];
+      if (!(d > 0.0)) { ok = false; break; }
+      const double l = std::sqrt(d), il = 1.0 / l;
+      colk[k] = l;
+      for (int i = k + 1; i < k0 + kb; ++i) colk[i] *= il;
+      for (int j = k + 1; j < k0 + kb; ++j) {
+        const double s = colk[j];
+        double* colj = &A[(size_t)j * n];
+        for (int i = j; i < k0 + kb; ++i) colj[i] -= colk[i] * s;
+      }
+    }
+    if (!ok) break;
+    const int r0 = k0 + kb, rs = n - r0;
+    if (rs <= 0) continue;
+    // panel solve: rows below the diagonal block, X L_kk' = B, row slices of 64 per task
+#pragma omp parallel for schedule(static)
+    for (int ib = 0; ib < (rs + NB - 1) / NB; ++ib) {
+      const int i0 = r0 + ib * NB, i1 = std::min(n, i0 + NB);
+      for (int k = k0; k < k0 + kb; ++k) {
+        double* colk = &A[(size_t)k * n];
+        const double il = 1.0 / colk[k];
+        for (int i = i0; i < i1; ++i) colk[i] *= il;
+        for (int j = k + 1; j < k0 + kb; ++j) {
+          const double s = colk[j];
+          double* colj = &A[(size_t)j * n];
+          for (int i = i0; i < i1; ++i) colj[i] -= colk[i] * s;
+        }
+      }
+    }
+    // trailing update, lower triangle, one column block per task
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int jb = 0; jb < (rs + NB - 1) / NB; ++jb) {
+      const int j0 = r0 + jb * NB, j1 = std::min(n, j0 + NB);
+      for (int j = j0; j < j1; ++j) {
+        double* colj = &A[(size_t)j * n];
+        for (int k = k0; k < k0 + kb; ++k) {
+          const double* colk = &A[(size_t)k * n];
+          const double s = colk[j];
+          for (int i = j; i < n; ++i) colj[i] -= colk[i] * s;
+        }
+      }
+    }
+  }
+  if (!ok) return false;
+  std::vector<double> y(rhs, rhs + n);
+  for (int j = 0; j < n; ++j) {
+    const double* col = &A[(size_t)j * n];
+    const double yj = (y[j] /= col[j]);
+    for (int i = j + 1; i < n; ++i) y[i] -= col[i] * yj;
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    const double* col = &A[(size_t)j * n];
+    double sacc = y[j];
+    for (int i = j + 1; i < n; ++i) sacc -= col[i] * y[i];
+    y[j] = sacc / col[j];
+  }
+  std::copy(y.begin(), y.end(), xout);
+  return true;
+}
+#endif
+
 bool dense_solve(Oracle& o, std::vector<double>& Aupper, const double* rhs, double* xout) {
   const int n = o.n_red;
   std::vector<double> H(Aupper);
   for (int c = 0; c < n; ++c)
     for (int r = 0; r < c; ++r) H[(size_t)r * n + c] = H[(size_t)c * n + r];  // lower(c,r) = upper(r,c)
+#ifdef _OPENMP
+  return blocked_llt_solve_omp(H, n, rhs, xout);
+#else
   return ldlt_solve(H, n, rhs, xout);
+#endif
 }
 
 // BlockSolver::setLambda / restoreDiagonal, block_solver.hpp:564-604
@@ -791,6 +974,54 @@ bool block_solve(Oracle& o) {
   if (!o.do_schur) return dense_solve(o, o.Hpp, o.b.data(), o.x.data());
   o.S = o.Hpp;
   std::fill(o.coeff.begin(), o.coeff.begin() + n, 0.0);
+#ifdef _OPENMP
+  if (o.variant == 0) {
+    // libppo_oracle_omp.so ONLY: the landmark loop split over the threads, each with its own copy of S and of the right-hand side's
+    // Schur term, summed at the end (same per-landmark arithmetic; another summation order)
+    const int nt = omp_get_max_threads();
+    std::vector<std::vector<double>> St(nt), ct(nt);
+#pragma omp parallel
+    {
+      const int t = omp_get_thread_num();
+      St[t].assign((size_t)n * n, 0.0);
+      ct[t].assign(n, 0.0);
+      double* S = St[t].data();
+#pragma omp for schedule(static)
+      for (int l = 0; l < o.n_lm; ++l) {
+        double* Dinv = &o.Dinv[(size_t)9 * l];
+        inverse3(&o.Hll[(size_t)9 * l], Dinv);
+        const double* bl = &o.b[(size_t)n + 3 * l];
+        double db[3];
+        for (int a = 0; a < 3; ++a) db[a] = Dinv[a * 3] * bl[0] + Dinv[a * 3 + 1] * bl[1] + Dinv[a * 3 + 2] * bl[2];
+        for (int s1 = o.hpl_start[l]; s1 < o.hpl_start[l + 1]; ++s1) {
+          const double* Bi = &o.hpl[(size_t)18 * s1];
+          const int r0 = o.red_col0[o.hpl_rb[s1]];
+          double BDinv[18];
+          for (int a = 0; a < 6; ++a)
+            for (int c = 0; c < 3; ++c) BDinv[a * 3 + c] = Bi[a * 3] * Dinv[c] + Bi[a * 3 + 1] * Dinv[3 + c] + Bi[a * 3 + 2] * Dinv[6 + c];
+          for (int a = 0; a < 6; ++a) ct[t][r0 + a] += Bi[a * 3] * db[0] + Bi[a * 3 + 1] * db[1] + Bi[a * 3 + 2] * db[2];
+          for (int s2 = s1; s2 < o.hpl_start[l + 1]; ++s2) {
+            const double* Bj = &o.hpl[(size_t)18 * s2];
+            const int c0 = o.red_col0[o.hpl_rb[s2]];
+            for (int a = 0; a < 6; ++a)
+              for (int c = 0; c < 6; ++c)
+                S[(size_t)(c0 + c) * n + r0 + a] -= BDinv[a * 3] * Bj[c * 3] + BDinv[a * 3 + 1] * Bj[c * 3 + 1] + BDinv[a * 3 + 2] * Bj[c * 3 + 2];
+          }
+        }
+      }
+#pragma omp for schedule(static)
+      for (int c = 0; c < n; ++c)
+        for (int tt = 0; tt < nt; ++tt) {
+          const double* src = &St[tt][(size_t)c * n];
+          double* dst = &o.S[(size_t)c * n];
+          for (int r = 0; r <= c; ++r) dst[r] += src[r];
+        }
+    }
+    for (int tt = 0; tt < nt; ++tt)
+      for (int i = 0; i < n; ++i) o.coeff[i] += ct[tt][i];
+  } else
+#endif
+  {
   const bool comp = o.variant == 2;
   if (comp) { o.S_c.assign(o.S.size(), 0.0); o.coeff_c.assign(o.coeff.size(), 0.0); }
   double dummy = 0.0;
@@ -822,6 +1053,7 @@ bool block_solve(Oracle& o) {
   if (comp) {
     for (size_t i = 0; i < o.S.size(); ++i) o.S[i] += o.S_c[i];
     for (int i = 0; i < n; ++i) o.coeff[i] += o.coeff_c[i];
+  }
   }
   for (int i = 0; i < n; ++i) o.bs[i] = o.b[i] - o.coeff[i];
   if (!dense_solve(o, o.S, o.bs.data(), o.x.data())) return false;

@@ -188,9 +188,11 @@ PPO_HD Mat3 plane_frame(Vec3 n) {
   const double r2 = n.x * n.x + n.y * n.y;
   const double r = sqrt(r2), nn = sqrt(r2 + n.z * n.z);
   double ca = 1.0, sa = 0.0;  // atan2(0, 0) = 0
-  if (r > 0.0) { const double ir = 1.0 / r; ca = n.x * ir; sa = n.y * ir; }
+  // (`!(r == 0)`, not `r > 0`: a NaN direction -- ominus_ver of two parallel normals, G2O_Plane3D.h:97-106 -- must come out as NaN,
+  //  as atan2 / AngleAxis give it in the reference, not be swallowed into an identity frame)
+  if (!(r == 0.0)) { const double ir = 1.0 / r; ca = n.x * ir; sa = n.y * ir; }
   double ce = 1.0, se = 0.0;
-  if (nn > 0.0) { const double in = 1.0 / nn; ce = r * in; se = n.z * in; }
+  if (!(nn == 0.0)) { const double in = 1.0 / nn; ce = r * in; se = n.z * in; }
   Mat3 R;
   R.a[0] = ca * ce; R.a[1] = -sa; R.a[2] = -(ca * se);
   R.a[3] = sa * ce; R.a[4] = ca;  R.a[5] = -(sa * se);

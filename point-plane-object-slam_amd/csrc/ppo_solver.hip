@@ -749,7 +749,14 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
       s->lambda *= s->ni;
       s->ni *= 2;
       it.accepted = 0;  // pop(): keep the current state
-      if (!(rho < 0)) rho = (info != 0) ? -1.0 : rho;
+      // (a failed factorisation gives rho = (chi2 - DBL_MAX) / 1e-3 = -inf: retried like every rejected trial -- unless chi2 itself is NaN,
+      //  in which case rho is NaN and the loop ends after this one attempt, exactly as levenberg.cpp:128-149 behaves)
+      if (info != 0) {
+        // The update of a failed factorisation is garbage, and so are the per-edge errors its evaluation left behind.  The reference
+        // applies the STALE solution of the last good solve instead and keeps THOSE errors (levenberg.cpp:110-146); the device restores
+        // the kept state's: one residual-only pass on it (rare path; DESIGN.md section 2 and the test that pins this deviation).
+        RC_TRY(launch_chi2(s, s->st[s->cur]));
+      }
       // (the rejected state's linearisation sits in the OTHER buffer: the kept state's system is intact, the retry reduces it again
       //  with the larger lambda and clears the other buffer on the way)
     }

@@ -334,3 +334,25 @@ def test_fixed_points_do_not_move_and_have_no_landmark_block(oracle):
     r = s.read()
     np.testing.assert_array_equal(r.point_xyz[::2], P["point_xyz"].reshape(-1, 3)[::2])
     assert np.abs(r.point_xyz[1::2] - P["point_xyz"].reshape(-1, 3)[1::2]).max() > 0
+
+
+@pytest.mark.parametrize("cfg,kw", [("small", dict(seed=1)), ("small", dict(seed=3, with_corners=True)), (dict(n_kf=20, n_points=1500, n_planes=8, n_cuboids=3), dict(seed=9))])
+def test_openmp_build_of_the_oracle_matches_the_single_threaded_one(oracle, cfg, kw, monkeypatch):
+    """oracle/libppo_oracle_omp.so (bench.py's secondary "best CPU" line, never the checker): edge loop and landmark loop on several
+    threads with per-thread accumulators, a blocked Cholesky instead of the unblocked pivoted LDLT.  Same accept / reject sequence,
+    same cost, estimates inside the spread any re-ordering of the sums has (tests/test_oracle_sensitivity.py)."""
+    import ctypes as C
+    import os
+    import sensitivity as S
+    from ppo_ba import binding as B
+    from ppo_ba import synth
+    monkeypatch.setenv("OMP_NUM_THREADS", "4")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libppo_oracle_omp.so")
+    omp = B._Backend(C.CDLL(path), "oracle_ba_")
+    P = synth.make_problem(cfg, **kw)
+    a, b = oracle.create(P, B.default_options()), omp.create(P, B.default_options())
+    ta, tb = a.run(), b.run()
+    assert S.schedule(ta) == S.schedule(tb)
+    assert abs(ta["iters"][-1]["chi2_after"] - tb["iters"][-1]["chi2_after"]) <= 1e-6 * ta["iters"][-1]["chi2_after"]  # BASELINE.md's bars
+    m = S.metrics(a.read(), b.read())
+    assert all(m[k] < bar for k, bar in S.BARS.items()), m
