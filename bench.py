@@ -59,7 +59,7 @@ def cpu_baseline(P, B, seconds_budget=12.0):
                            calls, iters, trials, dt, cpu_model(), os.cpu_count() or 0))
 
 
-TRAFFIC_FILES = ("r02_lin_traffic.json", "r01_lin_traffic.json")  # newest first
+TRAFFIC_FILES = ("r03_lin_traffic.json", "r02_lin_traffic.json", "r01_lin_traffic.json")  # newest first
 
 
 def cpu_baseline_openmp(P, B, seconds_budget=6.0):

@@ -455,6 +455,11 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
     return;
   }
   STAMP(7);
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_NO_LOOKAHEAD)
+  const bool updc = false;  // (timing experiment, WRONG results: a step that finds final tiles -- no previous-panel rows to load, no look-ahead update)
+#else
+  const bool updc = upd;
+#endif
   // ---- column workgroup: workgroup 0 owns the diagonal block, workgroups 1 + 2 (b - 1) + h the row halves h = 0, 1 of block b ----
   const int cw = blockIdx.x;
   const int b = cw == 0 ? 0 : 1 + ((cw - 1) >> 1);
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
   const int r0t = 2 * half, r1t = 2 * half + 1;  // the two 16-row tiles of the own half
   const int row0 = k0 + b * NB;
   const bool own = b > 0;
-  const bool uo = own && upd;
+  const bool uo = own && updc;
   // step 0 takes the right-hand side from rhs_in (the caller's b stays intact), later steps continue in rhs
   const double* rsrc = (k0 == 0) ? rhs_in : rhs;
   {
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
     // loads under `if`s the compiler drained each group before issuing the next, four memory round trips in a row.
     double2 td[NI], tq[NI], tb[NI / 2], tp[NI / 2];
     const double* pC = &A[(size_t)k0 * ld + k0];
-    const double* pQ = upd ? &A[(size_t)kp * ld + k0] : pC;   // L[k][k-1]
+    const double* pQ = updc ? &A[(size_t)kp * ld + k0] : pC;   // L[k][k-1]
     const double* pB = own ? &A[(size_t)k0 * ld + row0] : pC;
     const double* pP = uo ? &A[(size_t)kp * ld + row0] : pC;  // L[k+b][k-1]
     STAMP(15);
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
   __syncthreads();
   if (tid >= 256) return;  // loader waves
   STAMP(5);
-  if (upd) {
+  if (updc) {
     tile_update1(sL, wave, 0, wave == 0, sQ, sQ);  // block column 0 of the diagonal block: what potf2(0) needs
     __syncthreads();
   }
@@ -523,17 +528,17 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
     } else if (true) {
 #endif
     } else if (kk == 0) {
-      if (upd) tile_update1(sL, wave, 1, wave == 1, sQ, sQ);  // D(1,1) D(2,1) D(3,1): what the next factorisation needs
+      if (updc) tile_update1(sL, wave, 1, wave == 1, sQ, sQ);  // D(1,1) D(2,1) D(3,1): what the next factorisation needs
       if (uo) tile_update1(sB, r0t, wave - 1, false, sP, sQ);
     } else if (kk == 1) {
       if (wave == 1) {
         if (uo) tile_update1(sB, r0t, 3, false, sP, sQ);
         if (own) solve_rows<0>(sB, r0t, sL, sT);
       } else if (wave == 2) {
-        if (upd) tile_update1(sL, 2, 2, true, sQ, sQ);
+        if (updc) tile_update1(sL, 2, 2, true, sQ, sQ);
         if (uo) tile_update1(sB, r1t, 0, false, sP, sQ);
       } else {
-        if (upd) tile_update1(sL, 3, 2, false, sQ, sQ);
+        if (updc) tile_update1(sL, 3, 2, false, sQ, sQ);
         if (uo) tile_update1(sB, r1t, 1, false, sP, sQ);
       }
     } else if (kk == 2) {
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
         if (uo) tile_update1(sB, r1t, 2, false, sP, sQ);
         if (own) solve_rows<1>(sB, r0t, sL, sT);
       } else if (wave == 2) {
-        if (upd) tile_update1(sL, 3, 3, true, sQ, sQ);
+        if (updc) tile_update1(sL, 3, 3, true, sQ, sQ);
         if (uo) tile_update1(sB, r1t, 3, false, sP, sQ);
       } else {
         solve_rhs_row(sB, 0, sL, sT);

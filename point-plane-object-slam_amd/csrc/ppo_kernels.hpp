@@ -1047,6 +1047,9 @@ __device__ __forceinline__ void lin_cubproj_body_analytic(const Graph& g, const 
   double (*sG)[DM] = reinterpret_cast<double (*)[DM]>(smem + EPB * DM * 16 + EPB * DM);
   const int grp = threadIdx.x >> 3, k = threadIdx.x & 7;  // lane k = cuboid corner k
   const int i = vblock * EPB + grp;
+  // These few workgroups (16 for 500 bbox edges) share their SIMDs with three other waves each of the point / pose parts: time-sliced evenly
+  // their chain took 23 us against 6 us alone and ended the launch (tools/lin_stamps.py, JAC=1).  Raised issue priority gives it back.
+  __builtin_amdgcn_s_setprio(3);
   const bool in = grp < EPB && i < n_edges;
   const CubEdge& ed = (CORNER ? g.corner : g.bbox)[in ? i : 0];
   const bool act = in && (ed.flags & F_ACTIVE);
@@ -1156,6 +1159,7 @@ struct NumericShape<PtCubModel> {
 };
 __device__ __forceinline__ void lin_ptcub_body(const Graph& g, const State& st, int i, double delta, double* smem) {
   constexpr int DM = 3, NC = 9;
+  __builtin_amdgcn_s_setprio(3);  // (50 workgroups with the longest chain of the launch: see lin_cubproj_body_analytic)
   double (*sJ)[16] = reinterpret_cast<double (*)[16]>(smem);
   double* sW = smem + DM * 16;
   double* sG = sW + DM;

@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 from ppo_ba import binding as B, synth  # noqa: E402
 
 P = synth.make_problem(sys.argv[1] if len(sys.argv) > 1 else "cfg4", seed=1)
-s = B.hip_backend(test_hooks=True).create(P, B.default_options())
+s = B.hip_backend(test_hooks=True).create(P, B.default_options(jacobian_mode=int(os.environ.get("JAC", "0"))))  # JAC=1: analytic Jacobians
 for _ in range(5):
     s.linearize()
 s.close()
