@@ -20,10 +20,11 @@ from ppo_ba import synth  # noqa: E402
 
 def one(hip, orc, P, opt_kw, tag):
     o = B.default_options(**opt_kw)
-    so, sh = orc.create(P, o), hip.create(P, o)
+    jac = int(os.environ.get("JAC", "0"))  # JAC=1: the device runs with analytic Jacobians (the oracle is always the numeric reference)
+    so, sh = orc.create(P, o), hip.create(P, B.default_options(jacobian_mode=jac, **opt_kw))
     to, th = so.run(), sh.run()
     ro, rh = so.read(), sh.read()
-    sd = hip.create(P, B.default_options(deterministic=1, **opt_kw))
+    sd = hip.create(P, B.default_options(deterministic=1, jacobian_mode=jac, **opt_kw))
     td = sd.run()
     rd = sd.read()
     sd.close()
