@@ -104,6 +104,7 @@ struct Params {
   double ba_weight_bbox = 1.0, ba_weight_corner = 1.0, thHuberBbox2d = 80.0, thHuberConer2d = 10.0;
   bool fix_camera = false, fix_point = false;  // the only call site passes false, false (LocalMapping.cc:100)
   int image_width = 640, image_height = 480, object_boundary_margin = 5;  // literals of OPT:2456-2460
+  bool skip_single_observation_points = true;  // OPT:2336-2337; the points-only Optimizer::LocalBundleAdjustment (OPT:581-590) gives every local point a vertex
 };
 
 // ---- the flattened problem (owns the arrays a ppo_ba_problem points into) ----------------------------------------------------------
@@ -213,7 +214,7 @@ inline void flatten(const Window& w, const Params& par, Flat& f) {
   f.point_vertex.assign(w.points.size(), -1);
   for (int pi = 0; pi < (int)w.points.size(); ++pi) {
     const MapPointIn& p = w.points[pi];
-    if (p.n_observations == 1) continue;  // OPT:2336-2337
+    if (par.skip_single_observation_points && p.n_observations == 1) continue;  // OPT:2336-2337
     const int v = (int)f.point_src.size();
     f.point_vertex[pi] = v;
     f.point_src.push_back(pi);

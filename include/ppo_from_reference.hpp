@@ -41,6 +41,7 @@
 
 #include "ppo_ba.h"
 #include "ppo_flatten.hpp"
+#include "ppo_pose.h"
 
 namespace ppo_from_reference {
 
@@ -236,8 +237,9 @@ void store_used_points(const Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboid
 // ---- OPT:2892-2966: everything that touches the map, under Map::mMutexMapUpdate ------------------------------------------------------
 // Traits::make_mat(rows, cols) -> a CV_32F matrix; Traits::make_cuboid(qt, scale) -> a g2o::cuboid.
 template <class Traits, class KeyFrameT, class MapPointT, class MapPlaneT, class MapCuboidT, class MapT>
-void apply_write_back(const Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT>& g, const std::vector<KeyFrameT*>& kfs, const pf::WriteBack& wb, MapT* pMap) {
-  std::unique_lock<decltype(pMap->mMutexMapUpdate)> lock(pMap->mMutexMapUpdate);  // OPT:2892
+void apply_write_back(const Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT>& g, const std::vector<KeyFrameT*>& kfs, const pf::WriteBack& wb, MapT* pMap,
+                      bool reset_markers = true) {
+  std::unique_lock<decltype(pMap->mMutexMapUpdate)> lock(pMap->mMutexMapUpdate);  // OPT:2892 (points-only local BA: OPT:748)
   for (const pf::EraseObs& e : wb.erase_points) {  // OPT:2894-2903
     KeyFrameT* pKFi = kfs[e.keyframe];
     MapPointT* pMPi = g.lLocalMapPoints[e.object];
@@ -251,7 +253,8 @@ void apply_write_back(const Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT
     pMPi->EraseObservation(pKFi);
   }
   // keyframes (OPT:2917-2924): marker reset for EVERY local keyframe, pose for those that have a vertex
-  for (KeyFrameT* pKFrame : g.lLocalKeyFrames) pKFrame->mnBALocalForKF = 0;
+  if (reset_markers)
+    for (KeyFrameT* pKFrame : g.lLocalKeyFrames) pKFrame->mnBALocalForKF = 0;
   for (const pf::WriteBack::Pose& o : wb.poses) {
     auto T = Traits::make_mat(4, 4);
     for (int r = 0; r < 4; ++r)
@@ -259,7 +262,8 @@ void apply_write_back(const Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT
     kfs[o.keyframe]->SetPose(T);
   }
   // points (OPT:2927-2936)
-  for (MapPointT* pMP : g.lLocalMapPoints) pMP->mnBALocalForKF = 0;
+  if (reset_markers)
+    for (MapPointT* pMP : g.lLocalMapPoints) pMP->mnBALocalForKF = 0;
   for (const pf::WriteBack::Point& o : wb.points) {
     auto X = Traits::make_mat(3, 1);
     for (int a = 0; a < 3; ++a) X.template at<float>(a) = o.xyz[a];
@@ -268,12 +272,14 @@ void apply_write_back(const Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT
     pMP->UpdateNormalAndDepth();
   }
   // fixed cameras (OPT:2939-2944): markers only
-  for (KeyFrameT* pKFrame : g.lFixedCameras) {
-    pKFrame->mnBAFixedForKF = 0;
-    pKFrame->mnBALocalForKF = 0;
-  }
+  if (reset_markers)
+    for (KeyFrameT* pKFrame : g.lFixedCameras) {
+      pKFrame->mnBAFixedForKF = 0;
+      pKFrame->mnBALocalForKF = 0;
+    }
   // cuboids (OPT:2947-2957)
-  for (MapCuboidT* pMCuboid : g.lLocalMapCuboids) pMCuboid->mnBALocalForKF = 0;
+  if (reset_markers)
+    for (MapCuboidT* pMCuboid : g.lLocalMapCuboids) pMCuboid->mnBALocalForKF = 0;
   for (const pf::WriteBack::CuboidOut& o : wb.cuboids) {
     MapCuboidT* pMCuboid = g.lLocalMapCuboids[o.cuboid];
     pMCuboid->obj_been_optimized = true;
@@ -374,6 +380,131 @@ int local_ba_camera_plane_cuboids(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, 
   pf::write_back(w, par, f, s.result, wb);         // OPT:2840-2887 erase lists; float32 narrowing of Converter.cc
   apply_write_back<Traits>(g, kfs, wb, pMap);      // OPT:2892-2966
   return rc;
+}
+
+// ---- Optimizer::LocalBundleAdjustment (include/Optimizer.h, OPT:461-787) ---------------------------------------------
+// The points-only local BA LocalMapping runs while the map has at most five keyframes (src/LocalMapping.cc:103-108): the same protocol on
+// keyframes and points only.  Differences to the function above, each as in the reference: the gather does not look at cuboids or planes
+// (OPT:466-511); EVERY local point gets a vertex (no Observations() == 1 rule, OPT:581-590); `if (*pbStopFlag) return;` before the first
+// pass (OPT:664-665); the BA markers are NOT reset afterwards (vanilla ORB-SLAM2 compares them with the unique pKF->mnId).
+template <class MapPointT, class MapPlaneT, class MapCuboidT, class KeyFrameT>
+Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT> gather_window_points_only(KeyFrameT* pKF) {
+  Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT> g;
+  g.lLocalKeyFrames.push_back(pKF);
+  pKF->mnBALocalForKF = pKF->mnId;
+  const std::vector<KeyFrameT*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
+  for (KeyFrameT* pKFi : vNeighKFs) {
+    pKFi->mnBALocalForKF = pKF->mnId;
+    if (!pKFi->isBad()) g.lLocalKeyFrames.push_back(pKFi);
+  }
+  for (KeyFrameT* pKFl : g.lLocalKeyFrames) {
+    const std::vector<MapPointT*> vpMPs = pKFl->GetMapPointMatches();
+    for (MapPointT* pMP : vpMPs)
+      if (pMP && !pMP->isBad() && pMP->mnBALocalForKF != pKF->mnId) {
+        g.lLocalMapPoints.push_back(pMP);
+        pMP->mnBALocalForKF = pKF->mnId;
+      }
+  }
+  for (MapPointT* pMP : g.lLocalMapPoints) {
+    const auto observations = pMP->GetObservations();
+    for (const auto& mit : observations) {
+      KeyFrameT* pKFi = mit.first;
+      if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+        pKFi->mnBAFixedForKF = pKF->mnId;
+        if (!pKFi->isBad()) g.lFixedCameras.push_back(pKFi);
+      }
+    }
+  }
+  return g;
+}
+
+template <class Traits, class MapPointT = typename Traits::MapPoint, class MapPlaneT = typename Traits::MapPlane, class MapCuboidT = typename Traits::MapCuboid,
+          class KeyFrameT, class MapT, class SolveFn = LibrarySolver>
+int local_bundle_adjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, SolveFn solve = SolveFn()) {
+  auto g = gather_window_points_only<MapPointT, MapPlaneT, MapCuboidT>(pKF);  // OPT:463-511
+  pf::Window w;
+  std::vector<KeyFrameT*> kfs;
+  to_window(g, w, kfs);
+  pf::Params par;  // every plane / cuboid flag off: the window carries none
+  par.skip_single_observation_points = false;
+  pf::Flat f;
+  pf::flatten(w, par, f);  // OPT:525-662
+  if (pbStopFlag && *pbStopFlag) return PPO_BA_ABORTED;  // OPT:664-665
+  ppo_ba_options O;
+  ppo_ba_default_options(&O);  // 5 + 10 iterations, 5.991 / 7.815 (OPT:668, 715, 688, 703)
+  Solved s;
+  const int rc = solve(f.problem, O, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), s);
+  if (rc < 0) {
+    std::cerr << "LocalBundleAdjustment: " << ppo_ba_strerror(rc) << std::endl;
+    return rc;
+  }
+  pf::WriteBack wb;
+  pf::write_back(w, par, f, s.result, wb);                                  // OPT:719-745
+  apply_write_back<Traits>(g, kfs, wb, pMap, /*reset_markers=*/false);      // OPT:748-786
+  return rc;
+}
+
+// ---- Optimizer::PoseOptimization (include/Optimizer.h, OPT:247-459) through include/ppo_pose.h ---------------------------------
+// Frame members used: N, mvpMapPoints, mvbOutlier, mvKeysUn, mvuRight, mvInvLevelSigma2, mTcw, fx, fy, cx, cy, mbf, SetPose()
+// (include/Frame.h); MapPoint::mGlobalMutex is held while the map points are read (OPT:286), nothing is locked during the solve.
+struct PoseSolved {
+  double qt[7] = {0, 0, 0, 1, 0, 0, 0};
+  std::vector<uint8_t> outlier;
+  int32_t n_inliers = 0;
+};
+struct LibraryPoseSolver {
+  int operator()(const ppo_pose_problem& P, const ppo_pose_options& O, PoseSolved& s) const {
+    ppo_pose_result R{s.qt, s.outlier.data(), &s.n_inliers, nullptr, nullptr};
+    return ppo_pose_optimize(&P, &O, &R);
+  }
+};
+template <class Traits, class MapPointT = typename Traits::MapPoint, class FrameT, class SolveFn = LibraryPoseSolver>
+int pose_optimization(FrameT* pFrame, SolveFn solve = SolveFn()) {
+  std::vector<double> xw, obs, inv;
+  std::vector<size_t> index;
+  {
+    std::unique_lock<decltype(MapPointT::mGlobalMutex)> lock(MapPointT::mGlobalMutex);  // OPT:286
+    const int N = pFrame->N;
+    for (int i = 0; i < N; i++) {
+      MapPointT* pMP = pFrame->mvpMapPoints[i];
+      if (!pMP) continue;
+      pFrame->mvbOutlier[i] = false;  // OPT:297, 331
+      const auto& kpUn = pFrame->mvKeysUn[i];
+      const auto Xw = pMP->GetWorldPos();
+      for (int a = 0; a < 3; ++a) xw.push_back(Xw.template at<float>(a));
+      obs.push_back(kpUn.pt.x);
+      obs.push_back(kpUn.pt.y);
+      obs.push_back(pFrame->mvuRight[i]);  // < 0 selects the monocular edge (OPT:294)
+      inv.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
+      index.push_back((size_t)i);
+    }
+  }
+  if (index.size() < 3) return 0;  // OPT:372-373
+  float Tcw[16];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) Tcw[4 * r + c] = pFrame->mTcw.template at<float>(r, c);
+  double qt[7];
+  pf::pose_from_cv(Tcw, qt);  // Converter::toSE3Quat(pFrame->mTcw), OPT:263, 385
+  const double cam[5] = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf};
+  const int32_t off[2] = {0, (int32_t)index.size()};
+  ppo_pose_problem P{1, qt, cam, off, xw.data(), obs.data(), inv.data()};
+  ppo_pose_options O;
+  ppo_pose_default_options(&O);  // 4 x 10 iterations, 5.991 / 7.815, the Huber kernel dropped after the third round
+  PoseSolved s;
+  s.outlier.assign(index.size(), 0);
+  const int rc = solve(P, O, s);
+  if (rc != PPO_BA_OK) {
+    std::cerr << "PoseOptimization: " << ppo_ba_strerror(rc) << std::endl;
+    return 0;
+  }
+  for (size_t k = 0; k < index.size(); k++) pFrame->mvbOutlier[index[k]] = s.outlier[k] != 0;  // OPT:403-411, 432-441
+  float T[16];
+  pf::pose_to_cv(s.qt, T);
+  auto pose = Traits::make_mat(4, 4);
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) pose.template at<float>(r, c) = T[4 * r + c];
+  pFrame->SetPose(pose);  // OPT:455-456
+  return s.n_inliers;     // OPT:458
 }
 
 }  // namespace ppo_from_reference

@@ -88,7 +88,14 @@ struct KeyFrame {
   void EraseMapPointMatch(MapPoint* p);
   void EraseMapPlaneMatch(MapPlane* p);
 };
+struct GlobalRecordingMutex {  // MapPoint::mGlobalMutex
+  void lock() { assert(!held); held = true; ++count; }
+  void unlock() { assert(held); held = false; }
+  bool held = false;
+  int count = 0;
+};
 struct MapPoint {
+  static GlobalRecordingMutex mGlobalMutex;
   long unsigned int mnId = 0, mnBALocalForKF = 0;
   bool bad = false;
   Mat X{3, 1};
@@ -135,6 +142,19 @@ struct MapCuboid {
   std::unordered_map<KeyFrame*, size_t> GetObservations() { return obs; }
   std::vector<MapPoint*> GetUniqueMapPoints() { return unique; }
   void SetWorldPos(const Mat& P) { J->mutate("CB" + std::to_string(mnId) + ".SetWorldPos"); Twc = P; ++n_set; }
+};
+GlobalRecordingMutex MapPoint::mGlobalMutex;
+struct Frame {  // include/Frame.h
+  int N = 0;
+  std::vector<MapPoint*> mvpMapPoints;
+  std::vector<bool> mvbOutlier;
+  std::vector<KeyPoint> mvKeysUn;
+  std::vector<float> mvuRight, mvInvLevelSigma2{1.f, 0.6944f, 0.4823f, 0.3349f};
+  Mat mTcw{4, 4};
+  float fx = 500, fy = 510, cx = 320, cy = 240, mbf = 40;
+  int n_setpose = 0;
+  bool points_read_under_lock = true;
+  void SetPose(Mat T) { mTcw = T; ++n_setpose; }
 };
 void KeyFrame::EraseMapPointMatch(MapPoint* p) { J->mutate("KF" + std::to_string(mnId) + ".EraseMapPointMatch(MP" + std::to_string(p->mnId) + ")"); }
 void KeyFrame::EraseMapPlaneMatch(MapPlane* p) { J->mutate("KF" + std::to_string(mnId) + ".EraseMapPlaneMatch(PL" + std::to_string(p->mnId) + ")"); }
@@ -417,6 +437,88 @@ int main() {
       for (int i : {1, 2, 3}) CHECK(W.kf[i].n_setpose == 1);
       std::printf("(GPU: the mock window went through libppo_ba.so)\n");
     }
+  }
+  // ---- 6. Optimizer::LocalBundleAdjustment (points only, OPT:461-787): every point gets a vertex, markers stay, same lock order ---------
+  {
+    World W;
+    bool solver_saw_lock = true, stop = false;
+    int n_points_seen = -1;
+    struct PointsOnly {
+      bool* saw_lock; int* n_points;
+      int operator()(const ppo_ba_problem& P, const ppo_ba_options& O, const volatile uint8_t* st, pfr::Solved& s) const {
+        *n_points = P.n_points;
+        assert(P.n_planes == 0 && P.n_cuboids == 0 && P.n_plane_edges == 0 && P.n_bbox == 0 && P.n_ptcub == 0);
+        return FakeSolver{saw_lock, PPO_BA_OK}(P, O, st, s);
+      }
+    };
+    const int rc = pfr::local_bundle_adjustment<Traits>(&W.kf[1], &stop, &W.map, PointsOnly{&solver_saw_lock, &n_points_seen});
+    CHECK(rc == PPO_BA_OK && !solver_saw_lock);
+    CHECK(n_points_seen == 6);                                   // the single-observation point 103 HAS a vertex here (OPT:581-590)
+    CHECK(W.journal.lock_count == 1 && W.journal.unlocked_mutations == 0);
+    CHECK(W.mp[3].n_set == 1 && W.mp[3].n_update == 1);
+    for (int i : {1, 0, 2, 3}) CHECK(W.kf[i].n_setpose == 1);
+    CHECK(W.kf[6].n_setpose == 0);
+    CHECK(W.kf[7].mnBAFixedForKF == 0);                          // cuboid observers are not looked at
+    for (int i : {0, 1, 2, 3}) CHECK(W.kf[i].mnBALocalForKF == 1);  // vanilla ORB-SLAM2 leaves the markers
+    CHECK(W.kf[6].mnBAFixedForKF == 1 && W.mp[0].mnBALocalForKF == 1);
+    CHECK(!W.cb[0].obj_been_optimized && W.pl[0].n_set == 0);
+    bool up = true;
+    World W2;
+    bool called = false;
+    struct Never2 { bool* called; int operator()(const ppo_ba_problem&, const ppo_ba_options&, const volatile uint8_t*, pfr::Solved&) const { *called = true; return 0; } };
+    CHECK(pfr::local_bundle_adjustment<Traits>(&W2.kf[1], &up, &W2.map, Never2{&called}) == PPO_BA_ABORTED && !called && W2.journal.lock_count == 0);
+  }
+  // ---- 7. Optimizer::PoseOptimization (OPT:247-459) over a mock Frame --------------------------------------------------------------------
+  {
+    World W;  // (for its map points)
+    Frame F;
+    F.N = 10;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) F.mTcw.at<float>(r, c) = (r == c) ? 1.f : 0.f;
+    F.mTcw.at<float>(0, 3) = 0.25f;
+    for (int i = 0; i < 10; ++i) {
+      F.mvpMapPoints.push_back(i % 3 == 2 ? nullptr : &W.mp[i % 8]);
+      F.mvbOutlier.push_back(true);
+      KeyPoint kp; kp.pt.x = 100.f + 7 * i; kp.pt.y = 90.f + 3 * i; kp.octave = i % 4;
+      F.mvKeysUn.push_back(kp);
+      F.mvuRight.push_back(i % 2 ? kp.pt.x - 5.f : -1.f);
+    }
+    struct FakePose {
+      int* n_obs; bool* under_lock;
+      int operator()(const ppo_pose_problem& P, const ppo_pose_options& O, pfr::PoseSolved& s) const {
+        *under_lock = MapPoint::mGlobalMutex.held;
+        *n_obs = P.edge_offsets[1];
+        assert(P.n_frames == 1 && O.rounds == 4 && O.iters_per_round == 10);
+        assert(P.cam[0] == 500 && P.cam[4] == 40 && P.pose_qt[3] == 1.0 && P.pose_qt[4] == 0.25);
+        // observation 0 = feature 0: point 100, monocular, octave 0; observation 1 = feature 1: stereo
+        assert(P.obs[0] == 100.f && P.obs[1] == 90.f && P.obs[2] < 0 && P.obs[5] == 107.f - 5.f && P.inv_sigma2[1] == 0.6944f);
+        assert(P.xw[3] == 0.5f && P.xw[4] == 1.5f);
+        for (int a = 0; a < 7; ++a) s.qt[a] = P.pose_qt[a];
+        s.qt[5] = 0.75;  // ty
+        s.outlier[2] = 1;
+        s.n_inliers = *n_obs - 1;
+        return PPO_BA_OK;
+      }
+    };
+    int n_obs = 0;
+    bool under_lock = true;
+    const int inl = pfr::pose_optimization<Traits>(&F, FakePose{&n_obs, &under_lock});
+    CHECK(n_obs == 7 && inl == 6 && !under_lock && MapPoint::mGlobalMutex.count == 1 && !MapPoint::mGlobalMutex.held);
+    CHECK(F.n_setpose == 1 && F.mTcw.at<float>(1, 3) == 0.75f && F.mTcw.at<float>(0, 3) == 0.25f && F.mTcw.at<float>(3, 3) == 1.f);
+    // features 0 1 3 4 6 7 9 carry points: the third of them (feature 3) was marked an outlier, every other one is an inlier; features
+    // without a map point keep their flag
+    CHECK(F.mvbOutlier[3] && !F.mvbOutlier[0] && !F.mvbOutlier[1] && !F.mvbOutlier[4] && !F.mvbOutlier[9] && F.mvbOutlier[2] && F.mvbOutlier[5]);
+    // fewer than three correspondences: 0, nothing touched (OPT:372-373)
+    Frame G = F;
+    G.n_setpose = 0;
+    for (int i = 2; i < 10; ++i) G.mvpMapPoints[i] = nullptr;
+    bool called = false;
+    struct NeverPose { bool* c; int operator()(const ppo_pose_problem&, const ppo_pose_options&, pfr::PoseSolved&) const { *c = true; return 0; } };
+    CHECK(pfr::pose_optimization<Traits>(&G, NeverPose{&called}) == 0 && !called && G.n_setpose == 0);
+    // the real library: fails loudly without a GPU (returns 0 inliers, pose untouched), runs with one
+    Frame H = F;
+    H.n_setpose = 0;
+    const int r = pfr::pose_optimization<Traits>(&H);
+    CHECK((r == 0 && H.n_setpose == 0) || (r >= 0 && H.n_setpose == 1));
   }
   std::printf("from_reference_test ok\n");
   return 0;
