@@ -83,7 +83,11 @@ def cpu_baseline_openmp(P, B, seconds_budget=6.0):
     threads = max(1, min(8, os.cpu_count() or 1, quota))
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-    be = B._Backend(C.CDLL(path), "oracle_ba_")
+    lib = C.CDLL(path)
+    # (torch loaded libgomp long ago, with one thread per VISIBLE CPU -- 256 on the GPU box, whose container may use 16: the environment
+    #  variable is too late, the count is set through the library)
+    threads = int(lib.oracle_set_threads(threads))
+    be = B._Backend(lib, "oracle_ba_")
     s = be.create(P, B.default_options())
     iters = calls = 0
     dt = 0.0
@@ -95,7 +99,7 @@ def cpu_baseline_openmp(P, B, seconds_budget=6.0):
         iters += st["n_iters"]
         calls += 1
     s.close()
-    return dict(value=iters / dt, unit="LM iters/s", cores=int(os.environ["OMP_NUM_THREADS"]), kind="port+openmp", ms_per_call=1e3 * dt / calls,
+    return dict(value=iters / dt, unit="LM iters/s", cores=threads, kind="port+openmp", ms_per_call=1e3 * dt / calls,
                 sample="oracle/libppo_oracle_omp.so: %d complete 5+10 calls = %d LM iterations in %.1f s; OpenMP over the edges (linearisation, residuals), "
                        "the landmarks (Schur complement) and the tiles of a blocked Cholesky; same schedule and results to rounding as the 1-thread "
                        "port (tests/test_oracle_known_answers.py); the reference itself is single-threaded" % (calls, iters, dt))

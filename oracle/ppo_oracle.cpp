@@ -106,6 +106,10 @@ struct Oracle {
                     // 2 = the long sums (pose blocks of Hpp, b, the Schur complement S and its right-hand side) accumulated with a
                     // compensation term each (Neumaier's two-sum: the result a wider accumulator would give, rounded once at the end)
   std::vector<double> Hpp_c, b_c, S_c, coeff_c;  // compensation terms of variant 2
+#ifdef _OPENMP
+  std::vector<std::vector<double>> omp_S, omp_c, omp_Hd, omp_bp;  // per-thread accumulators of the OpenMP build, kept across calls: eight fresh
+                                                                    // 21 MB vectors per solve are eight threads page-faulting at once
+#endif
   bool only_pose = false;  // the unary Edge*SE3ProjectXYZOnlyPose flavour of the reprojection edges (pose-only optimisation)
   // ---- LM ----
   double lambda = -1, ni = 2;
@@ -538,8 +542,9 @@ void build_system_omp(Oracle& o) {
   const int nb = o.n_red_blocks, n = o.n_red;
   const size_t na = o.active.size();
   const int nt = omp_get_max_threads();
-  std::vector<std::vector<double>> Hd(nt), bp(nt);
-#pragma omp parallel
+  std::vector<std::vector<double>>&Hd = o.omp_Hd, &bp = o.omp_bp;
+  if ((int)Hd.size() < nt) { Hd.resize(nt); bp.resize(nt); }
+#pragma omp parallel num_threads(nt)
   {
     const int t = omp_get_thread_num();
     Hd[t].assign((size_t)nb * 81, 0.0);
@@ -938,7 +943,12 @@ bool blocked_llt_solve_omp(std::vector<double>& A, int n, const double* rhs, dou
 
 bool dense_solve(Oracle& o, std::vector<double>& Aupper, const double* rhs, double* xout) {
   const int n = o.n_red;
+#ifdef _OPENMP
+  static thread_local std::vector<double> H;  // (kept: see Oracle::omp_S)
+  H = Aupper;
+#else
   std::vector<double> H(Aupper);
+#endif
   for (int c = 0; c < n; ++c)
     for (int r = 0; r < c; ++r) H[(size_t)r * n + c] = H[(size_t)c * n + r];  // lower(c,r) = upper(r,c)
 #ifdef _OPENMP
@@ -979,11 +989,12 @@ bool block_solve(Oracle& o) {
     // libppo_oracle_omp.so ONLY: the landmark loop split over the threads, each with its own copy of S and of the right-hand side's
     // Schur term, summed at the end (same per-landmark arithmetic; another summation order)
     const int nt = omp_get_max_threads();
-    std::vector<std::vector<double>> St(nt), ct(nt);
-#pragma omp parallel
+    std::vector<std::vector<double>>&St = o.omp_S, &ct = o.omp_c;
+    if ((int)St.size() < nt) { St.resize(nt); ct.resize(nt); }
+#pragma omp parallel num_threads(nt)
     {
       const int t = omp_get_thread_num();
-      St[t].assign((size_t)n * n, 0.0);
+      St[t].assign((size_t)n * n, 0.0);  // (same size as last time: a fill, no allocation)
       ct[t].assign(n, 0.0);
       double* S = St[t].data();
 #pragma omp for schedule(static)
@@ -1381,6 +1392,18 @@ int oracle_ba_chi2_at(oracle_handle o, const double* pose_qt, const double* poin
 }
 
 void oracle_ba_destroy(oracle_handle o) { delete o; }
+
+// OpenMP build: number of threads of the following calls (the environment variable is read when libgomp is FIRST loaded -- in a process
+// that imported PyTorch that happened long before this library, with every visible CPU); the plain build ignores it.  Returns the value in use.
+int oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
 
 // Test aid for tests/test_oracle_sensitivity.py: 1 = sum the edges (chi2, H, b) and the landmarks (Schur complement) in reverse
 // order.  The algorithm, every formula and every input are unchanged; only the order of the floating-point additions differs --
