@@ -348,7 +348,9 @@ def test_openmp_build_of_the_oracle_matches_the_single_threaded_one(oracle, cfg,
     from ppo_ba import synth
     monkeypatch.setenv("OMP_NUM_THREADS", "4")
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libppo_oracle_omp.so")
-    omp = B._Backend(C.CDLL(path), "oracle_ba_")
+    lib = C.CDLL(path)
+    assert lib.oracle_set_threads(4) == 4
+    omp = B._Backend(lib, "oracle_ba_")
     P = synth.make_problem(cfg, **kw)
     a, b = oracle.create(P, B.default_options()), omp.create(P, B.default_options())
     ta, tb = a.run(), b.run()
