@@ -161,21 +161,9 @@ struct ColSweep {
     // 1/sqrt(d) = y0 (1 - e)^-1/2 = y0 (1 + e (1/2 + 3/8 e)) + O(e^3): five dependent operations instead of the six of two
     // Newton steps (this chain is the serial core of the whole solve), full double accuracy (2.2e-16 measured)
     const double y0 = __builtin_amdgcn_rsq(d);
-#ifdef PPO_CHOL_SHORT_CHAIN
-    // the scaled column as l0 (1 + q) with l0 = a y0 formed next to d y0: one dependent operation less per pivot than y = y0 (1 + q), l = a y
-    const double l0 = a[J] * y0, le0 = e[J] * y0;
-    const double e1 = __builtin_fma(-(d * y0), y0, 1.0);
-#ifdef PPO_CHOL_SECOND_ORDER  // (A/B only: drops the e1^2 term, 4e-15 instead of 2e-16 per pivot)
-    const double q = 0.5 * e1;
-#else
-    const double q = e1 * __builtin_fma(0.375, e1, 0.5);
-#endif
-    const double l = __builtin_fma(l0, q, l0), le = __builtin_fma(le0, q, le0);
-#else
     const double e1 = __builtin_fma(-(d * y0), y0, 1.0);
     const double y = __builtin_fma(y0, e1 * __builtin_fma(0.375, e1, 0.5), y0);
     const double l = a[J] * y, le = e[J] * y;
-#endif
     a[J] = l;
     e[J] = le;
     if constexpr (J + 1 < SB) {

@@ -3,7 +3,7 @@
 # the experiment builds): the register factorisation without its extra rows (half of its multiply-adds), without the MFMA jobs
 # that run in its shadow on the side waves, without both.
 cd "$(dirname "$0")"
-for flags in ${CHOL_FLAGS:-"" "-DPPO_CHOL_SHORT_CHAIN" "-DPPO_CHOL_SHORT_CHAIN -DPPO_CHOL_SECOND_ORDER" "-DPPO_CHOL_EXPERIMENT_NO_LOOKAHEAD" "-DPPO_CHOL_EXPERIMENT_NO_E" "-DPPO_CHOL_EXPERIMENT_NO_SIDE" "-DPPO_CHOL_TRAIL_DELAY_TICKS=300" "-DPPO_CHOL_TRAIL_DELAY_TICKS=500" "-DPPO_CHOL_TRAIL_DELAY_TICKS=700"}; do
+for flags in ${CHOL_FLAGS:-"" "-DPPO_CHOL_EXPERIMENT_NO_LOOKAHEAD" "-DPPO_CHOL_EXPERIMENT_NO_E" "-DPPO_CHOL_EXPERIMENT_NO_SIDE" "-DPPO_CHOL_TRAIL_DELAY_TICKS=300" "-DPPO_CHOL_TRAIL_DELAY_TICKS=500" "-DPPO_CHOL_TRAIL_DELAY_TICKS=700"}; do
   /opt/rocm/bin/hipcc -w -O3 -std=c++17 --offload-arch=gfx950 -DPPO_BA_TEST_HOOKS $flags -munsafe-fp-atomics -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16 -o /tmp/chol_check chol_check.hip
   echo "== flags: $flags"
   timeout 120 /tmp/chol_check panels 2>&1 | grep -E "^n (1194|1644| 600)"
