@@ -197,7 +197,9 @@ __device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], cons
     e[c] = pe[c];
   }
   int bad = 0;
+  if (o == SB) STAMP(40);  // (tools/chol_probe.hip: the second of the four register factorisations, taken apart)
   ColSweep<0>::run(a, e, bad);
+  if (o == SB) STAMP(41);
   if (!store) return bad;
   if (g == 0) {
 #pragma unroll
@@ -208,6 +210,7 @@ __device__ __forceinline__ int potf2_16(double (*sL)[LP], double (*sT)[17], cons
 #pragma unroll
     for (int c = 0; c < SB; ++c) qe[c] = e[c];
   }
+  if (o == SB) STAMP(42);
   return bad;
 }
 

@@ -164,8 +164,8 @@ int main() {
   printf("info %d max residual %.3e\n", info, rmax);
   // phase stamps of column workgroup 1 of the second step (update of panel 0 fused with the factorisation of panel 1)
   hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (n / 64 - 1)), dim3(256), 0, s, dA, n, 0, db, dws, dx, dinfo);
-  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (m - 1) + m * (m - 1) / 2), dim3(256), 0, s, dA, n, 64, db, dws, dx, dinfo); }
+  hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (n / 64 - 1)), dim3(ppo::kStepThreads), 0, s, dA, n, 0, db, dws, dx, dinfo);
+  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (m - 1) + m * (m - 1) / 2), dim3(ppo::kStepThreads), 0, s, dA, n, 64, db, dws, dx, dinfo); }
   hipStreamSynchronize(s);
   long long st[48];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
@@ -179,7 +179,7 @@ int main() {
   printf("  stored              +%.2f us\n", (st[4] - st[3]) * 0.01);
   for (int i = 8; i < 15; ++i) printf("  factor stamp %d: +%.2f us\n", i, (st[i] - (i == 8 ? st[1] : st[i - 1])) * 0.01);
   for (int kk = 0; kk < 4; ++kk) printf("  wave 1 side jobs of phase %d: %.2f us\n", kk, (st[28 + kk] - st[24 + kk]) * 0.01);
-  if (0) printf("  potf2(kk=1): LDS loads %.2f us, sweep %.2f, stores %.2f, then to the barrier stamp %.2f\n", (st[40] - st[9]) * 0.01, (st[41] - st[40]) * 0.01, (st[42] - st[41]) * 0.01, (st[10] - st[42]) * 0.01);
+  if (1) printf("  potf2(kk=1): LDS loads %.2f us, sweep %.2f, stores %.2f, then to the barrier stamp %.2f\n", (st[40] - st[9]) * 0.01, (st[41] - st[40]) * 0.01, (st[42] - st[41]) * 0.01, (st[10] - st[42]) * 0.01);
   // backward pipeline: block 1's view (stamps 22..29 = moment x_i was seen, i = 2..9)
   hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
   ppo::chol_factor_solve(dA, n, db, dx, dinfo, dws, s);
