@@ -19,7 +19,9 @@
 // "solver failed", levenberg.cpp:126-127).
 #include "ppo_chol.hpp"
 #include "ppo_dev.hpp"
+#include "ppo_pairs.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -35,6 +37,10 @@ constexpr int LP = 65;  // padded LDS row length (doubles): column walks are ban
 constexpr int SB = 16;  // sub-block of the diagonal factorization = MFMA tile edge
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+// 16-byte pairs as a native vector type: copies of HIP's double2 STRUCT are memcpys to the optimiser, and register arrays of them that
+// are filled from memory and emptied into LDS were left in scratch memory once chol_step grew
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2 d2v(double x, double y) { d2 v; v.x = x; v.y = y; return v; }
 constexpr unsigned long long kSentinel = 0xFFF8C0DEC0DE0001ull;  // "not written yet": a NaN payload no arithmetic produces
 constexpr int kSpinCap = 400000;
 
@@ -61,22 +67,22 @@ __device__ __forceinline__ double bcast(double v, int lane) {  // lane is wave-u
   return __hiloint2double(hi, lo);
 }
 
-// 64x64 tile at `base` (column-major, leading dimension ld) -> registers: thread t holds 8 double2, element pair
+// 64x64 tile at `base` (column-major, leading dimension ld) -> registers: thread t holds 8 d2, element pair
 // p = t + 256 i covers column p >> 5, rows 2 (p & 31) and +1.  All 8 loads are issued before any use.
-__device__ __forceinline__ void load_tile(const double* __restrict__ base, int ld, double2 (&t)[8]) {
+__device__ __forceinline__ void load_tile(const double* __restrict__ base, int ld, d2 (&t)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int p = threadIdx.x + 256 * i;
-    t[i] = *reinterpret_cast<const double2*>(&base[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
+    t[i] = *reinterpret_cast<const d2*>(&base[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
   }
 }
 // the same tile spread over NT threads (chol_step: the four compute waves plus four loader waves)
 template <int NT>
-__device__ __forceinline__ void load_tile_nt(const double* __restrict__ base, int ld, double2 (&t)[2048 / NT]) {
+__device__ __forceinline__ void load_tile_nt(const double* __restrict__ base, int ld, d2 (&t)[2048 / NT]) {
 #pragma unroll
   for (int i = 0; i < 2048 / NT; ++i) {
     const int p = threadIdx.x + NT * i;
-    t[i] = *reinterpret_cast<const double2*>(&base[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
+    t[i] = *reinterpret_cast<const d2*>(&base[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
   }
 }
 
@@ -396,39 +402,95 @@ __device__ __forceinline__ void solve_rhs_row(double (*sB)[LP], int kk, const do
 #define PPO_CHOL_STEP_THREADS 512
 #endif
 constexpr int kStepThreads = PPO_CHOL_STEP_THREADS;  // (256: no loader waves -- A/B builds)
-__global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info) {
+// The LDS of one workgroup of chol_step: the column / trailing workgroups' tiles, or -- the pair workgroups of an overlapped reduction -- the
+// transpose-sum buffers of the pair body (one allocation per launch: 147 KB, i.e. one workgroup per CU whatever its part)
+struct StepLds {
+  double sL[NB][LP];
+  double sB[NB + 1][LP];  // row NB carries r_k^T: the forward substitution is one more row of the block solve
+  double sT[NB / SB][SB][17];
+  __attribute__((aligned(16))) double sP[NB][UP];  // [m][row of block i] of the previous panel
+  __attribute__((aligned(16))) double sQ[NB][UP];  // [m][row of block j]
+  double sId[SB + 1][SB];  // identity rows + one zero row: the "extra rows" of lanes that carry none
+  int sBad;
+};
+union StepLdsU {
+  StepLds a;
+  double pairs[kStepThreads / 64][21][65];
+};
+// ---- overlapped reduction ---------------------------------------------------------------------------------------------------------
+// The Schur pair reduction (ppo_pairs.hpp, 42 us at the BASELINE size) fills the lower triangle of S before the factorisation can start --
+// but panel k only READS column block k, and while the column workgroups walk their serial chain (13 us per panel) 200 CUs have nothing
+// to do.  With the pair chunks ordered by column block, only the chunks of the first fin[0] column blocks are reduced ahead of the
+// factorisation; launch k of chol_step carries, as extra workgroups right behind its column workgroups, the chunks of the column blocks
+// [fin[k], fin[k + 1]).  fin[k] = number of column blocks that are FINAL (hold all their pair contributions) when launch k starts; the
+// schedule keeps fin[k] >= k + 1, so the column workgroups of launch k only ever read final blocks.  The trailing update of a tile and
+// the pair contributions to it are both sums, so their order does not matter -- but a tile the pair workgroups of THIS launch may be
+// adding to must take its update as atomic adds too (column blocks fin[k] .. fin[k + 1]: the last one because a 6-column pose block may
+// straddle a block boundary); every other tile keeps the plain read-modify-write.  The right-hand side receives pair contributions as
+// well: it is solved in place, its row updates are atomic adds.
+struct StepOverlap {
+  PairCtx ctx;
+  PairChunks pc;
+  int chunk_lo, chunk_hi;    // chunks the pair workgroups of this launch reduce
+  int npair_wg;              // their number (kStepThreads / 64 chunks each)
+  int atomic_lo, atomic_hi;  // trailing tiles of the column blocks [atomic_lo, atomic_hi] add their update atomically (none: lo > hi)
+};
+__host__ __device__ inline StepOverlap step_no_overlap(int nb) {
+  StepOverlap o{};
+  o.atomic_lo = 1;
+  o.atomic_hi = 0;
+  return o;
+}
+
+// (not inlined: as part of chol_step's body the pair code -- 234 VGPRs, 60 scalar registers of keyframe data -- pushed the column
+//  workgroups' prologue into scratch memory)
+__device__ __forceinline__ void step_pairs(const StepOverlap& ov, int bid, double (*s_buf)[21][65]) {
+  schur_pairs_body<kStepThreads / 64>(ov.ctx, ov.pc, ov.chunk_lo, ov.chunk_hi, bid, ov.npair_wg, s_buf, [](double* p, double v) { atomicAdd(p, v); });
+}
+
+// OV = false: the launch carries no pair workgroups and no tile takes atomic updates (ov is not read) -- the plain factorisation and the
+// later launches of an overlapped one; as ONE kernel the pair code's registers (240 against 182) and arguments cost every launch 0.4 us.
+template <bool OV>
+__global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info,
+                                                            int inplace_rhs, StepOverlap ov) {
   constexpr int NT = kStepThreads, NI = 2048 / NT;
-  __shared__ double sL[NB][LP];
-  __shared__ double sB[NB + 1][LP];  // row NB carries r_k^T: the forward substitution is one more row of the block solve
-  __shared__ double sT[NB / SB][SB][17];
-  __shared__ __attribute__((aligned(16))) double sP[NB][UP];  // [m][row of block i] of the previous panel
-  __shared__ __attribute__((aligned(16))) double sQ[NB][UP];  // [m][row of block j]
-  __shared__ int sBad;
-  __shared__ double sId[SB + 1][SB];  // identity rows + one zero row: the "extra rows" of lanes that carry none
+  __shared__ StepLdsU lds;
+  double (*const sL)[LP] = lds.a.sL;
+  double (*const sB)[LP] = lds.a.sB;
+  double (*const sT)[SB][17] = lds.a.sT;
+  double (*const sP)[UP] = lds.a.sP;
+  double (*const sQ)[UP] = lds.a.sQ;
+  double (*const sId)[SB] = lds.a.sId;
+  int& sBad = lds.a.sBad;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int m = (ld - k0) / NB;
   const int kp = k0 - NB;  // previous panel's column
   const bool upd = k0 > 0;
   STAMP(0);
   const int ncol = 1 + 2 * (m - 1);  // column workgroups of this launch
+  int npair_wg = 0;
+  if constexpr (OV) npair_wg = ov.npair_wg;
+  if (OV && (int)blockIdx.x >= ncol && (int)blockIdx.x < ncol + npair_wg) {
+    // ---- pair workgroup of an overlapped reduction: S -= W_j (D_l + lambda I)^-1 W_i' for chunks of column blocks that are not final yet
+    // (right behind the column workgroups in the grid: they are the long ones of the launch's shadow, the trailing tiles fill in)
+    step_pairs(ov, (int)blockIdx.x - ncol, lds.pairs);
+    return;
+  }
   if ((int)blockIdx.x >= ncol) {
     // ---- trailing tile (bi >= bj >= 1 relative to block k) --------------------------------------------------------------
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    int t = blockIdx.x - ncol, bi = 0;
+    int t = blockIdx.x - ncol - npair_wg, bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     const int bj = t - bi * (bi + 1) / 2;
     const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
-#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_TRAIL_DELAY_TICKS)  // (experiment: trailing tiles start late, the column workgroups' prologue has the memory system to itself)
-    {
-      const unsigned long long t_in = wall_clock64();
-      while (wall_clock64() - t_in < PPO_CHOL_TRAIL_DELAY_TICKS) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
-    double2 tp[NI], tq[NI];
+    const int cblk = c0 / NB;  // column block of the tile
+    bool atomic_out = false;  // pair workgroups of this launch may be adding to it
+    if constexpr (OV) atomic_out = cblk >= ov.atomic_lo && cblk <= ov.atomic_hi;
+    d2 tp[NI], tq[NI];
     load_tile_nt<NT>(&A[(size_t)kp * ld + r0], ld, tp);
     load_tile_nt<NT>(&A[(size_t)kp * ld + c0], ld, tq);
     double cold[2][2][4] = {};  // old values of the output quadrant, fetched while the panel tiles land (compute waves)
-    if (tid < 256) {
+    if (tid < 256 && !atomic_out) {
 #pragma unroll
       for (int jc = 0; jc < 2; ++jc)
 #pragma unroll
@@ -439,13 +501,25 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int p = tid + NT * i, mm = p >> 5, r = 2 * (p & 31);
-      *reinterpret_cast<double2*>(&sP[mm][r]) = tp[i];
-      *reinterpret_cast<double2*>(&sQ[mm][r]) = tq[i];
+      *reinterpret_cast<d2*>(&sP[mm][r]) = tp[i];
+      *reinterpret_cast<d2*>(&sQ[mm][r]) = tq[i];
     }
     __syncthreads();
     if (tid >= 256) return;  // loader waves
     v4d acc[2][2] = {};
     quadrant_product(sP, sQ, wr, wc, li, lk, acc);
+    if (atomic_out) {  // (16 lanes -> 16 consecutive rows of one column: one cache line per quarter wave)
+#pragma unroll
+      for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+        for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int c = wc + 16 * jc + lk + 4 * reg, r = wr + 16 * ir + li;
+            if (bi != bj || r >= c) atomicAdd(&A[(size_t)(c0 + c) * ld + r0 + r], -acc[jc][ir][reg]);
+          }
+      return;
+    }
 #pragma unroll
     for (int jc = 0; jc < 2; ++jc)
 #pragma unroll
@@ -476,7 +550,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
   {
     // Everything is requested unconditionally and back to back (what is not needed aliases the diagonal tile): with the
     // loads under `if`s the compiler drained each group before issuing the next, four memory round trips in a row.
-    double2 td[NI], tq[NI], tb[NI / 2], tp[NI / 2];
+    d2 td[NI], tq[NI], tb[NI / 2], tp[NI / 2];
     const double* pC = &A[(size_t)k0 * ld + k0];
     const double* pQ = updc ? &A[(size_t)kp * ld + k0] : pC;   // L[k][k-1]
     const double* pB = own ? &A[(size_t)k0 * ld + row0] : pC;
@@ -487,10 +561,10 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
     load_tile_nt<NT>(pQ, ld, tq);
     STAMP(17);
 #pragma unroll
-    for (int i = 0; i < NI / 2; ++i) {  // the own half: 32 rows x 64 columns, 16 double2 per column
+    for (int i = 0; i < NI / 2; ++i) {  // the own half: 32 rows x 64 columns, 16 d2 per column
       const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
-      tb[i] = *reinterpret_cast<const double2*>(&pB[(size_t)c * ld + r]);
-      tp[i] = *reinterpret_cast<const double2*>(&pP[(size_t)c * ld + r]);
+      tb[i] = *reinterpret_cast<const d2*>(&pB[(size_t)c * ld + r]);
+      tp[i] = *reinterpret_cast<const d2*>(&pP[(size_t)c * ld + r]);
     }
     const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
     STAMP(6);
@@ -499,14 +573,14 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
       const int p = tid + NT * i, c = p >> 5, r = 2 * (p & 31);
       sL[r][c] = (r >= c) ? td[i].x : 0.0;
       sL[r + 1][c] = (r + 1 >= c) ? td[i].y : 0.0;
-      *reinterpret_cast<double2*>(&sQ[c][r]) = tq[i];
+      *reinterpret_cast<d2*>(&sQ[c][r]) = tq[i];
     }
 #pragma unroll
     for (int i = 0; i < NI / 2; ++i) {
       const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
       sB[r][c] = tb[i].x;
       sB[r + 1][c] = tb[i].y;
-      *reinterpret_cast<double2*>(&sP[c][r]) = tp[i];
+      *reinterpret_cast<d2*>(&sP[c][r]) = tp[i];
     }
     if (tid < NB) sB[NB][tid] = rv;
     if (tid == 0) sBad = 0;
@@ -594,7 +668,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int p = tid + 256 * i, c = p >> 5, r = 2 * (p & 31);
-      if (r + 1 >= c) *reinterpret_cast<double2*>(&A[(size_t)(k0 + c) * ld + k0 + r]) = make_double2(sL[r][c], sL[r + 1][c]);
+      if (r + 1 >= c) *reinterpret_cast<d2*>(&A[(size_t)(k0 + c) * ld + k0 + r]) = d2v(sL[r][c], sL[r + 1][c]);
     }
     if (tid < NB) rhs[k0 + tid] = sB[NB][tid];  // y_k
     return;
@@ -604,16 +678,19 @@ __global__ __launch_bounds__(kStepThreads) void chol_step(double* __restrict__ A
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = tid + 256 * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
-    *reinterpret_cast<double2*>(&A[(size_t)(k0 + c) * ld + row0 + r]) = make_double2(sB[r][c], sB[r + 1][c]);
+    *reinterpret_cast<d2*>(&A[(size_t)(k0 + c) * ld + row0 + r]) = d2v(sB[r][c], sB[r + 1][c]);
   }
   if (tid < 32) {  // r_b -= L_bk y_k
     double sacc = 0.0;
 #pragma unroll 16
     for (int mm = 0; mm < NB; ++mm) sacc = __builtin_fma(sB[myrow][mm], sB[NB][mm], sacc);
-    rhs[row0 + myrow] = rold - sacc;
+    if (inplace_rhs) atomicAdd(&rhs[row0 + myrow], -sacc);  // (overlapped reduction: the pair workgroups may be adding to this row too)
+    else rhs[row0 + myrow] = rold - sacc;
   }
   STAMP(4);
 }
+
+[[maybe_unused]] constexpr auto chol_step = chol_step_t<false>;  // (tools/chol_probe.hip launches single steps)
 
 #ifdef PPO_BA_TEST_HOOKS
 #include "ppo_chol_fwd.inc"  // chol_fwd_all: the one-launch forward factorisation (measured, not adopted)
@@ -648,12 +725,12 @@ __global__ __launch_bounds__(256) void chol_back_all(const double* __restrict__ 
   const int tid = threadIdx.x, j = blockIdx.x >> 3, nb = ld / NB, k0 = j * NB;
   const int c = tid >> 2, part = tid & 3;  // 4 threads per column of block j, 16 rows of block i each
   // ---- everything that does not depend on other workgroups is fetched first
-  double2 td[8];
+  d2 td[8];
   load_tile(&A[(size_t)k0 * ld + k0], ld, td);
   double acc = (part == 0) ? y[k0 + c] : 0.0;
-  double2 lnext[8];
+  d2 lnext[8];
   if (nb - 1 > j) {
-    const double2* col = reinterpret_cast<const double2*>(&A[(size_t)(k0 + c) * ld + (size_t)(nb - 1) * NB + part * 16]);
+    const d2* col = reinterpret_cast<const d2*>(&A[(size_t)(k0 + c) * ld + (size_t)(nb - 1) * NB + part * 16]);
 #pragma unroll
     for (int r = 0; r < 8; ++r) lnext[r] = col[r];
   }
@@ -670,11 +747,11 @@ __global__ __launch_bounds__(256) void chol_back_all(const double* __restrict__ 
   bool timeout = false;
 #pragma unroll 1
   for (int i = nb - 1; i > j; --i) {
-    double2 lcur[8];
+    d2 lcur[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) lcur[r] = lnext[r];
     if (i - 1 > j) {
-      const double2* col = reinterpret_cast<const double2*>(&A[(size_t)(k0 + c) * ld + (size_t)(i - 1) * NB + part * 16]);
+      const d2* col = reinterpret_cast<const d2*>(&A[(size_t)(k0 + c) * ld + (size_t)(i - 1) * NB + part * 16]);
 #pragma unroll
       for (int r = 0; r < 8; ++r) lnext[r] = col[r];
     }
@@ -758,9 +835,9 @@ FwdWs carve(double* ws, int ld) {
 
 // One launch per panel + one for the backward substitution.  (The one-launch factorisation, ppo_chol_fwd.inc, exists only in the
 // test-hooks build: PPO_BA_CHOL_ONELAUNCH=1 selects it there; DESIGN.md 4.1 has the measurement.)
-int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s) {
+int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s, const CholOverlap* ov = nullptr) {
   const int nb = ld / NB;
-  double* y = ws;  // [ld] forward-substituted right-hand side
+  double* y = ov ? ov->ctx.bs : ws;  // [ld] forward-substituted right-hand side (overlapped reduction: in place, the pair workgroups add to it)
   int* flags = nullptr;
   int nflags = 0;
 #ifdef PPO_BA_TEST_HOOKS
@@ -780,7 +857,23 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
     for (int k = 0; k < nb; ++k) {
       const int k0 = k * NB;
       const int m = nb - k;  // column workgroups: 1 (diagonal) + 2 per block row below (row halves); then the trailing tiles
-      hipLaunchKernelGGL(chol_step, dim3(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0)), dim3(kStepThreads), 0, s, A, ld, k0, b, y, x, info);
+      StepOverlap o = step_no_overlap(nb);
+      if (ov) {  // ... then the pair workgroups of the column blocks [fin[k], fin[k + 1])
+        o.ctx = ov->ctx;
+        o.pc = ov->pc;
+        o.atomic_lo = ov->fin[k];
+        o.atomic_hi = ov->fin[k + 1] > ov->fin[k] ? ov->fin[k + 1] : ov->fin[k] - 1;  // (no pair workgroups in this launch: no atomic tiles)
+        o.chunk_lo = ov->cb_start[ov->fin[k]];
+        o.chunk_hi = ov->cb_start[ov->fin[k + 1]];
+        const int per_wg = kStepThreads / 64;
+        o.npair_wg = o.chunk_hi > o.chunk_lo ? ((o.chunk_hi - o.chunk_lo + per_wg - 1) / per_wg + 7) / 8 * 8 : 0;
+      }
+#ifdef PPO_BA_TEST_HOOKS
+      if (PPO_DEV_ENV("PPO_BA_OVERLAP_EMPTY")) o.chunk_hi = o.chunk_lo;  // timing experiment (WRONG results): the pair workgroups find nothing to do
+#endif
+      const dim3 grid(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0) + o.npair_wg);
+      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, o);
+      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, o);
     }
   }
   hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(256), 0, s, (const double*)A, ld, (const double*)y, x, info, flags, nflags);
@@ -816,6 +909,28 @@ int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, 
     }
   }
   return hipGraphLaunch(exec, stream) == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
+}
+
+// The overlapped variant: S's column blocks [fin[0], nb) are still being reduced by pair workgroups inside the first launches.
+int chol_factor_solve_overlapped(double* A, int ld, double* x, int* info, double* ws, const CholOverlap& ov, hipStream_t stream) {
+  if (ld % NB != 0 || kStepThreads != 512 || !ov.fin || !ov.cb_start) return PPO_BA_ERR_ARG;
+  if (ld == 0) return PPO_BA_OK;
+  return enqueue_all(A, ld, ov.ctx.bs, x, info, ws, stream, &ov);
+}
+
+// fin[k], k = 0 .. nb: column blocks of S that are final when launch k starts (fin[nb] = nb).  The reduction ahead of the factorisation
+// covers `first_blocks` (>= 1) column blocks; launch k then carries the next blocks as long as their chunks stay within a share of all
+// chunks (share0 for launch 0, which has no trailing tiles of its own), and always enough of them to keep fin[k + 1] >= k + 2.
+void chol_overlap_schedule(int nb, const int32_t* cb_start, int first_blocks, double share0, double share, int* fin) {
+  const long total = cb_start[nb];
+  fin[0] = std::min(nb, std::max(1, first_blocks));
+  for (int k = 0; k < nb; ++k) {
+    const int f = fin[k], need = std::min(nb, k + 2);
+    const long budget = (long)((k == 0 ? share0 : share) * (double)total);
+    int nf = f;
+    while (nf < nb && (nf < need || (long)cb_start[nf + 1] - cb_start[f] <= budget)) ++nf;
+    fin[k + 1] = nf;
+  }
 }
 
 void chol_release(double* A) {

@@ -2,11 +2,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
+
+#include "ppo_pairs.hpp"
 
 namespace ppo {
 // A: ld x ld column-major (ld = chol_padded_ld(n), pad diagonal = 1), lower triangle valid on entry, overwritten by L.  b: right-hand side (left intact;
 // must not alias x), x: solution, workspace: chol_workspace_doubles(n) doubles.  *info (device int) = 0 when A is positive definite, k > 0 when the leading minor of order k is not.
 int chol_factor_solve(double* A, int n, const double* b, double* x, int* info, double* workspace, hipStream_t stream);
+// Overlapped reduction (ppo_chol.hip, StepOverlap): only the pair chunks of the first fin[0] 64-column blocks of A have been reduced when this is
+// called; the launches of the factorisation carry the remaining chunks (ordered by column block: cb_start[c] = first chunk of block c, host
+// array of ld / 64 + 1 entries) as extra workgroups that add to A and to the right-hand side ctx.bs, which is solved IN PLACE.
+// fin: host array of ld / 64 + 1 entries from chol_overlap_schedule().
+struct CholOverlap {
+  PairCtx ctx;  // ctx.S == A
+  PairChunks pc;
+  const int32_t* cb_start;
+  const int* fin;
+};
+int chol_factor_solve_overlapped(double* A, int n, double* x, int* info, double* workspace, const CholOverlap& ov, hipStream_t stream);
+void chol_overlap_schedule(int nb, const int32_t* cb_start, int first_blocks, double share0, double share, int* fin);
 size_t chol_workspace_doubles(int n);
 int chol_padded_ld(int n);   // leading dimension the native solver needs (multiple of the panel width)
 void chol_release(double* A);  // drop the cached launch graph of a matrix that is about to be freed

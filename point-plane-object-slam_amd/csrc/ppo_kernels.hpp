@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "ppo_math.hpp"
+#include "ppo_pairs.hpp"
 
 namespace ppo {
 
@@ -372,25 +373,7 @@ __global__ __launch_bounds__(256) void k_lin_points(Graph g, State st) {
   lin_points_body<USE_LDS>(g, st, blockIdx.x, gridDim.x, smem, s_red);
 }
 
-// Sum `NV` per-lane values over the 64 lanes of a wave through LDS: lane t < NV returns the total of value t.
-// buf is this wave's [NV][65] scratch.  (Cheaper than 6 ds_bpermute rounds per value, and it leaves value t in lane t,
-// which is exactly the lane-contiguous layout the atomics that follow want.)
-template <int NV>
-__device__ __forceinline__ double wave_transpose_sum(const double* vals, double (*buf)[65]) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int v = 0; v < NV; ++v) buf[v][lane] = vals[v];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  double t = 0.0;
-  if (lane < NV) {
-#pragma unroll 16
-    for (int i = 0; i < 64; ++i) t += buf[lane][i];
-  }
-  __builtin_amdgcn_wave_barrier();
-  return t;
-}
+// (wave_transpose_sum: ppo_pairs.hpp)
 
 // ======================================================================================================
 // k_lin_poses: pose side + coupling blocks of the reprojection edges, streamed POSE-MAJOR.  The edges of every free
@@ -1270,8 +1253,13 @@ struct LinPlan {
   int nb[LIN_PARTS];     // workgroups per part
   int order[LIN_PARTS];  // grid order of the parts
 };
+#ifdef PPO_LIN_MAXWAVES  // (A/B builds: cap the waves per SIMD from above)
+#define PPO_LIN_OCC __attribute__((amdgpu_waves_per_eu(1, PPO_LIN_MAXWAVES)))
+#else
+#define PPO_LIN_OCC
+#endif
 template <bool USE_LDS, bool WITH_CORNERS, bool ANALYTIC = false>
-__global__ __launch_bounds__(256, PPO_LIN_WAVES) void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
+__global__ __launch_bounds__(256, PPO_LIN_WAVES) PPO_LIN_OCC void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
   extern __shared__ double smem[];
   int b = blockIdx.x, part = -1;
 #pragma unroll
@@ -1514,165 +1502,7 @@ __device__ __forceinline__ void schur_prep_body(const Graph& g, double lambda, i
   g.ul[(size_t)l * 3 + 2] = v02 * b0 + v12 * b1 + v22 * b2;
 }
 
-// Schur accumulation by POSE PAIR.  At create time every (slot_j, slot_i) pair of one landmark (pose_j >= pose_i) is
-// filed under its pose pair and each pair's list is cut into chunks; one wave reduces one chunk into 36 register
-// accumulators per lane, S(pj, pi) -= sum W_j (D_l + lambda I)^-1 W_i', and issues one atomic per entry of the 6x6 block
-// per CHUNK (instead of one per landmark).  Slots are numbered pose-major, so a pair's list walks two contiguous W
-// segments in order; the 3x3 inverse of the pair's landmark is an L2-resident gather.  (An earlier version first streamed
-// Z = W L^-T to memory in a launch of its own: 73 MB of traffic and 23 us that forming W D^-1 on the fly does not need.)
-// The self pairs (slot_j == slot_i) also carry the right-hand side: bs(pj) -= W_j (D_l + lambda I)^-1 b_l.
-struct PairChunks {
-  const int32_t* start;  // [n_chunks+1] into sj / si
-  const int32_t* colj;   // [n_chunks] reduced column of pose j (row block of S)
-  const int32_t* coli;   // [n_chunks] reduced column of pose i (column block of S)
-  const int32_t* sj;     // [n_entries]
-  const int32_t* si;     // [n_entries]
-  const int32_t* lm;     // [n_entries] landmark of the pair (saves the dependent slot -> landmark -> (D + lambda I)^-1 gather chain)
-  int n_chunks;
-};
-#ifndef PPO_PAIRS_NO_PREFETCH
-#define PPO_PAIRS_PREFETCH 1  // the next trip's gathers in flight during this trip's arithmetic: 43.8 -> 42.1 us (234 VGPRs, still 2 waves per SIMD)
-#endif
-__device__ __forceinline__ void schur_pairs_body(const Graph& g, const PairChunks& pc, int bid, int nblocks, double (*s_buf)[21][65]) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // One wave per chunk of one pose pair.  Chunks are ordered by (pose j, pose i) and every Z record is needed by ~7
-  // pairs, so the launch is made XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only),
-  // and each XCD is given a CONTIGUOUS range of chunks -- the Z segments of "its" keyframes then stay in its 4 MB L2
-  // instead of being streamed from HBM once per pair (264 MB -> ~36 MB at the BASELINE size).
-  const int per_xcd = (nblocks + 7) >> 3;
-  const int vb = (bid & 7) * per_xcd + (bid >> 3);
-  const int t = __builtin_amdgcn_readfirstlane(vb * 4 + wave);  // (uniform: the chunk header and the keyframe data become scalar loads)
-  if (t >= pc.n_chunks) return;
-  const int e1 = pc.start[t + 1];
-  const int colj = pc.colj[t], coli = pc.coli[t];
-  // rotation + fx, fy, bf of both keyframes at the linearisation point (left there by the pose side of the linearisation):
-  // uniform over the wave, kept in scalar registers
-  auto uni = [](double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-  };
-  // plan entries of the first trip, requested together with the keyframe data below (both hang on the chunk header only);
-  // inside the loop the next trip's entries are requested before this trip's arithmetic.  (clamped indices: unconditional loads)
-  int e = pc.start[t] + lane;
-  int sj, si, l;
-  {
-    const int ec = e < e1 ? e : (e1 > 0 ? e1 - 1 : 0);
-    sj = pc.sj[ec]; si = pc.si[ec]; l = pc.lm[ec];
-  }
-  double Rj[12], Ri[12];
-  {
-    const double* rj = &g.linR[(size_t)(colj / 6) * 12];
-    const double* ri = &g.linR[(size_t)(coli / 6) * 12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) { Rj[k] = uni(rj[k]); Ri[k] = uni(ri[k]); }
-  }
-  const FactorRec* const F4 = reinterpret_cast<const FactorRec*>(g.F);
-  // vals[6 r + c] = element (row c of pose j, column r of pose i) so that consecutive values are consecutive in memory
-  double vals[42];
-#pragma unroll
-  for (int k = 0; k < 42; ++k) vals[k] = 0.0;
-#ifdef PPO_PAIRS_PREFETCH
-  // (variant: the gathers of the NEXT trip -- (D + lambda I)^-1 and the two factor records -- are requested before this trip's arithmetic)
-  double2 p01, p23, p45;
-  FactorRec pfj{}, pfi{};
-  {
-    const double2* I2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l * 6]);
-    p01 = I2[0]; p23 = I2[1]; p45 = I2[2];
-    if (l < g.n_points) { pfj = F4[sj]; pfi = F4[si]; }
-  }
-#endif
-  for (; e < e1; e += 64) {
-#ifdef PPO_PAIRS_PREFETCH
-    const double2 i01 = p01, i23 = p23, i45 = p45;
-    const FactorRec fj_cur = pfj, fi_cur = pfi;
-#else
-    const double2* I2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l * 6]);  // 48-byte records: three 16-byte loads
-    const double2 i01 = I2[0], i23 = I2[1], i45 = I2[2];
-#endif
-    const double v00 = i01.x, v01 = i01.y, v02 = i23.x, v11 = i23.y, v12 = i45.x, v22 = i45.y;
-    const int en = e + 64 < e1 ? e + 64 : e1 - 1;
-    const int sj_n = pc.sj[en], si_n = pc.si[en], l_n = pc.lm[en];
-#ifdef PPO_PAIRS_PREFETCH
-    if (e + 64 < e1) {  // (uniform: the chunk has another trip)
-      const double2* J2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l_n * 6]);
-      p01 = J2[0]; p23 = J2[1]; p45 = J2[2];
-      if (l_n < g.n_points) { pfj = F4[sj_n]; pfi = F4[si_n]; }
-    }
-#endif
-    // S(j, i) -= L T Y' with  points: L = M_j, Y = M_i, T = R_j (D + lambda I)^-1 R_i'   planes: L = W_j, Y = W_i, T = (D + lambda I)^-1
-    double L[18], y[18], T[9], w[18];
-    const bool self = sj == si;
-    double u0 = 0.0, u1 = 0.0, u2 = 0.0;  // self pairs: (D + lambda I)^-1 b_l, rotated like T
-    if (self) { u0 = g.ul[(size_t)l * 3]; u1 = g.ul[(size_t)l * 3 + 1]; u2 = g.ul[(size_t)l * 3 + 2]; }
-    if (l < g.n_points) {
-#ifdef PPO_PAIRS_PREFETCH
-      const FactorRec fj = fj_cur, fi = fi_cur;
-#else
-      const FactorRec fj = F4[sj], fi = F4[si];
-#endif
-      const bool st_rows = __any(fj.ws < 0.0 || fi.ws < 0.0);
-      factor_M(fj, Rj[9], Rj[10], Rj[11], st_rows, L);
-      factor_M(fi, Ri[9], Ri[10], Ri[11], st_rows, y);
-      double A[9];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {  // A = R_j (D + lambda I)^-1
-        A[3 * r] = __builtin_fma(Rj[3 * r], v00, __builtin_fma(Rj[3 * r + 1], v01, Rj[3 * r + 2] * v02));
-        A[3 * r + 1] = __builtin_fma(Rj[3 * r], v01, __builtin_fma(Rj[3 * r + 1], v11, Rj[3 * r + 2] * v12));
-        A[3 * r + 2] = __builtin_fma(Rj[3 * r], v02, __builtin_fma(Rj[3 * r + 1], v12, Rj[3 * r + 2] * v22));
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          T[3 * r + c] = __builtin_fma(A[3 * r], Ri[3 * c], __builtin_fma(A[3 * r + 1], Ri[3 * c + 1], A[3 * r + 2] * Ri[3 * c + 2]));
-      if (self) {
-        const double t0 = u0, t1 = u1, t2 = u2;
-        u0 = __builtin_fma(Rj[0], t0, __builtin_fma(Rj[1], t1, Rj[2] * t2));
-        u1 = __builtin_fma(Rj[3], t0, __builtin_fma(Rj[4], t1, Rj[5] * t2));
-        u2 = __builtin_fma(Rj[6], t0, __builtin_fma(Rj[7], t1, Rj[8] * t2));
-      }
-    } else {
-      const double2* wp = reinterpret_cast<const double2*>(&g.W[(size_t)(sj - g.n_pt_slots) * 18]);
-      const double2* yp = reinterpret_cast<const double2*>(&g.W[(size_t)(si - g.n_pt_slots) * 18]);
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const double2 a = wp[q], b = yp[q];
-        L[2 * q] = a.x; L[2 * q + 1] = a.y; y[2 * q] = b.x; y[2 * q + 1] = b.y;
-      }
-      T[0] = v00; T[1] = v01; T[2] = v02; T[3] = v01; T[4] = v11; T[5] = v12; T[6] = v02; T[7] = v12; T[8] = v22;
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {  // w = L T
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        w[a * 3 + c] = __builtin_fma(L[a * 3], T[c], __builtin_fma(L[a * 3 + 1], T[3 + c], L[a * 3 + 2] * T[6 + c]));
-    }
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-        vals[6 * r + c] = __builtin_fma(w[c * 3], y[r * 3], __builtin_fma(w[c * 3 + 1], y[r * 3 + 1], __builtin_fma(w[c * 3 + 2], y[r * 3 + 2], vals[6 * r + c])));
-    if (self) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) vals[36 + c] += L[c * 3] * u0 + L[c * 3 + 1] * u1 + L[c * 3 + 2] * u2;
-    }
-    sj = sj_n; si = si_n; l = l_n;
-  }
-  const int n = g.ld;
-  const bool diag = colj == coli;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const double tot = wave_transpose_sum<21>(&vals[21 * half], s_buf[wave]);
-    const int v = 21 * half + lane;
-    if (lane < 21 && tot != 0.0) {
-      if (v < 36) {
-        const int r = v / 6, c = v - 6 * r;
-        if (!diag || c >= r) acc_add(g, &g.S[(size_t)(coli + r) * n + colj + c], -tot);
-      } else if (diag) {
-        acc_add(g, &g.bs[colj + (v - 36)], -tot);
-      }
-    }
-  }
-}
+// (PairChunks / schur_pairs_body: ppo_pairs.hpp -- shared with the fused launches of ppo_chol.hip)
 
 // ---- cuboid elimination -------------------------------------------------------------------------------------------
 // The reference keeps the 9-DoF cuboids in the dense system (they are not marginalised, Optimizer.cc:2172).  Here they
@@ -1751,21 +1581,34 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
   if (!(ea.flags & F_ACTIVE) || !(eb.flags & F_ACTIVE)) return;
   const int cola = g.pose_col[ea.pose], colb = g.pose_col[eb.pose];
   if (cola < 0 || colb < 0) return;
-  // row i of W_a (Hcc + lambda I)^-1, formed on the fly (the cuboid blocks are tiny and L2-resident)
+  // row i of W_a (Hcc + lambda I)^-1, formed on the fly (the cuboid blocks are tiny and L2-resident).  Every operand is requested up
+  // front (fully unrolled, 144 independent loads): as loops of load -> multiply-add this body was a 10 us chain of L2 round trips -- hidden
+  // behind the pair workgroups of a full reduction, but the whole length of the short launch an overlapped reduction starts with
   const double* Wa = wpc_of(g, ca) + i * 9;
   const double* Di = &g.cub_Dinv[(size_t)c * 81];
   const double* Zb = wpc_of(g, cb);
+  double wa[9], di[81], zb[54];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) wa[m] = Wa[m];
+#pragma unroll
+  for (int m = 0; m < 81; ++m) di[m] = Di[m];
+#pragma unroll
+  for (int m = 0; m < 54; ++m) zb[m] = Zb[m];
   double za[9];
+#pragma unroll
   for (int q = 0; q < 9; ++q) {
     double v = 0.0;
-    for (int m = 0; m < 9; ++m) v += Wa[m] * Di[m * 9 + q];
+#pragma unroll
+    for (int m = 0; m < 9; ++m) v += wa[m] * di[m * 9 + q];
     za[q] = v;
   }
   const bool self = qa == qb;
   const int n = g.ld;
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     double m = 0.0;  // M[i][j] = (Za Zb')[i][j]: row index on pose a, column index on pose b
-    for (int q = 0; q < 9; ++q) m += za[q] * Zb[j * 9 + q];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) m += za[q] * zb[j * 9 + q];
     if (self) {
       if (i >= j) acc_add(g, &g.S[(size_t)(cola + j) * n + cola + i], -m);
     } else if (cola > colb) {
@@ -1780,6 +1623,7 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
   if (self) {
     const double* u = &g.HC[(size_t)c * 54 + 45];  // b_c
     double v = 0.0;
+#pragma unroll
     for (int q = 0; q < 9; ++q) v += za[q] * u[q];
     acc_add(g, &g.bs[cola + i], -v);
   }
@@ -1794,7 +1638,11 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
 struct ReducePlan {
   int nb_asm, nb_prep, nb_cubprep, nb_zero;
   int nb_pairs, nb_cubschur;
+  int chunk_hi;  // the pair workgroups of stage 3 reduce the chunks [0, chunk_hi): all of them, or -- overlapped reduction -- those of the
+                 // first column blocks of S (the fused launches of the dense factorisation take the rest, ppo_chol.hip)
 };
+inline PairCtx pair_ctx_host(const Graph& g) { return PairCtx{g.linR, g.F, g.W, g.Dinv, g.ul, g.S, g.bs, g.n_points, g.n_pt_slots, g.ld}; }
+__device__ __forceinline__ PairCtx pair_ctx(const Graph& g) { return PairCtx{g.linR, g.F, g.W, g.Dinv, g.ul, g.S, g.bs, g.n_points, g.n_pt_slots, g.ld}; }
 __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp, ZeroPlan zother) {
   int b = blockIdx.x;
   if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
@@ -1820,12 +1668,12 @@ __global__ __launch_bounds__(256) void k_reduce_stage3(Graph g, PairChunks pc, R
   // the few cuboid workgroups first (a chain of dependent gathers: at the end of the grid they were a 5 us tail behind the pair
   // workgroups); their count is a multiple of 8, so the pair workgroups keep their workgroup -> XCD phase
   if (b < rp.nb_cubschur) { cub_schur_body(g, b); return; }
-  schur_pairs_body(g, pc, b - rp.nb_cubschur, rp.nb_pairs, s_buf);
+  schur_pairs_body<4>(pair_ctx(g), pc, 0, rp.chunk_hi, b - rp.nb_cubschur, rp.nb_pairs, s_buf, [&](double* p, double v) { acc_add(g, p, v); });
 }
 // single-part wrappers (measurement hooks)
 __global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
   __shared__ double s_buf[4][21][65];
-  schur_pairs_body(g, pc, blockIdx.x, gridDim.x, s_buf);
+  schur_pairs_body<4>(pair_ctx(g), pc, 0, pc.n_chunks, blockIdx.x, gridDim.x, s_buf, [&](double* p, double v) { acc_add(g, p, v); });
 }
 
 // Poses and cuboids in ONE launch of 64-thread workgroups: workgroup c < n_cuboids back-substitutes cuboid c (when the cuboids

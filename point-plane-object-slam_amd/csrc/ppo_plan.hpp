@@ -199,20 +199,22 @@ __device__ __forceinline__ void unpack_lower_big(long long t, int& a, int& c) {
   a = (int)r;
   c = (int)(t - r * (r + 1) / 2);
 }
-// one thread per landmark-major slot a: the keys of its pairs (a, b <= a), key = pose_a (pose_a + 1) / 2 + pose_b, at the position the
-// host builder's (landmark, a, b) loop would visit them; a histogram of the keys next to it
+// one thread per landmark-major slot a: the keys of its pairs (a, b <= a) -- down the columns of the lower triangle of the pose-pair
+// matrix, key = pose_b n_free - pose_b (pose_b - 1) / 2 + pose_a - pose_b -- at the position the host builder's (landmark, a, b) loop would
+// visit them; a histogram of the keys next to it
 __global__ __launch_bounds__(256) void k_plan_pair_keys(OwnedLandmarks own, const int32_t* __restrict__ slot_off, const int32_t* __restrict__ slot_col_lm,
                                                         const int32_t* __restrict__ slot_lm_lm, const int32_t* __restrict__ counts, const int32_t* __restrict__ pair_off,
-                                                        uint32_t* __restrict__ key, int32_t* __restrict__ key_count) {
+                                                        uint32_t n_free, uint32_t* __restrict__ key, int32_t* __restrict__ key_count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= counts[0]) return;
   const int l = slot_lm_lm[i], u = own.unit_of(l);
   if (u < 0) return;
   const int s0 = slot_off[l], a = i - s0;
-  const uint32_t pa = (uint32_t)(slot_col_lm[i] / 6), base_key = pa * (pa + 1) / 2;
+  const uint32_t pa = (uint32_t)(slot_col_lm[i] / 6);
   const int base = pair_off[u] + a * (a + 1) / 2;
   for (int b = 0; b <= a; ++b) {
-    const uint32_t k = base_key + (uint32_t)(slot_col_lm[s0 + b] / 6);
+    const uint32_t pb = (uint32_t)(slot_col_lm[s0 + b] / 6);
+    const uint32_t k = pb * n_free - (pb * (pb - 1u)) / 2u + (pa - pb);
     key[base + b] = k;
     atomicAdd(&key_count[k], 1);
   }
@@ -242,8 +244,8 @@ __global__ __launch_bounds__(256) void k_plan_chunk_counts(const int32_t* __rest
   if (k > n_keys) return;
   n_chunks[k] = k < n_keys ? (key_count[k] + chunk - 1) / chunk : 0;
 }
-// chunk headers: key k = pj (pj + 1) / 2 + pi owns the pairs [key_start[k], key_start[k + 1]), cut into chunks of `chunk`
-__global__ __launch_bounds__(256) void k_plan_chunk_fill(const int32_t* __restrict__ key_start, const int32_t* __restrict__ chunk_off, int n_keys, int chunk,
+// chunk headers: key k (column pi, row pj >= pi of the pose-pair matrix) owns the pairs [key_start[k], key_start[k + 1]), cut into chunks of `chunk`
+__global__ __launch_bounds__(256) void k_plan_chunk_fill(const int32_t* __restrict__ key_start, const int32_t* __restrict__ chunk_off, int n_keys, int n_free, int chunk,
                                                          int32_t* __restrict__ pc_colj, int32_t* __restrict__ pc_coli, int32_t* __restrict__ pc_start, int32_t* __restrict__ n_chunks_out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k > n_keys) return;
@@ -252,14 +254,29 @@ __global__ __launch_bounds__(256) void k_plan_chunk_fill(const int32_t* __restri
     *n_chunks_out = chunk_off[n_keys];
     return;
   }
-  int pj, pi;
-  unpack_lower_big(k, pj, pi);
+  // counted from the far end the column-major keys are the packed ROW-major lower triangle of the reversed numbering
+  int ra, rc;
+  unpack_lower_big((long long)n_keys - 1 - k, ra, rc);
+  const int pi = n_free - 1 - ra, pj = n_free - 1 - rc;
   const int c0 = chunk_off[k], c1 = chunk_off[k + 1];
   for (int c = c0; c < c1; ++c) {
     pc_colj[c] = 6 * pj;
     pc_coli[c] = 6 * pi;
     pc_start[c] = key_start[k] + (c - c0) * chunk;
   }
+}
+
+// first chunk of every 64-column block of S (the chunks are ordered by column): cb[c] = number of chunks with coli < 64 c, c = 0 .. nb
+__global__ __launch_bounds__(64) void k_plan_col_blocks(const int32_t* __restrict__ pc_coli, const int32_t* __restrict__ n_chunks, int nb, int32_t* __restrict__ cb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nb) return;
+  int lo = 0, hi = *n_chunks;  // first position with coli >= 64 c
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (pc_coli[mid] < 64 * c) lo = mid + 1;
+    else hi = mid;
+  }
+  cb[c] = lo;
 }
 
 // device-wide helpers over rocPRIM (temporary storage from the block cache; everything on the caller's stream)

@@ -97,6 +97,9 @@ struct ppo_ba_solver {
   DevBuf<double> d_pack;     // sharded runs: lower-triangle tiles of S + b, contiguous, for the all-reduce
   DevBuf<int32_t> d_pc_start, d_pc_colj, d_pc_coli, d_pc_sj, d_pc_si, d_pc_lm;  // pose-pair chunks of the Schur accumulation
   PairChunks pc{};
+  std::vector<int32_t> cb_start;  // [ld / 64 + 1] first pair chunk of every 64-column block of S (the chunks are ordered by column): the overlapped reduction
+  std::vector<int> fin;           // [ld / 64 + 1] its schedule (chol_overlap_schedule); empty: the reduction is never overlapped for this window
+  bool reduce_overlapped = false; // the last launch_reduce left the column blocks [fin[0], ld / 64) of S to the launches of the factorisation
   DevBuf<int32_t> d_po_start, d_po_end, d_po_pose;  // pose-major chunks of the reprojection edges
   PoseChunks posec{};
   DevBuf<double> d_W;
@@ -499,8 +502,11 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
 }
 
 // reduced system for `lambda` into S (lower triangle) / bs      (block_solver.hpp:354-439)
-int launch_reduce(ppo_ba_solver* s, double lambda) {
+int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
   const Graph& g = s->g;
+  // Overlapped reduction (ppo_chol.hip): only the pair chunks of the first column blocks of S are reduced here, the launches of the
+  // factorisation carry the rest.  (One rank, floating-point accumulation, native solver, and a caller that goes straight on to launch_solve.)
+  s->reduce_overlapped = allow_overlap && !s->fin.empty() && s->solver_kind == PPO_SOLVER_NATIVE && !g.det && !s->comm.active();
   const size_t n = g.ld;
   if (!s->S_is_zero) {  // (normally k_update_all of the previous trial has cleared S and b already)
     ZeroPlan zp{};
@@ -516,8 +522,13 @@ int launch_reduce(ppo_ba_solver* s, double lambda) {
   rp.nb_asm = nblk(work, 256);
   rp.nb_prep = nl > 0 ? nblk(nl, 256) : 0;
   rp.nb_cubprep = cub_stage ? nblk(g.n_cuboids, 256) : 0;
-  rp.nb_pairs = (nl > 0 && s->pc.n_chunks > 0) ? (nblk(s->pc.n_chunks, 4) + 7) / 8 * 8 : 0;
+  rp.chunk_hi = s->reduce_overlapped ? s->cb_start[s->fin[0]] : s->pc.n_chunks;
+  rp.nb_pairs = (nl > 0 && rp.chunk_hi > 0) ? (nblk(rp.chunk_hi, 4) + 7) / 8 * 8 : 0;
   rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? (nblk((long)g.n_cub_pairs * 8, 256) + 7) / 8 * 8 : 0;  // (multiple of 8: see k_reduce_stage3)
+  if (const char* e = PPO_DEV_ENV("PPO_BA_STAGE3_PROBE")) {  // timing experiments (WRONG results): 'c' no cuboid pair workgroups, 'p' no pose-pair workgroups
+    if (strchr(e, 'c')) rp.nb_cubschur = 0;
+    if (strchr(e, 'p')) rp.nb_pairs = 0;
+  }
   // ... and, in the same launch, clears the linearisation buffer that is not current: the (speculated) linearisation of the trial
   // state this reduction leads to is written there
   ZeroPlan zother{};
@@ -551,7 +562,13 @@ int launch_solve(ppo_ba_solver* s) {
   const Graph& g = s->g;
   const int n = g.n_red, ld = g.ld;
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
-    RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs_p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
+    if (s->reduce_overlapped) {
+      CholOverlap ov{pair_ctx_host(g), s->pc, s->cb_start.data(), s->fin.data()};
+      RC_TRY(chol_factor_solve_overlapped(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, ov, s->stream));
+      s->reduce_overlapped = false;
+    } else {
+      RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs_p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
+    }
   } else {
     HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs_p, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream));
@@ -693,7 +710,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
   do {
     const double lambda = s->lambda;
     phase_mark(s, PH_SCHUR);
-    RC_TRY(launch_reduce(s, lambda));
+    RC_TRY(launch_reduce(s, lambda, true));
     phase_mark(s, PH_FACTOR);
     RC_TRY(launch_solve(s));
     s->have_system = true;
@@ -1082,9 +1099,10 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     t_stage = s->stage;
     const int chunk = pair_chunk;
     const long nkeys = (long)nfree * (nfree + 1) / 2;
-    // (slot_col is a multiple of 6: pose = col / 6; the row base pj (pj + 1) / 2 of a pair key is looked up per a, not per pair)
-    SVec<int32_t> row_base(nfree + 1);
-    for (long pj = 0; pj <= nfree; ++pj) row_base[pj] = (int32_t)(pj * (pj + 1) / 2);
+    // (slot_col is a multiple of 6: pose = col / 6.  Keys run down the COLUMNS of the lower triangle -- key(pj >= pi) = col_base[pi] + pj - pi
+    //  -- so that the chunks come in the order in which the dense factorisation consumes the columns of S: chol_factor_solve_overlapped)
+    SVec<int32_t> col_base(nfree + 1);
+    for (long pi = 0; pi <= nfree; ++pi) col_base[pi] = (int32_t)(pi * nfree - pi * (pi - 1) / 2);
     // owned landmarks as one unit range: points [pt_first, pt_last) then planes [plane_first, plane_last)
     const int n_own_pt = g.pt_last - g.pt_first, n_own = n_own_pt + (g.plane_last - g.plane_first);
     auto lm_of = [&](int u) { return u < n_own_pt ? g.pt_first + u : Npt + g.plane_first + (u - n_own_pt); };
@@ -1094,8 +1112,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                     for (int u = u0; u < u1; ++u) {
                       const int l = lm_of(u);
                       for (int a = slot_off[l]; a < slot_off[l + 1]; ++a) {
-                        int32_t* const hr = h + row_base[slot_col[a] / 6];
-                        for (int b = slot_off[l]; b <= a; ++b) hr[slot_col[b] / 6]++;
+                        const int pa = slot_col[a] / 6;
+                        for (int b = slot_off[l]; b <= a; ++b) {
+                          const int pb = slot_col[b] / 6;
+                          h[col_base[pb] + pa - pb]++;
+                        }
                       }
                     }
                   },
@@ -1104,10 +1125,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                     for (int u = u0; u < u1; ++u) {
                       const int l = lm_of(u);
                       for (int a = slot_off[l]; a < slot_off[l + 1]; ++a) {
-                        int32_t* const cr = c + row_base[slot_col[a] / 6];
+                        const int pa = slot_col[a] / 6;
                         const int32_t ida = new_id[a];
                         for (int b = slot_off[l]; b <= a; ++b) {
-                          const int32_t pos = cr[slot_col[b] / 6]++;
+                          const int pb = slot_col[b] / 6;
+                          const int32_t pos = c[col_base[pb] + pa - pb]++;
                           pc_sj[pos] = ida;
                           pc_si[pos] = new_id[b];
                           pc_lm[pos] = l;
@@ -1116,8 +1138,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                     }
                   });
     pc_start.push_back(0);
-    for (long pj = 0, k = 0; pj < nfree; ++pj)
-      for (long pi = 0; pi <= pj; ++pi, ++k)
+    for (long pi = 0, k = 0; pi < nfree; ++pi)
+      for (long pj = pi; pj < nfree; ++pj, ++k)
         for (int32_t e = cnt[k]; e < cnt[k + 1]; e += chunk) {
           pc_colj.push_back((int32_t)(6 * pj));
           pc_coli.push_back((int32_t)(6 * pi));
@@ -1391,7 +1413,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream);
   ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_Dinv.alloc((size_t)Nc * 81) && s->d_xc.alloc((size_t)Nc * 9);
   PlanScratch plan_scratch;
-  ScopedDevBuf<int32_t> d_slot_off_lm, d_slot_col_lm, d_new_id, d_slot_lm_lm, d_pair_off, d_npairs, d_key_count, d_key_start, d_nchunks, d_chunk_off, d_n_chunks_out;
+  ScopedDevBuf<int32_t> d_slot_off_lm, d_slot_col_lm, d_new_id, d_slot_lm_lm, d_pair_off, d_npairs, d_key_count, d_key_start, d_nchunks, d_chunk_off, d_n_chunks_out, d_cb;
   ScopedDevBuf<int32_t> d_pl_off, d_pl_perm, d_pl_pose, d_seg, d_seg_cnt, d_counts;
   ScopedDevBuf<uint32_t> d_pose_key, d_pose_key_out, d_pair_key, d_pair_key_out, d_pair_perm, d_slot_key, d_slot_key_out, d_slot_order;
   int32_t* h_n_chunks = nullptr;  // (page-locked: the device's chunk count comes back with the final synchronisation)
@@ -1399,6 +1421,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     ok = ok && s->d_pc_start.upload(pc_start, s->stream) && s->d_pc_colj.upload(pc_colj, s->stream) && s->d_pc_coli.upload(pc_coli, s->stream);
     ok = ok && s->d_pc_sj.upload(pc_sj, s->stream) && s->d_pc_si.upload(pc_si, s->stream) && s->d_pc_lm.upload(pc_lm, s->stream);
     s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, (int)pc_colj.size()};
+    s->cb_start.assign(g.ld / 64 + 1, 0);
+    for (int c = 0; c <= g.ld / 64; ++c) s->cb_start[c] = (int32_t)(std::lower_bound(pc_coli.begin(), pc_coli.end(), (int32_t)(64 * c)) - pc_coli.begin());
   } else {
     // ---- device builder (ppo_plan.hpp): records + flags, pose-major index lists, Schur pair plan ------------------------------------
     // (landmark, pose) slots: gather + sort + unique per landmark, scan, compact, pose-major numbering by a stable sort
@@ -1470,7 +1494,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       if (!plan_exclusive_scan(plan_scratch, d_npairs.p, d_pair_off.p, (size_t)own.n_own + 1, s->stream)) return fail(PPO_BA_ERR_NOMEM);
       if (n_slot_bound > 0)
         hipLaunchKernelGGL(k_plan_pair_keys, dim3(nblk(n_slot_bound, 256)), dim3(256), 0, s->stream, own, d_slot_off_lm.p, d_slot_col_lm.p, d_slot_lm_lm.p, d_counts.p, d_pair_off.p,
-                           d_pair_key.p, d_key_count.p);
+                           (uint32_t)nfree, d_pair_key.p, d_key_count.p);
       if (n_pairs > 0) {
         hipLaunchKernelGGL(k_plan_fill_u32, dim3(nblk(n_pairs, 256)), dim3(256), 0, s->stream, d_pair_key.p, d_pair_off.p + own.n_own, (int)n_pairs, (uint32_t)nkeys);
         if (!plan_sort_positions(plan_scratch, d_pair_key.p, d_pair_key_out.p, d_pair_perm.p, (size_t)n_pairs, plan_bits((unsigned long long)nkeys), s->stream)) return fail(PPO_BA_ERR_NOMEM);
@@ -1481,12 +1505,17 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       if (!plan_exclusive_scan(plan_scratch, d_key_count.p, d_key_start.p, (size_t)nkeys + 1, s->stream) ||
           !plan_exclusive_scan(plan_scratch, d_nchunks.p, d_chunk_off.p, (size_t)nkeys + 1, s->stream))
         return fail(PPO_BA_ERR_NOMEM);
-      hipLaunchKernelGGL(k_plan_chunk_fill, dim3(nblk(nkeys + 1, 256)), dim3(256), 0, s->stream, d_key_start.p, d_chunk_off.p, (int)nkeys, pair_chunk, s->d_pc_colj.p, s->d_pc_coli.p,
+      hipLaunchKernelGGL(k_plan_chunk_fill, dim3(nblk(nkeys + 1, 256)), dim3(256), 0, s->stream, d_key_start.p, d_chunk_off.p, (int)nkeys, (int)nfree, pair_chunk, s->d_pc_colj.p, s->d_pc_coli.p,
                          s->d_pc_start.p, d_n_chunks_out.p);
     }
-    h_n_chunks = static_cast<int32_t*>(s->stage->take(4 * sizeof(int32_t)));  // [0] chunks, [1] slots, [2] point slots
-    if (!h_n_chunks) return fail(PPO_BA_ERR_NOMEM);
-    h_n_chunks[0] = h_n_chunks[1] = h_n_chunks[2] = 0;
+    const int n_cb = g.ld / 64 + 1;
+    h_n_chunks = static_cast<int32_t*>(s->stage->take((4 + (size_t)n_cb) * sizeof(int32_t)));  // [0] chunks, [1] slots, [2] point slots, [4 ..] first chunk of every column block
+    if (!h_n_chunks || !d_cb.alloc(n_cb)) return fail(PPO_BA_ERR_NOMEM);
+    for (int i = 0; i < 4 + n_cb; ++i) h_n_chunks[i] = 0;
+    if (own.n_own > 0 && nkeys > 0) {
+      hipLaunchKernelGGL(k_plan_col_blocks, dim3(nblk(n_cb, 64)), dim3(64), 0, s->stream, s->d_pc_coli.p, d_n_chunks_out.p, n_cb - 1, d_cb.p);
+      if (hipMemcpyAsync(h_n_chunks + 4, d_cb.p, (size_t)n_cb * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(PPO_BA_ERR_HIP);
+    }
     // (never HIP_TRY / RC_TRY once `s` exists: a plain return would leak the half-built solver and leave t_creating dangling)
     if (hipMemcpyAsync(h_n_chunks, d_n_chunks_out.p, sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(PPO_BA_ERR_HIP);
     if (hipMemcpyAsync(h_n_chunks + 1, d_counts.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(PPO_BA_ERR_HIP);
@@ -1565,10 +1594,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (reset_device(s) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
   if (dev_plan) {  // (reset_device has synchronised the stream: the plan is complete, its temporaries can go back to the block cache)
     s->pc.n_chunks = h_n_chunks[0];
+    s->cb_start.assign(h_n_chunks + 4, h_n_chunks + 4 + s->g.ld / 64 + 1);
     s->g.n_slots = h_n_chunks[1];
     s->g.n_pt_slots = h_n_chunks[2];
     plan_scratch.release();
-    for (DevBuf<int32_t>* b : {&d_slot_off_lm, &d_slot_col_lm, &d_new_id, &d_slot_lm_lm, &d_pair_off, &d_npairs, &d_key_count, &d_key_start, &d_nchunks, &d_chunk_off, &d_n_chunks_out,
+    for (DevBuf<int32_t>* b : {&d_slot_off_lm, &d_slot_col_lm, &d_new_id, &d_slot_lm_lm, &d_pair_off, &d_npairs, &d_key_count, &d_key_start, &d_nchunks, &d_chunk_off, &d_n_chunks_out, &d_cb,
                                &d_raw_mono_pose, &d_raw_mono_point, &d_raw_stereo_pose, &d_raw_stereo_point, &d_pl_off, &d_pl_perm, &d_pl_pose, &d_seg, &d_seg_cnt, &d_counts}) b->release();
     for (DevBuf<uint32_t>* b : {&d_pose_key, &d_pose_key_out, &d_pair_key, &d_pair_key_out, &d_pair_perm, &d_slot_key, &d_slot_key_out, &d_slot_order}) b->release();
     for (DevBuf<double>* b : {&d_raw_mono_obs, &d_raw_mono_info, &d_raw_mono_huber, &d_raw_stereo_obs, &d_raw_stereo_info, &d_raw_stereo_huber}) b->release();
@@ -1580,6 +1610,21 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     std::fprintf(stderr, "[ppo_ba] create: page-locked staging held by this handle %.1f MB (%.1f MB used)\n", cap / 1e6, used / 1e6);
   }
 
+  {  // schedule of the overlapped reduction (ppo_chol.hip): worth its bookkeeping when the factorisation has enough launches to hide the pair chunks in
+    // (measured, tools/overlap_ab.sh: config 4, 19 panels, 0.412 -> 0.388 ms per LM iteration; config 3, 10 panels, 0.231 -> 0.224; config 2, 5 panels, no difference)
+    const int nb = s->g.ld / 64;
+    int first_blocks = 1, min_chunks = 2048, min_nb = 8;
+    double share0 = 0.14, share = 0.10;
+    bool enabled = true;
+    if (const char* e = PPO_DEV_ENV("PPO_BA_OVERLAP")) {  // development aid: "0" = off, or "first_blocks,share0,share[,min_chunks[,min_nb]]"
+      if (e[0] == '0' && e[1] == 0) enabled = false;
+      else std::sscanf(e, "%d,%lf,%lf,%d,%d", &first_blocks, &share0, &share, &min_chunks, &min_nb);
+    }
+    if (enabled && nb >= std::max(2, min_nb) && (int)s->cb_start.size() == nb + 1 && s->cb_start[nb] == s->pc.n_chunks && s->pc.n_chunks >= std::max(1, min_chunks)) {
+      s->fin.assign(nb + 1, nb);
+      chol_overlap_schedule(nb, s->cb_start.data(), first_blocks, share0, share, s->fin.data());
+    }
+  }
   // algorithmic bytes of one linearisation, SURVEY.md 8(d)
   {
     long n_vp = 0;
@@ -1977,6 +2022,7 @@ int ppo_ba_debug_reduced(ppo_ba_handle s, double* S, double* b, double* x, int32
   }
   if (b) HIP_TRY(hipMemcpy(b, s->d_bs_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   if (x) {
+    if (PPO_DEV_ENV("PPO_BA_DEBUG_OVERLAP")) RC_TRY(launch_reduce(s, lambda, true));  // (test hook: x through the overlapped reduction, S and b above through the plain one)
     RC_TRY(launch_solve(s));
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(x, s->d_xr.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));

@@ -964,6 +964,86 @@ def test_device_built_plans_equal_the_host_built_ones(hip_hooks, monkeypatch):
             assert abs(sa["iters"][-1]["chi2_after"] - sb["iters"][-1]["chi2_after"]) <= 1e-7 * sa["iters"][-1]["chi2_after"]
 
 
+@pytest.mark.parametrize("cfg,kw", [("cfg4", dict(seed=1)), ("cfg3", dict(seed=3, stereo_frac=0.25, with_corners=True, fixed_observer_frac=0.1))])
+def test_overlapped_reduction_equals_the_plain_one(hip_hooks, monkeypatch, cfg, kw):
+    """The Schur pair reduction is OVERLAPPED with the dense factorisation (csrc/ppo_chol.hip, StepOverlap): only the pair chunks of the
+    first column blocks of S are reduced ahead of it, the launches of the first panels carry the rest as extra workgroups, trailing tiles
+    those may be adding to take their update as atomic adds, the right-hand side is solved in place.  Sums in another order, nothing else:
+    the plain reduction (test-hooks library, PPO_BA_OVERLAP=0) and three schedules -- the default, one column block per launch, and a
+    late start with large slices -- must walk the same LM history and end in the same state to round-off."""
+    P = synth.make_problem(cfg, **kw)
+    res = []
+    for ov in ("0", None, "1,0.0,0.0,0,2", "3,0.4,0.4,0,2"):
+        if ov is None:
+            monkeypatch.delenv("PPO_BA_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("PPO_BA_OVERLAP", ov)
+        s = hip_hooks.create(P, B.default_options())
+        st = s.run()
+        res.append((st, s.read()))
+        s.close()
+    (sa, ra) = res[0]
+    for (sb, rb) in res[1:]:
+        assert [(i["trials"], i["accepted"]) for i in sa["iters"]] == [(i["trials"], i["accepted"]) for i in sb["iters"]]
+        # (tools/overlap_diff.py: two PLAIN runs of config 4 differ by 1e-11 in the first iterations and by 3e-9 in the last ones -- floating-point
+        #  atomics, amplified along the flat directions of the window; the overlapped schedules stay within a few times that: 1e-10, 3e-8)
+        for k, (ia, ib) in enumerate(zip(sa["iters"], sb["iters"])):
+            assert abs(ia["chi2_after"] - ib["chi2_after"]) <= (2e-9 if k < 5 else 2e-7) * ia["chi2_after"], k
+        np.testing.assert_allclose(ra.pose_qt, rb.pose_qt, atol=2e-7)
+        d = np.linalg.norm(ra.point_xyz - rb.point_xyz, axis=1)  # (a few landmarks left with one active observation move by 1e-5: flat directions)
+        assert np.sqrt(np.mean(d ** 2)) < 1e-6 and np.quantile(d, 0.99) < 1e-5  # (a tenth of BASELINE.md's bars against the oracle)
+        assert np.mean(ra.mono_level != rb.mono_level) < 1e-4
+
+
+def _reduced_solution(hip_hooks, solver):
+    lib = hip_hooks.lib
+    n = C.c_int32()
+    lib.ppo_ba_debug_set_lambda.argtypes = [C.c_void_p, C.c_double]
+    assert lib.ppo_ba_debug_set_lambda(solver.h, 10.0) == 0  # (of the order of the first lambda of these windows: 1e-5 max diag H)
+    assert lib.ppo_ba_debug_reduced(solver.h, None, None, None, C.byref(n)) == 0
+    x = np.zeros(n.value)
+    assert lib.ppo_ba_debug_reduced(solver.h, None, None, x.ctypes.data_as(B.c_dp), None) == 0
+    return x
+
+
+def test_overlapped_reduction_solves_the_same_system_on_randomly_structured_windows(hip_hooks, monkeypatch):
+    """The sharp form of the test above, without fifteen LM iterations amplifying round-off: ONE reduced system, solved through the plain
+    reduction and through the overlapped one (test hook PPO_BA_DEBUG_OVERLAP), on windows of random size and composition that the
+    overlapped path would not normally take (two to six 64-column blocks; fixed points, fixed observers, stereo, planes with vertical /
+    parallel edges, cuboids with corners, empty classes, both elimination modes -- tools/random_sweep.py) and on configurations 3 and 4:
+    the pose updates agree to 1e-9 of their norm, in every schedule."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("random_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "random_sweep.py"))
+    rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rs)
+    cases = []
+    for seed in range(5100, 5130):
+        cfg, kw, elim = rs.random_case(seed)
+        cfg["n_kf"] += 22 + (seed % 3) * 10  # (25 .. 65 keyframes)
+        cfg["n_points"] *= 3
+        cases.append((cfg, kw, elim))
+    cases += [("cfg3", dict(seed=3, stereo_frac=0.25, with_corners=True, fixed_observer_frac=0.1), 1), ("cfg4", dict(seed=1), 1), ("cfg4", dict(seed=2), 0)]
+    worst = 0.0
+    for cfg, kw, elim in cases:
+        P = synth.make_problem(cfg, **kw)
+        xs = []
+        for ov, dbg in (("0", None), ("1,0.0,0.0,0,2", "1"), ("1,0.14,0.10,0,2", "1"), ("2,0.5,0.3,0,2", "1")):
+            monkeypatch.setenv("PPO_BA_OVERLAP", ov)
+            if dbg:
+                monkeypatch.setenv("PPO_BA_DEBUG_OVERLAP", dbg)
+            else:
+                monkeypatch.delenv("PPO_BA_DEBUG_OVERLAP", raising=False)
+            s = hip_hooks.create(P, B.default_options(eliminate_cuboids=elim))
+            xs.append(_reduced_solution(hip_hooks, s))
+            s.close()
+        assert np.all(np.isfinite(xs[0])) and np.linalg.norm(xs[0]) > 0
+        for x in xs[1:]:
+            dev = np.linalg.norm(x - xs[0]) / np.linalg.norm(xs[0])
+            worst = max(worst, dev)
+            assert dev < 1e-9, (cfg, kw, elim, dev)
+    print("worst relative deviation of the pose update: %.1e" % worst)
+
+
 def test_device_builder_on_randomly_structured_windows(hip_hooks, monkeypatch):
     """The device-side builder of slots, records and plans (csrc/ppo_plan.hpp) normally takes only large windows; the test-hooks library
     lets it take everything (PPO_BA_DEV_PLAN_MIN=0).  40 windows of random size and composition -- fixed points, fixed observers,
