@@ -448,11 +448,130 @@ __device__ __forceinline__ void step_pairs(const StepOverlap& ov, int bid, doubl
   schur_pairs_body<kStepThreads / 64>(ov.ctx, ov.pc, ov.chunk_lo, ov.chunk_hi, bid, ov.npair_wg, s_buf, [](double* p, double v) { atomicAdd(p, v); });
 }
 
+// ---- explicit inverses for the backward substitution ---------------------------------------------------------------------------
+// The backward substitution is a chain of n / 64 hand-offs (chol_back_all); with the diagonal block's factor L_kk alone every link is
+// "subtract L_{k+1,k}^T x_{k+1}, then a 64-step triangular sweep" (1.0 us of arithmetic behind a 0.5 us hand-off).  Launch k + 1 of the
+// forward phase therefore carries ONE extra workgroup that has the whole launch (13 us, 200 CUs idle) to form
+//   T_k = L_kk^-1   and   M_k = L_{k+1,k} T_k ,
+// after which a link of the chain is x_k = T_k^T (y_k - sum_{i > k+1} L_ik^T x_i) - M_k^T x_{k+1}: the first term is ready before x_{k+1}
+// arrives, the second is ONE 64 x 64 matrix-vector product out of registers.  (Block n/64 - 1, the head of the chain, keeps the sweep.)
+// T and M are stored row-major ([row of T / of block k+1][column = row of x_k]) so that lane r reads its column with coalesced loads.
+constexpr size_t kInvDoubles = 2 * (size_t)NB * NB;  // per block: T then M
+__device__ __forceinline__ void inv_block_wg(const double* __restrict__ A, int ld, int kp, double* __restrict__ inv_out, StepLds& L) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+  double (*const sL)[LP] = L.sL;   // L_kk (lower), row-major
+  double (*const sTm)[UP] = L.sP;  // T, row-major ( = k-major operand of the product below)
+  double (*const sL1)[UP] = L.sQ;  // L_{k+1,k}, k-major: sL1[m][row]
+  double (*const sX)[LP] = L.sB;   // scratch of the block recursion
+  double* const dinv = &L.sId[0][0];
+  {
+    d2 ta[4], tb[4];  // element pair p = tid + 512 i: column p >> 5, rows 2 (p & 31), +1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + 512 * i, c = p >> 5, r = 2 * (p & 31);
+      ta[i] = *reinterpret_cast<const d2*>(&A[(size_t)(kp + c) * ld + kp + r]);
+      tb[i] = *reinterpret_cast<const d2*>(&A[(size_t)(kp + c) * ld + kp + NB + r]);
+    }
+    for (int i = tid; i < NB * UP; i += 512) (&sTm[0][0])[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + 512 * i, c = p >> 5, r = 2 * (p & 31);
+      sL[r][c] = (r >= c) ? ta[i].x : 0.0;
+      sL[r + 1][c] = (r + 1 >= c) ? ta[i].y : 0.0;
+      *reinterpret_cast<d2*>(&sL1[c][r]) = tb[i];
+    }
+  }
+  __syncthreads();
+  if (tid < NB) dinv[tid] = 1.0 / sL[tid][tid];
+  __syncthreads();
+  // T = L_kk^-1 by block recursion (a lane-per-column substitution over all 64 rows is 2 016 dependent multiply-adds behind LDS reads:
+  // 25 us, longer than the launch it is meant to hide in).
+  // level 0: the four 16 x 16 diagonal blocks at once on one wave -- lane (b, c) solves column c of block b, 120 multiply-adds
+  if (wave == 0) {
+    const int o = 16 * (lane >> 4), c = lane & 15;
+    double t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double a0 = (r == c) ? 1.0 : 0.0, a1 = 0.0;
+#pragma unroll
+      for (int m = 0; m + 1 < r; m += 2) {
+        a0 = __builtin_fma(-sL[o + r][o + m], t[m], a0);
+        a1 = __builtin_fma(-sL[o + r][o + m + 1], t[m + 1], a1);
+      }
+      if (r & 1) a0 = __builtin_fma(-sL[o + r][o + r - 1], t[r - 1], a0);
+      t[r] = (a0 + a1) * dinv[o + r];
+      sTm[o + r][o + c] = t[r];
+    }
+  }
+  __syncthreads();
+  // level 1: T(hi, lo) = -T(hi, hi) (L(hi, lo) T(lo, lo)) for the 16-blocks (1, 0) and (3, 2): one output per thread
+  {
+    const int hi = 16 * (2 * (tid >> 8) + 1), lo = hi - 16, rr = (tid >> 4) & 15, cc = tid & 15;
+    double v = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v = __builtin_fma(sL[hi + rr][lo + m], sTm[lo + m][lo + cc], v);
+    sX[hi + rr][lo + cc] = v;
+    __syncthreads();
+    double w = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) w = __builtin_fma(sTm[hi + rr][hi + m], sX[hi + m][lo + cc], w);
+    __syncthreads();
+    sTm[hi + rr][lo + cc] = -w;
+  }
+  __syncthreads();
+  // level 2: the 32 x 32 block T(1, 0) = -T(1, 1) (L(1, 0) T(0, 0)): two outputs per thread
+  {
+    const int rr = tid >> 5, cc = tid & 31;
+    double v0 = 0.0, v1 = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < 32; ++m) {
+      const double tv = sTm[m][cc];
+      v0 = __builtin_fma(sL[32 + rr][m], tv, v0);
+      v1 = __builtin_fma(sL[48 + rr][m], tv, v1);
+    }
+    sX[32 + rr][cc] = v0;
+    sX[48 + rr][cc] = v1;
+    __syncthreads();
+    double w0 = 0.0, w1 = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < 32; ++m) {
+      const double xv = sX[32 + m][cc];
+      w0 = __builtin_fma(sTm[32 + rr][32 + m], xv, w0);
+      w1 = __builtin_fma(sTm[48 + rr][32 + m], xv, w1);
+    }
+    __syncthreads();
+    sTm[32 + rr][cc] = -w0;
+    sTm[48 + rr][cc] = -w1;
+  }
+  __syncthreads();
+  double* const To = inv_out;
+  double* const Mo = inv_out + (size_t)NB * NB;
+  if (wave >= 4) {  // T out (row-major), while waves 0..3 form M
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = (tid - 256) + 256 * i;
+      To[e] = sTm[e >> 6][e & 63];
+    }
+    return;
+  }
+  // M = L_{k+1,k} T on the matrix cores, as M^T = T^T L_{k+1,k}^T: both operands are k-major as they lie ([m][r'] and [m][c']), and the
+  // 16 consecutive lanes of an accumulator hold 16 consecutive r' of one row c' -- the row-major layout the backward substitution reads
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  v4d acc[2][2] = {};
+  quadrant_product(sTm, sL1, wr, wc, li, lk, acc);
+#pragma unroll
+  for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+    for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Mo[(size_t)(wc + 16 * jc + lk + 4 * reg) * NB + wr + 16 * ir + li] = acc[jc][ir][reg];
+}
+
 // OV = false: the launch carries no pair workgroups and no tile takes atomic updates (ov is not read) -- the plain factorisation and the
 // later launches of an overlapped one; as ONE kernel the pair code's registers (240 against 182) and arguments cost every launch 0.4 us.
 template <bool OV>
 __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info,
-                                                            int inplace_rhs, StepOverlap ov) {
+                                                            int inplace_rhs, double* __restrict__ inv, StepOverlap ov) {
   constexpr int NT = kStepThreads, NI = 2048 / NT;
   __shared__ StepLdsU lds;
   double (*const sL)[LP] = lds.a.sL;
@@ -468,18 +587,24 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
   const bool upd = k0 > 0;
   STAMP(0);
   const int ncol = 1 + 2 * (m - 1);  // column workgroups of this launch
-  int npair_wg = 0;
-  if constexpr (OV) npair_wg = ov.npair_wg;
-  if (OV && (int)blockIdx.x >= ncol && (int)blockIdx.x < ncol + npair_wg) {
-    // ---- pair workgroup of an overlapped reduction: S -= W_j (D_l + lambda I)^-1 W_i' for chunks of column blocks that are not final yet
-    // (right behind the column workgroups in the grid: they are the long ones of the launch's shadow, the trailing tiles fill in)
-    step_pairs(ov, (int)blockIdx.x - ncol, lds.pairs);
+  const int ninv = (inv != nullptr && upd) ? 1 : 0;
+  if (ninv && (int)blockIdx.x == ncol) {
+    // ---- T and M of the PREVIOUS panel's block for the backward substitution (first behind the column workgroups: the longest of the rest)
+    inv_block_wg(A, ld, kp, inv + (size_t)(kp / NB) * kInvDoubles, lds.a);
     return;
   }
-  if ((int)blockIdx.x >= ncol) {
+  int npair_wg = 0;
+  if constexpr (OV) npair_wg = ov.npair_wg;
+  if (OV && (int)blockIdx.x >= ncol + ninv && (int)blockIdx.x < ncol + ninv + npair_wg) {
+    // ---- pair workgroup of an overlapped reduction: S -= W_j (D_l + lambda I)^-1 W_i' for chunks of column blocks that are not final yet
+    // (right behind the column workgroups in the grid: they are the long ones of the launch's shadow, the trailing tiles fill in)
+    step_pairs(ov, (int)blockIdx.x - ncol - ninv, lds.pairs);
+    return;
+  }
+  if ((int)blockIdx.x >= ncol + ninv) {
     // ---- trailing tile (bi >= bj >= 1 relative to block k) --------------------------------------------------------------
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    int t = blockIdx.x - ncol - npair_wg, bi = 0;
+    int t = blockIdx.x - ncol - ninv - npair_wg, bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     const int bj = t - bi * (bi + 1) / 2;
     const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
@@ -710,90 +835,178 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
 __device__ __forceinline__ double load_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(256) void chol_back_all(const double* __restrict__ A, int ld, const double* __restrict__ y, double* x, int* __restrict__ info, int* flags,
-                                                     int nflags) {
+constexpr int kBackThreads = 320;  // four compute waves + the polling wave
+constexpr int kRing = 32;          // blocks of x the polling wave may run ahead of the slowest compute wave
+__global__ __launch_bounds__(kBackThreads) void chol_back_all(const double* __restrict__ A, int ld, const double* __restrict__ y, double* x, int* __restrict__ info, int* flags,
+                                                              int nflags, const double* __restrict__ inv) {
   __shared__ double sL[NB][LP];
   __shared__ double sV[NB];
+  __shared__ double sXr[kRing][NB];  // x_i as the polling wave saw them, slot i % kRing
+  __shared__ int s_seen;             // smallest i with x_i in the ring
+  __shared__ int s_prog[4];          // smallest i compute wave w has finished reading
+  __shared__ int s_red, s_dead;
   // every eighth workgroup works: workgroups are dealt to the 8 XCDs round-robin, so the whole pipeline sits behind ONE L2
   if (blockIdx.x & 7) {
     // the others have nothing to do in the product build (nflags = 0); in the test-hooks build they re-arm the hand-off flags of
     // the one-launch experiment for the next solve
     const int w = (blockIdx.x >> 3) * 7 + (blockIdx.x & 7) - 1, nw = (gridDim.x >> 3) * 7;
-    for (int i = w * 256 + threadIdx.x; i < nflags; i += nw * 256) flags[i] = 0;
+    for (int i = w * kBackThreads + threadIdx.x; i < nflags; i += nw * kBackThreads) flags[i] = 0;
     return;
   }
-  const int tid = threadIdx.x, j = blockIdx.x >> 3, nb = ld / NB, k0 = j * NB;
-  const int c = tid >> 2, part = tid & 3;  // 4 threads per column of block j, 16 rows of block i each
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = blockIdx.x >> 3, nb = ld / NB, k0 = j * NB;
+  const int c = (tid & 255) >> 2, part = tid & 3;  // compute waves: 4 threads per column of block j, 16 rows of block i each
+  // With T_j = L_jj^-1 and M_j = L_{j+1,j} T_j from the forward phase (inv_block_wg) the link of the chain is
+  //   x_j = T_j^T (y_j - sum_{i > j+1} L_ij^T x_i) - M_j^T x_{j+1};
+  // the head of the chain (block nb - 1, nothing to wait for) and a solve without the inverses keep the triangular sweep.
+  const bool use_inv = inv != nullptr && j < nb - 1;
+  const int i_last = use_inv ? j + 2 : j + 1;  // blocks i >= i_last are subtracted as L_ij^T x_i
+  volatile int* const v_seen = &s_seen;
+  volatile int* const v_prog = s_prog;
+  volatile int* const v_red = &s_red;
+  if (tid == 0) { s_seen = nb; s_red = 0; s_dead = 0; }
+  if (tid < 4) s_prog[tid] = nb;
+  if (wave == 4) {
+    // ---- the polling wave.  Hand-off is by data-tagged granules; a poll is ONE request of 512 bytes by the whole wave (the first lane-0-then-
+    // reload scheme paid two memory round trips, 0.4 us each, per block); it backs off with its distance from the pipeline front (25
+    // workgroups polling flat out made a hop 5 us) and runs ahead of the compute waves through a ring in LDS, so that what a compute wave
+    // does with x_i never delays the moment x_{i-1} is seen.
+    __syncthreads();
+    bool dead = false;
+#pragma unroll 1
+    for (int i = nb - 1; i > j; --i) {
+      if (i + kRing <= nb - 1) {  // the slot still holds block i + kRing: wait until every compute wave is through with it
+        while (max(max(v_prog[0], v_prog[1]), max(v_prog[2], v_prog[3])) > i + kRing) __builtin_amdgcn_s_sleep(2);
+      }
+      const double* xi = &x[(size_t)i * NB];
+      const int nap = min(i - j - 1, 24);
+      double v = load_sc1(&xi[lane]);
+      int spins = 0;
+      while (!dead && __any((unsigned long long)__double_as_longlong(v) == kSentinel)) {
+        if (++spins > kSpinCap) { dead = true; break; }
+        for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(4);
+        v = load_sc1(&xi[lane]);
+      }
+      sXr[i & (kRing - 1)][lane] = v;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) {
+        if (dead) s_dead = 1;
+        *v_seen = i;
+      }
+    }
+    return;
+  }
   // ---- everything that does not depend on other workgroups is fetched first
   d2 td[8];
-  load_tile(&A[(size_t)k0 * ld + k0], ld, td);
+  double trow[16];  // use_inv: T_j[16 wave + q][lane] -- this wave's share of c_j = T_j^T v (its 16 columns of block j are the 16 rows of T_j)
+  if (use_inv) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) trow[q] = inv[(size_t)j * kInvDoubles + (size_t)(16 * wave + q) * NB + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(trow[q]));  // (requested HERE: the compiler had moved these loads behind the loop, 1 - 3 us onto the chain)
+  } else {
+    load_tile(&A[(size_t)k0 * ld + k0], ld, td);
+  }
   double acc = (part == 0) ? y[k0 + c] : 0.0;
   d2 lnext[8];
-  if (nb - 1 > j) {
+  if (nb - 1 >= i_last) {
     const d2* col = reinterpret_cast<const d2*>(&A[(size_t)(k0 + c) * ld + (size_t)(nb - 1) * NB + part * 16]);
 #pragma unroll
     for (int r = 0; r < 8; ++r) lnext[r] = col[r];
   }
+  double mrow[16];  // use_inv: M_j[16 wave + q][lane] -- this wave's share of M_j^T x_{j+1}
+  if (use_inv) {
+    const double* Mj = &inv[(size_t)j * kInvDoubles + (size_t)NB * NB];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = tid + 256 * i, cc = p >> 5, r = 2 * (p & 31);
-    sL[r][cc] = (r >= cc) ? td[i].x : 0.0;
-    sL[r + 1][cc] = (r + 1 >= cc) ? td[i].y : 0.0;
+    for (int q = 0; q < 16; ++q) mrow[q] = Mj[(size_t)(16 * wave + q) * NB + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(mrow[q]));  // (the same)
   }
-  __shared__ double sX[2][NB];
-  __syncthreads();
-  double lcol[NB], inv = 1.0;
-  if (tid < NB) bwd_load_64(sL, lcol, inv);
-  bool timeout = false;
+  if (!use_inv) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = tid + 256 * i, cc = p >> 5, r = 2 * (p & 31);
+      sL[r][cc] = (r >= cc) ? td[i].x : 0.0;
+      sL[r + 1][cc] = (r + 1 >= cc) ? td[i].y : 0.0;
+    }
+  }
+  __syncthreads();  // (the only workgroup barrier: the polling wave joins it before its first poll)
 #pragma unroll 1
-  for (int i = nb - 1; i > j; --i) {
+  for (int i = nb - 1; i >= i_last; --i) {
     d2 lcur[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) lcur[r] = lnext[r];
-    if (i - 1 > j) {
+    if (i - 1 >= i_last) {
       const d2* col = reinterpret_cast<const d2*>(&A[(size_t)(k0 + c) * ld + (size_t)(i - 1) * NB + part * 16]);
 #pragma unroll
       for (int r = 0; r < 8; ++r) lnext[r] = col[r];
     }
-    if (tid < NB) {
-      // Pollers cost memory-side bandwidth (25 workgroups x 64 lanes spinning made a hop 5 us): ONE lane per workgroup
-      // spins on one granule, backing off with its distance from the pipeline front; then the wave reads all 64 and
-      // re-reads the stragglers (the 64 stores of a block are not ordered among themselves).
-      const double* xi = &x[(size_t)i * NB];
-      int spins = 0;
-      if (tid == 0) {
-        const int nap = min(i - j - 1, 24);
-        while ((unsigned long long)__double_as_longlong(load_sc1(xi)) == kSentinel) {
-          if (++spins > kSpinCap) break;
-          __builtin_amdgcn_s_sleep(1);
-          for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(4);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      double v = load_sc1(&xi[tid]);
-      while ((unsigned long long)__double_as_longlong(v) == kSentinel) {
-        if (++spins > kSpinCap) { timeout = true; break; }
-        __builtin_amdgcn_s_sleep(1);
-        v = load_sc1(&xi[tid]);
-      }
-      sX[i & 1][tid] = v;
-    }
+    while (*v_seen > i) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (i < 10) STAMPB(20 + i);
-    __syncthreads();
-    const double* xs = &sX[i & 1][part * 16];
+    const double* xs = &sXr[i & (kRing - 1)][part * 16];
+    double xv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xv[r] = xs[r];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      acc = __builtin_fma(-lcur[r].x, xs[2 * r], acc);
-      acc = __builtin_fma(-lcur[r].y, xs[2 * r + 1], acc);
+      acc = __builtin_fma(-lcur[r].x, xv[2 * r], acc);
+      acc = __builtin_fma(-lcur[r].y, xv[2 * r + 1], acc);
     }
+    if (lane == 0) v_prog[wave] = i;  // (LDS operations of a wave execute in order: the reads above are done)
   }
+  STAMPB(35);
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
-  if (part == 0) sV[c] = acc;
-  if (timeout) atomicMax(info, 1 << 30);
-  __syncthreads();
-  STAMPB(30);
-  if (tid < 64) store_sc1(&x[k0 + tid], bwd_vec_64(sV[tid], lcol, inv));
+  double xj;
+  if (use_inv) {
+    // Every wave forms its 16 terms of c_j = T_j^T v (column 16 wave + q of block j sits in lane 4 q) for all 64 rows -- ready before
+    // x_{j+1} shows up -- and then its 16 terms of M_j^T x_{j+1}; wave 0 adds the eight partial vectors.  (One wave holding a whole
+    // column of M_j in registers spilled: 256 registers per wave with five waves in the workgroup.)
+    double (*const sC)[NB] = reinterpret_cast<double (*)[NB]>(&sL[0][0]);  // [0..3] partial c_j, [4..7] partial M_j^T x_{j+1} (sL is free in this mode)
+    double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      p0 = __builtin_fma(trow[q], bcast(acc, 4 * q), p0);
+      p1 = __builtin_fma(trow[q + 1], bcast(acc, 4 * q + 4), p1);
+    }
+    sC[wave][lane] = p0 + p1;
+    STAMPB(36);
+    STAMPB(32);
+    while (*v_seen > j + 1) __builtin_amdgcn_s_sleep(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    STAMPB(33);
+    const double* xn = &sXr[(j + 1) & (kRing - 1)][16 * wave];
+    double xv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xv[q] = xn[q];
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      m0 = __builtin_fma(mrow[q], xv[q], m0);
+      m1 = __builtin_fma(mrow[q + 1], xv[q + 1], m1);
+    }
+    sC[4 + wave][lane] = m0 + m1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(&s_red, 1);
+    if (wave != 0) return;
+    while (*v_red < 4) __builtin_amdgcn_s_sleep(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    STAMPB(30);
+    xj = ((sC[0][tid] + sC[1][tid]) + (sC[2][tid] + sC[3][tid])) - ((sC[4][tid] + sC[5][tid]) + (sC[6][tid] + sC[7][tid]));
+    STAMPB(34);
+  } else {
+    if (part == 0) sV[c] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(&s_red, 1);
+    if (wave != 0) return;
+    while (*v_red < 4) __builtin_amdgcn_s_sleep(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double lcol[NB], inv_d = 1.0;  // lane r: the pre-scaled column r of L_jj (fetched here, not ahead of the loop: 128 registers the loop cannot spare)
+    bwd_load_64(sL, lcol, inv_d);
+    xj = bwd_vec_64(sV[tid], lcol, inv_d);
+  }
+  if (*(volatile int*)&s_dead) atomicMax(info, 1 << 30);
+  store_sc1(&x[k0 + tid], xj);
   STAMPB(31);
 }
 
@@ -833,6 +1046,17 @@ FwdWs carve(double* ws, int ld) {
 }
 #endif
 
+// doubles in front of the inverse blocks: y [ld] (+ the one-launch experiment's arrays in the test-hooks build)
+size_t inv_offset(int ld) {
+  const int nb = ld / NB;
+#ifdef PPO_BA_TEST_HOOKS
+  return ((size_t)ld + (size_t)nb * 4 * kPiece + (size_t)nb * nb * NB + (ws_flag_ints(nb) + 1) / 2 + 8 + 1) / 2 * 2;
+#else
+  (void)nb;
+  return (size_t)ld + 8;
+#endif
+}
+
 // One launch per panel + one for the backward substitution.  (The one-launch factorisation, ppo_chol_fwd.inc, exists only in the
 // test-hooks build: PPO_BA_CHOL_ONELAUNCH=1 selects it there; DESIGN.md 4.1 has the measurement.)
 int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s, const CholOverlap* ov = nullptr) {
@@ -840,11 +1064,16 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
   double* y = ov ? ov->ctx.bs : ws;  // [ld] forward-substituted right-hand side (overlapped reduction: in place, the pair workgroups add to it)
   int* flags = nullptr;
   int nflags = 0;
+  // T_k and M_k of every block but the last (inv_block_wg -> chol_back_all), at the end of the workspace
+  double* inv = nb >= 2 ? ws + inv_offset(ld) : nullptr;
 #ifdef PPO_BA_TEST_HOOKS
+  static const bool no_inv = []() { const char* e = PPO_DEV_ENV("PPO_BA_CHOL_NO_INV"); return e && e[0] == '1'; }();  // A/B: the backward substitution by triangular sweeps
+  if (no_inv) inv = nullptr;
   const FwdWs w = carve(ws, ld);
   flags = w.tile;
   nflags = (int)ws_flag_ints(nb);
   static const bool one_launch = []() { const char* e = PPO_DEV_ENV("PPO_BA_CHOL_ONELAUNCH"); return e && e[0] == '1'; }();
+  if (one_launch) inv = nullptr;  // (no chol_step launches: nobody forms T and M)
   if (one_launch) {
 #ifdef PPO_CHOL_FWD_ONE_XCD
     hipLaunchKernelGGL(chol_fwd_all, dim3(8 * (nb < 2 ? 1 : 1 + nb * (nb - 1) / 2)), dim3(256), 0, s, A, ld, b, x, info, w);
@@ -871,12 +1100,12 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
 #ifdef PPO_BA_TEST_HOOKS
       if (PPO_DEV_ENV("PPO_BA_OVERLAP_EMPTY")) o.chunk_hi = o.chunk_lo;  // timing experiment (WRONG results): the pair workgroups find nothing to do
 #endif
-      const dim3 grid(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0) + o.npair_wg);
-      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, o);
-      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, o);
+      const dim3 grid(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0) + o.npair_wg + (k > 0 && inv ? 1 : 0));
+      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
+      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
     }
   }
-  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(256), 0, s, (const double*)A, ld, (const double*)y, x, info, flags, nflags);
+  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(kBackThreads), 0, s, (const double*)A, ld, (const double*)y, x, info, flags, nflags, (const double*)inv);
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
 }
 
@@ -947,12 +1176,7 @@ void chol_release(double* A) {
 
 size_t chol_workspace_doubles(int n) {  // must be ZERO when first used (the hand-off flags live in it)
   const int ld = chol_padded_ld(n), nb = ld / NB;
-#ifdef PPO_BA_TEST_HOOKS
-  return (size_t)ld + (size_t)nb * 4 * kPiece + (size_t)nb * nb * NB + (ws_flag_ints(nb) + 1) / 2 + 8;
-#else
-  (void)nb;
-  return (size_t)ld + 8;
-#endif
+  return inv_offset(ld) + (size_t)nb * kInvDoubles;
 }
 int chol_padded_ld(int n) { return (n + NB - 1) / NB * NB; }
 int chol_default_backend() { return PPO_SOLVER_NATIVE; }

@@ -141,7 +141,7 @@ int main() {
       A[(size_t)r * n + c] = v;
     }
   double *dA, *dA0, *dx, *db, *dws; int* dinfo;
-  hipMalloc((void**)&dA, A.size() * 8); hipMalloc((void**)&dA0, A.size() * 8); hipMalloc((void**)&dx, n * 8); hipMalloc((void**)&db, n * 8); hipMalloc((void**)&dws, n * 8); hipMalloc((void**)&dinfo, 4);
+  hipMalloc((void**)&dA, A.size() * 8); hipMalloc((void**)&dA0, A.size() * 8); hipMalloc((void**)&dx, n * 8); hipMalloc((void**)&db, n * 8); hipMalloc((void**)&dws, ppo::chol_workspace_doubles(n) * 8); hipMemset(dws, 0, ppo::chol_workspace_doubles(n) * 8); hipMalloc((void**)&dinfo, 4);
   hipMemcpy(dA0, A.data(), A.size() * 8, hipMemcpyHostToDevice);
   hipStream_t s; hipStreamCreate(&s);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -164,8 +164,8 @@ int main() {
   printf("info %d max residual %.3e\n", info, rmax);
   // phase stamps of column workgroup 1 of the second step (update of panel 0 fused with the factorisation of panel 1)
   hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (n / 64 - 1)), dim3(ppo::kStepThreads), 0, s, dA, n, 0, db, dws, dx, dinfo, 0, ppo::step_no_overlap(n / 64));
-  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (m - 1) + m * (m - 1) / 2), dim3(ppo::kStepThreads), 0, s, dA, n, 64, db, dws, dx, dinfo, 0, ppo::step_no_overlap(n / 64)); }
+  hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (n / 64 - 1)), dim3(ppo::kStepThreads), 0, s, dA, n, 0, db, dws, dx, dinfo, 0, (double*)nullptr, ppo::step_no_overlap(n / 64));
+  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (m - 1) + m * (m - 1) / 2), dim3(ppo::kStepThreads), 0, s, dA, n, 64, db, dws, dx, dinfo, 0, (double*)nullptr, ppo::step_no_overlap(n / 64)); }
   hipStreamSynchronize(s);
   long long st[48];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
@@ -186,6 +186,7 @@ int main() {
   hipStreamSynchronize(s);
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
   for (int i = 9; i >= 3; --i) printf("  hop: x_%d seen -> x_%d seen  %.2f us\n", i, i - 1, (st[20 + i - 1] - st[20 + i]) * 0.01);
-  printf("  block 1: x_2 seen -> reduced %.2f us -> x_1 stored %.2f us\n", (st[30] - st[22]) * 0.01, (st[31] - st[30]) * 0.01);
+  printf("  block 1: x_3 seen -> loop left %.2f us -> partial c_1 written %.2f us -> x_2 seen %.2f us -> all partial products in %.2f us -> x_1 stored %.2f us\n", (st[35] - st[23]) * 0.01,
+         (st[36] - st[35]) * 0.01, (st[33] - st[36]) * 0.01, (st[30] - st[33]) * 0.01, (st[31] - st[30]) * 0.01);
   return 0;
 }
