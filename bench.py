@@ -244,6 +244,14 @@ def main():
             kernels[name] = {"us": 1e3 * ms_.value, "algorithmic_bytes": int(by_.value), "GBps": by_.value / (ms_.value * 1e-3) / 1e9}
     fac_ms = C.c_double()
     assert lib.ppo_ba_time_factor(solver.h, 10, C.byref(fac_ms)) == 0
+    fin = (C.c_int32 * 260)()
+    n_panels = int(lib.ppo_ba_overlap_schedule(solver.h, fin, 260))
+    reduction = {"overlapped_with_factorisation": n_panels > 0}
+    if n_panels > 0:
+        sched = [int(fin[k]) for k in range(n_panels + 1)]
+        reduction.update({"panel_launches": n_panels, "column_blocks_final_at_launch": sched[:next((k for k, f in enumerate(sched) if f >= n_panels), n_panels) + 1],
+                          "note": "pose-pair chunks ordered by 64-column block of S; only the first block(s) are reduced ahead of the dense factorisation, the "
+                                  "panel launches carry the rest as extra workgroups (csrc/ppo_chol.hip StepOverlap); factor_solve_ms is the dense solve alone"})
     achieved = k_bytes.value / (k_ms.value * 1e-3) / 1e9 if k_ms.value > 0 else 0.0
     traffic, traffic_source = committed_traffic(int(k_bytes.value))
     ld_dense = C.c_int32()
@@ -346,7 +354,7 @@ def main():
                 "dense_dim": int(ld_dense.value), "dense_ld": int((ld_dense.value + 63) // 64 * 64), "reference_reduced_dim": int(st["n_reduced"]),
                 "lm_iters_per_step": iters / a.steps, "solve_attempts_per_step": trials / a.steps,
                 "ms_per_lm_iter": 1e3 * dt / max(iters, 1), "solver_backend": int(a.solver),
-                "factor_solve_ms": fac_ms.value, "parallelism": "landmark-range x%d" % world,
+                "factor_solve_ms": fac_ms.value, "schur_reduction": reduction, "parallelism": "landmark-range x%d" % world,
                 "first_create_ms_incl_module_load": create_ms, "steady_state_call_ms": call_ms, "kernels": kernels,
                 "pose_only": pose_only, "device_ms_per_phase_of_one_call": phases,
                 "two_windows_concurrently": concurrent, "analytic_jacobians": analytic,

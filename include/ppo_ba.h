@@ -289,6 +289,14 @@ int ppo_ba_time_kernel(ppo_ba_handle h, int which, int reps, double* ms, int64_t
 /* Time `reps` factorisations of the current reduced system (HIP events); average ms in *ms. */
 int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
 
+/* The Schur reduction of windows with enough panels is OVERLAPPED with the dense factorisation (csrc/ppo_chol.hip): only the
+ * pose-pair chunks of the first column blocks of the reduced matrix are reduced ahead of it, the first panel launches carry the rest.
+ * Returns the number of 64-column blocks (= panel launches) of this window's dense system and fills fin[k], k < min(n, blocks + 1), with the
+ * number of column blocks that are final when launch k starts (fin[0]: reduced ahead of the factorisation); 0 when the reduction of this
+ * window is not overlapped (few panels, deterministic mode, sharded runs, the rocSOLVER backend).  ppo_ba_time_factor() times the dense
+ * solve ALONE, after a complete reduction. */
+int ppo_ba_overlap_schedule(ppo_ba_handle h, int32_t* fin, int32_t n);
+
 /* Re-linearise the current state and build the reduced system for the damping set with
  * ppo_ba_debug_set_lambda(): S is n*n column-major (returned symmetric), b the Schur right-hand side, x the
  * solution of S x = b.  n = ppo_ba_stats.n_reduced.  Any pointer may be NULL. */

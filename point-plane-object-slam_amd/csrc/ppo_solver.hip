@@ -2038,6 +2038,13 @@ int ppo_ba_debug_set_lambda(ppo_ba_handle s, double lambda) {
 
 int64_t ppo_ba_linearize_bytes(ppo_ba_handle s) { return s ? s->lin_bytes : -1; }
 
+int ppo_ba_overlap_schedule(ppo_ba_handle s, int32_t* fin, int32_t n) {
+  if (!s) return PPO_BA_ERR_ARG;
+  if (s->fin.empty() || s->solver_kind != PPO_SOLVER_NATIVE || s->g.det || s->comm.active()) return 0;
+  for (int k = 0; fin && k < n && k < (int)s->fin.size(); ++k) fin[k] = s->fin[k];
+  return s->g.ld / 64;
+}
+
 int ppo_ba_release_cached(void) {
   g_pool.trim();
   g_ctx_pool.trim();

@@ -348,6 +348,7 @@ def _declare(lib):
     lib.ppo_ba_linearize_bytes.argtypes = [C.c_void_p]
     lib.ppo_ba_time_linearize.argtypes = [C.c_void_p, C.c_int, c_dp]
     lib.ppo_ba_time_factor.argtypes = [C.c_void_p, C.c_int, c_dp]
+    lib.ppo_ba_overlap_schedule.argtypes = [C.c_void_p, c_ip, C.c_int32]
     lib.ppo_ba_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, C.POINTER(C.c_int64)]
     lib.ppo_ba_debug_reduced.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip]
     lib.ppo_ba_partition.argtypes = [C.POINTER(CProblem), C.c_int32, c_ip, c_ip]
@@ -381,6 +382,7 @@ def load_library(path=LIB_PATH):
         lib.ppo_ba_linearize_bytes.argtypes = [C.c_void_p]
         lib.ppo_ba_time_linearize.argtypes = [C.c_void_p, C.c_int, c_dp]
         lib.ppo_ba_time_factor.argtypes = [C.c_void_p, C.c_int, c_dp]
+        lib.ppo_ba_overlap_schedule.argtypes = [C.c_void_p, c_ip, C.c_int32]
         lib.ppo_ba_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, C.POINTER(C.c_int64)]
         lib.ppo_ba_debug_reduced.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip]
         lib.ppo_ba_partition.argtypes = [C.POINTER(CProblem), C.c_int32, c_ip, c_ip]

@@ -59,6 +59,9 @@ class StubLib:
         _set(ms, 0.28)
         return 0
 
+    def ppo_ba_overlap_schedule(self, h, fin, n):
+        return 0
+
 
 class StubSolver:
     h = None
