@@ -672,9 +672,13 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
   const bool uo = own && updc;
   // step 0 takes the right-hand side from rhs_in (the caller's b stays intact), later steps continue in rhs
   const double* rsrc = (k0 == 0) ? rhs_in : rhs;
+  double rold = 0.0;  // the right-hand-side entry this thread updates at the end (threads 8 r of a row-half workgroup)
   {
     // Everything is requested unconditionally and back to back (what is not needed aliases the diagonal tile): with the
     // loads under `if`s the compiler drained each group before issuing the next, four memory round trips in a row.
+    // (round 3) The own half and its previous-panel rows (a third of the bytes) are requested LAST and stored into LDS only after the
+    // column-0 update of the diagonal block: the critical tiles are waited for alone (memory operations of a wave complete in the order
+    // they were issued), the others land while the matrix cores work on what the first factorisation needs.
     d2 td[NI], tq[NI], tb[NI / 2], tp[NI / 2];
     const double* pC = &A[(size_t)k0 * ld + k0];
     const double* pQ = updc ? &A[(size_t)kp * ld + k0] : pC;   // L[k][k-1]
@@ -685,13 +689,14 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
     STAMP(16);
     load_tile_nt<NT>(pQ, ld, tq);
     STAMP(17);
+    const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
 #pragma unroll
     for (int i = 0; i < NI / 2; ++i) {  // the own half: 32 rows x 64 columns, 16 d2 per column
       const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
       tb[i] = *reinterpret_cast<const d2*>(&pB[(size_t)c * ld + r]);
       tp[i] = *reinterpret_cast<const d2*>(&pP[(size_t)c * ld + r]);
     }
-    const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
+    rold = rsrc[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0];  // (for the very end: requested here, not there; unconditional like the others)
     STAMP(6);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -700,6 +705,12 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
       sL[r + 1][c] = (r + 1 >= c) ? td[i].y : 0.0;
       *reinterpret_cast<d2*>(&sQ[c][r]) = tq[i];
     }
+    if (tid < NB) sB[NB][tid] = rv;
+    if (tid == 0) sBad = 0;
+    for (int i = tid; i < (SB + 1) * SB; i += NT) sId[i / SB][i % SB] = (i / SB == i % SB) ? 1.0 : 0.0;
+    __syncthreads();
+    STAMP(5);
+    if (updc && tid < 256) tile_update1(sL, wave, 0, wave == 0, sQ, sQ);  // block column 0 of the diagonal block: what potf2(0) needs
 #pragma unroll
     for (int i = 0; i < NI / 2; ++i) {
       const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
@@ -707,17 +718,9 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
       sB[r + 1][c] = tb[i].y;
       *reinterpret_cast<d2*>(&sP[c][r]) = tp[i];
     }
-    if (tid < NB) sB[NB][tid] = rv;
-    if (tid == 0) sBad = 0;
-    for (int i = tid; i < (SB + 1) * SB; i += NT) sId[i / SB][i % SB] = (i / SB == i % SB) ? 1.0 : 0.0;
   }
   __syncthreads();
   if (tid >= 256) return;  // loader waves
-  STAMP(5);
-  if (updc) {
-    tile_update1(sL, wave, 0, wave == 0, sQ, sQ);  // block column 0 of the diagonal block: what potf2(0) needs
-    __syncthreads();
-  }
   STAMP(1);
 #pragma unroll
   for (int kk = 0; kk < NB / SB; ++kk) {
@@ -733,13 +736,19 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
       if (updc) tile_update1(sL, wave, 1, wave == 1, sQ, sQ);  // D(1,1) D(2,1) D(3,1): what the next factorisation needs
       if (uo) tile_update1(sB, r0t, wave - 1, false, sP, sQ);
     } else if (kk == 1) {
+      // (first: the three tiles of the diagonal block that block column 0 still owes an update and that the factorisation running now does
+      //  not read -- (2,2) (3,2) (3,3); as part of the update round behind potf2(0) they made it two rounds of matrix instructions, 0.64 us
+      //  of the chain instead of 0.28)
       if (wave == 1) {
+        mfma_sub_16(sL, 3 * SB, 3 * SB, sL, 3 * SB, sL, 3 * SB, 0);
         if (uo) tile_update1(sB, r0t, 3, false, sP, sQ);
         if (own) solve_rows<0>(sB, r0t, sL, sT);
       } else if (wave == 2) {
+        mfma_sub_16(sL, 2 * SB, 2 * SB, sL, 2 * SB, sL, 2 * SB, 0);
         if (updc) tile_update1(sL, 2, 2, true, sQ, sQ);
         if (uo) tile_update1(sB, r1t, 0, false, sP, sQ);
       } else {
+        mfma_sub_16(sL, 3 * SB, 2 * SB, sL, 3 * SB, sL, 2 * SB, 0);
         if (updc) tile_update1(sL, 3, 2, false, sQ, sQ);
         if (uo) tile_update1(sB, r1t, 1, false, sP, sQ);
       }
@@ -768,12 +777,16 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
     STAMP(8 + 2 * kk);
     if (kk == NB / SB - 1) break;
     // trailing 16x16 tiles of the diagonal block (bi >= bj > kk): A[bi][bj] -= X_bi X_bj^T, dealt round-robin to the 4 waves
-    int t = 0;
+    if (kk == 0) {  // behind potf2(0) only block column 1 -- what potf2(1) reads; the other three tiles ride in the shadow of potf2(1)
+      if (wave < 3) mfma_sub_16(sL, (wave + 1) * SB, SB, sL, (wave + 1) * SB, sL, SB, o);
+    } else {
+      int t = 0;
 #pragma unroll
-    for (int bi = kk + 1; bi < NB / SB; ++bi)
+      for (int bi = kk + 1; bi < NB / SB; ++bi)
 #pragma unroll
-      for (int bj = kk + 1; bj <= bi; ++bj, ++t)
-        if ((t & 3) == wave) mfma_sub_16(sL, bi * SB, bj * SB, sL, bi * SB, sL, bj * SB, o);
+        for (int bj = kk + 1; bj <= bi; ++bj, ++t)
+          if ((t & 3) == wave) mfma_sub_16(sL, bi * SB, bj * SB, sL, bi * SB, sL, bj * SB, o);
+    }
     __syncthreads();
     STAMP(9 + 2 * kk);
   }
@@ -798,19 +811,23 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
     if (tid < NB) rhs[k0 + tid] = sB[NB][tid];  // y_k
     return;
   }
-  const int myrow = 32 * half + tid;  // (tid < 32) row of the block whose right-hand-side entry this thread updates
-  const double rold = (tid < 32) ? rsrc[row0 + myrow] : 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = tid + 256 * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
     *reinterpret_cast<d2*>(&A[(size_t)(k0 + c) * ld + row0 + r]) = d2v(sB[r][c], sB[r + 1][c]);
   }
-  if (tid < 32) {  // r_b -= L_bk y_k
+  {  // r_b -= L_bk y_k: eight threads per row (as 32 threads x 64 dependent multiply-adds this was 0.5 us at the very end of the launch)
+    const int myrow = 32 * half + (tid >> 3), m0 = 8 * (tid & 7);
     double sacc = 0.0;
-#pragma unroll 16
-    for (int mm = 0; mm < NB; ++mm) sacc = __builtin_fma(sB[myrow][mm], sB[NB][mm], sacc);
-    if (inplace_rhs) atomicAdd(&rhs[row0 + myrow], -sacc);  // (overlapped reduction: the pair workgroups may be adding to this row too)
-    else rhs[row0 + myrow] = rold - sacc;
+#pragma unroll
+    for (int mm = 0; mm < 8; ++mm) sacc = __builtin_fma(sB[myrow][m0 + mm], sB[NB][m0 + mm], sacc);
+    sacc += __shfl_xor(sacc, 1, 64);
+    sacc += __shfl_xor(sacc, 2, 64);
+    sacc += __shfl_xor(sacc, 4, 64);
+    if ((tid & 7) == 0) {
+      if (inplace_rhs) atomicAdd(&rhs[row0 + myrow], -sacc);  // (overlapped reduction: the pair workgroups may be adding to this row too)
+      else rhs[row0 + myrow] = rold - sacc;
+    }
   }
   STAMP(4);
 }
