@@ -140,8 +140,10 @@ struct Graph {
   const int32_t* cub_edge_off;  // [Nc+1] bbox / corner edges of a cuboid ...
   const int32_t* cub_edges;     // ... as (edge index << 1) | is_corner
   const int32_t* cp_cub;        // [n_cub_pairs] cuboid of an (edge a >= edge b) pair
-  const int32_t* cp_a;          // [n_cub_pairs] position of a in cub_edges
+  const int32_t* cp_a;          // [n_cub_pairs] edge a as (edge index << 1) | is_corner
   const int32_t* cp_b;
+  const int32_t* cp_cola;       // [n_cub_pairs] reduced column of edge a's keyframe (-1: fixed)
+  const int32_t* cp_colb;
   int n_cub_pairs;
   double* cub_Linv;             // [Nc][81] inverse Cholesky factor of Hcc + lambda I (row-major, lower)
   double* cub_Dinv;             // [Nc][81] (Hcc + lambda I)^-1, full symmetric
@@ -1574,13 +1576,11 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
   const int pr = t >> 3, i = t & 7;
   if (pr >= g.n_cub_pairs || i >= 6) return;
   const int c = g.cp_cub[pr];
-  const int qa = g.cp_a[pr], qb = g.cp_b[pr];
-  const int ca = g.cub_edges[qa], cb = g.cub_edges[qb];
-  const CubEdge& ea = cub_edge_of(g, ca);
-  const CubEdge& eb = cub_edge_of(g, cb);
-  if (!(ea.flags & F_ACTIVE) || !(eb.flags & F_ACTIVE)) return;
-  const int cola = g.pose_col[ea.pose], colb = g.pose_col[eb.pose];
+  const int ca = g.cp_a[pr], cb = g.cp_b[pr];
+  const int cola = g.cp_cola[pr], colb = g.cp_colb[pr];
   if (cola < 0 || colb < 0) return;
+  // (the activity flags are the one thing of a pair that changes between the passes: read next to the operands, applied at the end)
+  const uint32_t fa = cub_edge_of(g, ca).flags, fb = cub_edge_of(g, cb).flags;
   // row i of W_a (Hcc + lambda I)^-1, formed on the fly (the cuboid blocks are tiny and L2-resident).  Every operand is requested up
   // front (fully unrolled, 144 independent loads): as loops of load -> multiply-add this body was a 10 us chain of L2 round trips -- hidden
   // behind the pair workgroups of a full reduction, but the whole length of the short launch an overlapped reduction starts with
@@ -1602,7 +1602,8 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
     for (int m = 0; m < 9; ++m) v += wa[m] * di[m * 9 + q];
     za[q] = v;
   }
-  const bool self = qa == qb;
+  if (!(fa & F_ACTIVE) || !(fb & F_ACTIVE)) return;
+  const bool self = ca == cb;
   const int n = g.ld;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
