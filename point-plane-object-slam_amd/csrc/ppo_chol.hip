@@ -895,7 +895,7 @@ __global__ __launch_bounds__(kBackThreads) void chol_back_all(const double* __re
         while (max(max(v_prog[0], v_prog[1]), max(v_prog[2], v_prog[3])) > i + kRing) __builtin_amdgcn_s_sleep(2);
       }
       const double* xi = &x[(size_t)i * NB];
-      const int nap = min(i - j - 1, 24);
+      const int nap = i - j <= 2 ? 0 : min(i - j - 1, 24);  // (the two workgroups next in line poll flat out)
       double v = load_sc1(&xi[lane]);
       int spins = 0;
       while (!dead && __any((unsigned long long)__double_as_longlong(v) == kSentinel)) {
@@ -980,11 +980,19 @@ __global__ __launch_bounds__(kBackThreads) void chol_back_all(const double* __re
     // x_{j+1} shows up -- and then its 16 terms of M_j^T x_{j+1}; wave 0 adds the eight partial vectors.  (One wave holding a whole
     // column of M_j in registers spilled: 256 registers per wave with five waves in the workgroup.)
     double (*const sC)[NB] = reinterpret_cast<double (*)[NB]>(&sL[0][0]);  // [0..3] partial c_j, [4..7] partial M_j^T x_{j+1} (sL is free in this mode)
+    // (the 16 column sums of this wave go through its own corner of LDS: read back as one batch of broadcast reads -- as 16 readlane
+    //  pairs feeding the multiply-adds this was 0.36 us on the chain)
+    if (part == 0) sV[c] = acc;
+    wave_lds_fence();
+    double av[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) av[q] = sV[16 * wave + q];
+    __builtin_amdgcn_sched_barrier(0);
     double p0 = 0.0, p1 = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; q += 2) {
-      p0 = __builtin_fma(trow[q], bcast(acc, 4 * q), p0);
-      p1 = __builtin_fma(trow[q + 1], bcast(acc, 4 * q + 4), p1);
+      p0 = __builtin_fma(trow[q], av[q], p0);
+      p1 = __builtin_fma(trow[q + 1], av[q + 1], p1);
     }
     sC[wave][lane] = p0 + p1;
     STAMPB(36);
