@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
 // diagonal block and publishes x_j.  Hand-off is by data-tagged granules (MI355X_MICROARCH.md, handoff-1to1, ~1 us per
 // hop and no fences): x was pre-filled with a sentinel bit pattern by chol_step(0); the producer writes each value
 // with ONE 8-byte write-through (sc1) store, consumers poll the values they need with sc1 loads until none of them is the
-// sentinel.  Progress: workgroup nb-1 waits for nobody and nb <= 32 workgroups are always co-resident; every spin is
+// sentinel.  Progress: block nb-1 waits for nobody and is dispatched first, every other block waits only for blocks dispatched before it; every spin is
 // bounded (a timeout marks the solve as failed instead of hanging the device).
 // The per-panel launches this replaces cost ~7.5 us each (19 at n = 1216), this pipeline ~2 us per block.
 // ------------------------------------------------------------------------------------------------------------------
@@ -870,7 +870,10 @@ __global__ __launch_bounds__(kBackThreads) void chol_back_all(const double* __re
     for (int i = w * kBackThreads + threadIdx.x; i < nflags; i += nw * kBackThreads) flags[i] = 0;
     return;
   }
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = blockIdx.x >> 3, nb = ld / NB, k0 = j * NB;
+  // The head of the chain (block nb - 1) is the FIRST working workgroup of the grid and every workgroup waits only for workgroups dispatched
+  // before it: the chain makes progress however few of them are resident at once.  (All of them land on one XCD -- 32 CUs, one workgroup of
+  // five waves per CU: numbered the other way round the 33rd block could never start and the 32 in front of it waited for it for ever.)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nb = ld / NB, j = nb - 1 - (int)(blockIdx.x >> 3), k0 = j * NB;
   const int c = (tid & 255) >> 2, part = tid & 3;  // compute waves: 4 threads per column of block j, 16 rows of block i each
   // With T_j = L_jj^-1 and M_j = L_{j+1,j} T_j from the forward phase (inv_block_wg) the link of the chain is
   //   x_j = T_j^T (y_j - sum_{i > j+1} L_ij^T x_i) - M_j^T x_{j+1};

@@ -169,6 +169,33 @@ def test_native_cholesky_matches_rocsolver_and_oracle_ldlt(oracle_lib, hip, cfg,
     assert np.abs(xo - x).max() <= 1e-8 * np.abs(xo).max()
 
 
+def test_native_cholesky_beyond_the_resident_chain(hip):
+    """A window with more 64-column blocks (34) than workgroups of the backward substitution fit on the one XCD they all run on (32): the chain
+    must make progress with part of it resident (its head is the first workgroup dispatched) and its ring of x blocks must wrap.  Native
+    solver against rocSOLVER on the same reduced system, and the residual of both."""
+    P = synth.make_problem(dict(n_kf=360, n_points=6000, n_planes=20, n_cuboids=4), seed=11)
+    xs = {}
+    for kind in (1, 2):
+        s = hip.create(P, B.default_options(solver=kind))
+        n = C.c_int32()
+        hip.lib.ppo_ba_debug_set_lambda(s.h, C.c_double(3.0))
+        hip.lib.ppo_ba_debug_reduced(s.h, None, None, None, C.byref(n))
+        n = n.value
+        assert n > 32 * 64
+        S, b, x = np.zeros((n, n)), np.zeros(n), np.zeros(n)
+        assert hip.lib.ppo_ba_debug_reduced(s.h, dptr(S), dptr(b), dptr(x), None) == 0
+        assert np.all(np.isfinite(x)) and np.linalg.norm(S @ x - b) <= 1e-9 * np.linalg.norm(b)
+        xs[kind] = x
+        s.close()
+    assert np.abs(xs[1] - xs[2]).max() <= 1e-8 * np.abs(xs[1]).max()
+    # ... and a complete run through the default path (overlapped reduction, 34 panel launches)
+    s = hip.create(P, B.default_options())
+    st = s.run()
+    r = s.read()
+    s.close()
+    assert st["n_iters"] > 0 and np.all(np.isfinite(r.pose_qt)) and st["iters"][-1]["chi2_after"] < st["iters"][0]["chi2_before"]
+
+
 def test_fixed_points_and_all_but_one_pose_fixed(oracle, hip):
     P = synth.make_problem("small", seed=8)
     pf = np.zeros(P.sizes()["n_points"], np.uint8)

@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
   // the environment switch is read once per process (static): the per-panel arm runs in a separate process (argv[1] = "panels")
   const bool panels = argc > 1 && argv[1][0] == 'p';
   setenv("PPO_BA_CHOL_ONELAUNCH", panels ? "0" : "1", 1);
-  const int sizes[] = {64, 100, 128, 192, 320, 594, 1194, 1216, 1644, 2048};
+  const int sizes[] = {64, 100, 128, 192, 320, 594, 1194, 1216, 1644, 2048, 2112, 2600};
   for (int n : sizes) {
     std::vector<double> x; int info;
     run(n, panels, 6, &x, &info);

@@ -10,7 +10,7 @@
 #include "../point-plane-object-slam_amd/csrc/ppo_chol.hip"
 
 int main() {
-  const int sizes[] = {256, 320, 594, 1194, 1644, 2048};
+  const int sizes[] = {100, 128, 256, 320, 594, 1194, 1644, 2048, 2600, 4096};  // (2600, 4096: more blocks than the ring of the backward substitution holds)
   int bad = 0;
   for (int n : sizes) {
     const int ld = ppo::chol_padded_ld(n), nb = ld / 64;

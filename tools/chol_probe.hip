@@ -8,7 +8,7 @@
 #define PPO_CHOL_STAMPS 1
 __device__ long long g_stamps[48];
 #define STAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
-#define STAMPB(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#define STAMPB(i) do { if (blockIdx.x + 16 == gridDim.x && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)  // block 1 of the backward chain (the head is the first workgroup)
 #define STAMP1(i) do { if (blockIdx.x == 1 && threadIdx.x == 64) g_stamps[i] = wall_clock64(); } while (0)
 #include "../point-plane-object-slam_amd/csrc/ppo_chol.hip"
 
