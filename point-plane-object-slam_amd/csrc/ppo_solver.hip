@@ -911,9 +911,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   g.n_red = ncol;
   g.ld = chol_padded_ld(ncol);
   const int ld = g.ld;
-  // chol_back_all needs its ld/64 workgroups co-resident (they hand x over inside one launch): far beyond any local-BA
-  // window, but not unbounded -- past 256 blocks (2730 free poses) the automatic choice is rocSOLVER, an explicit request
-  // for the native solver is refused
+  // chol_back_all hands x over between its ld/64 workgroups inside one launch; the head of the chain is dispatched first, so it makes
+  // progress with any number of them resident (tested to 64 blocks).  The native solver is a latency design for local-BA sizes: past 256
+  // blocks (2730 free poses) the automatic choice is rocSOLVER, an explicit request for the native solver is refused
   if (s->solver_kind == PPO_SOLVER_NATIVE && ld / 64 > 256) {
     if (o->solver == PPO_SOLVER_NATIVE) return fail(PPO_BA_ERR_ARG);
     s->solver_kind = PPO_SOLVER_ROCSOLVER;
