@@ -10,6 +10,30 @@
 
 namespace ppo {
 
+// ---- plain data (also seen by host-only translation units through ppo_chol.hpp) ----------------------------------------------------------
+struct PairChunks {
+  const int32_t* start;  // [n_chunks+1] into sj / si
+  const int32_t* colj;   // [n_chunks] reduced column of pose j (row block of S)
+  const int32_t* coli;   // [n_chunks] reduced column of pose i (column block of S)
+  const int32_t* sj;     // [n_entries]
+  const int32_t* si;     // [n_entries]
+  const int32_t* lm;     // [n_entries] landmark of the pair (saves the dependent slot -> landmark -> (D + lambda I)^-1 gather chain)
+  int n_chunks;
+};
+
+// What the pair reduction reads and writes (a subset of Graph: the fused launches of the dense factorisation carry only this)
+struct PairCtx {
+  const double* linR;  // [ld / 6 + 2][12] rotation + fx, fy, bf at the linearisation point, by reduced column / 6
+  const double* F;     // [n_pt_slots][4] factor records of the point slots
+  const double* W;     // [n_slots - n_pt_slots][18] coupling blocks of the plane slots
+  const double* Dinv;  // [n_lm][6] (D + lambda I)^-1, packed upper
+  const double* ul;    // [n_lm][3] (D + lambda I)^-1 b_l
+  double* S;           // [ld][ld] column-major, lower triangle
+  double* bs;          // [ld]
+  int n_points, n_pt_slots, ld;
+};
+
+#ifdef __HIPCC__  // ---- device code ------------------------------------------------------------------------------------------------------
 // Sum `NV` per-lane values over the 64 lanes of a wave through LDS: lane t < NV returns the total of value t.
 // buf is this wave's [NV][65] scratch.  (Cheaper than 6 ds_bpermute rounds per value, and it leaves value t in lane t,
 // which is exactly the lane-contiguous layout the atomics that follow want.)
@@ -38,29 +62,9 @@ __device__ __forceinline__ double wave_transpose_sum(const double* vals, double 
 // segments in order; the 3x3 inverse of the pair's landmark is an L2-resident gather.  (An earlier version first streamed
 // Z = W L^-T to memory in a launch of its own: 73 MB of traffic and 23 us that forming W D^-1 on the fly does not need.)
 // The self pairs (slot_j == slot_i) also carry the right-hand side: bs(pj) -= W_j (D_l + lambda I)^-1 b_l.
-struct PairChunks {
-  const int32_t* start;  // [n_chunks+1] into sj / si
-  const int32_t* colj;   // [n_chunks] reduced column of pose j (row block of S)
-  const int32_t* coli;   // [n_chunks] reduced column of pose i (column block of S)
-  const int32_t* sj;     // [n_entries]
-  const int32_t* si;     // [n_entries]
-  const int32_t* lm;     // [n_entries] landmark of the pair (saves the dependent slot -> landmark -> (D + lambda I)^-1 gather chain)
-  int n_chunks;
-};
 #ifndef PPO_PAIRS_NO_PREFETCH
 #define PPO_PAIRS_PREFETCH 1  // the next trip's gathers in flight during this trip's arithmetic: 43.8 -> 42.1 us (234 VGPRs, still 2 waves per SIMD)
 #endif
-// What the pair reduction reads and writes (a subset of Graph: the fused launches of the dense factorisation carry only this)
-struct PairCtx {
-  const double* linR;  // [ld / 6 + 2][12] rotation + fx, fy, bf at the linearisation point, by reduced column / 6
-  const double* F;     // [n_pt_slots][4] factor records of the point slots
-  const double* W;     // [n_slots - n_pt_slots][18] coupling blocks of the plane slots
-  const double* Dinv;  // [n_lm][6] (D + lambda I)^-1, packed upper
-  const double* ul;    // [n_lm][3] (D + lambda I)^-1 b_l
-  double* S;           // [ld][ld] column-major, lower triangle
-  double* bs;          // [ld]
-  int n_points, n_pt_slots, ld;
-};
 // One workgroup of WAVES waves reduces WAVES chunks of [chunk_lo, chunk_hi); `add(p, v)` is the accumulation (*p += v across waves).
 template <int WAVES, class Add>
 __device__ __forceinline__ void schur_pairs_body(const PairCtx& g, const PairChunks& pc, int chunk_lo, int chunk_hi, int bid, int nblocks, double (*s_buf)[21][65], Add add) {
@@ -203,5 +207,7 @@ __device__ __forceinline__ void schur_pairs_body(const PairCtx& g, const PairChu
     }
   }
 }
+
+#endif  // __HIPCC__
 
 }  // namespace ppo
