@@ -20,6 +20,7 @@
 #include "ppo_chol.hpp"
 #include "ppo_dev.hpp"
 #include "ppo_pairs.hpp"
+#include "ppo_dpp.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -128,24 +129,7 @@ __device__ __forceinline__ void mfma_mul_16(double (*M)[LP], int r0, int c0, con
   for (int reg = 0; reg < 4; ++reg) M[r0 + lk + 4 * reg][c0 + li] = acc[reg];
 }
 
-// ---- f64 DPP: v_fmac_f64 / v_mov_b64 accept `row_newbcast:N` (source operand taken from lane N of the reader's own row of
-// 16 lanes), which turns "broadcast + multiply-add" into ONE instruction.  The wave that factors a 16x16 block is issue-bound
-// (tools/chol_probe.hip: ~4.5 cycles per instruction whatever the dependencies), so instruction count is what matters: the
-// v_readlane formulation needed 2 broadcasts + 1 FMA per element update.  `s_nop 1` covers the VALU-write -> DPP-read hazard,
-// which the compiler cannot see inside inline assembly.
-template <int C, bool FRESH>
-__device__ __forceinline__ void fmac_bcast(double& acc, double l_src, double mul) {  // acc -= l_src[lane C of my row] * mul
-  if constexpr (FRESH)  // l_src was written by the preceding VALU instruction
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(l_src), "v"(mul), "n"(C));
-  else
-    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(l_src), "v"(mul), "n"(C));
-}
-template <int C>
-__device__ __forceinline__ double row_bcast(double v) {
-  double d;
-  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "n"(C));
-  return d;
-}
+// (f64 DPP helpers fmac_bcast / row_bcast: ppo_dpp.hpp)
 
 template <int J, int C>
 struct ColUpdate {

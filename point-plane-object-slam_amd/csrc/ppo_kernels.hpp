@@ -25,6 +25,7 @@
 
 #include "ppo_math.hpp"
 #include "ppo_pairs.hpp"
+#include "ppo_dpp.hpp"
 
 namespace ppo {
 
@@ -1513,61 +1514,69 @@ __device__ __forceinline__ void schur_prep_body(const Graph& g, double lambda, i
 __device__ __forceinline__ const CubEdge& cub_edge_of(const Graph& g, int code) { return (code & 1) ? g.corner[code >> 1] : g.bbox[code >> 1]; }
 __device__ __forceinline__ const double* wpc_of(const Graph& g, int code) { return ((code & 1) ? g.Wpc_corner : g.Wpc_bbox) + (size_t)(code >> 1) * 54; }
 
+// One cuboid per ROW OF 16 LANES (round 3; as one thread per cuboid walking the 9x9 Cholesky factor, its inverse and their product in
+// registers this was a 3.7 us chain, the longest of stage 1's launch): lane r < 9 holds row r of Hcc + lambda I and row r of the identity;
+// the right-looking elimination is the register factorisation of ppo_chol.hip in small -- the broadcast-multiply-adds are single
+// v_fmac_f64 row_newbcast instructions, the identity rows come out as L^-T (the elimination is a right-multiplication by L^-T) -- and
+// (Hcc + lambda I)^-1 = L^-T L^-1 is nine broadcast dot products per lane.  A pivot that is not positive gives NaN, which propagates to S
+// and fails the dense factorisation as before.
+template <int J, int C>
+struct CubColUpdate {
+  static __device__ __forceinline__ void run(double (&a)[9], double (&e)[9], double l, double le) {
+    fmac_bcast<C, C == J + 1>(a[C], l, l);
+    fmac_bcast<C, false>(e[C], l, le);
+    if constexpr (C + 1 < 9) CubColUpdate<J, C + 1>::run(a, e, l, le);
+  }
+};
+template <int J>
+struct CubColSweep {
+  static __device__ __forceinline__ void run(double (&a)[9], double (&e)[9]) {
+    const double d = row_bcast<J>(a[J]);
+    const double y0 = __builtin_amdgcn_rsq(d);  // (5e-8) + one third-order correction: 2.2e-16, see ppo_chol.hip
+    const double e1 = __builtin_fma(-(d * y0), y0, 1.0);
+    const double y = (d > 0.0) ? __builtin_fma(y0, e1 * __builtin_fma(0.375, e1, 0.5), y0) : __builtin_nan("");
+    const double l = a[J] * y, le = e[J] * y;
+    a[J] = l;
+    e[J] = le;
+    if constexpr (J + 1 < 9) {
+      CubColUpdate<J, J + 1>::run(a, e, l, le);
+      CubColSweep<J + 1>::run(a, e);
+    }
+  }
+};
+template <int B>
+struct CubDinvRow {  // acc[b] = -sum_k e_b[k] e_mine[k]
+  static __device__ __forceinline__ void run(const double (&e)[9], double (&acc)[9]) {
+    acc[B] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) fmac_bcast<B, false>(acc[B], e[k], e[k]);
+    if constexpr (B + 1 < 9) CubDinvRow<B + 1>::run(e, acc);
+  }
+};
+constexpr int kCubPerBlock = 16;  // 256 threads: 16 rows of 16 lanes
 __device__ __forceinline__ void cub_prep_body(const Graph& g, double lambda, int vb) {
-  const int c = vb * blockDim.x + threadIdx.x;
-  if (c >= g.n_cuboids || g.cub_col[c] < 0) return;
-  // everything stays in registers (all loops unrolled, L and L^-1 as full 9x9 register arrays of which only the lower
-  // halves are live): with L^-1 built in global memory the read-after-write chain made this one thread the 10 us tail of
-  // the whole launch
-  double L[9][9], Li[9][9];
-  const double* hc = &g.HC[(size_t)c * 54];
+  const int r = threadIdx.x & 15, c = vb * kCubPerBlock + (threadIdx.x >> 4);
+  const bool live = c < g.n_cuboids && g.cub_col[c] >= 0 && r < 9;
+  double a[9], e[9];
+  const double* hc = &g.HC[(size_t)(live ? c : 0) * 54];
 #pragma unroll
-  for (int r = 0; r < 9; ++r)
-#pragma unroll
-    for (int k = 0; k <= r; ++k) L[r][k] = hc[packed_lower(r, k)] + (r == k ? lambda : 0.0);
-#pragma unroll
-  for (int j = 0; j < 9; ++j) {  // in-place Cholesky, lower
-    double d = L[j][j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-    const double ljj = sqrt(d);  // NaN if not positive: propagates to S and fails the dense factorisation
-    const double inv = 1.0 / ljj;
-    L[j][j] = ljj;
-    Li[j][j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < 9; ++i) {
-      double v = L[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-      L[i][j] = v * inv;
-    }
+  for (int k = 0; k < 9; ++k) {
+    const int rr = r < 9 ? r : 0;
+    const double v = hc[rr >= k ? packed_lower(rr, k) : packed_lower(k, rr)] + (rr == k ? lambda : 0.0);
+    a[k] = live ? v : (r == k ? 1.0 : 0.0);  // (idle lanes and rows carry the identity: no NaN traffic)
+    e[k] = (r == k) ? 1.0 : 0.0;
   }
+  CubColSweep<0>::run(a, e);
+  // lane r now holds row r of L in a[0 .. r] and row r of L^-T in e[r .. 8] (zeros in front)
+  double acc[9];
+  CubDinvRow<0>::run(e, acc);
+  if (!live) return;
+  double* out = &g.cub_Linv[(size_t)c * 81];  // L^-1, row-major, lower: L^-1[i][r] = (L^-T)[r][i]
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {  // column j of L^-1 by forward substitution
-#pragma unroll
-    for (int i = j + 1; i < 9; ++i) {
-      double v = 0.0;
-#pragma unroll
-      for (int k = j; k < i; ++k) v -= L[i][k] * Li[k][j];
-      Li[i][j] = v * Li[i][i];
-    }
-  }
-  double* out = &g.cub_Linv[(size_t)c * 81];
-#pragma unroll
-  for (int i = 0; i < 9; ++i)
-#pragma unroll
-    for (int j = 0; j < 9; ++j) out[i * 9 + j] = (j <= i) ? Li[i][j] : 0.0;
+  for (int i = 0; i < 9; ++i) out[i * 9 + r] = (i >= r) ? e[i] : 0.0;
   double* di = &g.cub_Dinv[(size_t)c * 81];  // (Hcc + lambda I)^-1 = L^-T L^-1, full symmetric storage
 #pragma unroll
-  for (int a = 0; a < 9; ++a)
-#pragma unroll
-    for (int b = 0; b <= a; ++b) {
-      double v = 0.0;
-#pragma unroll
-      for (int k = a; k < 9; ++k) v += Li[k][a] * Li[k][b];
-      di[a * 9 + b] = v;
-      di[b * 9 + a] = v;
-    }
+  for (int b = 0; b < 9; ++b) di[r * 9 + b] = -acc[b];
 }
 // S -= Z_a Z_b' for every (edge a >= edge b) pair of one cuboid: 8 lanes per pair, lane i < 6 owns row i of the block,
 // so the six lanes of a pair hit six consecutive addresses per column (one atomic line-op)

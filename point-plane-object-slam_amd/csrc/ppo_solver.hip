@@ -521,10 +521,15 @@ int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
   const long work = (long)g.n_pose_free * 27 + (long)g.n_cuboids * 54 + (long)(g.n_bbox + g.n_corner) * 54 + (g.ld - g.n_red);
   rp.nb_asm = nblk(work, 256);
   rp.nb_prep = nl > 0 ? nblk(nl, 256) : 0;
-  rp.nb_cubprep = cub_stage ? nblk(g.n_cuboids, 256) : 0;
+  rp.nb_cubprep = cub_stage ? nblk(g.n_cuboids, kCubPerBlock) : 0;
   rp.chunk_hi = s->reduce_overlapped ? s->cb_start[s->fin[0]] : s->pc.n_chunks;
   rp.nb_pairs = (nl > 0 && rp.chunk_hi > 0) ? (nblk(rp.chunk_hi, 4) + 7) / 8 * 8 : 0;
   rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? (nblk((long)g.n_cub_pairs * 8, 256) + 7) / 8 * 8 : 0;  // (multiple of 8: see k_reduce_stage3)
+  if (const char* e = PPO_DEV_ENV("PPO_BA_STAGE1_PROBE")) {  // timing experiments (WRONG results): parts of stage 1 left out -- 'c' cuboid blocks, 'l' landmark blocks, 'a' assembly
+    if (strchr(e, 'c')) rp.nb_cubprep = 0;
+    if (strchr(e, 'l')) rp.nb_prep = 0;
+    if (strchr(e, 'a')) rp.nb_asm = 0;
+  }
   if (const char* e = PPO_DEV_ENV("PPO_BA_STAGE3_PROBE")) {  // timing experiments (WRONG results): 'c' no cuboid pair workgroups, 'p' no pose-pair workgroups
     if (strchr(e, 'c')) rp.nb_cubschur = 0;
     if (strchr(e, 'p')) rp.nb_pairs = 0;
