@@ -140,6 +140,7 @@ struct Graph {
   int elim_cub;
   const int32_t* cub_edge_off;  // [Nc+1] bbox / corner edges of a cuboid ...
   const int32_t* cub_edges;     // ... as (edge index << 1) | is_corner
+  const int32_t* cub_edge_col;  // [n_cub_edges] reduced column of the listed edge's keyframe (-1: fixed)
   const int32_t* cp_cub;        // [n_cub_pairs] cuboid of an (edge a >= edge b) pair
   const int32_t* cp_a;          // [n_cub_pairs] edge a as (edge index << 1) | is_corner
   const int32_t* cp_b;
@@ -1700,12 +1701,28 @@ __device__ __forceinline__ void update_reduced_body(const Graph& g, const State&
       const int a = lane / 9;
       double part = 0.0;
       if (lane < 54) {
-        for (int q = g.cub_edge_off[c]; q < g.cub_edge_off[c + 1]; ++q) {
-          const int code = g.cub_edges[q];
-          const CubEdge& e = cub_edge_of(g, code);
-          const int pcol = g.pose_col[e.pose];
-          if (!(e.flags & F_ACTIVE) || pcol < 0) continue;
-          part += wpc_of(g, code)[lane] * g.xr[pcol + a];
+        // eight edges per trip, their loads independent of each other (as a loop of edge list -> edge -> pose -> column -> x, one edge after the
+        // other, this was a 15 us chain -- the longest of the update launch); the products are added in list order as before
+        const int q0 = g.cub_edge_off[c], q1 = g.cub_edge_off[c + 1];
+        for (int q = q0; q < q1; q += 8) {
+          int code[8], pcol[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int qq = min(q + u, q1 - 1);
+            code[u] = g.cub_edges[qq];
+            pcol[u] = g.cub_edge_col[qq];
+          }
+          double w[8], xv[8];
+          uint32_t fl[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            fl[u] = cub_edge_of(g, code[u]).flags;
+            w[u] = wpc_of(g, code[u])[lane];
+            xv[u] = g.xr[max(pcol[u], 0) + a];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (q + u < q1 && (fl[u] & F_ACTIVE) && pcol[u] >= 0) part += w[u] * xv[u];
         }
         sp[lane] = part;
       }

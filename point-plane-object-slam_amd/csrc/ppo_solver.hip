@@ -103,7 +103,7 @@ struct ppo_ba_solver {
   DevBuf<int32_t> d_po_start, d_po_end, d_po_pose;  // pose-major chunks of the reprojection edges
   PoseChunks posec{};
   DevBuf<double> d_W;
-  DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cp_cub, d_cp_a, d_cp_b, d_cp_cola, d_cp_colb;  // cuboid elimination plan
+  DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cub_edge_col, d_cp_cub, d_cp_a, d_cp_b, d_cp_cola, d_cp_colb;  // cuboid elimination plan
   DevBuf<double> d_cub_Linv, d_cub_Dinv, d_xc;
   DevBuf<int> d_info;
 #ifdef PPO_BA_TEST_HOOKS
@@ -279,7 +279,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release(); s->d_pc_lm.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
-  s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release(); s->d_cp_cola.release(); s->d_cp_colb.release();
+  s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cub_edge_col.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release(); s->d_cp_cola.release(); s->d_cp_colb.release();
   s->d_cub_Linv.release(); s->d_cub_Dinv.release(); s->d_xc.release();
   if (s->blas) rocblas_destroy_handle(s->blas);
   for (hipEvent_t e : s->ph_events) (void)hipEventDestroy(e);
@@ -594,6 +594,11 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   up.nb_lm = nl > 0 ? nblk((long)PPO_UPD_LPP * nl, 256) : 0;
   up.nb_zero = nb * (nb + 1) / 2;
   up.S = s->d_S.p; up.bs = s->d_bs_p; up.ld = g.ld;
+  if (const char* e = PPO_DEV_ENV("PPO_BA_UPDATE_PROBE")) {  // timing experiments (WRONG results): parts of the update launch left out -- 'l' landmarks, 'z' clearing of S
+    if (strchr(e, 'l')) up.nb_lm = 0;
+    if (strchr(e, 'z')) up.nb_zero = 0;
+    if (strchr(e, 'r')) up.nb_red = 0;  // ('r': cuboids and poses)
+  }
   const int grid = up.nb_red + up.nb_lm + up.nb_zero;
   if (s->use_lds) hipLaunchKernelGGL(k_update_all<true>, dim3(grid), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda, up);
   else hipLaunchKernelGGL(k_update_all<false>, dim3(grid), dim3(256), 0, s->stream, g, cur, tr, lambda, up);
@@ -1325,7 +1330,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   mark("  flags");
   // ---- cuboid elimination plan: edges per cuboid and all (a >= b) pairs of them -----------------------------------------
-  SVec<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cp_cub, cp_a, cp_b, cp_cola, cp_colb;
+  SVec<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cub_edge_col, cp_cub, cp_a, cp_b, cp_cola, cp_colb;
   {
     std::vector<std::vector<int32_t>> per(Nc);
     for (int e = 0; e < p->n_bbox; ++e) per[p->bbox_cuboid[e]].push_back(e << 1);
@@ -1335,6 +1340,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       cub_edges.insert(cub_edges.end(), per[c].begin(), per[c].end());
     }
     cub_edge_off[Nc] = (int32_t)cub_edges.size();
+    cub_edge_col.resize(cub_edges.size());  // reduced column of every listed edge's keyframe (static; saves the edge -> pose -> column walk of the cuboid back-substitution)
+    for (size_t q = 0; q < cub_edges.size(); ++q) {
+      const int32_t code = cub_edges[q];
+      cub_edge_col[q] = pose_col[(code & 1) ? p->corner_pose[code >> 1] : p->bbox_pose[code >> 1]];
+    }
     s->n_cub_edges = (int)cub_edges.size();
     if (g.elim_cub)
       for (int c = 0; c < Nc; ++c)
@@ -1420,7 +1430,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
   if (s->comm.active()) ok = ok && s->d_pack.alloc((size_t)(ld / 64) * (ld / 64 + 1) / 2 * 4096 + ld);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
-  ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream);
+  ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream) && s->d_cub_edge_col.upload(cub_edge_col, s->stream);
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream) &&
        s->d_cp_cola.upload(cp_cola, s->stream) && s->d_cp_colb.upload(cp_colb, s->stream);
   ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_Dinv.alloc((size_t)Nc * 81) && s->d_xc.alloc((size_t)Nc * 9);
@@ -1581,7 +1591,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     use_lin_buffer(s, 0);
     if (nW) (void)hipMemsetAsync(s->d_W.p, 0, nW * sizeof(double), s->stream);
   }
-  g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p; g.cp_cola = s->d_cp_cola.p; g.cp_colb = s->d_cp_colb.p;
+  g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cub_edge_col = s->d_cub_edge_col.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p; g.cp_cola = s->d_cp_cola.p; g.cp_colb = s->d_cp_colb.p;
   g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_Dinv = s->d_cub_Dinv.p; g.xc = s->d_xc.p;
   g.Dinv = s->d_Dinv.p; g.ul = s->d_ul.p; s->d_bs_p = s->d_S.p + (size_t)ld * ld; g.S = s->d_S.p; g.bs = s->d_bs_p; g.xr = s->d_xr.p;
   s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
