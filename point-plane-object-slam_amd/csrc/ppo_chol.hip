@@ -12,7 +12,10 @@
 //     forward substitution costs nothing extra.  The remaining workgroups of the launch apply panel k-1's update to one
 //     64x64 tile of the trailing matrix each (64 FP64 MFMAs per wave);
 //   * chol_back_all: the backward substitution in one launch, one workgroup per block, pipelined through data-tagged
-//     8-byte granules (no fences, no grid barrier);
+//     8-byte granules (no fences, no grid barrier); a link of the chain is a matrix-vector product with explicit inverses
+//     (T_k = L_kk^-1, M_k = L_{k+1,k} T_k) that one extra workgroup per panel launch prepares (inv_block_wg);
+//   * overlapped reduction (chol_factor_solve_overlapped, StepOverlap): the panel launches also carry the pose-pair chunks of
+//     the Schur complement for the column blocks they have not reached yet (ppo_pairs.hpp) -- DESIGN.md 4.6;
 //   * n/64 + 1 launches per solve (optionally captured once into a hipGraph and replayed, PPO_BA_CHOL_GRAPH=1).
 // FMAs are written explicitly (__builtin_fma): the library is built with -ffp-contract=off for the numeric Jacobians.
 // info follows LAPACK potrf: 0 = positive definite, j > 0 = leading minor j is not (the LM loop treats that as
