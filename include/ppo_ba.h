@@ -296,6 +296,11 @@ int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
  * window is not overlapped (few panels, deterministic mode, sharded runs, the rocSOLVER backend).  ppo_ba_time_factor() times the dense
  * solve ALONE, after a complete reduction. */
 int ppo_ba_overlap_schedule(ppo_ba_handle h, int32_t* fin, int32_t n);
+/* The schedule rule itself (host only, no GPU needed): for n_blocks 64-column blocks whose pose-pair chunks start at first_chunk[c]
+ * (n_blocks + 1 entries, non-decreasing), fin[0 .. n_blocks] as ppo_ba_create would choose it with `first_blocks` blocks reduced ahead and at
+ * most share0 / share of all chunks carried by launch 0 / by every later launch.  Guarantees: fin is non-decreasing, fin[k] >= min(n_blocks,
+ * k + 1) (the column workgroups of launch k only read final blocks), fin[n_blocks] = n_blocks. */
+int ppo_ba_overlap_plan(int32_t n_blocks, const int32_t* first_chunk, int32_t first_blocks, double share0, double share, int32_t* fin);
 
 /* Re-linearise the current state and build the reduced system for the damping set with
  * ppo_ba_debug_set_lambda(): S is n*n column-major (returned symmetric), b the Schur right-hand side, x the

@@ -2060,6 +2060,16 @@ int ppo_ba_debug_set_lambda(ppo_ba_handle s, double lambda) {
 
 int64_t ppo_ba_linearize_bytes(ppo_ba_handle s) { return s ? s->lin_bytes : -1; }
 
+int ppo_ba_overlap_plan(int32_t n_blocks, const int32_t* first_chunk, int32_t first_blocks, double share0, double share, int32_t* fin) {
+  if (n_blocks < 1 || !first_chunk || !fin || !(share0 >= 0.0) || !(share >= 0.0)) return PPO_BA_ERR_ARG;
+  for (int c = 0; c < n_blocks; ++c)
+    if (first_chunk[c] < 0 || first_chunk[c + 1] < first_chunk[c]) return PPO_BA_ERR_ARG;
+  std::vector<int> f(n_blocks + 1, n_blocks);
+  chol_overlap_schedule(n_blocks, first_chunk, first_blocks, share0, share, f.data());
+  for (int k = 0; k <= n_blocks; ++k) fin[k] = f[k];
+  return PPO_BA_OK;
+}
+
 int ppo_ba_overlap_schedule(ppo_ba_handle s, int32_t* fin, int32_t n) {
   if (!s) return PPO_BA_ERR_ARG;
   if (s->fin.empty() || s->solver_kind != PPO_SOLVER_NATIVE || s->g.det || s->comm.active()) return 0;

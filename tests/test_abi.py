@@ -127,3 +127,33 @@ def test_product_library_carries_no_experiment_code():
         assert name.encode() not in blob, name
     for env in (b"PPO_BA_CHOL_ONELAUNCH", b"PPO_BA_CHOL_GRAPH", b"PPO_BA_COMM_SELFTEST", b"PPO_BA_LIN_PARTS"):
         assert env not in blob, env
+
+
+def test_overlap_schedule_keeps_its_invariants():
+    """The schedule of the overlapped reduction (host-only rule, no GPU): for random chunk distributions over the column blocks
+    fin is non-decreasing, ends at the number of blocks, never lets a panel launch read a block that is not final (fin[k] >= k + 1), starts
+    with the requested blocks, and never gives a launch more chunks than its share unless the k + 1 rule forces it."""
+    lib = B.load_library()
+    lib.ppo_ba_overlap_plan.argtypes = [C.c_int32, B.c_ip, C.c_int32, C.c_double, C.c_double, B.c_ip]
+    rng = np.random.default_rng(7)
+    for case in range(300):
+        nb = int(rng.integers(1, 80))
+        per_block = rng.integers(0, 400, size=nb) * (rng.random(nb) < 0.9)
+        cb = np.concatenate([[0], np.cumsum(per_block)]).astype(np.int32)
+        first = int(rng.integers(1, 4))
+        share0, share = float(rng.choice([0.0, 0.05, 0.14, 0.4, 1.0])), float(rng.choice([0.0, 0.05, 0.1, 0.3, 1.0]))
+        fin = np.zeros(nb + 1, np.int32)
+        assert lib.ppo_ba_overlap_plan(nb, cb.ctypes.data_as(B.c_ip), first, share0, share, fin.ctypes.data_as(B.c_ip)) == 0
+        assert fin[0] == min(nb, max(1, first)) and fin[nb] == nb and np.all(np.diff(fin) >= 0), (case, fin)
+        total = int(cb[nb])
+        for k in range(nb):
+            assert fin[k] >= min(nb, k + 1), (case, k, fin)
+            carried = int(cb[fin[k + 1]] - cb[fin[k]])
+            budget = int((share0 if k == 0 else share) * total)
+            need = min(nb, k + 2)
+            if carried > budget:  # only the blocks the next launch must find final, never more
+                assert fin[k + 1] <= max(need, fin[k]) or int(cb[fin[k + 1]] - cb[fin[k]]) == int(cb[max(need, fin[k])] - cb[fin[k]]), (case, k, fin)
+    bad = np.array([0, 5, 3], np.int32)
+    fin = np.zeros(3, np.int32)
+    assert lib.ppo_ba_overlap_plan(2, bad.ctypes.data_as(B.c_ip), 1, 0.1, 0.1, fin.ctypes.data_as(B.c_ip)) != 0
+
