@@ -432,7 +432,7 @@ __host__ __device__ inline StepOverlap step_no_overlap(int nb) {
 // (not inlined: as part of chol_step's body the pair code -- 234 VGPRs, 60 scalar registers of keyframe data -- pushed the column
 //  workgroups' prologue into scratch memory)
 __device__ __forceinline__ void step_pairs(const StepOverlap& ov, int bid, double (*s_buf)[21][65]) {
-  schur_pairs_body<kStepThreads / 64>(ov.ctx, ov.pc, ov.chunk_lo, ov.chunk_hi, bid, ov.npair_wg, s_buf, [](double* p, double v) { atomicAdd(p, v); });
+  schur_pairs_body<kStepThreads / 64, false>(ov.ctx, ov.pc, ov.chunk_lo, ov.chunk_hi, bid, ov.npair_wg, s_buf, [](double* p, double v) { atomicAdd(p, v); });
 }
 
 // ---- explicit inverses for the backward substitution ---------------------------------------------------------------------------

@@ -144,6 +144,7 @@ struct Graph {
   const int32_t* cp_cub;        // [n_cub_pairs] cuboid of an (edge a >= edge b) pair
   const int32_t* cp_a;          // [n_cub_pairs] edge a as (edge index << 1) | is_corner
   const int32_t* cp_b;
+  const int32_t* cp_off;        // [Nc+1] pairs of a cuboid (they are listed cuboid by cuboid)
   const int32_t* cp_cola;       // [n_cub_pairs] reduced column of edge a's keyframe (-1: fixed)
   const int32_t* cp_colb;
   int n_cub_pairs;
@@ -1555,9 +1556,10 @@ struct CubDinvRow {  // acc[b] = -sum_k e_b[k] e_mine[k]
   }
 };
 constexpr int kCubPerBlock = 16;  // 256 threads: 16 rows of 16 lanes
-__device__ __forceinline__ void cub_prep_body(const Graph& g, double lambda, int vb) {
-  const int r = threadIdx.x & 15, c = vb * kCubPerBlock + (threadIdx.x >> 4);
-  const bool live = c < g.n_cuboids && g.cub_col[c] >= 0 && r < 9;
+// the row of 16 lanes this thread belongs to factors cuboid c (c < 0: an idle row); s_di != nullptr: (Hcc + lambda I)^-1 also goes to LDS
+__device__ __forceinline__ void cub_factor_row(const Graph& g, double lambda, int c, double* s_di) {
+  const int r = threadIdx.x & 15;
+  const bool live = c >= 0 && c < g.n_cuboids && g.cub_col[c] >= 0 && r < 9;
   double a[9], e[9];
   const double* hc = &g.HC[(size_t)(live ? c : 0) * 54];
 #pragma unroll
@@ -1577,42 +1579,78 @@ __device__ __forceinline__ void cub_prep_body(const Graph& g, double lambda, int
   for (int i = 0; i < 9; ++i) out[i * 9 + r] = (i >= r) ? e[i] : 0.0;
   double* di = &g.cub_Dinv[(size_t)c * 81];  // (Hcc + lambda I)^-1 = L^-T L^-1, full symmetric storage
 #pragma unroll
-  for (int b = 0; b < 9; ++b) di[r * 9 + b] = -acc[b];
-}
-// S -= Z_a Z_b' for every (edge a >= edge b) pair of one cuboid: 8 lanes per pair, lane i < 6 owns row i of the block,
-// so the six lanes of a pair hit six consecutive addresses per column (one atomic line-op)
-__device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
-  const int t = vb * blockDim.x + threadIdx.x;
-  const int pr = t >> 3, i = t & 7;
-  if (pr >= g.n_cub_pairs || i >= 6) return;
-  const int c = g.cp_cub[pr];
-  const int ca = g.cp_a[pr], cb = g.cp_b[pr];
-  const int cola = g.cp_cola[pr], colb = g.cp_colb[pr];
-  if (cola < 0 || colb < 0) return;
-  // (the activity flags are the one thing of a pair that changes between the passes: read next to the operands, applied at the end)
-  const uint32_t fa = cub_edge_of(g, ca).flags, fb = cub_edge_of(g, cb).flags;
-  // row i of W_a (Hcc + lambda I)^-1, formed on the fly (the cuboid blocks are tiny and L2-resident).  Every operand is requested up
-  // front (fully unrolled, 144 independent loads): as loops of load -> multiply-add this body was a 10 us chain of L2 round trips -- hidden
-  // behind the pair workgroups of a full reduction, but the whole length of the short launch an overlapped reduction starts with
-  const double* Wa = wpc_of(g, ca) + i * 9;
-  const double* Di = &g.cub_Dinv[(size_t)c * 81];
-  const double* Zb = wpc_of(g, cb);
-  double wa[9], di[81], zb[54];
-#pragma unroll
-  for (int m = 0; m < 9; ++m) wa[m] = Wa[m];
-#pragma unroll
-  for (int m = 0; m < 81; ++m) di[m] = Di[m];
-#pragma unroll
-  for (int m = 0; m < 54; ++m) zb[m] = Zb[m];
-  double za[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    double v = 0.0;
-#pragma unroll
-    for (int m = 0; m < 9; ++m) v += wa[m] * di[m * 9 + q];
-    za[q] = v;
+  for (int b = 0; b < 9; ++b) {
+    di[r * 9 + b] = -acc[b];
+    if (s_di) s_di[r * 9 + b] = -acc[b];
   }
-  if (!(fa & F_ACTIVE) || !(fb & F_ACTIVE)) return;
+}
+__device__ __forceinline__ void cub_prep_body(const Graph& g, double lambda, int vb) {
+  cub_factor_row(g, lambda, vb * kCubPerBlock + (int)(threadIdx.x >> 4), nullptr);
+}
+// one (edge a >= edge b) pair of a cuboid, lane i < 6 of its 8 lanes; Di: (Hcc + lambda I)^-1 of the pair's cuboid (global memory or LDS)
+struct CubPairOps {  // what a pair needs besides the cuboid's inverse: requested in one go (fused stage 1: BEFORE the inverse exists)
+  int ca, cb, cola, colb;
+  uint32_t fa, fb;
+  double wa[9], zb[54];
+  bool ok;
+};
+template <bool WITH_ZB>
+__device__ __forceinline__ void cub_pair_load(const Graph& g, int pr, int i, bool valid, CubPairOps& o) {
+  o.ok = false;
+  if (!valid || i >= 6) return;
+  o.ca = g.cp_a[pr]; o.cb = g.cp_b[pr];
+  o.cola = g.cp_cola[pr]; o.colb = g.cp_colb[pr];
+  if (o.cola < 0 || o.colb < 0) return;
+  // (the activity flags are the one thing of a pair that changes between the passes: read next to the operands, applied at the end)
+  o.fa = cub_edge_of(g, o.ca).flags; o.fb = cub_edge_of(g, o.cb).flags;
+  // Every operand is requested up front (fully unrolled, independent loads): as loops of load -> multiply-add this body was a 10 us chain of
+  // L2 round trips -- hidden behind the pair workgroups of a full reduction, but the whole length of a short launch
+  const double* Wa = wpc_of(g, o.ca) + i * 9;
+  const double* Zb = wpc_of(g, o.cb);
+#pragma unroll
+  for (int m = 0; m < 9; ++m) o.wa[m] = Wa[m];
+  if constexpr (WITH_ZB) {
+#pragma unroll
+    for (int m = 0; m < 54; ++m) o.zb[m] = Zb[m];
+  }
+  o.ok = true;
+}
+// lane i < 6 of the pair's 8 lanes: row i of W_a (Hcc + lambda I)^-1 W_b' and of the right-hand side; Di: the cuboid's inverse (global memory or LDS)
+// (DI_LDS: the inverse lies in LDS and is read where it is used -- as 81 register copies next to the pair's operands this body needed 337
+//  registers and halved the occupancy of every other part of the fused stage-1 launch)
+template <bool DI_LDS>
+__device__ __forceinline__ void cub_pair_compute(const Graph& g, int pr, int i, const CubPairOps& o, const double* Di) {
+  if (!o.ok) return;
+  const int ca = o.ca, cb = o.cb, cola = o.cola, colb = o.colb;
+  double za[9];
+  double zb_late[DI_LDS ? 54 : 1];
+  if constexpr (DI_LDS) {
+    // (fused stage 1: edge b's block is requested here, not ahead of the factorisation -- 108 registers held across it were what pushed the
+    //  launch to one wave per SIMD -- and lands while the row of W_a (Hcc + lambda I)^-1 is formed out of LDS)
+    const double* Zb = wpc_of(g, cb);
+#pragma unroll
+    for (int m = 0; m < 54; ++m) zb_late[m] = Zb[m];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < 9; ++m) v += o.wa[m] * Di[m * 9 + q];
+      za[q] = v;
+    }
+  } else {
+    double di[81];
+#pragma unroll
+    for (int m = 0; m < 81; ++m) di[m] = Di[m];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < 9; ++m) v += o.wa[m] * di[m * 9 + q];
+      za[q] = v;
+    }
+  }
+  if (!(o.fa & F_ACTIVE) || !(o.fb & F_ACTIVE)) return;
+  const double* zb = DI_LDS ? zb_late : o.zb;
   const bool self = ca == cb;
   const int n = g.ld;
 #pragma unroll
@@ -1632,7 +1670,7 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
     }
   }
   if (self) {
-    const double* u = &g.HC[(size_t)c * 54 + 45];  // b_c
+    const double* u = &g.HC[(size_t)g.cp_cub[pr] * 54 + 45];  // b_c
     double v = 0.0;
 #pragma unroll
     for (int q = 0; q < 9; ++q) v += za[q] * u[q];
@@ -1640,6 +1678,38 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
   }
 }
 
+template <bool DI_LDS>
+__device__ __forceinline__ void cub_pair_body(const Graph& g, int pr, int i, const double* Di) {
+  CubPairOps o;
+  cub_pair_load<!DI_LDS>(g, pr, i, true, o);
+  cub_pair_compute<DI_LDS>(g, pr, i, o, Di);
+}
+__device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
+  const int t = vb * blockDim.x + threadIdx.x;
+  const int pr = t >> 3;
+  if (pr >= g.n_cub_pairs) return;
+  cub_pair_body<false>(g, pr, t & 7, &g.cub_Dinv[(size_t)g.cp_cub[pr] * 81]);
+}
+// ONE workgroup per cuboid: its 9x9 block factored and inverted by the first row of 16 lanes, then all its edge pairs against the
+// inverse in LDS -- preparation and use in one workgroup, so that the cuboid terms need no launch of their own behind stage 1
+// (kCubFusedSplit workgroups per cuboid, each factoring the block for itself -- 1.5 us -- and taking every kCubFusedSplit-th round of 32 pairs:
+//  a cuboid seen from ten keyframes has 55 pairs, as two rounds in one workgroup the chain was 16 us)
+constexpr int kCubFusedSplit = 2;
+__device__ __forceinline__ void cub_fused_body(const Graph& g, double lambda, int vb, double* s_di) {
+  const int c = vb / kCubFusedSplit, part = vb % kCubFusedSplit;
+  const int per_round = (int)(blockDim.x >> 3), i = threadIdx.x & 7;
+  const bool live = g.cub_col[c] >= 0;
+  // this thread's pair of the first round: its operands are requested BEFORE the block is factored (they do not depend on it)
+  int pr = g.cp_off[c] + part * per_round + (int)(threadIdx.x >> 3);
+  const int pr_end = g.cp_off[c + 1];
+  CubPairOps o;
+  cub_pair_load<false>(g, pr, i, live && pr < pr_end, o);
+  if (threadIdx.x < 64) cub_factor_row(g, lambda, threadIdx.x < 16 ? c : -1, s_di);  // (every part writes the same cub_Linv / cub_Dinv: identical values)
+  __syncthreads();
+  if (!live) return;
+  cub_pair_compute<true>(g, pr, i, o, s_di);
+  for (pr += kCubFusedSplit * per_round; pr < pr_end; pr += kCubFusedSplit * per_round) cub_pair_body<true>(g, pr, i, s_di);
+}
 
 // ---- the reduction to the pose system in three launches (horizontal fusion of independent parts) ---------------------------
 // stage 1: assemble Hpp + lambda I into S | invert the landmark blocks | invert the cuboid blocks
@@ -1649,12 +1719,18 @@ __device__ __forceinline__ void cub_schur_body(const Graph& g, int vb) {
 struct ReducePlan {
   int nb_asm, nb_prep, nb_cubprep, nb_zero;
   int nb_pairs, nb_cubschur;
+  int nb_cubfused, nb_pairs1;  // stage 1 of an overlapped reduction: one workgroup per cuboid (block + its pairs) and the pair chunks [0, chunk_hi)
+                               // with their landmark blocks inverted on the fly -- no stage-3 launch at all
   int chunk_hi;  // the pair workgroups of stage 3 reduce the chunks [0, chunk_hi): all of them, or -- overlapped reduction -- those of the
                  // first column blocks of S (the fused launches of the dense factorisation take the rest, ppo_chol.hip)
 };
-inline PairCtx pair_ctx_host(const Graph& g) { return PairCtx{g.linR, g.F, g.W, g.Dinv, g.ul, g.S, g.bs, g.n_points, g.n_pt_slots, g.ld}; }
-__device__ __forceinline__ PairCtx pair_ctx(const Graph& g) { return PairCtx{g.linR, g.F, g.W, g.Dinv, g.ul, g.S, g.bs, g.n_points, g.n_pt_slots, g.ld}; }
-__global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp, ZeroPlan zother) {
+inline PairCtx pair_ctx_host(const Graph& g) { return PairCtx{g.linR, g.F, g.W, g.Dinv, g.ul, g.S, g.bs, g.n_points, g.n_pt_slots, g.ld, g.D, g.bl, 0.0}; }
+__device__ __forceinline__ PairCtx pair_ctx(const Graph& g, double lambda = 0.0) { return PairCtx{g.linR, g.F, g.W, g.Dinv, g.ul, g.S, g.bs, g.n_points, g.n_pt_slots, g.ld, g.D, g.bl, lambda}; }
+// FUSED: stage 1 of an overlapped reduction, with the cuboid workgroups and the pair workgroups of the first column block(s) (a second
+// instantiation: the pair code needs every register a wave can have, the plain stage 1 a third of them)
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp, ZeroPlan zother, PairChunks pc) {
+  __shared__ double s_buf[FUSED ? 4 : 1][FUSED ? 21 : 2][65];  // (FUSED: pair workgroups; the cuboid workgroups keep their inverse in its first 81 entries)
   int b = blockIdx.x;
   if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
   // (acc[ACC_DETBAD] is NOT cleared here: assemble_body of this very launch may raise it -- k_publish clears it once it is copied out)
@@ -1664,6 +1740,15 @@ __global__ __launch_bounds__(256) void k_reduce_stage1(Graph g, double lambda, R
     p[1] = 0.0;
   }
   // (the cuboid workgroup first: one thread per cuboid walks a 9x9 Cholesky + inverse, the longest chain of the launch)
+  if constexpr (FUSED) {
+    if (b < rp.nb_cubfused) { cub_fused_body(g, lambda, b, &s_buf[0][0][0]); return; }
+    b -= rp.nb_cubfused;
+    if (b < rp.nb_pairs1) {
+      schur_pairs_body<4, true>(pair_ctx(g, lambda), pc, 0, rp.chunk_hi, b, rp.nb_pairs1, s_buf, [&](double* p, double v) { acc_add(g, p, v); });
+      return;
+    }
+    b -= rp.nb_pairs1;
+  }
   if (b < rp.nb_cubprep) { cub_prep_body(g, lambda, b); return; }
   b -= rp.nb_cubprep;
   if (b < rp.nb_asm) { assemble_body(g, lambda, b); return; }
@@ -1679,12 +1764,12 @@ __global__ __launch_bounds__(256) void k_reduce_stage3(Graph g, PairChunks pc, R
   // the few cuboid workgroups first (a chain of dependent gathers: at the end of the grid they were a 5 us tail behind the pair
   // workgroups); their count is a multiple of 8, so the pair workgroups keep their workgroup -> XCD phase
   if (b < rp.nb_cubschur) { cub_schur_body(g, b); return; }
-  schur_pairs_body<4>(pair_ctx(g), pc, 0, rp.chunk_hi, b - rp.nb_cubschur, rp.nb_pairs, s_buf, [&](double* p, double v) { acc_add(g, p, v); });
+  schur_pairs_body<4, false>(pair_ctx(g), pc, 0, rp.chunk_hi, b - rp.nb_cubschur, rp.nb_pairs, s_buf, [&](double* p, double v) { acc_add(g, p, v); });
 }
 // single-part wrappers (measurement hooks)
 __global__ __launch_bounds__(256) void k_schur_pairs(Graph g, PairChunks pc) {
   __shared__ double s_buf[4][21][65];
-  schur_pairs_body<4>(pair_ctx(g), pc, 0, pc.n_chunks, blockIdx.x, gridDim.x, s_buf, [&](double* p, double v) { acc_add(g, p, v); });
+  schur_pairs_body<4, false>(pair_ctx(g), pc, 0, pc.n_chunks, blockIdx.x, gridDim.x, s_buf, [&](double* p, double v) { acc_add(g, p, v); });
 }
 
 // Poses and cuboids in ONE launch of 64-thread workgroups: workgroup c < n_cuboids back-substitutes cuboid c (when the cuboids

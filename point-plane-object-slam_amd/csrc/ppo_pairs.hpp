@@ -31,6 +31,10 @@ struct PairCtx {
   double* S;           // [ld][ld] column-major, lower triangle
   double* bs;          // [ld]
   int n_points, n_pt_slots, ld;
+  // FLY variant (the chunks reduced in the launch that also forms Dinv / ul: they invert their landmarks' blocks themselves)
+  const double* D;     // [n_lm][6] packed upper
+  const double* bl;    // [n_lm][3]
+  double lambda;
 };
 
 #ifdef __HIPCC__  // ---- device code ------------------------------------------------------------------------------------------------------
@@ -66,7 +70,24 @@ __device__ __forceinline__ double wave_transpose_sum(const double* vals, double 
 #define PPO_PAIRS_PREFETCH 1  // the next trip's gathers in flight during this trip's arithmetic: 43.8 -> 42.1 us (234 VGPRs, still 2 waves per SIMD)
 #endif
 // One workgroup of WAVES waves reduces WAVES chunks of [chunk_lo, chunk_hi); `add(p, v)` is the accumulation (*p += v across waves).
-template <int WAVES, class Add>
+// (D + lambda I)^-1 of a 3x3 landmark block (packed upper in, packed upper out) through its Cholesky factor, reciprocal square roots with
+// one third-order correction (2.2e-16) instead of square roots and divisions
+__device__ __forceinline__ double pairs_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-(x * y0), y0, 1.0);
+  return (x > 0.0) ? __builtin_fma(y0, e * __builtin_fma(0.375, e, 0.5), y0) : __builtin_nan("");
+}
+__device__ __forceinline__ void pairs_inv3(double d00, double d01, double d02, double d11, double d12, double d22, double lambda, double (&v)[6]) {
+  d00 += lambda; d11 += lambda; d22 += lambda;
+  const double i00 = pairs_rsqrt(d00), l10 = d01 * i00, l20 = d02 * i00;
+  const double i11 = pairs_rsqrt(d11 - l10 * l10), l21 = (d12 - l20 * l10) * i11;
+  const double i22 = pairs_rsqrt(d22 - l20 * l20 - l21 * l21);
+  const double i10 = -l10 * i00 * i11, i21 = -l21 * i11 * i22, i20 = -(l20 * i00 + l21 * i10) * i22;
+  v[0] = i00 * i00 + i10 * i10 + i20 * i20; v[1] = i10 * i11 + i20 * i21; v[2] = i20 * i22;
+  v[3] = i11 * i11 + i21 * i21; v[4] = i21 * i22; v[5] = i22 * i22;
+}
+// FLY: the landmark blocks are inverted here from D and lambda (and (D + lambda I)^-1 b_l formed from b_l) instead of being read from Dinv / ul
+template <int WAVES, bool FLY, class Add>
 __device__ __forceinline__ void schur_pairs_body(const PairCtx& g, const PairChunks& pc, int chunk_lo, int chunk_hi, int bid, int nblocks, double (*s_buf)[21][65], Add add) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // One wave per chunk of one pose pair.  Chunks are ordered by (pose i, pose j) and every Z record is needed by ~7
@@ -109,7 +130,7 @@ __device__ __forceinline__ void schur_pairs_body(const PairCtx& g, const PairChu
   double2 p01, p23, p45;
   FactorRec pfj{}, pfi{};
   {
-    const double2* I2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l * 6]);
+    const double2* I2 = reinterpret_cast<const double2*>(&(FLY ? g.D : g.Dinv)[(size_t)l * 6]);
     p01 = I2[0]; p23 = I2[1]; p45 = I2[2];
     if (l < g.n_points) { pfj = F4[sj]; pfi = F4[si]; }
   }
@@ -119,15 +140,21 @@ __device__ __forceinline__ void schur_pairs_body(const PairCtx& g, const PairChu
     const double2 i01 = p01, i23 = p23, i45 = p45;
     const FactorRec fj_cur = pfj, fi_cur = pfi;
 #else
-    const double2* I2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l * 6]);  // 48-byte records: three 16-byte loads
+    const double2* I2 = reinterpret_cast<const double2*>(&(FLY ? g.D : g.Dinv)[(size_t)l * 6]);  // 48-byte records: three 16-byte loads
     const double2 i01 = I2[0], i23 = I2[1], i45 = I2[2];
 #endif
-    const double v00 = i01.x, v01 = i01.y, v02 = i23.x, v11 = i23.y, v12 = i45.x, v22 = i45.y;
+    double v00 = i01.x, v01 = i01.y, v02 = i23.x, v11 = i23.y, v12 = i45.x, v22 = i45.y;
+    if constexpr (FLY) {
+      double vi[6];
+      pairs_inv3(v00, v01, v02, v11, v12, v22, g.lambda, vi);
+      v00 = vi[0]; v01 = vi[1]; v02 = vi[2]; v11 = vi[3]; v12 = vi[4]; v22 = vi[5];
+    }
     const int en = e + 64 < e1 ? e + 64 : e1 - 1;
     const int sj_n = pc.sj[en], si_n = pc.si[en], l_n = pc.lm[en];
 #ifdef PPO_PAIRS_PREFETCH
-    if (e + 64 < e1) {  // (uniform: the chunk has another trip)
-      const double2* J2 = reinterpret_cast<const double2*>(&g.Dinv[(size_t)l_n * 6]);
+    if (!FLY && e + 64 < e1) {  // (uniform: the chunk has another trip.  FLY: no prefetch -- with the inversion's registers on top the wave would need
+                                //  more than 256 and the launch would hold half as many workgroups; the gathers are requested at the end of the trip)
+      const double2* J2 = reinterpret_cast<const double2*>(&(FLY ? g.D : g.Dinv)[(size_t)l_n * 6]);
       p01 = J2[0]; p23 = J2[1]; p45 = J2[2];
       if (l_n < g.n_points) { pfj = F4[sj_n]; pfi = F4[si_n]; }
     }
@@ -136,7 +163,14 @@ __device__ __forceinline__ void schur_pairs_body(const PairCtx& g, const PairChu
     double L[18], y[18], T[9], w[18];
     const bool self = sj == si;
     double u0 = 0.0, u1 = 0.0, u2 = 0.0;  // self pairs: (D + lambda I)^-1 b_l, rotated like T
-    if (self) { u0 = g.ul[(size_t)l * 3]; u1 = g.ul[(size_t)l * 3 + 1]; u2 = g.ul[(size_t)l * 3 + 2]; }
+    if (self) {
+      if constexpr (FLY) {
+        const double b0 = g.bl[(size_t)l * 3], b1 = g.bl[(size_t)l * 3 + 1], b2 = g.bl[(size_t)l * 3 + 2];
+        u0 = v00 * b0 + v01 * b1 + v02 * b2; u1 = v01 * b0 + v11 * b1 + v12 * b2; u2 = v02 * b0 + v12 * b1 + v22 * b2;
+      } else {
+        u0 = g.ul[(size_t)l * 3]; u1 = g.ul[(size_t)l * 3 + 1]; u2 = g.ul[(size_t)l * 3 + 2];
+      }
+    }
     if (l < g.n_points) {
 #ifdef PPO_PAIRS_PREFETCH
       const FactorRec fj = fj_cur, fi = fi_cur;
@@ -190,6 +224,13 @@ __device__ __forceinline__ void schur_pairs_body(const PairCtx& g, const PairChu
       for (int c = 0; c < 6; ++c) vals[36 + c] += L[c * 3] * u0 + L[c * 3 + 1] * u1 + L[c * 3 + 2] * u2;
     }
     sj = sj_n; si = si_n; l = l_n;
+#ifdef PPO_PAIRS_PREFETCH
+    if (FLY && e + 64 < e1) {
+      const double2* J2 = reinterpret_cast<const double2*>(&g.D[(size_t)l * 6]);
+      p01 = J2[0]; p23 = J2[1]; p45 = J2[2];
+      if (l < g.n_points) { pfj = F4[sj]; pfi = F4[si]; }
+    }
+#endif
   }
   const int n = g.ld;
   const bool diag = colj == coli;

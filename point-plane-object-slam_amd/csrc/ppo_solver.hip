@@ -103,7 +103,7 @@ struct ppo_ba_solver {
   DevBuf<int32_t> d_po_start, d_po_end, d_po_pose;  // pose-major chunks of the reprojection edges
   PoseChunks posec{};
   DevBuf<double> d_W;
-  DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cub_edge_col, d_cp_cub, d_cp_a, d_cp_b, d_cp_cola, d_cp_colb;  // cuboid elimination plan
+  DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cub_edge_col, d_cp_cub, d_cp_a, d_cp_b, d_cp_cola, d_cp_colb, d_cp_off;  // cuboid elimination plan
   DevBuf<double> d_cub_Linv, d_cub_Dinv, d_xc;
   DevBuf<int> d_info;
 #ifdef PPO_BA_TEST_HOOKS
@@ -279,7 +279,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release(); s->d_pc_lm.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
-  s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cub_edge_col.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release(); s->d_cp_cola.release(); s->d_cp_colb.release();
+  s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cub_edge_col.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release(); s->d_cp_cola.release(); s->d_cp_colb.release(); s->d_cp_off.release();
   s->d_cub_Linv.release(); s->d_cub_Dinv.release(); s->d_xc.release();
   if (s->blas) rocblas_destroy_handle(s->blas);
   for (hipEvent_t e : s->ph_events) (void)hipEventDestroy(e);
@@ -543,7 +543,22 @@ int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
     rp.nb_zero = std::max(1, std::min(nblk((long)zero_plan_doubles(zother) / 2, 256), s->n_cu));
     s->lin_clean[s->lin_buf ^ 1] = true;
   }
-  hipLaunchKernelGGL(k_reduce_stage1, dim3(rp.nb_asm + rp.nb_prep + rp.nb_cubprep + rp.nb_zero), dim3(256), 0, s->stream, g, lambda, rp, zother);
+  // Overlapped reduction: what has to be in S before the first panel launch -- the pair chunks of the first column block(s) and the cuboid
+  // terms -- rides in stage 1's launch instead of a launch of its own behind it: the pair workgroups invert their landmarks' blocks
+  // themselves (they cannot wait for the landmark part of the same launch), every cuboid gets ONE workgroup that factors its block and
+  // then forms its edge pairs.  (8.8 + 10.9 us in two launches -> one launch of the longer chain.)
+  bool fuse_a = s->reduce_overlapped;
+  if (const char* e = PPO_DEV_ENV("PPO_BA_FUSE_A")) fuse_a = fuse_a && !(e[0] == '0' && e[1] == 0);  // (A/B: "0" keeps the two launches)
+  if (fuse_a) {
+    rp.nb_cubfused = rp.nb_cubprep > 0 ? g.n_cuboids * kCubFusedSplit : 0;
+    rp.nb_cubprep = 0;
+    rp.nb_pairs1 = rp.nb_pairs;
+    rp.nb_pairs = 0;
+    rp.nb_cubschur = 0;
+  }
+  const dim3 grid1(rp.nb_cubfused + rp.nb_pairs1 + rp.nb_asm + rp.nb_prep + rp.nb_cubprep + rp.nb_zero);
+  if (fuse_a) hipLaunchKernelGGL(k_reduce_stage1<true>, grid1, dim3(256), 0, s->stream, g, lambda, rp, zother, s->pc);
+  else hipLaunchKernelGGL(k_reduce_stage1<false>, grid1, dim3(256), 0, s->stream, g, lambda, rp, zother, s->pc);
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
   if (g.det) {  // S and b were summed as fixed-point integers (assembly, pair chunks, cuboid terms): back to doubles before anybody factors them
     ZeroPlan zp{};
@@ -1330,7 +1345,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   mark("  flags");
   // ---- cuboid elimination plan: edges per cuboid and all (a >= b) pairs of them -----------------------------------------
-  SVec<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cub_edge_col, cp_cub, cp_a, cp_b, cp_cola, cp_colb;
+  SVec<int32_t> cub_edge_off(Nc + 1, 0), cub_edges, cub_edge_col, cp_cub, cp_a, cp_b, cp_cola, cp_colb, cp_off(Nc + 1, 0);
   {
     std::vector<std::vector<int32_t>> per(Nc);
     for (int e = 0; e < p->n_bbox; ++e) per[p->bbox_cuboid[e]].push_back(e << 1);
@@ -1347,7 +1362,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     }
     s->n_cub_edges = (int)cub_edges.size();
     if (g.elim_cub)
-      for (int c = 0; c < Nc; ++c)
+      for (int c = 0; c < Nc; ++c) {
+        cp_off[c] = (int32_t)cp_cub.size();
         for (int a = cub_edge_off[c]; a < cub_edge_off[c + 1]; ++a)
           for (int b = cub_edge_off[c]; b <= a; ++b) {
             // a pair carries everything that does not change after create -- the two edge codes and their keyframes' columns -- so that the
@@ -1356,6 +1372,9 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
             cp_cub.push_back(c); cp_a.push_back(cub_edges[a]); cp_b.push_back(cub_edges[b]);
             cp_cola.push_back(col_of(cub_edges[a])); cp_colb.push_back(col_of(cub_edges[b]));
           }
+      }
+    cp_off[Nc] = (int32_t)cp_cub.size();
+    if (!g.elim_cub) for (int c = 0; c <= Nc; ++c) cp_off[c] = 0;
   }
 
   // ---- initial estimates, canonicalised like the reference's converters ------------------------------------------
@@ -1432,7 +1451,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
   ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream) && s->d_cub_edge_col.upload(cub_edge_col, s->stream);
   ok = ok && s->d_cp_cub.upload(cp_cub, s->stream) && s->d_cp_a.upload(cp_a, s->stream) && s->d_cp_b.upload(cp_b, s->stream) &&
-       s->d_cp_cola.upload(cp_cola, s->stream) && s->d_cp_colb.upload(cp_colb, s->stream);
+       s->d_cp_cola.upload(cp_cola, s->stream) && s->d_cp_colb.upload(cp_colb, s->stream) && s->d_cp_off.upload(cp_off, s->stream);
   ok = ok && s->d_cub_Linv.alloc((size_t)Nc * 81) && s->d_cub_Dinv.alloc((size_t)Nc * 81) && s->d_xc.alloc((size_t)Nc * 9);
   PlanScratch plan_scratch;
   ScopedDevBuf<int32_t> d_slot_off_lm, d_slot_col_lm, d_new_id, d_slot_lm_lm, d_pair_off, d_npairs, d_key_count, d_key_start, d_nchunks, d_chunk_off, d_n_chunks_out, d_cb;
@@ -1591,7 +1610,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     use_lin_buffer(s, 0);
     if (nW) (void)hipMemsetAsync(s->d_W.p, 0, nW * sizeof(double), s->stream);
   }
-  g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cub_edge_col = s->d_cub_edge_col.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p; g.cp_cola = s->d_cp_cola.p; g.cp_colb = s->d_cp_colb.p;
+  g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cub_edge_col = s->d_cub_edge_col.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p; g.cp_cola = s->d_cp_cola.p; g.cp_colb = s->d_cp_colb.p; g.cp_off = s->d_cp_off.p;
   g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_Dinv = s->d_cub_Dinv.p; g.xc = s->d_xc.p;
   g.Dinv = s->d_Dinv.p; g.ul = s->d_ul.p; s->d_bs_p = s->d_S.p + (size_t)ld * ld; g.S = s->d_S.p; g.bs = s->d_bs_p; g.xr = s->d_xr.p;
   s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
