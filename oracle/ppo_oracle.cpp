@@ -1470,6 +1470,68 @@ int oracle_ba_reduced(oracle_handle o, double lambda, int lm_first, int lm_last,
   return PPO_BA_OK;
 }
 int oracle_ba_num_landmarks(oracle_handle o) { return o ? o->n_lm : -1; }
+
+// ---- hooks of the reference-binary pins (oracle/pin_orbslam_prebuilt.py, tests/test_orbslam_pin.py) ----------------------------
+// Overwrite the CURRENT estimates with the given numbers, bit for bit (no quaternion / plane normalisation: the pinning script
+// writes its values straight into the reference's vertex objects too).  Any pointer may be NULL.
+int oracle_ba_set_state(oracle_handle o, const double* pose_qt, const double* point_xyz, const double* plane_coef, const double* cuboid_qt,
+                        const double* cuboid_scale) {
+  if (!o) return PPO_BA_ERR_ARG;
+  auto get_se3 = [](const double* q) { SE3 T; T.r = Quat{q[0], q[1], q[2], q[3]}; T.t = mk(q[4], q[5], q[6]); return T; };
+  if (pose_qt) for (int i = 0; i < o->n_poses; ++i) o->pose[i] = get_se3(&pose_qt[7 * i]);
+  if (point_xyz) for (int i = 0; i < o->n_points; ++i) o->point[i] = mk(point_xyz[3 * i], point_xyz[3 * i + 1], point_xyz[3 * i + 2]);
+  if (plane_coef) for (int i = 0; i < o->n_planes; ++i) for (int a = 0; a < 4; ++a) o->plane[i].c[a] = plane_coef[4 * i + a];
+  if (cuboid_qt) for (int i = 0; i < o->n_cuboids; ++i) o->cuboid[i].pose = get_se3(&cuboid_qt[7 * i]);
+  if (cuboid_scale) for (int i = 0; i < o->n_cuboids; ++i) o->cuboid[i].scale = mk(cuboid_scale[3 * i], cuboid_scale[3 * i + 1], cuboid_scale[3 * i + 2]);
+  return PPO_BA_OK;
+}
+// The measurement plane of plane edge `idx` as the oracle holds it (after its Converter::toPlane3D / Plane3D(v) restatement).
+int oracle_ba_plane_meas(oracle_handle o, int idx, double out[4]) {
+  if (!o || idx < 0 || idx >= o->n_edges[E_PLANE]) return PPO_BA_ERR_ARG;
+  std::memcpy(out, o->pl_meas_plane[idx].c, 4 * sizeof(double));
+  return PPO_BA_OK;
+}
+// One block of the system assembled by the last oracle_ba_linearize: H(a, b) row-major (rows of vertex a, columns of vertex b) and
+// the right-hand side of vertex a.  Vertex types: 0 pose, 1 point, 2 plane, 3 cuboid.  tb < 0: the diagonal block of a.
+// Returns the number of rows, 0 when a vertex is not in the system (fixed / inactive) or the pair has no block.
+int oracle_ba_block(oracle_handle o, int ta, int ia, int tb, int ib, double* H, double* bvec) {
+  if (!o || ta < 0 || ta > 3) return PPO_BA_ERR_ARG;
+  if (tb < 0) { tb = ta; ib = ia; }
+  if (ia < 0 || ia >= (int)o->hidx[ta].size() || ib < 0 || ib >= (int)o->hidx[tb].size()) return PPO_BA_ERR_ARG;
+  if (o->hidx[ta][ia] < 0 || o->hidx[tb][ib] < 0) return 0;
+  const int da = kVDim[ta], db = kVDim[tb];
+  const bool la = (ta == V_POINT || ta == V_PLANE), lb = (tb == V_POINT || tb == V_PLANE);
+  if (bvec)
+    for (int r = 0; r < da; ++r) bvec[r] = la ? o->b[(size_t)o->n_red + o->col0[ta][ia] + r] : o->b[o->col0[ta][ia] + r];
+  if (!H) return da;
+  if (!la && !lb) {  // reduced partition: upper blocks are stored
+    const int r0 = o->col0[ta][ia], c0 = o->col0[tb][ib];
+    for (int r = 0; r < da; ++r)  // a diagonal block is filled completely, an off-diagonal one only above the diagonal
+      for (int c = 0; c < db; ++c) H[r * db + c] = (r0 <= c0) ? HPP(*o, r0 + r, c0 + c) : HPP(*o, c0 + c, r0 + r);
+    return da;
+  }
+  if (la && lb) {
+    if (ta != tb || ia != ib) return 0;
+    std::copy(&o->Hll[(size_t)9 * o->hidx[ta][ia]], &o->Hll[(size_t)9 * o->hidx[ta][ia]] + 9, H);
+    return 3;
+  }
+  // landmark x reduced block (either order): hpl slots hold the 6 x 3 block (pose rows)
+  const int l = la ? o->hidx[ta][ia] : o->hidx[tb][ib];
+  const int rb = la ? o->hidx[tb][ib] : o->hidx[ta][ia];
+  const int dred = la ? db : da;
+  if (dred != 6) { std::fill(H, H + da * db, 0.0); return da; }  // cuboid x plane: structurally present in g2o, identically zero
+  for (int s = o->hpl_start[l]; s < o->hpl_start[l + 1]; ++s)
+    if (o->hpl_rb[s] == rb) {
+      const double* blk = &o->hpl[(size_t)18 * s];
+      for (int a = 0; a < 6; ++a)
+        for (int c = 0; c < 3; ++c) {
+          if (la) H[c * 6 + a] = blk[a * 3 + c];
+          else H[a * 3 + c] = blk[a * 3 + c];
+        }
+      return da;
+    }
+  return 0;
+}
 // dense symmetric solve through the restated LDLT (column-major full matrix in, lower triangle used)
 int oracle_ldlt_solve(const double* A, int n, const double* rhs, double* x) {
   std::vector<double> M(A, A + (size_t)n * n);
@@ -1502,6 +1564,15 @@ void oracle_pose_oplus(const double qt[7], const double upd[6], double out[7]) {
 void oracle_plane_oplus(const double c[4], const double upd[3], double out[4]) {
   const Plane p = plane_oplus(plane_from_vector(c), upd);
   std::memcpy(out, p.c, sizeof(p.c));
+}
+// Plane3D(const Vector4D&) (via_cv = 0) or Converter::toPlane3D (via_cv = 1: sign flip before the normalisation)
+void oracle_plane_normalize(const double v[4], int via_cv, double out[4]) {
+  const Plane p = via_cv ? plane_from_cv(v) : plane_from_vector(v);
+  std::memcpy(out, p.c, sizeof(p.c));
+}
+void oracle_exptwist_norollpitch(const double upd[6], double qt[7]) {
+  const SE3 T = exptwist_norollpitch(upd);
+  qt[0] = T.r.x; qt[1] = T.r.y; qt[2] = T.r.z; qt[3] = T.r.w; qt[4] = T.t[0]; qt[5] = T.t[1]; qt[6] = T.t[2];
 }
 void oracle_plane_ominus(const double a[4], const double b[4], int kind, double* e) {
   const Plane pa = plane_from_vector(a), pb = plane_from_vector(b);

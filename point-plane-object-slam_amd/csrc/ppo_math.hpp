@@ -187,7 +187,10 @@ PPO_HD void sincos_step(double x, double& s, double& c) {
 PPO_HD Mat3 plane_frame(Vec3 n) {
   const double r2 = n.x * n.x + n.y * n.y;
   const double r = sqrt(r2), nn = sqrt(r2 + n.z * n.z);
-  double ca = 1.0, sa = 0.0;  // atan2(0, 0) = 0
+  // r == 0 (a normal exactly along z): atan2(+-0, +0) = +-0 but atan2(+-0, -0) = +-pi -- the sign of a ZERO x decides the chart,
+  // and the reference does produce (-0, -0, 1) whenever Plane3D::normalize flips (0, 0, -1, d < 0).  Pinned on the reference
+  // binary (tests/test_orbslam_pin.py, plane_oplus case 37).
+  double ca = __builtin_signbit(n.x) ? -1.0 : 1.0, sa = __builtin_signbit(n.y) ? -0.0 : 0.0;
   // (`!(r == 0)`, not `r > 0`: a NaN direction -- ominus_ver of two parallel normals, G2O_Plane3D.h:97-106 -- must come out as NaN,
   //  as atan2 / AngleAxis give it in the reference, not be swallowed into an identity frame)
   if (!(r == 0.0)) { const double ir = 1.0 / r; ca = n.x * ir; sa = n.y * ir; }

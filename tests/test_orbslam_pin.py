@@ -1,0 +1,159 @@
+"""The plane / cuboid half of the path against the reference's OWN prebuilt lib/libORB_SLAM2.so.
+
+tests/golden/orbslam_prebuilt.json holds inputs and outputs of the reference binary for Plane3D / VertexPlane, VertexCuboid,
+exptwist_norollpitch and every custom edge class (computeError, chi2, the numeric linearizeOplus, constructQuadraticForm with a
+Huber kernel), produced in the build container by oracle/pin_orbslam_prebuilt.py with a trap armed on every symbol that is
+not reference code (`sink_hits_during_pinned_calls` = 0 is part of the fixture).  Checked here, on the CPU:
+  * the oracle (the CPU restatement every GPU parity test is measured against), and
+  * the product's device math (csrc/ppo_math.hpp compiled for the host as libppo_hostcheck.so).
+Tolerances: residuals, state updates and the cuboid-side Jacobians are held to rounding (<= 5e-15; most are bit-identical).  A
+numerically differentiated column is (e(x + d) - e(x - d)) / 2d with d = 1e-9, so one unit in the last place of a residual of
+size ~1 moves it by ~1e-7, and a few ulps of the pose / plane oplus by ~1e-6: J, H and b of those edges are held to 1e-5 of the
+block's largest entry (measured: <= 2.5e-6) -- the reference's own noise floor, the same one tests/test_golden.py documents for
+the reprojection edges.
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+sys.path.insert(0, os.path.join(REPO, "point-plane-object-slam_amd"))
+import oracle_py  # noqa: E402
+import pin_orbslam_prebuilt as pin  # noqa: E402
+from ppo_ba import binding as B  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "orbslam_prebuilt.json")
+
+ROUNDING = 5e-15
+DIFFERENCED = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(GOLD) as fh:
+        g = json.load(fh)
+    assert g["trap"]["sink_hits_during_pinned_calls"] == 0
+    return g["cases"]
+
+
+@pytest.fixture(scope="module")
+def worst(gold):
+    return pin.check(verbose=False)
+
+
+def test_fixture_covers_every_custom_type(gold):
+    for key, n in (("plane_normalize", 32), ("plane_oplus", 32), ("cuboid_oplus", 32), ("exptwist_norollpitch", 16), ("edge_plane", 32),
+                   ("edge_plane_ver", 32), ("edge_plane_par", 32), ("edge_bbox", 32), ("edge_corner", 32), ("edge_ptcub", 32), ("edge_cubpl", 8),
+                   ("edge_cuboid3d", 32)):
+        assert len(gold[key]) >= n, key
+    # the special cases the reference has: the d < 0 flip, the 0 / 0 of ominus_ver, every flag combination of the cuboid vertex
+    assert any(c["raw"][3] < 0 for c in gold["plane_normalize"])
+    assert any(np.isnan(c["error"]).all() for c in gold["edge_plane_ver"])
+    assert {c["flags"] for c in gold["cuboid_oplus"]} == set(range(8))
+    assert any(c["fixedscale"][0] > 0 for c in gold["cuboid_oplus"])
+    assert any(c["fix1"] for c in gold["edge_plane"]) and any(c["fix0"] for c in gold["edge_bbox"])
+    assert any(len(c["points"]) == 0 for c in gold["edge_ptcub"]) and any(c["prior_half"][0] > 0 for c in gold["edge_ptcub"])
+
+
+@pytest.mark.parametrize("key", ["plane_normalize", "plane_normalize_via_converter", "plane_oplus", "cuboid_oplus_qt", "cuboid_oplus_scale",
+                                 "exptwist_norollpitch"])
+def test_oracle_vertex_types_match_the_reference_binary(worst, key):
+    assert worst[key] <= 1e-15, (key, worst[key])
+
+
+@pytest.mark.parametrize("kind", ["plane", "plane_ver", "plane_par", "bbox", "corner", "ptcub", "cubpl"])
+def test_oracle_edges_match_the_reference_binary(worst, kind):
+    assert worst["edge_%s_error" % kind] <= ROUNDING
+    assert worst["edge_%s_chi2" % kind] <= 1e-12
+    numeric_both = kind.startswith("plane")  # both Jacobians differentiate through an oplus that rounds
+    for key, differenced in (("J0", True), ("H0", True), ("b0", True), ("J1", numeric_both), ("H1", numeric_both), ("b1", numeric_both), ("H01", True)):
+        k = "edge_%s_%s" % (kind, key)
+        if k not in worst:
+            assert kind == "ptcub"
+            continue
+        if kind in ("ptcub", "cubpl"):
+            assert worst[k] == 0.0, (k, worst[k])  # bit for bit: the cuboid oplus and the point-boundary error reproduce exactly
+        else:
+            assert worst[k] <= (DIFFERENCED if differenced else ROUNDING), (k, worst[k])
+    if kind.startswith("plane"):
+        assert worst["edge_%s_meas_normalized" % kind] == 0.0
+
+
+def test_unary_numeric_driver_is_bit_exact(worst):
+    """BaseUnaryEdge::linearizeOplus (base_unary_edge.hpp:82-123) does not exist in libg2o.so; libORB_SLAM2.so instantiates it for
+    EdgePointCuboidOnlyObject, and the oracle follows it bit for bit (Jacobian, H and b)."""
+    assert worst["edge_ptcub_J0"] == 0.0 and worst["edge_ptcub_H0"] == 0.0 and worst["edge_ptcub_b0"] == 0.0
+
+
+# ---- the product's device math (ppo_math.hpp on the host) against the same vectors ---------------------------------------------------
+@pytest.fixture(scope="module")
+def hc():
+    path = os.path.join(B.PKG_ROOT, "csrc", "libppo_hostcheck.so")
+    if not os.path.exists(path):
+        pytest.skip("libppo_hostcheck.so not built (run __graft_entry__.build())")
+    return C.CDLL(path)
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def arr(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def test_device_plane_oplus(hc, gold):
+    worst = 0.0
+    for c in gold["plane_oplus"]:
+        o = np.zeros(4)
+        hc.hc_plane_oplus(dptr(arr(c["coef"])), dptr(arr(c["update"])), dptr(o))
+        worst = max(worst, pin.rel_dev(o, c["out"]))
+    assert worst <= 2e-15, worst
+
+
+def test_device_cuboid_oplus(hc, gold):
+    hc.hc_cuboid_oplus.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    worst = 0.0
+    for c in gold["cuboid_oplus"]:
+        o = np.zeros(10)
+        hc.hc_cuboid_oplus(dptr(arr(c["qt"] + c["scale"])), dptr(arr(c["update"])), c["flags"], dptr(arr(c["fixedscale"])), dptr(o))
+        worst = max(worst, pin.rel_dev(o, c["out_qt"] + c["out_scale"]))
+    assert worst <= 2e-15, worst
+
+
+@pytest.mark.parametrize("kind", ["plane", "plane_ver", "plane_par"])
+def test_device_plane_residuals(hc, gold, kind):
+    hc.hc_plane_residual.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_int, C.POINTER(C.c_double)]
+    worst = 0.0
+    for c in gold["edge_" + kind]:
+        e = np.zeros(3)
+        hc.hc_plane_residual(dptr(arr(c["v1"])), dptr(arr(c["v0_normalized"])), dptr(arr(c["meas_normalized"])), ["plane", "plane_ver", "plane_par"].index(kind), dptr(e))
+        worst = max(worst, pin.rel_dev(e[:len(c["error"])], c["error"]))
+    assert worst <= 1e-14, worst
+
+
+@pytest.mark.parametrize("kind", ["bbox", "corner"])
+def test_device_cuboid_projection_residuals(hc, gold, kind):
+    worst = 0.0
+    for c in gold["edge_" + kind]:
+        e = np.zeros(16)
+        getattr(hc, "hc_" + kind)(dptr(arr(c["v0"])), dptr(arr(c["v1"])), dptr(arr(c["K"])), dptr(arr(c["meas"])), dptr(e))
+        worst = max(worst, pin.rel_dev(e[:len(c["error"])], c["error"]))
+    assert worst <= 1e-12, worst  # pixels of size ~500: a few ulps
+
+
+def test_device_point_cuboid_residual(hc, gold):
+    hc.hc_ptcub.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    worst = 0.0
+    for c in gold["edge_ptcub"]:
+        e = np.zeros(3)
+        pts = arr(c["points"]).reshape(-1) if len(c["points"]) else np.zeros(3)
+        hc.hc_ptcub(dptr(arr(c["v0"])), dptr(pts), len(c["points"]), c["margin_ratio"], dptr(arr(c["prior_half"])), dptr(e))
+        worst = max(worst, pin.rel_dev(e, c["error"]))
+    assert worst <= 1e-14, worst
