@@ -1,0 +1,31 @@
+"""Development aid: per-quantity deviation of a backend from the reference's own LM run (tests/golden/orbslam_prebuilt_lm.json)."""
+import json, os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "point-plane-object-slam_amd")); sys.path.insert(0, os.path.join(REPO, "oracle"))
+from ppo_ba import binding as B
+import oracle_py
+cases = json.load(open(os.path.join(REPO, "tests", "golden", "orbslam_prebuilt_lm.json")))["cases"]
+which = sys.argv[1] if len(sys.argv) > 1 else "hip"
+be = B.hip_backend() if which == "hip" else oracle_py.backend()
+det = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for k, c in enumerate(cases):
+    P = B.Problem(**{n: np.array(v) for n, v in c["problem"].items()})
+    R = c["result"]
+    s = be.create(P, B.default_options(deterministic=det)); st = s.run(); r = s.read(); s.close()
+    it = st["iters"]
+    first = R["iter_first_trial"] + [len(R["lambda_trials"])]
+    tr_ref = [first[i + 1] - first[i] for i in range(len(first) - 1)]
+    tr = [a["trials"] for a in it]
+    fs = R["final_state"]
+    lv = R["levels_after_pass1"]
+    line = "case %d: trials %s  final chi2 rel %.1e" % (k, "same" if tr == tr_ref else "%s vs ref %s" % (tr, tr_ref), abs(it[-1]["chi2_after"] - R["final_chi2"]) / R["final_chi2"])
+    line += "  pose %.1e point %.1e" % (np.abs(r.pose_qt - np.array(fs["pose_qt"])).max(), np.abs(r.point_xyz - np.array(fs["point_xyz"])).max())
+    if len(fs["plane_coef"]): line += " plane %.1e" % np.abs(r.plane_coef - np.array(fs["plane_coef"])).max()
+    if len(fs["cuboid_qt"]): line += " cub %.1e scale %.1e" % (np.abs(r.cuboid_qt - np.array(fs["cuboid_qt"])).max(), np.abs(r.cuboid_scale - np.array(fs["cuboid_scale"])).max())
+    for name, got in (("plane", r.pl_chi2), ("bbox", r.bbox_chi2), ("corner", r.corner_chi2), ("ptcub", r.ptcub_chi2), ("cubpl", r.cubpl_chi2)):
+        ref = np.array(R["final_edge_chi2"][name])
+        if ref.size:
+            act = np.array(lv[name], dtype=int) == 0
+            line += " | %s chi2 %.1e/%.0f" % (name, np.abs(got[act] - ref[act]).max(), np.abs(ref[act]).max())
+    print(line)
