@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PPO_BA_ABI_VERSION 1
+#define PPO_BA_ABI_VERSION 2  /* 2: the 9-D camera-object edge (cub3d_*), th_cub3d_norm */
 
 /* return codes: 0 ok, <0 error, >0 early termination */
 enum {
@@ -153,6 +153,16 @@ typedef struct ppo_ba_problem {
   const double* cubpl_meas;    /* [n][3] */
   const double* cubpl_info;    /* [n][3] */
   const double* cubpl_huber;   /* [n] */
+
+  /* -- EdgeSE3Cuboid (g2o_cuboid.h:322-352): the 9-D camera-object 3-D measurement of Optimizer::LocalBACameraPointCuboids2D,
+   *    Optimizer.cc:1767-1800 (optimize_with_cuboid_3d).  error = min over the measured box turned by -90 / 0 / 90 / 180 degrees
+   *    about its z axis of [log(meas_world^-1 * cuboid), scale - meas scale] (cuboid::min_log_error, g2o_cuboid.h:83-109) -------- */
+  int32_t n_cub3d;
+  const int32_t* cub3d_pose;   /* slot 0 */
+  const int32_t* cub3d_cuboid; /* slot 1 */
+  const double* cub3d_meas;    /* [n][10] measured cuboid in the CAMERA frame (MapCuboid::cuboid_local_meas): qx qy qz qw tx ty tz sx sy sz */
+  const double* cub3d_info;    /* [n][9]  (ba_weight_SE3 * meas_quality)^2, Optimizer.cc:1785-1789 */
+  const double* cub3d_huber;   /* [n]     thHuberSE3 itself (not its square root), Optimizer.cc:1793 */
 } ppo_ba_problem;
 
 typedef struct ppo_ba_options {
@@ -186,6 +196,7 @@ typedef struct ppo_ba_options {
   int32_t rank, world_size;
   uint8_t comm_id[128];
   int32_t verbose;
+  double th_cub3d_norm;     /* thHuberSE3 (900), compared with |e| of the 9-D camera-object edges, Optimizer.cc:1875-1882 */
 } ppo_ba_options;
 
 /* one record per LM iteration (one OptimizationAlgorithmLevenberg::solve call) */
@@ -234,6 +245,7 @@ typedef struct ppo_ba_result {
   double* corner_chi2;    double* corner_errnorm; uint8_t* corner_level;
   double* ptcub_chi2;
   double* cubpl_chi2;
+  double* cub3d_chi2;     double* cub3d_errnorm;  uint8_t* cub3d_level;
 } ppo_ba_result;
 
 typedef struct ppo_ba_solver* ppo_ba_handle;
@@ -335,6 +347,9 @@ int ppo_ba_release_cached(void);
 int64_t ppo_ba_linearize_bytes(ppo_ba_handle h);
 
 /* Host-only helpers (no GPU needed). */
+/* sizeof() of the ABI structs as THIS library was compiled: 0 ppo_ba_problem, 1 ppo_ba_options, 2 ppo_ba_stats, 3 ppo_ba_result,
+ * 4 ppo_ba_iter_stat; -1 otherwise.  A binding (ctypes, cgo ...) compares its own mirror against it instead of trusting a count. */
+int64_t ppo_ba_sizeof(int32_t which);
 /* Range-partition landmarks (points then planes) into world_size contiguous edge-balanced ranges:
  * fills first_point[world_size+1], first_plane[world_size+1]. */
 int ppo_ba_partition(const ppo_ba_problem* p, int32_t world_size, int32_t* first_point, int32_t* first_plane);

@@ -74,6 +74,8 @@ struct CuboidObsIn {
   int bbox_x = 0, bbox_y = 0, bbox_w = 0, bbox_h = 0;  // local_object->bbox_2d (cv::Rect)
   double corners_2d[16] = {0};                   // local_object->box_corners_2d, interleaved u0 v0 .. u7 v7 (OPT:2514-2519)
   double meas_quality = 1;
+  double local_meas_qt[7] = {0, 0, 0, 1, 0, 0, 0};  // local_object->cuboid_local_meas.pose (camera frame; qx qy qz qw tx ty tz) and
+  double local_meas_scale[3] = {1, 1, 1};           // .scale: the 3-D measurement of Optimizer::LocalBACameraPointCuboids2D (OPT:1784)
 };
 struct ObjectPointIn {
   float xyz[3] = {0, 0, 0};  // UniquePoints[j]->GetWorldPos()
@@ -99,6 +101,9 @@ struct Window {
 struct Params {
   bool optimize_with_plane_3d = false, optimize_with_cuboid_2d = false, optimize_with_corners_2d = false, optimize_with_pt_obj_3d = false,
        optimize_with_cuboid_plane = false;
+  bool optimize_with_cuboid_3d = false;  // the 9-D camera-object edge: only Optimizer::LocalBACameraPointCuboids2D reads it (OPT:1768)
+  double ba_weight_SE3 = 1.0, thHuberSE3 = 900.0;   // src/Parameters.cc:60,65
+  double cuboid_3d_meas_quality = 0.75;            // the literal of OPT:1787
   double plane_angle_info = 1.0, plane_dist_info = 100.0, plane_chi = 500.0;
   double cuboid_plane_angle_info = 2.0, cuboid_plane_dist_info = 100.0, cuboid_plane_chi = 500.0;
   double ba_weight_bbox = 1.0, ba_weight_corner = 1.0, thHuberBbox2d = 80.0, thHuberConer2d = 10.0;
@@ -113,7 +118,8 @@ struct Flat {
   std::vector<double> pose_qt, pose_cam, point_xyz, plane_coef, cuboid_qt, cuboid_scale;
   std::vector<uint8_t> pose_fixed, point_fixed, cuboid_flags, pl_kind;
   std::vector<int32_t> mono_point, mono_pose, stereo_point, stereo_pose, pl_plane, pl_pose, bbox_pose, bbox_cuboid, corner_pose, corner_cuboid, ptcub_cuboid,
-      ptcub_offsets, cubpl_cuboid, cubpl_plane;
+      ptcub_offsets, cubpl_cuboid, cubpl_plane, cub3d_pose, cub3d_cuboid;
+  std::vector<double> cub3d_meas, cub3d_info, cub3d_huber;
   std::vector<double> mono_obs, mono_info, mono_huber, stereo_obs, stereo_info, stereo_huber, pl_meas, pl_info, pl_huber, bbox_meas, bbox_info, bbox_huber,
       bbox_K, corner_meas, corner_info, corner_huber, corner_K, ptcub_points, ptcub_margin_ratio, ptcub_info, cubpl_meas, cubpl_info, cubpl_huber;
   // index maps back to the window (for the write-back)
@@ -263,6 +269,20 @@ inline void flatten(const Window& w, const Params& par, Flat& f) {
         for (int a = 0; a < 9; ++a) vk.push_back((double)w.keyframes[o.kf].K[a]);
       }
   }
+  // ---- camera-cuboid 3-D measurement edges (EdgeSE3Cuboid, OPT:1767-1800: Optimizer::LocalBACameraPointCuboids2D only) ------------
+  // no image-boundary test here; information (ba_weight_SE3 * 0.75)^2 on all nine rows; the kernel delta is thHuberSE3 ITSELF (OPT:1793)
+  if (par.optimize_with_cuboid_3d)
+    for (int ci = 0; ci < (int)w.cuboids.size(); ++ci)
+      for (const CuboidObsIn& o : w.cuboids[ci].obs) {
+        if (o.kf < 0 || o.kf >= nkf || w.keyframes[o.kf].bad || f.kf_pose[o.kf] < 0) continue;
+        const double is = par.ba_weight_SE3 * par.cuboid_3d_meas_quality, info = is * is;
+        f.cub3d_pose.push_back(f.kf_pose[o.kf]);
+        f.cub3d_cuboid.push_back(ci);
+        for (int a = 0; a < 7; ++a) f.cub3d_meas.push_back(o.local_meas_qt[a]);
+        for (int a = 0; a < 3; ++a) f.cub3d_meas.push_back(o.local_meas_scale[a]);
+        for (int a = 0; a < 9; ++a) f.cub3d_info.push_back(info);
+        f.cub3d_huber.push_back(par.thHuberSE3);
+      }
   // ---- point-object edges (OPT:2556-2655) ------------------------------------------------------------------------------------
   f.ptcub_used.assign(w.cuboids.size(), std::vector<int>());
   f.ptcub_offsets.push_back(0);
@@ -336,6 +356,8 @@ inline void flatten(const Window& w, const Params& par, Flat& f) {
   q.ptcub_margin_ratio = dp(f.ptcub_margin_ratio); q.ptcub_info = dp(f.ptcub_info);
   q.n_cubpl = (int32_t)f.cubpl_cuboid.size(); q.cubpl_cuboid = ip(f.cubpl_cuboid); q.cubpl_plane = ip(f.cubpl_plane); q.cubpl_meas = dp(f.cubpl_meas);
   q.cubpl_info = dp(f.cubpl_info); q.cubpl_huber = dp(f.cubpl_huber);
+  q.n_cub3d = (int32_t)f.cub3d_pose.size(); q.cub3d_pose = ip(f.cub3d_pose); q.cub3d_cuboid = ip(f.cub3d_cuboid); q.cub3d_meas = dp(f.cub3d_meas);
+  q.cub3d_info = dp(f.cub3d_info); q.cub3d_huber = dp(f.cub3d_huber);
 }
 
 // ---- write-back (OPT:2840-2966) --------------------------------------------------------------------------------------------------

@@ -60,8 +60,9 @@ struct Gathered {
 // covisible keyframes that are not bad (OPT:1999-2009; a bad neighbour is MARKED but not pushed); their map points / cuboids / planes
 // that exist, are not bad and are not marked yet (OPT:2012-2064); fixed cameras = the other observers of the local points and of the
 // local cuboids (OPT:2068-2100; plane observers are NOT collected) -- marked first, pushed only if not bad.
+// with_planes = false: the gather of Optimizer::LocalBACameraPointCuboids2D (OPT:1255-1343), which never looks at the planes.
 template <class MapPointT, class MapPlaneT, class MapCuboidT, class KeyFrameT>
-Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT> gather_window(KeyFrameT* pKF) {
+Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT> gather_window(KeyFrameT* pKF, bool with_planes = true) {
   Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT> g;
   g.lLocalKeyFrames.push_back(pKF);
   pKF->mnBALocalForKF = pKF->mnId;
@@ -86,6 +87,7 @@ Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT> gather_window(KeyFrameT* p
         pMC->mnBALocalForKF = pKF->mnId;
       }
   }
+  if (with_planes)
   for (KeyFrameT* pKFl : g.lLocalKeyFrames) {
     const std::vector<MapPlaneT*> vpMPs = pKFl->mvpMapPlanes;
     for (MapPlaneT* pMP : vpMPs)
@@ -202,6 +204,13 @@ void to_window(const Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT>& g, p
         o.corners_2d[2 * k + 1] = lo->box_corners_2d(1, k);
       }
       o.meas_quality = lo->meas_quality;
+      {  // the 3-D measurement of the detection (camera frame), read by the 9-D edge of LocalBACameraPointCuboids2D only (OPT:1784)
+        const auto& lm = lo->cuboid_local_meas;
+        const auto& lq = lm.pose.rotation();
+        const auto& lt = lm.pose.translation();
+        o.local_meas_qt[0] = lq.x(); o.local_meas_qt[1] = lq.y(); o.local_meas_qt[2] = lq.z(); o.local_meas_qt[3] = lq.w();
+        for (int a = 0; a < 3; ++a) { o.local_meas_qt[4 + a] = lt[a]; o.local_meas_scale[a] = lm.scale[a]; }
+      }
       c.obs.push_back(o);
     }
     const std::vector<MapPointT*> UniquePoints = pMC->GetUniqueMapPoints();
@@ -339,6 +348,7 @@ inline void options_from_params(const pf::Params& par, ppo_ba_options& O) {
   O.chi2_plane = par.plane_chi;             // OPT:2791
   O.th_bbox_norm = par.thHuberBbox2d;       // OPT:2774
   O.th_corner_norm = par.thHuberConer2d;    // OPT:2783
+  O.th_cub3d_norm = par.thHuberSE3;         // OPT:1878
 }
 
 // ---- the whole of Optimizer::LocalBACameraPlaneCuboids (include/Optimizer.h:62) ------------------------------------------------------
@@ -354,6 +364,7 @@ int local_ba_camera_plane_cuboids(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, 
   to_window(g, w, kfs);
   par.fix_camera = fixCamera;
   par.fix_point = fixPoint;
+  par.optimize_with_cuboid_3d = false;  // the 9-D camera-object edge exists only in LocalBACameraPointCuboids2D (OPT:1767-1800)
   pf::Flat f;
   pf::flatten(w, par, f);  // OPT:2120-2714
   store_used_points(g, f);
@@ -379,6 +390,50 @@ int local_ba_camera_plane_cuboids(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, 
   pf::WriteBack wb;
   pf::write_back(w, par, f, s.result, wb);         // OPT:2840-2887 erase lists; float32 narrowing of Converter.cc
   apply_write_back<Traits>(g, kfs, wb, pMap);      // OPT:2892-2966
+  return rc;
+}
+
+// ---- Optimizer::LocalBACameraPointCuboids2D (include/Optimizer.h, OPT:1252-1992) ---------------------------------------
+// The point + cuboid local BA (its call site in LocalMapping is commented out, src/LocalMapping.cc:97).  Differences to the function
+// above, each as in the reference: planes are neither gathered nor optimised nor written back; the 9-D camera-object edge EdgeSE3Cuboid
+// is added when par.optimize_with_cuboid_3d is set (OPT:1767-1800) and classified by |e| > thHuberSE3 between the passes (OPT:1875-1882).
+template <class Traits, class MapPointT = typename Traits::MapPoint, class MapPlaneT = typename Traits::MapPlane, class MapCuboidT = typename Traits::MapCuboid,
+          class KeyFrameT, class MapT, class SolveFn = LibrarySolver>
+int local_ba_camera_point_cuboids_2d(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, bool fixCamera, bool fixPoint, pf::Params par, SolveFn solve = SolveFn()) {
+  static_assert(sizeof(bool) == 1, "the stop flag is handed to the library as one byte");
+  auto g = gather_window<MapPointT, MapPlaneT, MapCuboidT>(pKF, /*with_planes=*/false);  // OPT:1255-1343
+  pf::Window w;
+  std::vector<KeyFrameT*> kfs;
+  to_window(g, w, kfs);
+  par.fix_camera = fixCamera;
+  par.fix_point = fixPoint;
+  par.optimize_with_plane_3d = false;      // this function has no plane vertices or edges
+  par.optimize_with_cuboid_plane = false;
+  pf::Flat f;
+  pf::flatten(w, par, f);  // OPT:1355-1800
+  store_used_points(g, f);
+  auto reset_markers = [&]() {
+    for (KeyFrameT* k : g.lLocalKeyFrames) k->mnBALocalForKF = 0;
+    for (KeyFrameT* k : g.lFixedCameras) { k->mnBAFixedForKF = 0; k->mnBALocalForKF = 0; }
+    for (MapPointT* p : g.lLocalMapPoints) p->mnBALocalForKF = 0;
+    for (MapCuboidT* c : g.lLocalMapCuboids) c->mnBALocalForKF = 0;
+  };
+  if (pbStopFlag && *pbStopFlag) {  // OPT:1809-1811
+    reset_markers();
+    return PPO_BA_ABORTED;
+  }
+  ppo_ba_options O;
+  options_from_params(par, O);
+  Solved s;
+  const int rc = solve(f.problem, O, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), s);
+  if (rc < 0) {
+    std::cerr << "LocalBACameraPointCuboids2D: " << ppo_ba_strerror(rc) << std::endl;
+    reset_markers();
+    return rc;
+  }
+  pf::WriteBack wb;
+  pf::write_back(w, par, f, s.result, wb);         // OPT:1898-1925 erase lists
+  apply_write_back<Traits>(g, kfs, wb, pMap);      // OPT:1927-1991 (no planes in the window: nothing is written to one)
   return rc;
 }
 

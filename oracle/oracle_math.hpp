@@ -8,6 +8,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 namespace orc {
 
@@ -329,6 +330,72 @@ inline Cuboid cuboid_oplus(const Cuboid& est, const double upd[9], unsigned flag
   else
     nc.scale = add(est.scale, mk(upd[6], upd[7], upd[8]));
   return nc;
+}
+// SE3Quat::log, Thirdparty/g2o/g2o/types/se3quat.h:229-266 (deltaR: se3_ops.hpp:40-47)
+inline void se3_log(const SE3& T, double out[6]) {
+  const M3 R = quat_to_matrix(T.r);
+  const double d = 0.5 * (R.m[0][0] + R.m[1][1] + R.m[2][2] - 1);
+  const V3 dR = mk(R.m[2][1] - R.m[1][2], R.m[0][2] - R.m[2][0], R.m[1][0] - R.m[0][1]);
+  V3 omega;
+  M3 Vinv;
+  const M3 I = identity3();
+  if (d > 0.99999) {
+    omega = scl(dR, 0.5);
+    const M3 Om = skew(omega);
+    const M3 Om2 = mul(Om, Om);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Vinv.m[i][j] = I.m[i][j] - 0.5 * Om.m[i][j] + (1. / 12.) * Om2.m[i][j];
+  } else {
+    const double theta = std::acos(d);
+    omega = scl(dR, theta / (2 * std::sqrt(1 - d * d)));
+    const M3 Om = skew(omega);
+    const M3 Om2 = mul(Om, Om);
+    const double k = (1 - theta / (2 * std::tan(theta / 2))) / (theta * theta);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Vinv.m[i][j] = I.m[i][j] - 0.5 * Om.m[i][j] + k * Om2.m[i][j];
+  }
+  const V3 ups = mul(Vinv, T.t);
+  for (int i = 0; i < 3; ++i) { out[i] = omega[i]; out[i + 3] = ups[i]; }
+}
+// cuboid::rotate_cuboid, include/g2o_cuboid.h:112-123: the same box with another face called "front"
+inline Cuboid cuboid_rotate(const Cuboid& c, double yaw_angle) {
+  Cuboid r;
+  const SE3 rot = se3_make(Quat{0, 0, std::sin(yaw_angle * 0.5), std::cos(yaw_angle * 0.5)}, mk(0, 0, 0));
+  r.pose = se3_mul(c.pose, rot);
+  r.scale = c.scale;
+  if ((yaw_angle == M_PI / 2.0) || (yaw_angle == -M_PI / 2.0) || (yaw_angle == 3 * M_PI / 2.0)) std::swap(r.scale[0], r.scale[1]);
+  return r;
+}
+// cuboid::cube_log_error, include/g2o_cuboid.h:73-80
+inline void cuboid_log_error(const Cuboid& self, const Cuboid& other, double e[9]) {
+  const SE3 diff = se3_mul(se3_inverse(other.pose), self.pose);
+  se3_log(diff, e);
+  for (int i = 0; i < 3; ++i) e[6 + i] = self.scale[i] - other.scale[i];
+}
+// cuboid::min_log_error, include/g2o_cuboid.h:83-109: the smallest of the four errors against the measured box turned by
+// -90, 0, 90, 180 degrees about its z axis (Eigen's minCoeff keeps the FIRST minimum)
+inline void cuboid_min_log_error(const Cuboid& self, const Cuboid& other, double e[9]) {
+  const double angles[4] = {-1, 0, 1, 2};
+  double best = 0;
+  for (int i = 0; i < 4; ++i) {
+    double ei[9];
+    cuboid_log_error(self, cuboid_rotate(other, angles[i] * M_PI / 2.0), ei);
+    double n2 = 0;
+    for (int k = 0; k < 9; ++k) n2 += ei[k] * ei[k];
+    const double n = std::sqrt(n2);
+    if (i == 0 || n < best) {
+      best = n;
+      for (int k = 0; k < 9; ++k) e[k] = ei[k];
+    }
+  }
+}
+// EdgeSE3Cuboid::computeError, include/g2o_cuboid.h:332-341: the measured cuboid (camera frame) taken to the world with the
+// inverse of the world->camera pose, compared with the cuboid vertex
+inline void cuboid3d_error(const SE3& Tcw, const Cuboid& global_cube, const Cuboid& meas_local, double e[9]) {
+  Cuboid esti;
+  esti.pose = se3_mul(se3_inverse(Tcw), meas_local.pose);
+  esti.scale = meas_local.scale;
+  cuboid_min_log_error(global_cube, esti, e);
 }
 // corner sign table, include/g2o_cuboid.h:202-204
 static const double kCornerSign[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};

@@ -89,7 +89,7 @@ class RefRun:
             assert addV(self.optimizer.ctypes.data, v.ctypes.data, None)
             self.points.append(v); vid += 1
         # ---- edges, class by class (the order the oracle and the product sum them in) ----
-        self.edges = {k: [] for k in ("plane", "mono", "stereo", "bbox", "corner", "ptcub", "cubpl")}
+        self.edges = {k: [] for k in ("plane", "mono", "stereo", "bbox", "corner", "ptcub", "cubpl", "cub3d")}
         kinds = ("plane", "plane_ver", "plane_par")
         for i in range(len(A.get("pl_plane", []))):
             kind = kinds[int(A["pl_kind"][i]) if len(A.get("pl_kind", [])) else 0]
@@ -127,6 +127,12 @@ class RefRun:
                        float(A["cubpl_huber"][i]))
             assert addE(self.optimizer.ctypes.data, e.ctypes.data)
             self.edges["cubpl"].append(("cubpl", e))
+        for i in range(len(A.get("cub3d_pose", []))):  # EdgeSE3Cuboid of Optimizer::LocalBACameraPointCuboids2D (OPT:1767-1800)
+            m = list(A["cub3d_meas"][i])
+            e = W.edge("cuboid3d", self.poses[int(A["cub3d_pose"][i])], self.cuboids[int(A["cub3d_cuboid"][i])], m[:7] + [0.0] + m[7:], A["cub3d_info"][i],
+                       float(A["cub3d_huber"][i]))
+            assert addE(self.optimizer.ctypes.data, e.ctypes.data)
+            self.edges["cub3d"].append(("cuboid3d", e))
         # ---- Optimizer.cc:2108-2113: BlockSolverX(LinearSolverDense) + OptimizationAlgorithmLevenberg ----
         ls = self.linear_solver = O.aligned(0x80)  # operator new(0x78) at the compiled call site
         u64(ls)[0] = R.vtable(LSD)
@@ -230,6 +236,9 @@ class RefRun:
         for k, e in self.edges["corner"]:   # :2780-2787
             if self.err_norm(k, e) > opt["th_corner_norm"]:
                 set_level1(e)
+        for k, e in self.edges["cub3d"]:    # OPT:1875-1882 (LocalBACameraPointCuboids2D)
+            if self.err_norm(k, e) > opt["th_cub3d_norm"]:
+                set_level1(e)
         for k, e in self.edges["plane"]:    # :2789-2814
             if W.chi2(k, e) > (opt["chi2_plane"] if k == "plane" else opt["chi2_plane_vp"]):
                 set_level1(e)
@@ -270,8 +279,11 @@ CASES = [
     # the numerically differentiated edges
     (dict(n_kf=9, n_points=150, n_planes=0, n_cuboids=0), dict(seed=8, stereo_frac=0.4)),
     (dict(n_kf=12, n_points=200, n_planes=0, n_cuboids=0), dict(seed=9, noise_scale=4.0, outlier_frac=0.1)),
+    # Optimizer::LocalBACameraPointCuboids2D (OPT:1252-1992): points + cuboids, no planes, with the 9-D camera-object edge EdgeSE3Cuboid
+    (dict(n_kf=8, n_points=80, n_planes=0, n_cuboids=2), dict(seed=10, with_cuboid3d=True)),
+    (dict(n_kf=10, n_points=120, n_planes=0, n_cuboids=3), dict(seed=11, with_cuboid3d=True, with_corners=True, noise_scale=3.0, outlier_frac=0.1)),
 ]
-OPT_KEYS = ("iters_pass1", "iters_pass2", "chi2_mono", "chi2_stereo", "chi2_plane", "chi2_plane_vp", "th_bbox_norm", "th_corner_norm")
+OPT_KEYS = ("iters_pass1", "iters_pass2", "chi2_mono", "chi2_stereo", "chi2_plane", "chi2_plane_vp", "th_bbox_norm", "th_corner_norm", "th_cub3d_norm")
 
 
 def generate():

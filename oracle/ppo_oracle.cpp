@@ -48,7 +48,7 @@ using namespace orc;
 namespace {
 
 enum VType { V_POSE = 0, V_POINT = 1, V_PLANE = 2, V_CUBOID = 3, V_NONE = -1 };
-enum EType { E_PLANE = 0, E_MONO, E_STEREO, E_BBOX, E_CORNER, E_PTCUB, E_CUBPL, E_NTYPES };
+enum EType { E_PLANE = 0, E_MONO, E_STEREO, E_BBOX, E_CORNER, E_PTCUB, E_CUBPL, E_CUB3D, E_NTYPES };
 static const int kVDim[4] = {6, 3, 3, 9};
 static const int kMaxDim = 16;
 
@@ -75,6 +75,7 @@ struct Oracle {
   std::vector<uint8_t> pl_kind;
   std::vector<Plane> pl_meas_plane;
   std::vector<double> bbox_K, corner_K;
+  std::vector<Cuboid> cub3d_meas;  // EdgeSE3Cuboid measurement (camera frame)
   std::vector<int> ptcub_off;
   std::vector<double> ptcub_pts, ptcub_margin, ptcub_prior;
   // ---- state ----
@@ -128,6 +129,7 @@ int edge_dim(const Oracle& o, int type, int idx) {
     case E_CORNER: return 16;
     case E_PTCUB: return 3;
     case E_CUBPL: return 3;
+    case E_CUB3D: return 9;
   }
   return 0;
 }
@@ -140,7 +142,7 @@ void edge_vertices(const Oracle& o, int type, int idx, int& t0, int& i0, int& t1
   switch (type) {
     case E_PLANE: t0 = V_PLANE; t1 = V_POSE; break;
     case E_MONO: case E_STEREO: t0 = V_POINT; t1 = V_POSE; break;
-    case E_BBOX: case E_CORNER: t0 = V_POSE; t1 = V_CUBOID; break;
+    case E_BBOX: case E_CORNER: case E_CUB3D: t0 = V_POSE; t1 = V_CUBOID; break;
     case E_PTCUB: t0 = V_CUBOID; t1 = V_NONE; i1 = -1; break;
     case E_CUBPL: t0 = V_CUBOID; t1 = V_PLANE; break;
   }
@@ -244,6 +246,12 @@ void compute_error(const Oracle& o, int type, int idx, const void* a, const void
     }
     case E_CUBPL: {  // G2O_Plane3D.h:470-473: _error = _measurement
       for (int i = 0; i < 3; ++i) e[i] = o.e_meas[type][3 * idx + i];
+      break;
+    }
+    case E_CUB3D: {  // EdgeSE3Cuboid::computeError, include/g2o_cuboid.h:332-341 (Optimizer::LocalBACameraPointCuboids2D, OPT:1767-1800)
+      const SE3& T = *static_cast<const SE3*>(a);
+      const Cuboid& c = *static_cast<const Cuboid*>(bptr);
+      cuboid3d_error(T, c, o.cub3d_meas[idx], e);
       break;
     }
   }
@@ -386,7 +394,7 @@ double edge_chi2(const Oracle& o, int type, int idx) {  // base_edge.h:58-61 wit
     const double w = o.e_info[type][idx];
     for (int i = 0; i < dim; ++i) s += e[i] * (w * e[i]);
   } else {
-    const int stride = (type == E_BBOX) ? 4 : (type == E_CORNER ? 16 : 3);
+    const int stride = (type == E_BBOX) ? 4 : (type == E_CORNER ? 16 : (type == E_CUB3D ? 9 : 3));
     const double* w = &o.e_info[type][(size_t)stride * idx];
     for (int i = 0; i < dim; ++i) s += e[i] * (w[i] * e[i]);
   }
@@ -394,7 +402,7 @@ double edge_chi2(const Oracle& o, int type, int idx) {  // base_edge.h:58-61 wit
 }
 double info_at(const Oracle& o, int type, int idx, int i) {
   if (type == E_MONO || type == E_STEREO) return o.e_info[type][idx];
-  const int stride = (type == E_BBOX) ? 4 : (type == E_CORNER ? 16 : 3);
+  const int stride = (type == E_BBOX) ? 4 : (type == E_CORNER ? 16 : (type == E_CUB3D ? 9 : 3));
   return o.e_info[type][(size_t)stride * idx + i];
 }
 
@@ -608,7 +616,7 @@ void build_system_omp(Oracle& o) {
       if (free0) add_diag(t0, i0, J0, d0);
       if (free1) add_diag(t1, i1, J1, d1);
       if (free0 && free1) {
-        if (er.type == E_BBOX || er.type == E_CORNER) {
+        if (er.type == E_BBOX || er.type == E_CORNER || er.type == E_CUB3D) {
           const int r0 = o.col0[t0][i0], c0 = o.col0[t1][i1];
           for (int a = 0; a < d0; ++a)
             for (int c = 0; c < d1; ++c) {
@@ -718,7 +726,7 @@ void build_system(Oracle& o) {
     if (free0) add_diag(t0, i0, J0, d0);
     if (free1) add_diag(t1, i1, J1, d1);
     if (free0 && free1) {
-      if (er.type == E_BBOX || er.type == E_CORNER) {  // pose (slot 0) x cuboid (slot 1): upper block of Hpp
+      if (er.type == E_BBOX || er.type == E_CORNER || er.type == E_CUB3D) {  // pose (slot 0) x cuboid (slot 1): upper block of Hpp
         const int r0 = o.col0[t0][i0], c0 = o.col0[t1][i1];
         for (int a = 0; a < d0; ++a)
           for (int c = 0; c < d1; ++c) {
@@ -1207,6 +1215,8 @@ void classify_outliers(Oracle& o) {
     if (err_norm(o, E_BBOX, i) > o.opt.th_bbox_norm) o.level[E_BBOX][i] = 1;
   for (int i = 0; i < o.n_edges[E_CORNER]; ++i)
     if (err_norm(o, E_CORNER, i) > o.opt.th_corner_norm) o.level[E_CORNER][i] = 1;
+  for (int i = 0; i < o.n_edges[E_CUB3D]; ++i)  // Optimizer.cc:1875-1882 (LocalBACameraPointCuboids2D); the kernel stays
+    if (err_norm(o, E_CUB3D, i) > o.opt.th_cub3d_norm) o.level[E_CUB3D][i] = 1;
   for (int i = 0; i < o.n_edges[E_PLANE]; ++i) {
     const double th = o.pl_kind[i] == 0 ? o.opt.chi2_plane : o.opt.chi2_plane_vp;
     if (edge_chi2(o, E_PLANE, i) > th) o.level[E_PLANE][i] = 1;
@@ -1289,6 +1299,14 @@ int oracle_ba_create(const ppo_ba_problem* p, const ppo_ba_options* opt, oracle_
   copy_in(o->ptcub_margin, p->ptcub_margin_ratio, (size_t)p->n_ptcub, 1.0);
   copy_in(o->ptcub_prior, p->ptcub_prior_half, (size_t)3 * p->n_ptcub, 0.0);
   set_edges(E_CUBPL, p->n_cubpl, p->cubpl_cuboid, p->cubpl_plane, p->cubpl_meas, 3, p->cubpl_info, 3, p->cubpl_huber);
+  set_edges(E_CUB3D, p->n_cub3d, p->cub3d_pose, p->cub3d_cuboid, p->cub3d_meas, 10, p->cub3d_info, 9, p->cub3d_huber);
+  o->cub3d_meas.resize(p->n_cub3d);
+  for (int i = 0; i < p->n_cub3d; ++i) {  // g2o::cuboid measurement as MapCuboid::cuboid_local_meas holds it (values as given)
+    const double* m = &p->cub3d_meas[10 * i];
+    o->cub3d_meas[i].pose.r = Quat{m[0], m[1], m[2], m[3]};
+    o->cub3d_meas[i].pose.t = mk(m[4], m[5], m[6]);
+    o->cub3d_meas[i].scale = mk(m[7], m[8], m[9]);
+  }
   reset_state(*o);
   *out = o;
   return PPO_BA_OK;
@@ -1357,6 +1375,8 @@ int oracle_ba_read(oracle_handle o, ppo_ba_result* r) {
   put_chi(E_CORNER, r->corner_chi2, r->corner_level);
   put_chi(E_PTCUB, r->ptcub_chi2, nullptr);
   put_chi(E_CUBPL, r->cubpl_chi2, nullptr);
+  put_chi(E_CUB3D, r->cub3d_chi2, r->cub3d_level);
+  if (r->cub3d_errnorm) for (int i = 0; i < o->n_edges[E_CUB3D]; ++i) r->cub3d_errnorm[i] = err_norm(*o, E_CUB3D, i);
   if (r->mono_depth_positive) for (int i = 0; i < o->n_edges[E_MONO]; ++i) r->mono_depth_positive[i] = depth_positive(*o, E_MONO, i);
   if (r->stereo_depth_positive) for (int i = 0; i < o->n_edges[E_STEREO]; ++i) r->stereo_depth_positive[i] = depth_positive(*o, E_STEREO, i);
   if (r->bbox_errnorm) for (int i = 0; i < o->n_edges[E_BBOX]; ++i) r->bbox_errnorm[i] = err_norm(*o, E_BBOX, i);
@@ -1470,6 +1490,7 @@ int oracle_ba_reduced(oracle_handle o, double lambda, int lm_first, int lm_last,
   return PPO_BA_OK;
 }
 int oracle_ba_num_landmarks(oracle_handle o) { return o ? o->n_lm : -1; }
+int oracle_has_cuboid3d(void) { return 1; }  // the 9-D camera-object edge (E_CUB3D) is implemented
 
 // ---- hooks of the reference-binary pins (oracle/pin_orbslam_prebuilt.py, tests/test_orbslam_pin.py) ----------------------------
 // Overwrite the CURRENT estimates with the given numbers, bit for bit (no quaternion / plane normalisation: the pinning script

@@ -42,6 +42,7 @@ void ppo_ba_default_options(ppo_ba_options* o) {
   o->chi2_plane_vp = 200.0;
   o->th_bbox_norm = 80.0;
   o->th_corner_norm = 10.0;
+  o->th_cub3d_norm = 900.0;  /* thHuberSE3, src/Parameters.cc:65 */
   o->solver = PPO_SOLVER_AUTO;
   o->eliminate_cuboids = 1;
   o->world_size = 1;
@@ -80,6 +81,17 @@ int ppo_ba_partition(const ppo_ba_problem* p, int32_t world, int32_t* first_poin
   split(p->n_points, wp, first_point);
   split(p->n_planes, wl, first_plane);
   return PPO_BA_OK;
+}
+
+int64_t ppo_ba_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(ppo_ba_problem);
+    case 1: return (int64_t)sizeof(ppo_ba_options);
+    case 2: return (int64_t)sizeof(ppo_ba_stats);
+    case 3: return (int64_t)sizeof(ppo_ba_result);
+    case 4: return (int64_t)sizeof(ppo_ba_iter_stat);
+  }
+  return -1;
 }
 
 }  // extern "C"

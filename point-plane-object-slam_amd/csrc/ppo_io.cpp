@@ -51,6 +51,8 @@ const Field kFields[] = {
     PF(ptcub_margin_ratio, T_F64, n_ptcub, 1), PF(ptcub_prior_half, T_F64, n_ptcub, 3), PF(ptcub_info, T_F64, n_ptcub, 3), PF(ptcub_huber, T_F64, n_ptcub, 1),
     PF(cubpl_cuboid, T_I32, n_cubpl, 1), PF(cubpl_plane, T_I32, n_cubpl, 1), PF(cubpl_meas, T_F64, n_cubpl, 3), PF(cubpl_info, T_F64, n_cubpl, 3),
     PF(cubpl_huber, T_F64, n_cubpl, 1),
+    PF(cub3d_pose, T_I32, n_cub3d, 1), PF(cub3d_cuboid, T_I32, n_cub3d, 1), PF(cub3d_meas, T_F64, n_cub3d, 10), PF(cub3d_info, T_F64, n_cub3d, 9),
+    PF(cub3d_huber, T_F64, n_cub3d, 1),
 };
 struct Count {
   const char* name;
@@ -58,7 +60,7 @@ struct Count {
 };
 #define PC(name) {#name, offsetof(ppo_ba_problem, name)}
 const Count kCounts[] = {PC(n_poses), PC(n_points), PC(n_planes), PC(n_cuboids), PC(n_mono), PC(n_stereo), PC(n_plane_edges),
-                         PC(n_bbox), PC(n_corner), PC(n_ptcub), PC(n_cubpl)};
+                         PC(n_bbox), PC(n_corner), PC(n_ptcub), PC(n_cubpl), PC(n_cub3d)};
 
 int32_t count_of(const ppo_ba_problem* p, size_t off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p) + off); }
 const void* ptr_of(const ppo_ba_problem* p, size_t off) { return *reinterpret_cast<const void* const*>(reinterpret_cast<const char*>(p) + off); }

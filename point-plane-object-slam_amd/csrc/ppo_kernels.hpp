@@ -58,7 +58,8 @@ struct PlaneEdge {  // 88 B
   uint32_t flags;  // bit0 active, bit1 robust, bits 8..9 kind
   int32_t pad[2];
 };
-struct CubEdge {  // bbox (dim 4) and corner (dim 16) edges share one record
+struct CubEdge {  // bbox (dim 4) and corner (dim 16) edges share one record; so does the 9-D camera-object edge EdgeSE3Cuboid (dim 9,
+                   // meas = the measured cuboid qx qy qz qw tx ty tz sx sy sz, K unused), stored behind the corner edges
   double meas[16], info[16], huber, K[9];
   int32_t pose, cuboid;
   uint32_t flags;
@@ -89,6 +90,7 @@ struct Graph {
   int n_poses, n_points, n_planes, n_cuboids, n_pose_free, n_red, n_lm, n_slots;
   int ld;  // leading dimension of S (n_red rounded up to the Cholesky panel width; pad rows/cols are identity)
   int n_mono, n_stereo, n_pl, n_bbox, n_corner, n_ptcub;
+  int n_corner2d;  // corner[0 .. n_corner2d) are corner-projection edges, corner[n_corner2d .. n_corner) 9-D camera-object edges (dim 9)
   const double* pose_cam;      // [Np][5]
   const int32_t* pose_col;     // [Np] column of the pose block in the reduced system, -1 fixed / unused
   const int32_t* pose_free_id; // [Np] dense id among free poses (index into HB), -1 otherwise
@@ -555,7 +557,7 @@ __global__ void k_classify_points(Graph g, State st, double th_mono, double th_s
   }
 }
 // Optimizer.cc:2771-2814 for the plane and cuboid-projection edges
-__global__ void k_classify_small(Graph g, double th_plane, double th_vp, double th_bbox, double th_corner) {
+__global__ void k_classify_small(Graph g, double th_plane, double th_vp, double th_bbox, double th_corner, double th_cub3d) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < g.n_pl) {
     uint32_t f = g.pl[i].flags;
@@ -565,7 +567,7 @@ __global__ void k_classify_small(Graph g, double th_plane, double th_vp, double 
     g.pl[i].flags = f;
   }
   if (i < g.n_bbox && g.bbox_norm[i] > th_bbox) g.bbox[i].flags &= ~F_ACTIVE;      // kernel stays on
-  if (i < g.n_corner && g.corner_norm[i] > th_corner) g.corner[i].flags &= ~F_ACTIVE;
+  if (i < g.n_corner && g.corner_norm[i] > (i < g.n_corner2d ? th_corner : th_cub3d)) g.corner[i].flags &= ~F_ACTIVE;  // (Optimizer.cc:1875-1882 for the 9-D edge)
 }
 
 // ======================================================================================================
@@ -642,8 +644,10 @@ struct CubProjModelT {  // bbox (CORNER = false, 4 residual rows) or corner edge
       const double* fs = &g.cub_fixedscale[3 * ed.cuboid];
       cb = cuboid_boxplus(cb, u, g.cub_flags[ed.cuboid], fs[0], fs[1], fs[2]);
     }
-    if (corner) corner_residual(T, cb, ed.K, ed.meas, e);
-    else bbox_residual(T, cb, ed.K, ed.meas, e);
+    if (corner) {
+      if (ed.dim == 9) cub3d_residual(T, cb, ed.meas, e);
+      else corner_residual(T, cb, ed.K, ed.meas, e);
+    } else bbox_residual(T, cb, ed.K, ed.meas, e);
   }
   __device__ double info(int i, int r) const { return E(i).info[r]; }
   __device__ double huber_delta(int i) const { return (E(i).flags & F_ROBUST) ? E(i).huber : 0.0; }
@@ -944,6 +948,87 @@ __device__ __forceinline__ void lin_cubproj_body(const Graph& g, const State& st
   LIN_STAMP(g, 3);
   block_atomic_add(g, chi_local, ACC_CHI2, s_red);
   LIN_STAMP(g, 4);
+}
+
+// ---- the 9-D camera-object edge (EdgeSE3Cuboid, Optimizer::LocalBACameraPointCuboids2D): ONE edge per workgroup, one lane per residual -------
+// 31 lanes: the two signs of 15 columns + the base residual, each the whole chain (four SE3 logarithms).  This edge class is switched
+// off in the reference's own call site (optimize_with_cuboid_3d, src/LocalMapping.cc:97): it is built for completeness of the path, not
+// tuned; the records live behind the corner-projection edges (g.corner[n_corner2d ..]) and share their Hessian blocks and W storage.
+__device__ __forceinline__ void lin_cub3d_body(const Graph& g, const State& st, int i, double delta, double* smem) {
+  constexpr int DM = 16, NC = 15, DIM = 9;
+  double (*sJ)[16] = reinterpret_cast<double (*)[16]>(smem);  // [row][col]
+  double* sW = smem + DM * 16;
+  double* sG = sW + DM;
+  double* s_red = sG + DM;
+  const CubEdge& ed = g.corner[i];
+  const int tid = threadIdx.x, c = tid >> 1;
+  const bool act = ed.flags & F_ACTIVE;  // (uniform)
+  const bool col = tid < 2 * NC, base = tid == 2 * NC;
+  const int fid = g.pose_free_id[ed.pose];
+  const bool fr = col && (c >= 6 || g.pose_col[ed.pose] >= 0);
+  double chi_local = 0.0;
+  if (act && tid < 64) {
+    double e[DIM];
+#pragma unroll
+    for (int q = 0; q < DIM; ++q) e[q] = 0.0;
+    if (fr || base) {
+      Pose T = load_pose(&st.pose_qt[7 * ed.pose]);
+      Cub cb = load_cub(&st.cub[10 * ed.cuboid]);
+      const double step = (tid & 1) ? -delta : delta;
+      double d[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) d[q] = (!base && q == (c < 6 ? c : c - 6)) ? step : 0.0;
+      if (!base && c < 6) T = pose_boxplus(T, d);
+      else if (!base) {
+        const double* fs = &g.cub_fixedscale[3 * ed.cuboid];
+        cb = cuboid_boxplus(cb, d, g.cub_flags[ed.cuboid], fs[0], fs[1], fs[2]);
+      }
+      cub3d_residual(T, cb, ed.meas, e);
+    }
+    const double scalar = 1.0 / (2 * delta);
+#pragma unroll
+    for (int q = 0; q < DIM; ++q) {
+      const double em = __shfl_down(e[q], 1, 64);  // lane 2c + 1 holds e(x [-] delta e_c)
+      if (col && !(tid & 1)) sJ[q][c] = fr ? scalar * (e[q] - em) : 0.0;
+    }
+    if (base) {
+      double chi2 = 0, nrm = 0;
+#pragma unroll
+      for (int q = 0; q < DIM; ++q) { chi2 += e[q] * (ed.info[q] * e[q]); nrm += e[q] * e[q]; }
+      g.corner_chi2[i] = chi2;
+      g.corner_norm[i] = sqrt(nrm);
+      double rho0, rho1;
+      huber(chi2, (ed.flags & F_ROBUST) ? ed.huber : 0.0, rho0, rho1);
+      chi_local = rho0;
+#pragma unroll
+      for (int q = 0; q < DIM; ++q) { sW[q] = rho1 * ed.info[q]; sG[q] = -(ed.info[q] * e[q]) * rho1; }
+    }
+  }
+  __syncthreads();
+#ifdef PPO_BA_TEST_HOOKS
+  if (!(g.dbg & 1))
+#endif
+  if (act && tid < 135) {
+    // 135 entries, one per lane: pose block (21 packed lower + 6) | cuboid block (45 packed lower + 9) | W pose rows x cuboid cols (6 x 9)
+    if (tid < 27) {
+      if (fid >= 0) {
+        double val;
+        if (tid < 21) { int a, c2; unpack_lower(tid, a, c2); val = quad_H<DM>(sJ, sW, DIM, a, c2); }
+        else val = quad_b<DM>(sJ, sG, DIM, tid - 21);
+        acc_add(g, &g.HB[(size_t)fid * 27 + tid], val);
+      }
+    } else if (tid < 81) {
+      const int q = tid - 27;
+      double val;
+      if (q < 45) { int a, c2; unpack_lower(q, a, c2); val = quad_H<DM>(sJ, sW, DIM, 6 + a, 6 + c2); }
+      else val = quad_b<DM>(sJ, sG, DIM, 6 + (q - 45));
+      acc_add(g, &g.HC[(size_t)ed.cuboid * 54 + q], val);
+    } else if (fid >= 0) {
+      const int q = tid - 81;
+      (g.Wpc_corner + (size_t)i * 54)[q] = quad_H<DM>(sJ, sW, DIM, q / 9, 6 + q % 9);
+    }
+  }
+  block_atomic_add(g, chi_local, ACC_CHI2, s_red);
 }
 
 // ---- analytic mode (options.jacobian_mode = PPO_JAC_ANALYTIC) ------------------------------------------------------------------------
@@ -1253,7 +1338,7 @@ using CornerModel = CubProjModelT<true>;
 #define PPO_LIN_WAVES 3  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this): 120 VGPRs, nothing spills,
                         // 4 waves per SIMD resident
 #endif
-enum { LIN_PLANE = 0, LIN_BBOX = 1, LIN_CORNER = 2, LIN_PTCUB = 3, LIN_POSE = 4, LIN_POINTS = 5, LIN_PARTS = 6 };
+enum { LIN_PLANE = 0, LIN_BBOX = 1, LIN_CORNER = 2, LIN_PTCUB = 3, LIN_POSE = 4, LIN_POINTS = 5, LIN_CUB3D = 6, LIN_PARTS = 7 };
 struct LinPlan {
   int nb[LIN_PARTS];     // workgroups per part
   int order[LIN_PARTS];  // grid order of the parts
@@ -1289,9 +1374,12 @@ __global__ __launch_bounds__(256, PPO_LIN_WAVES) PPO_LIN_OCC void k_linearize_al
       break;
     case LIN_CORNER:
       if (WITH_CORNERS) {  // compiled in only for windows that have corner edges
-        if (ANALYTIC) lin_cubproj_body_analytic<true>(g, st, g.n_corner, b, smem);
+        if (ANALYTIC) lin_cubproj_body_analytic<true>(g, st, g.n_corner2d, b, smem);
         else lin_cubproj_body<true>(g, st, b, delta, smem);
       }
+      break;
+    case LIN_CUB3D:  // always numeric (the derivative of a minimum over four SE3 logarithms is not written out)
+      if (WITH_CORNERS) lin_cub3d_body(g, st, g.n_corner2d + b, delta, smem);
       break;
     case LIN_PTCUB: lin_ptcub_body(g, st, b, delta, smem); break;
     case LIN_POSE: LIN_STAMP(g, 0); lin_poses_body(g, st, pc, b, smem); LIN_STAMP(g, 4); break;

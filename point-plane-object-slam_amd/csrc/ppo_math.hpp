@@ -165,6 +165,29 @@ PPO_HD Pose exp_se3(const double* u) {
 }
 PPO_HD Pose pose_boxplus(const Pose& T, const double* u) { return compose(exp_se3(u), T); }
 
+// SE3 logarithm with g2o's branches (SE3Quat::log, Thirdparty/g2o/g2o/types/se3quat.h:229-266): [omega, upsilon]
+PPO_HD void log_se3(const Pose& T, double* out) {
+  const Mat3 R = rotmat(T.q);
+  const double d = 0.5 * (R.a[0] + R.a[4] + R.a[8] - 1);
+  const Vec3 dR = v3(R.a[7] - R.a[5], R.a[2] - R.a[6], R.a[3] - R.a[1]);
+  Vec3 om;
+  double k;
+  if (d > 0.99999) {
+    om = dR * 0.5;
+    k = 1. / 12.;
+  } else {
+    const double th = acos(d);
+    om = dR * (th / (2 * sqrt(1 - d * d)));
+    k = (1 - th / (2 * tan(th / 2))) / (th * th);
+  }
+  Mat3 W, W2;
+  skew_sq(om, W, W2);
+  Mat3 Vi;
+  for (int i = 0; i < 9; ++i) Vi.a[i] = ((i == 0 || i == 4 || i == 8) ? 1.0 : 0.0) - 0.5 * W.a[i] + k * W2.a[i];
+  const Vec3 up = matvec(Vi, T.t);
+  out[0] = om.x; out[1] = om.y; out[2] = om.z; out[3] = up.x; out[4] = up.y; out[5] = up.z;
+}
+
 // ---- planes ------------------------------------------------------------------------------------------
 PPO_HD PlaneC plane_canon(double nx, double ny, double nz, double d) {
   const double inv = 1. / sqrt(nx * nx + ny * ny + nz * nz);
@@ -322,6 +345,35 @@ PPO_HD void corner_residual(const Pose& Tcw, const Cub& c, const double* K, cons
     cuboid_corner_px(c, Rwo, Rcw, Tcw.t, K, k, u, v);
     e[2 * k] = u - meas[2 * k];
     e[2 * k + 1] = v - meas[2 * k + 1];
+  }
+}
+
+// EdgeSE3Cuboid::computeError (include/g2o_cuboid.h:332-341) with cuboid::min_log_error (:83-109): the measured cuboid (camera frame,
+// meas = qx qy qz qw tx ty tz sx sy sz as given) goes to the world with Tcw^-1; of the four copies of it turned by -90 / 0 / 90 / 180
+// degrees about its own z axis (the half extents x, y swapped for the quarter turns) the one with the smallest 9-D error
+// [log(copy^-1 * cuboid), scale - copy scale] is the residual (the FIRST minimum, as Eigen's minCoeff).
+PPO_HD void cub3d_residual(const Pose& Tcw, const Cub& c, const double* meas, double* e) {
+  Cub m;
+  m.T = compose(inverse(Tcw), Pose{Quat{meas[0], meas[1], meas[2], meas[3]}, Vec3{meas[4], meas[5], meas[6]}});
+  m.s = v3(meas[7], meas[8], meas[9]);
+  const double kPi2 = 1.5707963267948966;  // M_PI / 2.0
+  double best = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const double yaw = (double)(i - 1) * 3.141592653589793 / 2.0;  // rotate_angles(i) * M_PI / 2.0, left to right like the reference
+    const Pose turn{canon(Quat{0.0, 0.0, sin(yaw * 0.5), cos(yaw * 0.5)}), Vec3{0.0, 0.0, 0.0}};
+    const Pose mp = compose(m.T, turn);
+    const bool swap = (yaw == kPi2) || (yaw == -kPi2);
+    const Vec3 ms = swap ? v3(m.s.y, m.s.x, m.s.z) : m.s;
+    double ei[9];
+    log_se3(compose(inverse(mp), c.T), ei);
+    ei[6] = c.s.x - ms.x; ei[7] = c.s.y - ms.y; ei[8] = c.s.z - ms.z;
+    double n2 = 0.0;
+    for (int k = 0; k < 9; ++k) n2 += ei[k] * ei[k];
+    const double n = sqrt(n2);
+    if (i == 0 || n < best) {
+      best = n;
+      for (int k = 0; k < 9; ++k) e[k] = ei[k];
+    }
   }
 }
 // ---- analytic Jacobians (options.jacobian_mode = PPO_JAC_ANALYTIC; SURVEY.md section 7 H1: "numeric first, analytic later") ------------

@@ -109,7 +109,7 @@ struct ppo_ba_solver {
 #ifdef PPO_BA_TEST_HOOKS
   DevBuf<unsigned long long> d_stamps;  // PPO_BA_LIN_STAMPS (development aid)
   std::string stamp_path;
-  int stamp_plan[6] = {0, 0, 0, 0, 0, 0}, stamp_order[6] = {0, 1, 2, 3, 4, 5};
+  int stamp_plan[LIN_PARTS] = {0, 0, 0, 0, 0, 0, 0}, stamp_order[LIN_PARTS] = {0, 1, 2, 3, 4, 5, 6};
 #endif
   size_t state_doubles = 0;
   double* h_pinned = nullptr;  // mapped host memory: ACC_N doubles, the factorisation info (as a double), a sequence number
@@ -181,7 +181,7 @@ bool idx_ok(const int32_t* p, int n, int hi) { return all_slices((size_t)n, [&](
 
 int validate(const ppo_ba_problem* p) {
   REQ(p->n_poses >= 0 && p->n_points >= 0 && p->n_planes >= 0 && p->n_cuboids >= 0);
-  REQ(p->n_mono >= 0 && p->n_stereo >= 0 && p->n_plane_edges >= 0 && p->n_bbox >= 0 && p->n_corner >= 0 && p->n_ptcub >= 0 && p->n_cubpl >= 0);
+  REQ(p->n_mono >= 0 && p->n_stereo >= 0 && p->n_plane_edges >= 0 && p->n_bbox >= 0 && p->n_corner >= 0 && p->n_ptcub >= 0 && p->n_cubpl >= 0 && p->n_cub3d >= 0);
   if (p->n_poses) { REQ(p->pose_qt && p->pose_fixed && p->pose_cam); FIN(p->pose_qt, 7 * (size_t)p->n_poses); FIN(p->pose_cam, 5 * (size_t)p->n_poses); }
   for (int i = 0; i < p->n_poses; ++i) { const double* q = &p->pose_qt[7 * (size_t)i]; REQ(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] > 0.0); }  // (canon_quat divides by the norm)
   if (p->n_points) { REQ(p->point_xyz); FIN(p->point_xyz, 3 * (size_t)p->n_points); }
@@ -213,6 +213,12 @@ int validate(const ppo_ba_problem* p) {
     REQ(p->corner_pose && p->corner_cuboid && p->corner_meas && p->corner_info && p->corner_huber && p->corner_K);
     REQ(idx_ok(p->corner_pose, p->n_corner, p->n_poses) && idx_ok(p->corner_cuboid, p->n_corner, p->n_cuboids));
     FIN(p->corner_meas, 16 * (size_t)p->n_corner); FIN(p->corner_info, 16 * (size_t)p->n_corner); FIN(p->corner_K, 9 * (size_t)p->n_corner); FIN(p->corner_huber, p->n_corner);
+  }
+  if (p->n_cub3d) {
+    REQ(p->cub3d_pose && p->cub3d_cuboid && p->cub3d_meas && p->cub3d_info && p->cub3d_huber);
+    REQ(idx_ok(p->cub3d_pose, p->n_cub3d, p->n_poses) && idx_ok(p->cub3d_cuboid, p->n_cub3d, p->n_cuboids));
+    FIN(p->cub3d_meas, 10 * (size_t)p->n_cub3d); FIN(p->cub3d_info, 9 * (size_t)p->n_cub3d); FIN(p->cub3d_huber, p->n_cub3d);
+    for (int i = 0; i < p->n_cub3d; ++i) { const double* q = &p->cub3d_meas[10 * (size_t)i]; REQ(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] > 0.0); }
   }
   if (p->n_ptcub) {
     REQ(p->ptcub_cuboid && p->ptcub_offsets && p->ptcub_margin_ratio && p->ptcub_info);
@@ -253,9 +259,9 @@ void free_all(ppo_ba_solver* s) {
       unsigned long long t0 = ~0ull;
       for (size_t b = 0; b < n / 8; ++b) if (h[8 * b] && h[8 * b] < t0) t0 = h[8 * b];
       if (FILE* f = std::fopen(s->stamp_path.c_str(), "w")) {
-        static const char* names[6] = {"plane", "bbox", "corner", "ptcub", "pose", "points"};
+        static const char* names[LIN_PARTS] = {"plane", "bbox", "corner", "ptcub", "pose", "points", "cub3d"};
         size_t b = 0;
-        for (int oi = 0; oi < 6; ++oi)
+        for (int oi = 0; oi < LIN_PARTS; ++oi)
           for (int k = 0, part = s->stamp_order[oi]; k < s->stamp_plan[part]; ++k, ++b) {
             std::fprintf(f, "%s", names[part]);
             for (int j = 0; j < 5; ++j) std::fprintf(f, " %lld", h[8 * b + j] ? (long long)(h[8 * b + j] - t0) : -1LL);
@@ -432,16 +438,17 @@ int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st) {
   lp.nb[LIN_PLANE] = (g.plane_last > g.plane_first && g.n_pl > 0) ? nblk(g.n_pl, ana ? kAnaPlaneEPB : NumericShape<PlaneModel>::EPB) : 0;
   if (g.owns_reduced) {
     lp.nb[LIN_BBOX] = ana ? (g.n_bbox ? nblk(g.n_bbox, kAnaBboxEPB) : 0) : g.n_bbox;
-    lp.nb[LIN_CORNER] = ana ? (g.n_corner ? nblk(g.n_corner, kAnaCornerEPB) : 0) : g.n_corner;
+    lp.nb[LIN_CORNER] = ana ? (g.n_corner2d ? nblk(g.n_corner2d, kAnaCornerEPB) : 0) : g.n_corner2d;
+    lp.nb[LIN_CUB3D] = g.n_corner - g.n_corner2d;  // the 9-D camera-object edges behind the corner edges: one workgroup each, always numeric
     lp.nb[LIN_PTCUB] = g.n_ptcub;
   }
   const int npts = g.pt_last - g.pt_first;
   lp.nb[LIN_POSE] = (npts > 0 && s->posec.n_chunks > 0) ? nblk(s->posec.n_chunks, 4) : 0;
   lp.nb[LIN_POINTS] = npts > 0 ? std::min(nblk((long)PPO_LIN_LPP * npts, 256), 4 * s->n_cu) : 0;
   // longest-running workgroups first (tools/lin_stamps.py): landmark side 19 us, planes 16, pose side 14, cuboid projections 8, point-cuboid 6
-  static const int kOrder[LIN_PARTS] = {LIN_POINTS, LIN_PLANE, LIN_POSE, LIN_CORNER, LIN_BBOX, LIN_PTCUB};
+  static const int kOrder[LIN_PARTS] = {LIN_POINTS, LIN_PLANE, LIN_POSE, LIN_CUB3D, LIN_CORNER, LIN_BBOX, LIN_PTCUB};
   for (int i = 0; i < LIN_PARTS; ++i) lp.order[i] = kOrder[i];
-  if (const char* e = PPO_DEV_ENV("PPO_BA_LIN_ORDER")) {  // development aid: six digits, a permutation of 012345 (plane bbox corner ptcub pose points)
+  if (const char* e = PPO_DEV_ENV("PPO_BA_LIN_ORDER")) {  // development aid: seven digits, a permutation of 0123456 (plane bbox corner ptcub pose points cub3d)
     int seen = 0;
     for (int i = 0; i < LIN_PARTS && e[i] >= '0' && e[i] < '0' + LIN_PARTS; ++i) { lp.order[i] = e[i] - '0'; seen |= 1 << (e[i] - '0'); }
     if (seen != (1 << LIN_PARTS) - 1) for (int i = 0; i < LIN_PARTS; ++i) lp.order[i] = kOrder[i];
@@ -449,7 +456,7 @@ int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st) {
   if (const char* e = PPO_DEV_ENV("PPO_BA_LIN_PARTS")) {  // development aid: time the parts of the fused launch separately
     const int m = atoi(e);
     if (!(m & 1)) lp.nb[LIN_PLANE] = 0;
-    if (!(m & 2)) lp.nb[LIN_BBOX] = lp.nb[LIN_CORNER] = 0;
+    if (!(m & 2)) lp.nb[LIN_BBOX] = lp.nb[LIN_CORNER] = lp.nb[LIN_CUB3D] = 0;
     if (!(m & 4)) lp.nb[LIN_PTCUB] = 0;
     if (!(m & 8)) lp.nb[LIN_POSE] = 0;
     if (!(m & 16)) lp.nb[LIN_POINTS] = 0;
@@ -465,7 +472,7 @@ int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st) {
   }
 #endif
   if (grid > 0) {
-    const bool cor = lp.nb[LIN_CORNER] > 0;
+    const bool cor = lp.nb[LIN_CORNER] > 0 || lp.nb[LIN_CUB3D] > 0;
     const dim3 gd(grid), bd(256);
     const double dl = s->opt.numeric_delta;
     if (ana) {  // (the point-cuboid edges stay numeric in this mode)
@@ -897,7 +904,14 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   mark("validate, device, streams");
   Graph& g = s->g;
   g.n_poses = p->n_poses; g.n_points = p->n_points; g.n_planes = p->n_planes; g.n_cuboids = p->n_cuboids;
-  g.n_mono = p->n_mono; g.n_stereo = p->n_stereo; g.n_pl = p->n_plane_edges; g.n_bbox = p->n_bbox; g.n_corner = p->n_corner; g.n_ptcub = p->n_ptcub;
+  g.n_mono = p->n_mono; g.n_stereo = p->n_stereo; g.n_pl = p->n_plane_edges; g.n_bbox = p->n_bbox; g.n_ptcub = p->n_ptcub;
+  // The 9-D camera-object edges (EdgeSE3Cuboid, cub3d_*) are stored BEHIND the corner-projection edges in the same records: every
+  // pose x cuboid structure below (blocks, W storage, elimination lists, classification, per-edge outputs) covers both.
+  g.n_corner2d = p->n_corner;
+  g.n_corner = p->n_corner + p->n_cub3d;
+  const int n_corner_all = g.n_corner;
+  auto corner_pose_of = [p](int e) { return e < p->n_corner ? p->corner_pose[e] : p->cub3d_pose[e - p->n_corner]; };
+  auto corner_cuboid_of = [p](int e) { return e < p->n_corner ? p->corner_cuboid[e] : p->cub3d_cuboid[e - p->n_corner]; };
   s->n_cubpl = p->n_cubpl;
   const int Np = p->n_poses, Npt = p->n_points, Npl = p->n_planes, Nc = p->n_cuboids;
 
@@ -917,7 +931,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   for (int e = 0; e < p->n_plane_edges; ++e) pose_used[p->pl_pose[e]] = 1;
   for (int e = 0; e < p->n_bbox; ++e) { pose_used[p->bbox_pose[e]] = 1; cub_used[p->bbox_cuboid[e]] = 1; }
-  for (int e = 0; e < p->n_corner; ++e) { pose_used[p->corner_pose[e]] = 1; cub_used[p->corner_cuboid[e]] = 1; }
+  for (int e = 0; e < n_corner_all; ++e) { pose_used[corner_pose_of(e)] = 1; cub_used[corner_cuboid_of(e)] = 1; }
   for (int e = 0; e < p->n_ptcub; ++e) cub_used[p->ptcub_cuboid[e]] = 1;
   SVec<int32_t> pose_col(Np, -1), pose_free_id(Np, -1), cub_col(Nc, -1);
   int nfree = 0;
@@ -1270,6 +1284,16 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   };
   fill_cub(s->h_bbox, p->n_bbox, p->bbox_pose, p->bbox_cuboid, p->bbox_meas, p->bbox_info, p->bbox_huber, p->bbox_K, 4);
   fill_cub(s->h_corner, p->n_corner, p->corner_pose, p->corner_cuboid, p->corner_meas, p->corner_info, p->corner_huber, p->corner_K, 16);
+  s->h_corner.resize(n_corner_all);
+  for (int e = 0; e < p->n_cub3d; ++e) {  // EdgeSE3Cuboid: measured cuboid (10 values as given, like MapCuboid::cuboid_local_meas), 9 information entries
+    CubEdge& m = s->h_corner[p->n_corner + e];
+    std::memset(&m, 0, sizeof(m));
+    for (int i = 0; i < 10; ++i) m.meas[i] = p->cub3d_meas[10 * (size_t)e + i];
+    for (int i = 0; i < 9; ++i) m.info[i] = p->cub3d_info[9 * (size_t)e + i];
+    m.huber = p->cub3d_huber[e];
+    m.pose = p->cub3d_pose[e]; m.cuboid = p->cub3d_cuboid[e]; m.dim = 9;
+    m.flags = F_ACTIVE | F_ROBUST;
+  }
   s->h_ptcub.resize(p->n_ptcub);
   for (int e = 0; e < p->n_ptcub; ++e) {
     PtCubEdge& m = s->h_ptcub[e];
@@ -1349,7 +1373,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   {
     std::vector<std::vector<int32_t>> per(Nc);
     for (int e = 0; e < p->n_bbox; ++e) per[p->bbox_cuboid[e]].push_back(e << 1);
-    for (int e = 0; e < p->n_corner; ++e) per[p->corner_cuboid[e]].push_back((e << 1) | 1);
+    for (int e = 0; e < n_corner_all; ++e) per[corner_cuboid_of(e)].push_back((e << 1) | 1);
     for (int c = 0; c < Nc; ++c) {
       cub_edge_off[c] = (int32_t)cub_edges.size();
       cub_edges.insert(cub_edges.end(), per[c].begin(), per[c].end());
@@ -1358,7 +1382,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     cub_edge_col.resize(cub_edges.size());  // reduced column of every listed edge's keyframe (static; saves the edge -> pose -> column walk of the cuboid back-substitution)
     for (size_t q = 0; q < cub_edges.size(); ++q) {
       const int32_t code = cub_edges[q];
-      cub_edge_col[q] = pose_col[(code & 1) ? p->corner_pose[code >> 1] : p->bbox_pose[code >> 1]];
+      cub_edge_col[q] = pose_col[(code & 1) ? corner_pose_of(code >> 1) : p->bbox_pose[code >> 1]];
     }
     s->n_cub_edges = (int)cub_edges.size();
     if (g.elim_cub)
@@ -1368,7 +1392,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
           for (int b = cub_edge_off[c]; b <= a; ++b) {
             // a pair carries everything that does not change after create -- the two edge codes and their keyframes' columns -- so that the
             // kernel starts its operand loads one round trip after its first load (it used to walk pair -> edge list -> edge -> pose -> column)
-            auto col_of = [&](int32_t code) { return pose_col[(code & 1) ? p->corner_pose[code >> 1] : p->bbox_pose[code >> 1]]; };
+            auto col_of = [&](int32_t code) { return pose_col[(code & 1) ? corner_pose_of(code >> 1) : p->bbox_pose[code >> 1]]; };
             cp_cub.push_back(c); cp_a.push_back(cub_edges[a]); cp_b.push_back(cub_edges[b]);
             cp_cola.push_back(col_of(cub_edges[a])); cp_colb.push_back(col_of(cub_edges[b]));
           }
@@ -1436,7 +1460,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_pl0.upload(s->h_pl, s->stream);
   ok = ok && s->d_bbox0.upload(s->h_bbox, s->stream) && s->d_corner0.upload(s->h_corner, s->stream);
   ok = ok && s->d_init.upload(h_state, s->stream) && s->d_state[0].alloc(s->state_doubles) && s->d_state[1].alloc(s->state_doubles);
-  const size_t n_chi = (size_t)p->n_mono + p->n_stereo + p->n_plane_edges + 2 * (size_t)p->n_bbox + 2 * (size_t)p->n_corner + p->n_ptcub;
+  const size_t n_chi = (size_t)p->n_mono + p->n_stereo + p->n_plane_edges + 2 * (size_t)p->n_bbox + 2 * (size_t)n_corner_all + p->n_ptcub;
   ok = ok && s->d_chi2_all.alloc(n_chi);
   // arena: HB | HC | acc | D | bl;  d_W: factor records of the point slots | linearisation-point rotations | W of the plane slots
   g.n_pt_slots = n_point_slots;  // (device builder: upper bounds here, the exact counts come back with the final synchronisation)
@@ -1445,7 +1469,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_arena.alloc(2 * (nHB + nHC + nD + nbl) + ACC_TOTAL) && s->d_W.alloc(nW);
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
-  ok = ok && s->d_Wpc.alloc(2 * (size_t)(p->n_bbox + p->n_corner) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
+  ok = ok && s->d_Wpc.alloc(2 * (size_t)(p->n_bbox + n_corner_all) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
   ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
   if (s->comm.active()) ok = ok && s->d_pack.alloc((size_t)(ld / 64) * (ld / 64 + 1) / 2 * 4096 + ld);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
@@ -1586,8 +1610,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     g.pl_chi2 = c; c += p->n_plane_edges;
     g.bbox_chi2 = c; c += p->n_bbox;
     g.bbox_norm = c; c += p->n_bbox;
-    g.corner_chi2 = c; c += p->n_corner;
-    g.corner_norm = c; c += p->n_corner;
+    g.corner_chi2 = c; c += n_corner_all;
+    g.corner_norm = c; c += n_corner_all;
     g.ptcub_chi2 = c;
   }
   {
@@ -1605,7 +1629,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       s->lb[0].W = w; s->lb[1].W = w + nWpl; w += 2 * nWpl;
       for (int b = 0; b < 2; ++b) { s->lb[b].F = w; w += nF; s->lb[b].linR = w; w += nLinR; }
       double* c = s->d_Wpc.p;
-      for (int b = 0; b < 2; ++b) { s->lb[b].Wpc_bbox = c; c += (size_t)p->n_bbox * 54; s->lb[b].Wpc_corner = c; c += (size_t)p->n_corner * 54; }
+      for (int b = 0; b < 2; ++b) { s->lb[b].Wpc_bbox = c; c += (size_t)p->n_bbox * 54; s->lb[b].Wpc_corner = c; c += (size_t)n_corner_all * 54; }
     }
     use_lin_buffer(s, 0);
     if (nW) (void)hipMemsetAsync(s->d_W.p, 0, nW * sizeof(double), s->stream);
@@ -1672,7 +1696,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     for (int e = 0; e < p->n_plane_edges; ++e) n_vp += (p->pl_kind && p->pl_kind[e]) ? 1 : 0;
     int n_fixed = 0;
     for (int i = 0; i < Np; ++i) n_fixed += (pose_col[i] < 0);
-    s->lin_bytes = 176L * p->n_mono + 184L * p->n_stereo + 208L * (p->n_plane_edges - n_vp) + 200L * n_vp + 576L * p->n_bbox + 768L * p->n_corner +
+    s->lin_bytes = 176L * p->n_mono + 184L * p->n_stereo + 208L * (p->n_plane_edges - n_vp) + 200L * n_vp + 576L * p->n_bbox + 768L * p->n_corner + 720L * p->n_cub3d +  // (9-D edge: 2 indices + 10 measurement + 9 information + the 6 x 9 block)
+                  
                    96L * Npt + 104L * Npl + 512L * Nc + 272L * nfree + 56L * n_fixed;
   }
   t_creating = nullptr;
@@ -1728,7 +1753,7 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
     const int nsm = std::max({g.n_pl, g.n_bbox, g.n_corner});
     if (nsm > 0)
       hipLaunchKernelGGL(k_classify_small, dim3(nblk(nsm, 256)), dim3(256), 0, s->stream, g, s->opt.chi2_plane, s->opt.chi2_plane_vp,
-                         s->opt.th_bbox_norm, s->opt.th_corner_norm);
+                         s->opt.th_bbox_norm, s->opt.th_corner_norm, s->opt.th_cub3d_norm);
     HIP_TRY(hipGetLastError());
     t2 = std::chrono::steady_clock::now();
     RC_TRY(optimize(s, 1, s->opt.iters_pass2, stop));
@@ -1761,7 +1786,8 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
   SVec<CubEdge> hb(g.n_bbox), hc(g.n_corner);
   if (s->state_doubles) HIP_TRY(hipMemcpyAsync(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   // (only what the caller's non-NULL pointers ask for crosses the bus: the per-edge chi2 block is the largest part of a read)
-  const bool want_chi = r->mono_chi2 || r->stereo_chi2 || r->pl_chi2 || r->bbox_chi2 || r->bbox_errnorm || r->corner_chi2 || r->corner_errnorm || r->ptcub_chi2;
+  const bool want_chi = r->mono_chi2 || r->stereo_chi2 || r->pl_chi2 || r->bbox_chi2 || r->bbox_errnorm || r->corner_chi2 || r->corner_errnorm || r->ptcub_chi2 ||
+                        r->cub3d_chi2 || r->cub3d_errnorm;
   if (chi.size() && want_chi) HIP_TRY(hipMemcpyAsync(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   if (g.n_mono && r->mono_level) HIP_TRY(hipMemcpyAsync(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
   if (g.n_stereo && r->stereo_level) HIP_TRY(hipMemcpyAsync(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -1842,10 +1868,16 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
     if (r->bbox_errnorm) r->bbox_errnorm[e] = n_bb[e];
     if (r->bbox_level) r->bbox_level[e] = (hb[e].flags & F_ACTIVE) ? 0 : 1;
   }
-  for (int e = 0; e < g.n_corner; ++e) {
+  for (int e = 0; e < g.n_corner2d; ++e) {
     if (r->corner_chi2) r->corner_chi2[e] = c_co[e];
     if (r->corner_errnorm) r->corner_errnorm[e] = n_co[e];
     if (r->corner_level) r->corner_level[e] = (hc[e].flags & F_ACTIVE) ? 0 : 1;
+  }
+  const int n_cub3d = g.n_corner - g.n_corner2d;  // the 9-D camera-object edges sit behind the corner edges
+  for (int e = 0; e < n_cub3d; ++e) {
+    if (r->cub3d_chi2) r->cub3d_chi2[e] = c_co[g.n_corner2d + e];
+    if (r->cub3d_errnorm) r->cub3d_errnorm[e] = n_co[g.n_corner2d + e];
+    if (r->cub3d_level) r->cub3d_level[e] = (hc[g.n_corner2d + e].flags & F_ACTIVE) ? 0 : 1;
   }
   if (r->ptcub_chi2) for (int e = 0; e < g.n_ptcub; ++e) r->ptcub_chi2[e] = c_pc[e];
   if (r->cubpl_chi2) for (int e = 0; e < s->n_cubpl; ++e) r->cubpl_chi2[e] = s->cubpl_chi2[e];
@@ -1858,7 +1890,8 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
         {r->stereo_chi2, nullptr, (size_t)g.n_stereo, 1}, {nullptr, r->stereo_level, (size_t)g.n_stereo, 1}, {nullptr, r->stereo_depth_positive, (size_t)g.n_stereo, 1},
         {r->pl_chi2, nullptr, (size_t)g.n_pl, 2}, {nullptr, r->pl_level, (size_t)g.n_pl, 2},
         {r->bbox_chi2, nullptr, (size_t)g.n_bbox, 3}, {r->bbox_errnorm, nullptr, (size_t)g.n_bbox, 3}, {nullptr, r->bbox_level, (size_t)g.n_bbox, 3},
-        {r->corner_chi2, nullptr, (size_t)g.n_corner, 3}, {r->corner_errnorm, nullptr, (size_t)g.n_corner, 3}, {nullptr, r->corner_level, (size_t)g.n_corner, 3},
+        {r->corner_chi2, nullptr, (size_t)g.n_corner2d, 3}, {r->corner_errnorm, nullptr, (size_t)g.n_corner2d, 3}, {nullptr, r->corner_level, (size_t)g.n_corner2d, 3},
+        {r->cub3d_chi2, nullptr, (size_t)n_cub3d, 3}, {r->cub3d_errnorm, nullptr, (size_t)n_cub3d, 3}, {nullptr, r->cub3d_level, (size_t)n_cub3d, 3},
         {r->ptcub_chi2, nullptr, (size_t)g.n_ptcub, 3}};
     SVec<uint8_t> own_mono(g.n_mono, 0), own_stereo(g.n_stereo, 0), own_pl(g.n_pl, 0);
     for (int k = 0; k < g.n_mono; ++k) own_mono[s->mono_perm[k]] = s->hk_mono_point[k] >= g.pt_first && s->hk_mono_point[k] < g.pt_last;

@@ -32,6 +32,7 @@ _PROBLEM_FIELDS = [
     ("n_ptcub", C.c_int32), ("ptcub_cuboid", c_ip), ("ptcub_offsets", c_ip), ("ptcub_points", c_dp), ("ptcub_margin_ratio", c_dp),
     ("ptcub_prior_half", c_dp), ("ptcub_info", c_dp), ("ptcub_huber", c_dp),
     ("n_cubpl", C.c_int32), ("cubpl_cuboid", c_ip), ("cubpl_plane", c_ip), ("cubpl_meas", c_dp), ("cubpl_info", c_dp), ("cubpl_huber", c_dp),
+    ("n_cub3d", C.c_int32), ("cub3d_pose", c_ip), ("cub3d_cuboid", c_ip), ("cub3d_meas", c_dp), ("cub3d_info", c_dp), ("cub3d_huber", c_dp),
 ]
 
 
@@ -48,7 +49,7 @@ class COptions(C.Structure):
         ("th_bbox_norm", C.c_double), ("th_corner_norm", C.c_double),
         ("deterministic", C.c_int32), ("solver", C.c_int32), ("eliminate_cuboids", C.c_int32),
         ("device_id", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
-        ("comm_id", C.c_uint8 * 128), ("verbose", C.c_int32),
+        ("comm_id", C.c_uint8 * 128), ("verbose", C.c_int32), ("th_cub3d_norm", C.c_double),
     ]
 
 
@@ -80,6 +81,7 @@ _RESULT_FIELDS = [
     ("bbox_chi2", c_dp), ("bbox_errnorm", c_dp), ("bbox_level", c_bp),
     ("corner_chi2", c_dp), ("corner_errnorm", c_dp), ("corner_level", c_bp),
     ("ptcub_chi2", c_dp), ("cubpl_chi2", c_dp),
+    ("cub3d_chi2", c_dp), ("cub3d_errnorm", c_dp), ("cub3d_level", c_bp),
 ]
 
 
@@ -104,6 +106,7 @@ _WIDTH = {
     "corner_huber": ("n_corner", 1), "corner_K": ("n_corner", 9),
     "ptcub_cuboid": ("n_ptcub", 1), "ptcub_margin_ratio": ("n_ptcub", 1), "ptcub_prior_half": ("n_ptcub", 3), "ptcub_info": ("n_ptcub", 3), "ptcub_huber": ("n_ptcub", 1),
     "cubpl_cuboid": ("n_cubpl", 1), "cubpl_plane": ("n_cubpl", 1), "cubpl_meas": ("n_cubpl", 3), "cubpl_info": ("n_cubpl", 3), "cubpl_huber": ("n_cubpl", 1),
+    "cub3d_pose": ("n_cub3d", 1), "cub3d_cuboid": ("n_cub3d", 1), "cub3d_meas": ("n_cub3d", 10), "cub3d_info": ("n_cub3d", 9), "cub3d_huber": ("n_cub3d", 1),
 }
 _OPTIONAL = {"point_fixed", "cuboid_flags", "cuboid_fixedscale", "pl_kind", "ptcub_prior_half", "ptcub_huber"}
 
@@ -221,6 +224,7 @@ class Result:
         self.bbox_chi2 = z(sizes["n_bbox"]); self.bbox_errnorm = z(sizes["n_bbox"]); self.bbox_level = z(sizes["n_bbox"], 1, np.uint8)
         self.corner_chi2 = z(sizes["n_corner"]); self.corner_errnorm = z(sizes["n_corner"]); self.corner_level = z(sizes["n_corner"], 1, np.uint8)
         self.ptcub_chi2 = z(sizes["n_ptcub"]); self.cubpl_chi2 = z(sizes["n_cubpl"])
+        self.cub3d_chi2 = z(sizes["n_cub3d"]); self.cub3d_errnorm = z(sizes["n_cub3d"]); self.cub3d_level = z(sizes["n_cub3d"], 1, np.uint8)
 
     def as_struct(self):
         s = CResult()
@@ -320,12 +324,12 @@ class Solver:
 def default_options(**over):
     """The reference's constants (comments on ppo_ba_options in include/ppo_ba.h)."""
     o = COptions()
-    o.abi_version = 1
+    o.abi_version = 2
     o.iters_pass1, o.iters_pass2 = 5, 10
     o.lm_tau, o.lm_max_trials, o.lm_lower, o.lm_upper = 1e-5, 10, 1.0 / 3.0, 2.0 / 3.0
     o.numeric_delta, o.jacobian_mode = 1e-9, 0
     o.chi2_mono, o.chi2_stereo, o.chi2_plane, o.chi2_plane_vp = 5.991, 7.815, 500.0, 200.0
-    o.th_bbox_norm, o.th_corner_norm = 80.0, 10.0
+    o.th_bbox_norm, o.th_corner_norm, o.th_cub3d_norm = 80.0, 10.0, 900.0
     o.deterministic, o.solver, o.eliminate_cuboids = 0, 0, 1
     o.device_id, o.rank, o.world_size, o.verbose = 0, 0, 1, 0
     for k, v in over.items():

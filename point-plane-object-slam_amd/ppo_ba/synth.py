@@ -184,7 +184,7 @@ class _ScaledRng:
 
 
 def make_problem(config="cfg4", seed=1, outlier_frac=0.05, stereo_frac=0.0, with_corners=False, with_vp_planes=0,
-                 fixed_observer_frac=0.0, flags=None, noise_scale=1.0, world_size=1):
+                 fixed_observer_frac=0.0, flags=None, noise_scale=1.0, world_size=1, with_cuboid3d=False):
     """Build one seeded graph.  ``config`` is a key of CONFIGS or a dict with n_kf/n_points/n_planes/n_cuboids."""
     cfg = dict(CONFIGS[config]) if isinstance(config, str) else dict(config)
     if cfg.pop("points_per_rank", False):
@@ -400,6 +400,34 @@ def make_problem(config="cfg4", seed=1, outlier_frac=0.05, stereo_frac=0.0, with
     P.set("cubpl_info", np.tile([3282.8 / (2.0 * 2.0), 3282.8 / (2.0 * 2.0), 100.0 * 100.0], (n_cp, 1)))
     P.set("cubpl_huber", np.full(n_cp, float(np.float32(np.sqrt(500.0)))))
 
+    # 9-D camera-object edges (EdgeSE3Cuboid, Optimizer::LocalBACameraPointCuboids2D, Optimizer.cc:1767-1800): one per cuboid observation, the
+    # measured cuboid in the CAMERA frame; every other measurement names another face "front" (a quarter / half turn about the box's z axis
+    # with the x / y half extents swapped for the quarter turns), which is what cuboid::min_log_error exists for.  Own random stream: the
+    # arrays above do not depend on this option.
+    if with_cuboid3d and n_cb > 0:
+        r3 = np.random.default_rng([int(seed), 3])
+        c3_pose, c3_cub, c3_meas = [], [], []
+        for e in range(len(bbox_pose)):
+            j, i = int(bbox_pose[e]), int(bbox_cub[e])
+            yaw = 2 * np.arctan2(cub_qt_true[i, 2], cub_qt_true[i, 3])
+            turn = int(r3.integers(0, 4)) if e % 2 else 0
+            yaw_m = yaw + turn * np.pi / 2 + r3.normal() * np.deg2rad(3.0) * noise_scale
+            Rwo = np.array([[np.cos(yaw_m), -np.sin(yaw_m), 0], [np.sin(yaw_m), np.cos(yaw_m), 0], [0, 0, 1]])
+            Rco = Rcw[j] @ Rwo
+            tco = Rcw[j] @ cub_qt_true[i, 4:] + tcw[j] + r3.normal(size=3) * 0.05 * noise_scale
+            hs = cub_scale_true[i].copy()
+            if turn % 2:
+                hs[[0, 1]] = hs[[1, 0]]
+            hs = hs + r3.normal(size=3) * 0.02 * noise_scale
+            q = quat_from_matrix(Rco)
+            if q[3] < 0:
+                q = -q
+            c3_pose.append(j); c3_cub.append(i); c3_meas.append(np.concatenate([q, tco, hs]))
+        n3 = len(c3_pose)
+        P.set("cub3d_pose", np.array(c3_pose, dtype=np.int32)); P.set("cub3d_cuboid", np.array(c3_cub, dtype=np.int32))
+        P.set("cub3d_meas", np.array(c3_meas).reshape(n3, 10))
+        P.set("cub3d_info", np.full((n3, 9), (1.0 * 0.75) ** 2))   # (ba_weight_SE3 * 0.75)^2, Optimizer.cc:1785-1789
+        P.set("cub3d_huber", np.full(n3, 900.0))                   # thHuberSE3 itself, Optimizer.cc:1793
     P.meta = dict(config=config if isinstance(config, str) else "custom", seed=seed,
                   truth=dict(Rcw=Rcw, tcw=tcw, points=X_true, planes=planes_true, cuboid_qt=cub_qt_true, cuboid_scale=cub_scale_true))
     return P

@@ -130,6 +130,7 @@ struct MapCuboid {
   long unsigned int mnBALocalForKF = 0;
   bool bad = false, obj_been_optimized = false;
   cuboid cuboid_global_data, cuboid_global_opti;
+  cuboid cuboid_local_meas;  // the detection's 3-D measurement in the camera frame (include/MapCuboid.h), read by LocalBACameraPointCuboids2D
   double meas_quality = 0.7;
   Vec4 bbox_vec;
   Rect bbox_2d;
@@ -437,6 +438,47 @@ int main() {
       for (int i : {1, 2, 3}) CHECK(W.kf[i].n_setpose == 1);
       std::printf("(GPU: the mock window went through libppo_ba.so)\n");
     }
+  }
+  // ---- 5b. Optimizer::LocalBACameraPointCuboids2D (OPT:1252-1992): no planes anywhere, the 9-D camera-object edges when the flag is set -----
+  {
+    World W;
+    for (size_t d = 0; d < W.local_det.size(); ++d) {  // give every detection a 3-D measurement
+      W.local_det[d].cuboid_local_meas = W.cb[0].cuboid_global_data;
+      W.local_det[d].cuboid_local_meas.scale[0] = 0.3 + 0.01 * (double)d;
+    }
+    pf::Params par;
+    par.optimize_with_plane_3d = par.optimize_with_cuboid_plane = true;  // must be ignored by this entry point
+    par.optimize_with_cuboid_2d = par.optimize_with_cuboid_3d = par.optimize_with_pt_obj_3d = true;
+    bool solver_saw_lock = true, stop = false;
+    int n_cub3d = -1, n_bbox = -1;
+    double huber0 = 0, info0 = 0, th = 0, meas7 = 0;
+    struct Capture {
+      bool* saw_lock; int* n_cub3d; int* n_bbox; double* huber0; double* info0; double* th; double* meas7;
+      int operator()(const ppo_ba_problem& P, const ppo_ba_options& O, const volatile uint8_t* st, pfr::Solved& s) const {
+        assert(P.n_planes == 0 && P.n_plane_edges == 0 && P.n_cubpl == 0);
+        *n_cub3d = P.n_cub3d; *n_bbox = P.n_bbox; *th = O.th_cub3d_norm;
+        if (P.n_cub3d > 0) { *huber0 = P.cub3d_huber[0]; *info0 = P.cub3d_info[4]; *meas7 = P.cub3d_meas[7]; }
+        return FakeSolver{saw_lock, PPO_BA_OK}(P, O, st, s);
+      }
+    };
+    const int rc = pfr::local_ba_camera_point_cuboids_2d<Traits>(&W.kf[1], &stop, &W.map, false, false, par,
+                                                                 Capture{&solver_saw_lock, &n_cub3d, &n_bbox, &huber0, &info0, &th, &meas7});
+    CHECK(rc == PPO_BA_OK && !solver_saw_lock);
+    CHECK(n_cub3d >= 3 && n_cub3d >= n_bbox);                   // every non-bad observer of a local cuboid, no image-boundary test (OPT:1767-1800)
+    CHECK(huber0 == 900.0 && th == 900.0);                      // thHuberSE3 itself, as delta and as the classification threshold (OPT:1793, 1878)
+    CHECK(info0 == 0.75 * 0.75);                                // (ba_weight_SE3 * 0.75)^2 (OPT:1785-1789)
+    CHECK(meas7 >= 0.3 && meas7 < 0.35);                        // the detection's cuboid_local_meas.scale
+    CHECK(W.journal.lock_count == 1 && W.journal.unlocked_mutations == 0);
+    for (int i : {1, 0, 2, 3}) CHECK(W.kf[i].n_setpose == 1);
+    CHECK(W.cb[0].obj_been_optimized && W.cb[0].n_set == 1);
+    for (int k = 0; k < 3; ++k) CHECK(W.pl[k].n_set == 0 && W.pl[k].mnBALocalForKF == 0);  // planes are never touched, not even marked
+    for (int i : {0, 1, 2, 3, 6, 7}) CHECK(W.kf[i].mnBALocalForKF == 0 && W.kf[i].mnBAFixedForKF == 0);
+    // the main entry point never builds the 9-D edge, whatever the flag says
+    World W2;
+    int n2 = -1;
+    struct Count3d { int* n; int operator()(const ppo_ba_problem& P, const ppo_ba_options& O, const volatile uint8_t* st, pfr::Solved& s) const {
+      *n = P.n_cub3d; bool dummy = false; return FakeSolver{&dummy, PPO_BA_OK}(P, O, st, s); } };
+    CHECK(pfr::local_ba_camera_plane_cuboids<Traits>(&W2.kf[1], &stop, &W2.map, false, false, par, Count3d{&n2}) == PPO_BA_OK && n2 == 0);
   }
   // ---- 6. Optimizer::LocalBundleAdjustment (points only, OPT:461-787): every point gets a vertex, markers stay, same lock order ---------
   {

@@ -29,7 +29,7 @@ def test_header_symbols_exported():
 
 def test_version_and_strerror():
     lib = B.load_library()
-    assert lib.ppo_ba_version() == 1
+    assert lib.ppo_ba_version() == 2  # 2: the 9-D camera-object edge (cub3d_*)
     assert lib.ppo_ba_strerror(0) == b"ok"
     assert b"HIP" in lib.ppo_ba_strerror(-4)
 
@@ -41,7 +41,7 @@ def test_default_options_match_reference_constants():
     assert (o.iters_pass1, o.iters_pass2, o.lm_max_trials) == (5, 10, 10)  # Optimizer.cc:2728,2837; levenberg.cpp:51
     assert o.lm_tau == 1e-5 and o.numeric_delta == 1e-9
     assert (o.chi2_mono, o.chi2_stereo, o.chi2_plane, o.chi2_plane_vp) == (5.991, 7.815, 500.0, 200.0)
-    assert (o.th_bbox_norm, o.th_corner_norm) == (80.0, 10.0)
+    assert (o.th_bbox_norm, o.th_corner_norm, o.th_cub3d_norm) == (80.0, 10.0, 900.0)  # Parameters.cc:63-65
     p = B.default_options()
     for k, _ in B.COptions._fields_:
         if k not in ("comm_id",):
@@ -52,7 +52,14 @@ def test_struct_sizes_match_header():
     # sizes derived from the C declarations: guards against silent layout drift between header and ctypes mirror
     assert C.sizeof(B.CIterStat) == 4 * 4 + 3 * 8 + 2 * 4
     assert C.sizeof(B.CStats) == 8 + 64 * C.sizeof(B.CIterStat) + 4 * 4 + 9 * 8
-    assert C.sizeof(B.CResult) == 21 * 8
+    assert C.sizeof(B.CResult) == 24 * 8
+    # ... and against the library itself: sizeof() of every ABI struct as the C compiler laid it out
+    lib = B.load_library()
+    lib.ppo_ba_sizeof.restype = C.c_int64
+    lib.ppo_ba_sizeof.argtypes = [C.c_int32]
+    for which, mirror in enumerate((B.CProblem, B.COptions, B.CStats, B.CResult, B.CIterStat)):
+        assert lib.ppo_ba_sizeof(which) == C.sizeof(mirror), (which, mirror.__name__)
+    assert lib.ppo_ba_sizeof(99) == -1
 
 
 def test_partition_is_contiguous_and_balanced():

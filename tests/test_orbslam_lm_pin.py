@@ -85,8 +85,9 @@ def check_against_reference_run(backend, case, tol_lambda, tol_chi2, gate=1.0, t
         assert abs(a["chi2_before"] - chi_ref) <= (min(1e-9, tc) if k == 0 else tc) * chi_ref, (k, a["chi2_before"], chi_ref)
     assert abs(it[-1]["chi2_after"] - R["final_chi2"]) <= 1e-6 * R["final_chi2"]
     lv = R["levels_after_pass1"]
-    for name, got in (("mono", r.mono_level), ("stereo", r.stereo_level), ("plane", r.pl_level), ("bbox", r.bbox_level), ("corner", r.corner_level)):
-        assert np.array_equal(got, np.array(lv[name], dtype=np.uint8)), name
+    for name, got in (("mono", r.mono_level), ("stereo", r.stereo_level), ("plane", r.pl_level), ("bbox", r.bbox_level), ("corner", r.corner_level),
+                      ("cub3d", r.cub3d_level)):
+        assert np.array_equal(got, np.array(lv.get(name, []), dtype=np.uint8)), name
     fs = R["final_state"]
     ref_pose, ref_pt = np.array(fs["pose_qt"]), np.array(fs["point_xyz"])
     # BASELINE.md section 2, parity gate
@@ -112,11 +113,14 @@ def check_against_reference_run(backend, case, tol_lambda, tol_chi2, gate=1.0, t
     # per-edge chi2 of the custom edges at the final state (active edges).  Bar: a bbox residual of ~10 px with Omega = 0.49 turns a
     # state deviation of 1e-5 m (the gate above; f / z ~ 160 px per metre) into 2 e Omega de ~ 1.6e-2 of chi2 -- 1e-3 of the
     # largest chi2 (~50) is the tighter of the two statements
-    for name, got in (("plane", r.pl_chi2), ("bbox", r.bbox_chi2), ("corner", r.corner_chi2), ("ptcub", r.ptcub_chi2), ("cubpl", r.cubpl_chi2)):
-        ref = np.array(R["final_edge_chi2"][name])
+    for name, got in (("plane", r.pl_chi2), ("bbox", r.bbox_chi2), ("corner", r.corner_chi2), ("ptcub", r.ptcub_chi2), ("cubpl", r.cubpl_chi2),
+                      ("cub3d", r.cub3d_chi2)):
+        ref = np.array(R["final_edge_chi2"].get(name, []))
         if ref.size == 0:
             continue
         act = np.array(lv[name], dtype=int) == 0
+        if not act.any():
+            continue  # (every edge of the class was culled between the passes)
         assert np.abs(got[act] - ref[act]).max() <= 1e-3 * max(1.0, np.abs(ref[act]).max()), name
 
 
@@ -130,7 +134,8 @@ def test_fixture_is_the_reference_and_exercises_the_schedule():
         lv = c["result"]["levels_after_pass1"]
         kinds |= {k for k, v in lv.items() if len(v)}
         assert all(c["result"]["solve_ok"])
-    assert kinds == {"plane", "mono", "stereo", "bbox", "corner", "ptcub", "cubpl"}
+    assert kinds == {"plane", "mono", "stereo", "bbox", "corner", "ptcub", "cubpl", "cub3d"}
+    assert sum(1 for c in CASES if len(c["problem"].get("cub3d_pose", []))) >= 2  # Optimizer::LocalBACameraPointCuboids2D windows (9-D edge)
     assert sum(1 for c in CASES if is_points_only(c)) >= 2
     assert any(sum(c["result"]["levels_after_pass1"]["plane"]) > 0 for c in CASES) or any(sum(c["result"]["levels_after_pass1"]["bbox"]) > 0 for c in CASES)
     assert any(1 in c["problem"].get("pl_kind", []) for c in CASES) and any(2 in c["problem"].get("pl_kind", []) for c in CASES)

@@ -67,11 +67,12 @@ def test_oracle_vertex_types_match_the_reference_binary(worst, key):
     assert worst[key] <= 1e-15, (key, worst[key])
 
 
-@pytest.mark.parametrize("kind", ["plane", "plane_ver", "plane_par", "bbox", "corner", "ptcub", "cubpl"])
+@pytest.mark.parametrize("kind", ["plane", "plane_ver", "plane_par", "bbox", "corner", "ptcub", "cubpl", "cuboid3d"])
 def test_oracle_edges_match_the_reference_binary(worst, kind):
     assert worst["edge_%s_error" % kind] <= ROUNDING
     assert worst["edge_%s_chi2" % kind] <= 1e-12
-    numeric_both = kind.startswith("plane")  # both Jacobians differentiate through an oplus that rounds
+    numeric_both = kind.startswith("plane") or kind == "cuboid3d"  # both Jacobians differentiate through an oplus that rounds, or
+    #                                                                  (cuboid3d) through acos / tan of a near-identity rotation
     for key, differenced in (("J0", True), ("H0", True), ("b0", True), ("J1", numeric_both), ("H1", numeric_both), ("b1", numeric_both), ("H01", True)):
         k = "edge_%s_%s" % (kind, key)
         if k not in worst:
@@ -146,6 +147,16 @@ def test_device_cuboid_projection_residuals(hc, gold, kind):
         getattr(hc, "hc_" + kind)(dptr(arr(c["v0"])), dptr(arr(c["v1"])), dptr(arr(c["K"])), dptr(arr(c["meas"])), dptr(e))
         worst = max(worst, pin.rel_dev(e[:len(c["error"])], c["error"]))
     assert worst <= 1e-12, worst  # pixels of size ~500: a few ulps
+
+
+def test_device_cuboid_3d_residual(hc, gold):
+    """EdgeSE3Cuboid (the 9-D camera-object edge of LocalBACameraPointCuboids2D): the four-way yaw ambiguity picks the same copy."""
+    worst = 0.0
+    for c in gold["edge_cuboid3d"]:
+        e = np.zeros(9)
+        hc.hc_cub3d(dptr(arr(c["v0"])), dptr(arr(c["v1"])), dptr(arr(c["meas"])), dptr(e))
+        worst = max(worst, pin.rel_dev(e, c["error"]))
+    assert worst <= 1e-14, worst
 
 
 def test_device_point_cuboid_residual(hc, gold):

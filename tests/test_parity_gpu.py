@@ -64,6 +64,9 @@ CASES = [
     ("small", dict(seed=5, fixed_observer_frac=0.3)),
     (dict(n_kf=12, n_points=400, n_planes=0, n_cuboids=0), dict(seed=6)),  # points only (config 2 shape)
     (dict(n_kf=12, n_points=400, n_planes=6, n_cuboids=0), dict(seed=7)),  # + planes (config 3 shape)
+    # the 9-D camera-object edge EdgeSE3Cuboid of Optimizer::LocalBACameraPointCuboids2D (Optimizer.cc:1767-1800)
+    ("small", dict(seed=9, with_cuboid3d=True)),
+    (dict(n_kf=12, n_points=300, n_planes=0, n_cuboids=3), dict(seed=10, with_cuboid3d=True, with_corners=True)),  # points + cuboids only
 ]
 
 
@@ -134,13 +137,14 @@ def test_full_protocol_matches_oracle(oracle, hip, cfg, kw, elim):
     compare_levels(ro.stereo_level, rh.stereo_level, ro.stereo_chi2, o.chi2_stereo)
     compare_levels(ro.pl_level, rh.pl_level, ro.pl_chi2, o.chi2_plane)
     assert np.array_equal(ro.bbox_level, rh.bbox_level)
+    assert np.array_equal(ro.cub3d_level, rh.cub3d_level)
     np.testing.assert_array_equal(ro.mono_depth_positive, rh.mono_depth_positive)
-    for name in ("mono_chi2", "stereo_chi2", "pl_chi2", "bbox_chi2", "corner_chi2", "ptcub_chi2", "cubpl_chi2"):
+    for name in ("mono_chi2", "stereo_chi2", "pl_chi2", "bbox_chi2", "corner_chi2", "ptcub_chi2", "cubpl_chi2", "cub3d_chi2"):
         a, b = getattr(ro, name), getattr(rh, name)
         if a.size:
             # cuboid-derived residuals inherit the 1e-5 tolerance of the cuboid state they are evaluated at; the plane
             # residual chi2 = 3282.8 * angle^2 + 1e4 * dist^2 magnifies the 1e-6 tolerance of the plane coefficients
-            tol = 1e-5 if name in ("bbox_chi2", "corner_chi2", "ptcub_chi2", "pl_chi2") else 1e-6
+            tol = 1e-5 if name in ("bbox_chi2", "corner_chi2", "ptcub_chi2", "pl_chi2", "cub3d_chi2") else 1e-6
             assert np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max()), name
 
 
@@ -714,6 +718,9 @@ def _full_size_against_oracle(oracle, hip, P, with_spread, hip_only=None):
     compare_levels(ro.pl_level, rh.pl_level, ro.pl_chi2, o.chi2_plane)
     assert np.array_equal(ro.bbox_level, rh.bbox_level)
     assert np.array_equal(ro.corner_level, rh.corner_level)
+    assert np.array_equal(ro.cub3d_level, rh.cub3d_level)
+    if ro.cub3d_chi2.size:
+        assert np.abs(ro.cub3d_chi2 - rh.cub3d_chi2).max() <= 1e-5 * max(1.0, np.abs(ro.cub3d_chi2).max())
     so.close(); sh.close()
 
 
@@ -725,13 +732,14 @@ def test_baseline_configurations_match_the_oracle_at_full_size(oracle, hip, cfg)
 
 
 @pytest.mark.parametrize("kw", [dict(stereo_frac=0.2), dict(with_corners=True), dict(with_vp_planes=1000), dict(fixed_observer_frac=0.1),
-                                dict(stereo_frac=0.2, with_corners=True, with_vp_planes=1000, fixed_observer_frac=0.1)],
-                         ids=["stereo20", "corners", "vp1000", "fixedobs10", "all"])
+                                dict(stereo_frac=0.2, with_corners=True, with_vp_planes=1000, fixed_observer_frac=0.1), dict(with_cuboid3d=True)],
+                         ids=["stereo20", "corners", "vp1000", "fixedobs10", "all", "cuboid3d"])
 def test_config4_edge_class_options_match_the_oracle_at_full_size(oracle, hip, kw):
     """The config-4 options of SURVEY.md section 8(d) at FULL size (they met the oracle only on 10-keyframe graphs before): 20 % stereo
     observations (multi-chunk StereoEdgeP segments, Optimizer.cc:2393-2422), the 16-D corner edges on all 500 cuboid observations
     (the second kernel variant, Optimizer.cc:2493-2551), 1 000 vertical + 1 000 parallel plane edges (Optimizer.cc:2262-2307),
-    10 % additional fixed observers, and all of them together."""
+    10 % additional fixed observers, and all of them together; and the 9-D camera-object edge of Optimizer::LocalBACameraPointCuboids2D on all
+    500 cuboid observations (Optimizer.cc:1767-1800)."""
     _full_size_against_oracle(oracle, hip, synth.make_problem("cfg4", seed=1, **kw), with_spread=False)
 
 

@@ -23,9 +23,9 @@ for k, c in enumerate(cases):
     line += "  pose %.1e point %.1e" % (np.abs(r.pose_qt - np.array(fs["pose_qt"])).max(), np.abs(r.point_xyz - np.array(fs["point_xyz"])).max())
     if len(fs["plane_coef"]): line += " plane %.1e" % np.abs(r.plane_coef - np.array(fs["plane_coef"])).max()
     if len(fs["cuboid_qt"]): line += " cub %.1e scale %.1e" % (np.abs(r.cuboid_qt - np.array(fs["cuboid_qt"])).max(), np.abs(r.cuboid_scale - np.array(fs["cuboid_scale"])).max())
-    for name, got in (("plane", r.pl_chi2), ("bbox", r.bbox_chi2), ("corner", r.corner_chi2), ("ptcub", r.ptcub_chi2), ("cubpl", r.cubpl_chi2)):
-        ref = np.array(R["final_edge_chi2"][name])
-        if ref.size:
-            act = np.array(lv[name], dtype=int) == 0
+    for name, got in (("plane", r.pl_chi2), ("bbox", r.bbox_chi2), ("corner", r.corner_chi2), ("ptcub", r.ptcub_chi2), ("cubpl", r.cubpl_chi2), ("cub3d", r.cub3d_chi2)):
+        ref = np.array(R["final_edge_chi2"].get(name, []))
+        act = np.array(lv.get(name, []), dtype=int) == 0
+        if ref.size and act.any():
             line += " | %s chi2 %.1e/%.0f" % (name, np.abs(got[act] - ref[act]).max(), np.abs(ref[act]).max())
     print(line)
