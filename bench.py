@@ -59,7 +59,7 @@ def cpu_baseline(P, B, seconds_budget=12.0):
                            calls, iters, trials, dt, cpu_model(), os.cpu_count() or 0))
 
 
-TRAFFIC_FILES = ("r03_lin_traffic.json", "r02_lin_traffic.json", "r01_lin_traffic.json")  # newest first
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 (vector = matrix) peak: half the 157.3 TF FP32 rate of /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def cpu_baseline_openmp(P, B, seconds_budget=6.0):
@@ -108,14 +108,23 @@ def cpu_baseline_openmp(P, B, seconds_budget=6.0):
 def committed_traffic(k_bytes):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/rNN_lin_traffic.json, made by
     tools/pmc_traffic.sh on this exact workload: FETCH_SIZE / WRITE_SIZE in separate --pmc runs), and the file they came from;
-    (None, None) when absent or made for a different graph.  The counters are not collected inside this run."""
-    for name in TRAFFIC_FILES:
+    (None, None) when absent or made for a different graph.  The counters are not collected inside this run.  The NEWEST round's file
+    is tried first; a newer file that cannot be used (another graph, a schema without the two fields) is named on stderr."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_lin_traffic.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)), reverse=True)
+    for f in files:
+        name = os.path.basename(f)
         try:
-            j = json.load(open(os.path.join(REPO, "profiles", name)))
-            if int(j.get("algorithmic_bytes", -1)) == int(k_bytes):
-                return float(j["hbm_bytes_per_launch"]), "profiles/" + name
-        except Exception:
-            pass
+            j = json.load(open(f))
+            if "hbm_bytes_per_launch" not in j or "algorithmic_bytes" not in j:
+                raise KeyError("no algorithmic_bytes / hbm_bytes_per_launch on top level")
+            if int(j["algorithmic_bytes"]) != int(k_bytes):
+                raise ValueError("made for %d algorithmic bytes, this workload has %d" % (int(j["algorithmic_bytes"]), int(k_bytes)))
+            return float(j["hbm_bytes_per_launch"]), "profiles/" + name
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("bench.py: profiles/%s skipped for roofline.traffic: %s\n" % (name, e))
     return None, None
 
 
@@ -366,6 +375,17 @@ def main():
                                              "algorithmic_bytes": lin_bytes, "launch_ms": lin_ms.value,
                                              "achieved": lin_bytes / (lin_ms.value * 1e-3) / 1e9}},
         }
+        # the kernel group that owns the clock: the dense solve of the reduced pose system (chol_step x panels + chol_back_all), FP64 on the
+        # MFMA / vector units.  flops = n^3 / 3 + 2 n^2 at the dimension actually factored; launch_ms = the solve alone after a complete
+        # reduction (ppo_ba_time_factor).  A latency chain, not a throughput kernel: the fraction says how far from a GEMM it is.
+        n_d = float(ld_dense.value)
+        dense_flops = n_d ** 3 / 3.0 + 2.0 * n_d ** 2
+        dense_tf = dense_flops / (fac_ms.value * 1e-3) / 1e12 if fac_ms.value > 0 else 0.0
+        out["roofline_dense"] = {"bound": "mfma", "kernel": "chol_step x %d + chol_back_all" % ((ld_dense.value + 63) // 64), "dtype": "f64",
+                                 "flops": dense_flops, "launch_ms": fac_ms.value, "achieved": dense_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": dense_tf / FP64_PEAK_TFLOPS, "share_of_lm_iteration": fac_ms.value / (1e3 * dt / max(trials, 1)),
+                                 "note": "the panel chain is issue- and latency-bound (one workgroup's 16x16 register factorisations per panel, DESIGN.md 4.1), "
+                                         "not FLOP-bound: share_of_lm_iteration is the figure to lower"}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P, B)
             omp = cpu_baseline_openmp(P, B)

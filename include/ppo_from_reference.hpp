@@ -222,7 +222,12 @@ void to_window(const Gathered<KeyFrameT, MapPointT, MapPlaneT, MapCuboidT>& g, p
         continue;
       }
       op.bad = up->isBad();
-      op.n_object_observations = up->MapObjObservations[pMC];
+      // (find(), not operator[]: the reference reads MapObjObservations[pMC] only for non-bad points inside the point-object branch
+      //  (OPT:2571-2574), where operator[] may insert; here nothing is ever inserted into MapPoint state other threads share)
+      if (!op.bad) {
+        const auto it = up->MapObjObservations.find(pMC);
+        op.n_object_observations = it == up->MapObjObservations.end() ? 0 : (int)it->second;
+      }
       const auto X = up->GetWorldPos();
       for (int a = 0; a < 3; ++a) op.xyz[a] = X.template at<float>(a);
       c.unique_points.push_back(op);
@@ -374,10 +379,8 @@ int local_ba_camera_plane_cuboids(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, 
     for (MapPointT* p : g.lLocalMapPoints) p->mnBALocalForKF = 0;
     for (MapCuboidT* c : g.lLocalMapCuboids) c->mnBALocalForKF = 0;
   };
-  if (pbStopFlag && *pbStopFlag) {  // OPT:2723-2725: abort before optimising, no write-back
-    reset_markers();
-    return PPO_BA_ABORTED;
-  }
+  if (pbStopFlag && *pbStopFlag) return PPO_BA_ABORTED;  // OPT:2723-2725: `return` before optimising -- no write-back, and the BA markers
+                                                          // STAY set, as in the reference (the next call overwrites them with its own pKF->mnId)
   ppo_ba_options O;
   options_from_params(par, O);
   Solved s;
@@ -418,10 +421,7 @@ int local_ba_camera_point_cuboids_2d(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMa
     for (MapPointT* p : g.lLocalMapPoints) p->mnBALocalForKF = 0;
     for (MapCuboidT* c : g.lLocalMapCuboids) c->mnBALocalForKF = 0;
   };
-  if (pbStopFlag && *pbStopFlag) {  // OPT:1809-1811
-    reset_markers();
-    return PPO_BA_ABORTED;
-  }
+  if (pbStopFlag && *pbStopFlag) return PPO_BA_ABORTED;  // OPT:1809-1811: markers stay set, as in the reference
   ppo_ba_options O;
   options_from_params(par, O);
   Solved s;

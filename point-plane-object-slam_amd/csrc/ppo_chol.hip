@@ -1113,7 +1113,7 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
         o.npair_wg = o.chunk_hi > o.chunk_lo ? ((o.chunk_hi - o.chunk_lo + per_wg - 1) / per_wg + 7) / 8 * 8 : 0;
       }
 #ifdef PPO_BA_TEST_HOOKS
-      if (PPO_DEV_ENV("PPO_BA_OVERLAP_EMPTY")) o.chunk_hi = o.chunk_lo;  // timing experiment (WRONG results): the pair workgroups find nothing to do
+      if (PPO_DEV_PROBE("PPO_BA_OVERLAP_EMPTY")) o.chunk_hi = o.chunk_lo;  // timing experiment (WRONG results): the pair workgroups find nothing to do
 #endif
       const dim3 grid(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0) + o.npair_wg + (k > 0 && inv ? 1 : 0));
       if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
@@ -1170,7 +1170,8 @@ void chol_overlap_schedule(int nb, const int32_t* cb_start, int first_blocks, do
   fin[0] = std::min(nb, std::max(1, first_blocks));
   for (int k = 0; k < nb; ++k) {
     const int f = fin[k], need = std::min(nb, k + 2);
-    const long budget = (long)((k == 0 ? share0 : share) * (double)total);
+    const double sh = std::min(1.0, std::max(0.0, k == 0 ? share0 : share));  // (a share is a fraction of all chunks: NaN, inf and > 1 are clamped
+    const long budget = (long)(sh * (double)total);                            //  before the conversion, which is undefined outside the range of long)
     int nf = f;
     while (nf < nb && (nf < need || (long)cb_start[nf + 1] - cb_start[f] <= budget)) ++nf;
     fin[k + 1] = nf;

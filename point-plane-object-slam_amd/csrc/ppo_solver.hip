@@ -532,12 +532,12 @@ int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
   rp.chunk_hi = s->reduce_overlapped ? s->cb_start[s->fin[0]] : s->pc.n_chunks;
   rp.nb_pairs = (nl > 0 && rp.chunk_hi > 0) ? (nblk(rp.chunk_hi, 4) + 7) / 8 * 8 : 0;
   rp.nb_cubschur = (cub_stage && g.n_cub_pairs > 0) ? (nblk((long)g.n_cub_pairs * 8, 256) + 7) / 8 * 8 : 0;  // (multiple of 8: see k_reduce_stage3)
-  if (const char* e = PPO_DEV_ENV("PPO_BA_STAGE1_PROBE")) {  // timing experiments (WRONG results): parts of stage 1 left out -- 'c' cuboid blocks, 'l' landmark blocks, 'a' assembly
+  if (const char* e = PPO_DEV_PROBE("PPO_BA_STAGE1_PROBE")) {  // timing experiments (WRONG results): parts of stage 1 left out -- 'c' cuboid blocks, 'l' landmark blocks, 'a' assembly
     if (strchr(e, 'c')) rp.nb_cubprep = 0;
     if (strchr(e, 'l')) rp.nb_prep = 0;
     if (strchr(e, 'a')) rp.nb_asm = 0;
   }
-  if (const char* e = PPO_DEV_ENV("PPO_BA_STAGE3_PROBE")) {  // timing experiments (WRONG results): 'c' no cuboid pair workgroups, 'p' no pose-pair workgroups
+  if (const char* e = PPO_DEV_PROBE("PPO_BA_STAGE3_PROBE")) {  // timing experiments (WRONG results): 'c' no cuboid pair workgroups, 'p' no pose-pair workgroups
     if (strchr(e, 'c')) rp.nb_cubschur = 0;
     if (strchr(e, 'p')) rp.nb_pairs = 0;
   }
@@ -616,7 +616,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   up.nb_lm = nl > 0 ? nblk((long)PPO_UPD_LPP * nl, 256) : 0;
   up.nb_zero = nb * (nb + 1) / 2;
   up.S = s->d_S.p; up.bs = s->d_bs_p; up.ld = g.ld;
-  if (const char* e = PPO_DEV_ENV("PPO_BA_UPDATE_PROBE")) {  // timing experiments (WRONG results): parts of the update launch left out -- 'l' landmarks, 'z' clearing of S
+  if (const char* e = PPO_DEV_PROBE("PPO_BA_UPDATE_PROBE")) {  // timing experiments (WRONG results): parts of the update launch left out -- 'l' landmarks, 'z' clearing of S
     if (strchr(e, 'l')) up.nb_lm = 0;
     if (strchr(e, 'z')) up.nb_zero = 0;
     if (strchr(e, 'r')) up.nb_red = 0;  // ('r': cuboids and poses)
@@ -773,6 +773,9 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     RC_TRY(fetch_acc_wait(s));
     int info = 0;
     info = (int)s->h_pinned[ACC_N];
+    // A hand-off of the backward substitution that timed out (chol_back_all's spin cap, info = 1 << 30) is a SOLVER FAILURE, not a
+    // "not positive" matrix: it must not be retried with a larger lambda as if the reference's LDLT had rejected the system.
+    if (info >= (1 << 30)) return PPO_BA_ERR_SOLVER;
     if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) info = 1 << 29;  // an addend that was not finite / out of the fixed-point range: the system is not usable
     double tempChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
     if (info != 0 || !std::isfinite(s->h_pinned[ACC_SCALE])) tempChi = std::numeric_limits<double>::max();  // solver not ok (:126-127)

@@ -421,6 +421,8 @@ int main() {
     const int rc = pfr::local_ba_camera_plane_cuboids<Traits>(&W.kf[1], &stop, &W.map, false, false, par, Never{&called});
     CHECK(rc == PPO_BA_ABORTED && !called && W.journal.lock_count == 0 && W.journal.ev.empty());
     for (int i = 0; i < 9; ++i) CHECK(W.kf[i].n_setpose == 0);
+    for (int i : {0, 1, 2, 3}) CHECK(W.kf[i].mnBALocalForKF == 1);  // the reference `return`s with the markers set (OPT:2723-2725) ...
+    CHECK(W.kf[6].mnBAFixedForKF == 1 && W.mp[0].mnBALocalForKF == 1 && W.cb[0].mnBALocalForKF == 1);  // ... every one of them
   }
   // ---- 5. the real library without a usable GPU fails loudly and leaves the map alone (with a GPU it succeeds) -------------------------
   {

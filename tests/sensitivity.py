@@ -54,12 +54,28 @@ def quat_angle(qa, qb):
     return 2.0 * min(np.linalg.norm(qa - qb), np.linalg.norm(qa + qb))
 
 
-def metrics(ra, rb):
-    """The quantities of the parity bar between two results."""
+def determined_points(P, r):
+    """Points the second pass determines: at least two observations still active (level 0) in result `r` -- >= 4 residual rows for 3
+    unknowns.  A landmark the culling left with ONE observation sits on a flat direction of the cost (its depth along the ray is held only
+    by the damping): DESIGN.md section 6 keeps those out of the point RMSE, and so does the reference's own practice of erasing them later."""
+    n = r.point_xyz.shape[0]
+    cnt = np.zeros(n)
+    if P["mono_point"].size:
+        np.add.at(cnt, P["mono_point"].reshape(-1)[r.mono_level.reshape(-1) == 0], 1)
+    if P["stereo_point"].size:
+        np.add.at(cnt, P["stereo_point"].reshape(-1)[r.stereo_level.reshape(-1) == 0], 1)
+    return cnt >= 2
+
+
+def metrics(ra, rb, points=None):
+    """The quantities of the parity bar between two results (points: boolean mask of the points that enter the point RMSE)."""
     n = ra.pose_qt.shape[0]
+    d_pt = np.sum((ra.point_xyz - rb.point_xyz) ** 2, axis=1) if ra.point_xyz.size else np.zeros(0)
+    if points is not None and d_pt.size:
+        d_pt = d_pt[points]
     m = {"t": float(np.sqrt(np.mean(np.sum((ra.pose_qt[:, 4:] - rb.pose_qt[:, 4:]) ** 2, axis=1)))),
          "r": max(quat_angle(ra.pose_qt[i, :4], rb.pose_qt[i, :4]) for i in range(n)),
-         "p": float(np.sqrt(np.mean(np.sum((ra.point_xyz - rb.point_xyz) ** 2, axis=1)))) if ra.point_xyz.size else 0.0,
+         "p": float(np.sqrt(np.mean(d_pt))) if d_pt.size else 0.0,
          "pl": float(np.abs(ra.plane_coef - rb.plane_coef).max()) if ra.plane_coef.size else 0.0,
          "cb": float(per_cuboid(ra, rb).max()) if ra.cuboid_qt.size else 0.0}
     return m
@@ -75,14 +91,14 @@ def per_point(ra, rb):
     return np.linalg.norm(ra.point_xyz - rb.point_xyz, axis=1) if ra.point_xyz.size else np.zeros(0)
 
 
-def spread(runs):
+def spread(runs, points=None):
     """Largest metric between the base run and any variant, and the per-cuboid / per-point maxima."""
     base = runs[0][1]
     m = {k: 0.0 for k in ("t", "r", "p", "pl", "cb")}
     cub = np.zeros(base.cuboid_qt.shape[0])
     pts = np.zeros(base.point_xyz.shape[0])
     for _, r in runs[1:]:
-        mm = metrics(base, r)
+        mm = metrics(base, r, points)
         for k in m:
             m[k] = max(m[k], mm[k])
         if cub.size:

@@ -316,8 +316,9 @@ def test_rejected_trials_follow_the_reference_schedule(oracle, hip, det):
     assert gap <= 1e-6, gap
     m = S.metrics(ro, rh)
     oo, _, _ = S.spread(S.oracle_runs(oracle, P, B.default_options(), variants=S.VARIANTS))
-    for k, bar in S.BARS.items():
-        assert m[k] <= max(10 * bar, oo[k]), (k, m[k], oo[k])
+    print("rejected-trials window (det=%d): deviation / oracle spread %s" % (det, {k: "%.1e / %.1e" % (m[k], oo[k]) for k in S.BARS}))
+    for k, bar in S.BARS.items():  # inside the bar, or inside what the reference algorithm's own rounding leaves open on this window
+        assert m[k] <= max(bar, oo[k]), (k, m[k], oo[k])
 
 
 def _not_positive_window():
@@ -521,73 +522,103 @@ def _schedules_may_differ(to, th, runs):
     return th["iters"][first]["trials"] > 1
 
 
-def test_randomly_structured_windows_against_the_oracle(oracle, hip):
-    """60 windows of random size and composition (3-23 keyframes, 30-700 points, 0-8 planes, 0-4 cuboids, stereo share, corner
-    edges, vertical / parallel planes, fixed observers, 0-20 % gross outliers, both elimination modes; tools/random_sweep.py).
-    Three requirements per window (numbers: tools/optimality_sweep.py over 200 windows, profiles/r03_optimality.txt):
-      1. DIRECT OPTIMALITY -- the oracle's objective (its pass-2 active set, levels and kernels) evaluated at the DEVICE's final
-         state equals the oracle's own minimum: relative gap <= max(5e-7, 5 x the gap the oracle's own four rounding-only re-runs
-         show on that window) when the device walked the oracle's accept / reject sequence (measured over 200 windows in one pass:
-         never above 2 x; the re-runs themselves reach 1.9e-6; the same window repeated: tools/gap_repeat.py), <= 1e-4 when it did not
-         and requirement 3 excuses that.
-      2. every quantity of BASELINE.md's bar is inside the bar, OR the window does not define it to the bar: the oracle's own spread over
-         the four re-runs -- or the device's own spread between its default and deterministic modes -- reaches 0.3 of the deviation
-         (measured minimum 0.57 for the oracle's in one pass over 200 windows; it was 0.05 in round 2; the device's spread was added when
-         repeated runs of the suite showed the SAME windows inside the bar in one run and outside in the next).  13 of 200 windows use
-         this, 12 of them by the point RMSE alone (landmarks left with one observation).
-      3. the same accept / reject sequence, or a demonstrably marginal one (_schedules_may_differ; 2 of 200)."""
+def _random_sweep_module():
     import importlib.util
-    import sensitivity as S
     spec = importlib.util.spec_from_file_location("random_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "random_sweep.py"))
     rs = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rs)
-    n = 60
+    return rs
+
+
+N_RANDOM_WINDOWS = 60
+
+
+def test_randomly_structured_windows_against_the_oracle(oracle, hip):
+    """60 windows of random size and composition (3-23 keyframes, 30-700 points, 0-8 planes, 0-4 cuboids, stereo share, corner
+    edges, vertical / parallel planes, fixed observers, 0-20 % gross outliers, both elimination modes; tools/random_sweep.py), the
+    device in DETERMINISTIC mode (options.deterministic = 1: bit-reproducible, so this test has no run-to-run component; the default
+    mode is held to the deterministic result by the next test).  The only excuse for a deviation is the ORACLE's own spread -- how far
+    the reference algorithm's result moves on that window when nothing but its rounding changes (summation order, FMA contraction,
+    compensated sums: tests/sensitivity.py).  Three requirements per window (numbers: tools/strict_sweep.py over 300 windows,
+    profiles/r04_strict_sweep.txt):
+      1. DIRECT OPTIMALITY -- the oracle's objective (its pass-2 active set, levels and kernels) evaluated at the DEVICE's final
+         state equals the oracle's own minimum: relative gap <= max(5e-7, 5 x the gap of the oracle's own four re-runs) when the device
+         walked the oracle's accept / reject sequence (300 windows: never violated), <= 1e-4 when it did not and requirement 3 holds.
+      2. every quantity of BASELINE.md's bar is inside the bar, OR the oracle's own spread of that quantity on that window reaches 0.3 of
+         the deviation (4 of 300 windows: plane coefficients 1.1e-6 against a spread of 3.6e-7, a rotation, a cuboid).  The point RMSE is
+         taken over the points the second pass determines (>= 2 active observations, sensitivity.determined_points); the others -- on a
+         flat direction of the cost -- must stay within 1e-2 m.
+      3. the same accept / reject sequence, or a demonstrably marginal one (_schedules_may_differ; 2 of 300)."""
+    import sensitivity as S
+    rs = _random_sweep_module()
+    n = N_RANDOM_WINDOWS
     n_out = n_sched = 0
     for seed in range(3000, 3000 + n):
         cfg, kw, elim = rs.random_case(seed)
         P = synth.make_problem(cfg, **kw)
         opt = B.default_options(eliminate_cuboids=elim)
-        so, sh = oracle.create(P, opt), hip.create(P, opt)
+        so, sh = oracle.create(P, opt), hip.create(P, B.default_options(eliminate_cuboids=elim, deterministic=1))
         to, th = so.run(), sh.run()
         ro, rh = so.read(), sh.read()
-        m = S.metrics(ro, rh)
+        pts = S.determined_points(P, ro)
+        m = S.metrics(ro, rh, pts)
         assert m["t"] < 1e-3 and m["r"] < 1e-3, (seed, cfg, kw, m)  # nothing diverges
+        if ro.point_xyz.size:
+            assert np.linalg.norm(ro.point_xyz - rh.point_xyz, axis=1).max() < 1e-2, (seed, cfg, kw)
         runs = S.oracle_runs(oracle, P, opt, variants=S.VARIANTS)
         own_gap = max(S.optimality_gap(oracle, so, ro, r)[0] for _, r in runs[1:])
         gap, _, _ = S.optimality_gap(oracle, so, ro, rh)
         same_schedule = S.schedule(to) == S.schedule(th)
-        # (floor 5e-7: half of BASELINE.md's bar on the final chi2.  tools/gap_repeat.py, the SAME window solved 100 - 300 times: seed 3051 --
-        #  16 keyframes, 52 points, 45 distinct LM histories in 100 runs -- gap median 5e-8, maximum 1.9e-7 against an oracle-variant gap of
-        #  2.7e-8; seed 3001 walks a second LM history in 5 of 300 runs and ends 1.4e-5 away then, which requirement 3 has to excuse.  The
-        #  same figures at the first commit of this round: a property of floating-point atomics on marginal windows, not of a kernel.)
         if same_schedule:
             assert gap <= max(5e-7, 5 * own_gap), (seed, gap, own_gap, cfg, kw)
         else:
             assert gap <= 1e-4, (seed, gap, own_gap, cfg, kw)
-        oo, _, _ = S.spread(runs)
+        oo, _, _ = S.spread(runs, pts)
         out = [k for k, bar in S.BARS.items() if m[k] >= bar]
-        if out:
-            # ... or the DEVICE's own summation order does not define it to the bar there (the same window in deterministic mode and once
-            # more in the default mode: floating-point atomics arrive in another order every run).  tools/inv_accuracy.py: 6 of these 60 windows
-            # are outside the bar in some runs and inside in others -- seed 3051's planes in 2 of 5 runs with 2.1e-6 against an oracle spread
-            # of 3.3e-7 -- with and without the explicit inverses of the backward substitution alike; requirement 1 above is what holds the
-            # result itself.
-            hs = {k: 0.0 for k in S.BARS}
-            for o2 in (B.default_options(eliminate_cuboids=elim, deterministic=1), opt):
-                s2 = hip.create(P, o2)
-                s2.run()
-                m2 = S.metrics(rh, s2.read())
-                s2.close()
-                hs = {k: max(hs[k], m2[k]) for k in hs}
-            for k in out:
-                assert max(oo[k], hs[k]) >= 0.3 * m[k], (seed, k, m[k], oo[k], hs[k], cfg, kw)
+        for k in out:
+            assert oo[k] >= 0.3 * m[k], (seed, k, m[k], oo[k], cfg, kw)
         n_out += bool(out)
         if not same_schedule:
             n_sched += 1
             assert _schedules_may_differ(to, th, runs), (seed, cfg, kw, S.schedule(to), S.schedule(th))
         so.close(); sh.close()
-    # drift guard: measured 5 windows outside the bar and 1 differing schedule among these 60 (7 % / 1 % over 200)
-    assert n_out <= 9 and n_sched <= 4, (n_out, n_sched)
+    print("random windows, deterministic mode: %d of %d used the oracle-spread excuse, %d walked another (marginal) schedule" % (n_out, n, n_sched))
+    # drift guard: measured 0 windows outside the bar and 1 differing schedule among these 60 (4 and 2 among 300)
+    assert n_out <= 3 and n_sched <= 3, (n_out, n_sched)
+
+
+def test_default_mode_stays_near_the_deterministic_result(oracle, hip):
+    """The same 60 windows in the DEFAULT mode (floating-point atomics: the order in which the addends of a cross-wave sum arrive changes
+    from run to run) against the deterministic result of the same library: that isolates the noise of the atomic order from any error of
+    a kernel, which the previous test would have caught.  Bound per quantity of BASELINE.md's bar: max(3 x the bar, 5 x the oracle's own
+    spread on that window).  Measured over 300 windows (tools/strict_sweep.py): never violated; the largest ratios to the bar are
+    translation 3.8, rotation 11, point RMSE 10, plane 14, cuboid 1.2 -- all on windows whose oracle spread is as large (seed 3178: plane
+    spread 9.2e-6) or where the two runs walk different, marginal schedules (seed 3220)."""
+    import sensitivity as S
+    rs = _random_sweep_module()
+    n_sched = n_beyond_bar = 0
+    for seed in range(3000, 3000 + N_RANDOM_WINDOWS):
+        cfg, kw, elim = rs.random_case(seed)
+        P = synth.make_problem(cfg, **kw)
+        sd = hip.create(P, B.default_options(eliminate_cuboids=elim, deterministic=1))
+        s0 = hip.create(P, B.default_options(eliminate_cuboids=elim))
+        td, t0 = sd.run(), s0.run()
+        rd, r0 = sd.read(), s0.read()
+        sd.close(); s0.close()
+        pts = S.determined_points(P, rd)
+        m = S.metrics(rd, r0, pts)
+        beyond = [k for k, bar in S.BARS.items() if m[k] >= bar]
+        if beyond or S.schedule(td) != S.schedule(t0):
+            runs = S.oracle_runs(oracle, P, B.default_options(eliminate_cuboids=elim), variants=S.VARIANTS)
+            oo, _, _ = S.spread(runs, S.determined_points(P, runs[0][1]))
+            for k in beyond:
+                assert m[k] < max(3 * S.BARS[k], 5 * oo[k]), (seed, k, m[k], oo[k], cfg, kw)
+            if S.schedule(td) != S.schedule(t0):
+                n_sched += 1
+                assert _schedules_may_differ(td, t0, runs) or _schedules_may_differ(runs[0][0], t0, runs), (seed, cfg, kw, S.schedule(td), S.schedule(t0))
+        n_beyond_bar += bool(beyond)
+    print("random windows, default vs deterministic mode: %d of %d beyond the bar somewhere, %d with another (marginal) schedule" % (n_beyond_bar, N_RANDOM_WINDOWS, n_sched))
+    assert n_beyond_bar <= 8 and n_sched <= 4, (n_beyond_bar, n_sched)
 
 
 def test_sharded_code_path_with_a_one_rank_rccl_communicator(hip_hooks, monkeypatch):
@@ -668,15 +699,17 @@ def test_landmark_sharding_gives_the_single_rank_answer(hip_hooks, cfg, kw, worl
 
 
 def _full_size_against_oracle(oracle, hip, P, with_spread, hip_only=None):
-    """Complete 5 + 10 protocol on both sides: same accept / reject schedule, chi2 per iteration at 1e-6, final estimates at
-    BASELINE.md's bars, same outlier sets, and the DIRECT check: the oracle's objective evaluated at the device's final state equals
-    its own minimum (relative gap <= max(1e-7, 5 x the gap between the oracle's own four rounding-only re-runs; measured <= 2 x,
-    tools/optimality_sweep.py full).  Cuboids and points: each one inside the bar, OR within FIVE times that same cuboid's / point's
-    spread between those re-runs of the ORACLE (thirty in round 2; measured <= 1.5 x) -- a deviation is only accepted where the
-    reference algorithm's own result is not defined to the bar (tests/test_oracle_sensitivity.py) -- and the device's own spread
-    (default against deterministic mode) stays within the same five times."""
+    """Complete 5 + 10 protocol, the device in DETERMINISTIC mode against the oracle: same accept / reject schedule, chi2 per iteration at
+    1e-6, final estimates at BASELINE.md's bars, same outlier sets, and the DIRECT check: the oracle's objective evaluated at the
+    device's final state equals its own minimum (relative gap <= max(1e-7, 5 x the gap between the oracle's own four rounding-only
+    re-runs; measured <= 2 x, tools/optimality_sweep.py full).  Cuboids and points: each one inside the bar, OR within FIVE times that same
+    cuboid's / point's spread between those re-runs of the ORACLE (measured <= 1.5 x) -- a deviation is only accepted where the reference
+    algorithm's own result is not defined to the bar (tests/test_oracle_sensitivity.py).  No excuse comes from the device.
+    Then the DEFAULT mode (floating-point atomics, the overlapped reduction: what bench.py times) is held to the deterministic result:
+    same schedule, every quantity within max(3 x the bar, 5 x the oracle's spread of that cuboid / point / quantity)."""
     import sensitivity as S
-    so, sh = both(oracle, hip, P, hip_only=hip_only)
+    opt_det = B.default_options(deterministic=1, **(hip_only or {}))
+    so, sh = oracle.create(P, B.default_options()), hip.create(P, opt_det)
     to, th = so.run(), sh.run()
     assert [(i["pass_"], i["iteration"], i["trials"], i["accepted"]) for i in to["iters"]] == [(i["pass_"], i["iteration"], i["trials"], i["accepted"]) for i in th["iters"]]
     for a, b in zip(to["iters"], th["iters"]):
@@ -691,23 +724,27 @@ def _full_size_against_oracle(oracle, hip, P, with_spread, hip_only=None):
     d_cb = S.per_cuboid(ro, rh)
     p_rmse = np.sqrt(np.mean(d_pt ** 2))
     gap, _, _ = S.optimality_gap(oracle, so, ro, rh)
-    need_spread = p_rmse >= 1e-5 or (d_cb.size and d_cb.max() >= 1e-5) or gap > 1e-7
+    # the default mode next to it
+    s0 = hip.create(P, B.default_options(**(hip_only or {})))
+    t0 = s0.run()
+    r0 = s0.read()
+    s0.close()
+    m0 = S.metrics(rh, r0)
+    d0_cb, d0_pt = S.per_cuboid(rh, r0), S.per_point(rh, r0)
+    default_beyond = [k for k, bar in S.BARS.items() if m0[k] >= bar]
+    need_spread = p_rmse >= 1e-5 or (d_cb.size and d_cb.max() >= 1e-5) or gap > 1e-7 or bool(default_beyond)
+    s_cb = s_pt = oo = None
     if need_spread or with_spread:
-        # measured on MI355X (tools/optimality_sweep.py full, config 4 and its five option sets): point RMSE 3e-8 .. 1.4e-5, one to five
+        # measured on MI355X (tools/optimality_sweep.py full, config 4 and its option sets): point RMSE 3e-8 .. 1.4e-5, one to five
         # of the 50 cuboids beyond 1e-5 (worst 2.6e-4 where the oracle's own re-runs differ by 4.1e-4), gap 1e-10 .. 1.6e-7
         runs = S.oracle_runs(oracle, P, B.default_options(), variants=S.VARIANTS)
         own_gap = max(S.optimality_gap(oracle, so, ro, r)[0] for _, r in runs[1:])
         assert gap <= max(1e-7, 5 * own_gap), (gap, own_gap)
-        _, s_cb, s_pt = S.spread(runs)
+        oo, s_cb, s_pt = S.spread(runs)
         if d_cb.size:
             assert (d_cb < np.maximum(1e-5, 5 * s_cb)).all(), (np.sort(d_cb)[::-1][:5], np.sort(s_cb)[::-1][:5])
             assert int((d_cb >= 1e-5).sum()) <= int((s_cb > 2e-6).sum())
             assert np.mean(d_cb < 1e-5) >= 0.9
-            sd = hip.create(P, B.default_options(deterministic=1, **(hip_only or {})))
-            sd.run()
-            h_cb = S.per_cuboid(rh, sd.read())
-            sd.close()
-            assert (h_cb < np.maximum(1e-5, 5 * s_cb)).all(), (np.sort(h_cb)[::-1][:5], np.sort(s_cb)[::-1][:5])
         if p_rmse >= 1e-5:
             assert (d_pt < np.maximum(1e-5, 5 * s_pt)).all()
             assert np.sqrt(np.mean(d_pt[s_pt < 1e-6] ** 2)) < 1e-5
@@ -721,6 +758,18 @@ def _full_size_against_oracle(oracle, hip, P, with_spread, hip_only=None):
     assert np.array_equal(ro.cub3d_level, rh.cub3d_level)
     if ro.cub3d_chi2.size:
         assert np.abs(ro.cub3d_chi2 - rh.cub3d_chi2).max() <= 1e-5 * max(1.0, np.abs(ro.cub3d_chi2).max())
+    # ---- default mode against the deterministic result ----
+    assert S.schedule(t0) == S.schedule(th), (S.schedule(t0), S.schedule(th))
+    assert abs(t0["iters"][-1]["chi2_after"] - th["iters"][-1]["chi2_after"]) <= 1e-6 * th["iters"][-1]["chi2_after"]
+    for k in default_beyond:
+        if k == "cb":
+            assert (d0_cb < np.maximum(3 * S.BARS["cb"], 5 * s_cb)).all(), (np.sort(d0_cb)[::-1][:5], np.sort(s_cb)[::-1][:5])
+        elif k == "p":
+            assert (d0_pt < np.maximum(3 * S.BARS["p"], 5 * s_pt)).all()
+        else:
+            assert m0[k] < max(3 * S.BARS[k], 5 * oo[k]), (k, m0[k], oo[k])
+    print("full size: deterministic vs oracle gap %.1e, point RMSE %.1e, worst cuboid %.1e; default vs deterministic %s" %
+          (gap, p_rmse, d_cb.max() if d_cb.size else 0.0, {k: "%.1e" % v for k, v in m0.items()}))
     so.close(); sh.close()
 
 

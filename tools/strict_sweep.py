@@ -1,0 +1,49 @@
+"""Development aid: the random-window comparison of tests/test_parity_gpu.py in numbers, for the deterministic and the default mode.
+Per window: schedule equal?, optimality gap vs the oracle's own variant gap, which BASELINE.md quantities are outside the bar and what the
+oracle's own spread is there, and how far the default mode is from the deterministic result.   python tools/strict_sweep.py [n] [first_seed]"""
+import importlib.util, os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "point-plane-object-slam_amd")); sys.path.insert(0, os.path.join(REPO, "oracle")); sys.path.insert(0, os.path.join(REPO, "tests"))
+from ppo_ba import binding as B, synth
+import oracle_py, sensitivity as S
+spec = importlib.util.spec_from_file_location("random_sweep", os.path.join(REPO, "tools", "random_sweep.py"))
+rs = importlib.util.module_from_spec(spec); spec.loader.exec_module(rs)
+oracle, hip = oracle_py.backend(), B.hip_backend()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+tot = {"det_out": 0, "det_out_unexcused": 0, "det_sched": 0, "det_gap_fail": 0, "def_far": 0}
+worst_ratio = {k: 0.0 for k in S.BARS}
+for seed in range(s0, s0 + n):
+    cfg, kw, elim = rs.random_case(seed)
+    P = synth.make_problem(cfg, **kw)
+    opt = B.default_options(eliminate_cuboids=elim)
+    so = oracle.create(P, opt); to = so.run(); ro = so.read()
+    runs = S.oracle_runs(oracle, P, opt, variants=S.VARIANTS)
+    own_gap = max(S.optimality_gap(oracle, so, ro, r)[0] for _, r in runs[1:])
+    det_pts = S.determined_points(P, ro)
+    oo, _, _ = S.spread(runs, det_pts)
+    res = {}
+    for name, det in (("det", 1), ("def", 0)):
+        sh = hip.create(P, B.default_options(eliminate_cuboids=elim, deterministic=det)); th = sh.run(); rh = sh.read(); sh.close()
+        res[name] = (th, rh)
+    th, rh = res["det"]
+    m = S.metrics(ro, rh, det_pts)
+    loose = float(np.linalg.norm(ro.point_xyz - rh.point_xyz, axis=1).max()) if ro.point_xyz.size else 0.0
+    gap = S.optimality_gap(oracle, so, ro, rh)[0]
+    same = S.schedule(to) == S.schedule(th)
+    out = [k for k, bar in S.BARS.items() if m[k] >= bar]
+    unex = [k for k in out if oo[k] < 0.3 * m[k]]
+    md = S.metrics(rh, res["def"][1], det_pts)
+    same_def = S.schedule(res["def"][0]) == S.schedule(th)
+    far = [k for k, bar in S.BARS.items() if md[k] >= max(3 * bar, 5 * oo[k])]
+    for k in S.BARS:
+        worst_ratio[k] = max(worst_ratio[k], md[k] / S.BARS[k])
+    tot["det_out"] += bool(out); tot["det_out_unexcused"] += bool(unex); tot["det_sched"] += (not same)
+    tot["det_gap_fail"] += (same and gap > max(5e-7, 5 * own_gap)); tot["def_far"] += bool(far)
+    if out or not same or far or not same_def:
+        print("[%d/%d determined, worst point %.1e] " % (det_pts.sum(), det_pts.size, loose), end="")
+        print("seed %d sched_det=%s sched_def_vs_det=%s gap %.1e own %.1e | det out %s unexcused %s | def-vs-det %s far %s" % (
+            seed, same, same_def, gap, own_gap, {k: "%.1e(own %.1e)" % (m[k], oo[k]) for k in out}, unex, {k: "%.1e" % md[k] for k in S.BARS if md[k] >= S.BARS[k]}, far))
+    so.close()
+print("totals", tot, "worst default-vs-deterministic / bar", {k: "%.2f" % v for k, v in worst_ratio.items()})
