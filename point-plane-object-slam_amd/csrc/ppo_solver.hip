@@ -1680,9 +1680,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
 
   {  // schedule of the overlapped reduction (ppo_chol.hip): worth its bookkeeping when the factorisation has enough launches to hide the pair chunks in
     // (measured, tools/overlap_ab.sh: config 4, 19 panels, 0.412 -> 0.388 ms per LM iteration; config 3, 10 panels, 0.231 -> 0.224; config 2, 5 panels, no difference)
+    // round 4 (tools/overlap_ab.sh, tools/small_window_trace.py): it also pays on FEW panels -- the fused first stage saves the launch of the pair
+    // stage, and with larger shares per launch the pair chunks still hide behind the panels: config 2 (5 panels) 8 010 -> 8 330 LM iterations/s,
+    // 50 KF / 5 000 points / 16 planes (5 panels) 164 -> 154 us per iteration, 30 KF / 2 000 points (3 panels) 91 -> 88, 15 KF / 800 points (2 panels)
+    // 75.6 -> 73.3.  Gate: two panels and a handful of chunks.
     const int nb = s->g.ld / 64;
-    int first_blocks = 1, min_chunks = 2048, min_nb = 8;
-    double share0 = 0.14, share = 0.10;
+    int first_blocks = 1, min_chunks = 16, min_nb = 2;
+    double share0 = nb >= 8 ? 0.14 : 0.50, share = nb >= 8 ? 0.10 : 0.35;
     bool enabled = true;
     if (const char* e = PPO_DEV_ENV("PPO_BA_OVERLAP")) {  // development aid: "0" = off, or "first_blocks,share0,share[,min_chunks[,min_nb]]"
       if (e[0] == '0' && e[1] == 0) enabled = false;
