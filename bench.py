@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (pose-only, concurrent windows, phase times): "
                     "used for the rocprofv3 runs so that the kernel statistics hold the headline workload only")
     ap.add_argument("--lin-reps", type=int, default=200)
+    ap.add_argument("--solve-on-owner", type=int, default=0, help="N > 1: 1 = reduce (S, b) to rank 0, solve there, broadcast x (options.solve_on_owner)")
     a = ap.parse_args()
 
     import numpy as np
@@ -193,7 +194,7 @@ def main():
     P = synth.make_problem(a.config, seed=a.seed, with_corners=a.with_corners, world_size=world)  # (cfg5w: 50 000 points per rank)
     weak = isinstance(synth.CONFIGS.get(a.config), dict) and synth.CONFIGS[a.config].get("points_per_rank", False)
     sizes = P.sizes()
-    opt = B.default_options(device_id=local_rank, rank=rank, world_size=world, solver=a.solver)
+    opt = B.default_options(device_id=local_rank, rank=rank, world_size=world, solver=a.solver, solve_on_owner=a.solve_on_owner if world > 1 else 0)
     if world > 1:
         ident = np.zeros(128, np.uint8)
         if rank == 0:
@@ -265,6 +266,38 @@ def main():
     traffic, traffic_source = committed_traffic(int(k_bytes.value))
     ld_dense = C.c_int32()
     lib.ppo_ba_debug_reduced(solver.h, None, None, None, C.byref(ld_dense))  # dimension of the system the dense solve factors
+
+    # N > 1: what one solve attempt spends in its exchange steps, each timed alone with HIP events (outside the timed region), the other
+    # variant of the (S, b) exchange beside the one in use, and the complete call in that other variant -- so that ONE lease of a multi-GPU
+    # node answers "which exchange, and what share of an iteration is it"
+    multi = {}
+    if world > 1:
+        coll = np.zeros(4)
+        assert lib.ppo_ba_time_collectives(solver.h, 20, coll.ctypes.data_as(B.c_dp)) == 0
+        solver.reset()
+        multi = {"us_per_solve_attempt": {"sb_allreduce_incl_pack_unpack": 1e3 * coll[0], "sb_reduce_to_rank0_plus_bcast_x": 1e3 * coll[1],
+                                          "scalar_allreduce": 1e3 * coll[2], "dense_solve_every_rank": 1e3 * fac_ms.value},
+                 "packed_sb_bytes": int(coll[3]), "exchange_in_use": "reduce+bcast" if a.solve_on_owner else "allreduce",
+                 "note": "strong scaling of ONE window: linearisation, Schur terms, back-substitution shard; the dense solve (factor_solve_ms) does not"}
+        other = B.default_options(device_id=local_rank, rank=rank, world_size=world, solver=a.solver, solve_on_owner=0 if a.solve_on_owner else 1)
+        for i in range(128):
+            other.comm_id[i] = opt.comm_id[i]
+        so = B.hip_backend().create(P, other)
+        so.run()
+        barrier()
+        t_o = time.perf_counter()
+        n_o = 0
+        for _ in range(max(3, a.steps // 4)):
+            so.reset()
+            n_o += so.run()["n_iters"]
+        barrier()
+        dt_o = time.perf_counter() - t_o
+        if dist is not None:
+            tt = torch.tensor([dt_o], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_o = float(tt.item())
+        so.close()
+        multi["other_exchange"] = {"exchange": "allreduce" if a.solve_on_owner else "reduce+bcast", "lm_iters_per_s": n_o / dt_o}
 
     # what a per-call user pays around the LM iterations (host flattening + PCIe upload, read-back): steady state, i.e. with
     # the library's block cache warm as in a running SLAM process; never part of `value`
@@ -366,7 +399,7 @@ def main():
                 "factor_solve_ms": fac_ms.value, "schur_reduction": reduction, "parallelism": "landmark-range x%d" % world,
                 "first_create_ms_incl_module_load": create_ms, "steady_state_call_ms": call_ms, "kernels": kernels,
                 "pose_only": pose_only, "device_ms_per_phase_of_one_call": phases,
-                "two_windows_concurrently": concurrent, "analytic_jacobians": analytic,
+                "two_windows_concurrently": concurrent, "analytic_jacobians": analytic, "multi_gpu": multi,
             },
             "roofline": {"bound": "hbm", "kernel": "k_linearize_all", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -197,6 +197,10 @@ typedef struct ppo_ba_options {
   uint8_t comm_id[128];
   int32_t verbose;
   double th_cub3d_norm;     /* thHuberSE3 (900), compared with |e| of the 9-D camera-object edges, Optimizer.cc:1875-1882 */
+  int32_t solve_on_owner;   /* multi-GPU only.  0 (default): the packed (S, b) is ALL-REDUCED and every rank factors it redundantly (no broadcast:
+                             * BASELINE.json north_star).  1: (S, b) is REDUCED to rank 0 (half the ring traffic), rank 0 alone factors and solves,
+                             * x and the factorisation flag are broadcast.  Same results on every rank either way. */
+  int32_t pad_;
 } ppo_ba_options;
 
 /* one record per LM iteration (one OptimizationAlgorithmLevenberg::solve call) */
@@ -297,6 +301,12 @@ enum {
   PPO_BA_KERNEL_LINEARIZE_ALL = 6 /* the fused linearisation launch of the product path (no zeroing) */
 };
 int ppo_ba_time_kernel(ppo_ba_handle h, int which, int reps, double* ms, int64_t* bytes);
+
+/* Sharded runs (every rank calls it): average milliseconds of the exchange steps of ONE solve attempt, each timed alone with HIP events:
+ * out[0] pack + all-reduce of (S, b) + unpack, out[1] pack + reduce to rank 0 + unpack there + broadcast of x and the flag
+ * (options.solve_on_owner), out[2] the all-reduce of the three trial scalars, out[3] bytes of the packed (S, b).  Zeros on a single rank.
+ * S, b, x hold garbage afterwards: ppo_ba_reset() before the next run. */
+int ppo_ba_time_collectives(ppo_ba_handle h, int reps, double* out);
 
 /* Time `reps` factorisations of the current reduced system (HIP events); average ms in *ms. */
 int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);

@@ -64,12 +64,16 @@ struct Comm {
   typedef int (*fn_get_id)(UniqueId*);
   typedef int (*fn_init_rank)(void**, int, UniqueId, int);
   typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  typedef int (*fn_reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t);   // ncclReduce(send, recv, count, type, op, root, comm, stream)
+  typedef int (*fn_bcast)(const void*, void*, size_t, int, int, void*, hipStream_t);         // ncclBroadcast(send, recv, count, type, root, comm, stream)
   typedef int (*fn_destroy)(void*);
   void* lib = nullptr;
   void* comm = nullptr;
   fn_get_id get_id = nullptr;
   fn_init_rank init_rank = nullptr;
   fn_allreduce allreduce = nullptr;
+  fn_reduce reduce = nullptr;
+  fn_bcast bcast = nullptr;
   fn_destroy comm_destroy = nullptr;
   int rank = 0, world = 1;
 #ifdef PPO_BA_TEST_HOOKS
@@ -104,8 +108,10 @@ struct Comm {
     get_id = (fn_get_id)dlsym(lib, "ncclGetUniqueId");
     init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
     allreduce = (fn_allreduce)dlsym(lib, "ncclAllReduce");
+    reduce = (fn_reduce)dlsym(lib, "ncclReduce");
+    bcast = (fn_bcast)dlsym(lib, "ncclBroadcast");
     comm_destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
-    return get_id && init_rank && allreduce && comm_destroy;
+    return get_id && init_rank && allreduce && reduce && bcast && comm_destroy;
   }
   int unique_id(uint8_t out[128]) {
     if (!load()) return -1;
@@ -170,6 +176,40 @@ struct Comm {
     if (loop) return loop_reduce(buf, n, 0, s);
 #endif
     return allreduce(buf, buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, s) == 0 ? 0 : -1;
+  }
+  // options.solve_on_owner: the sum lands on rank 0 only (half the traffic of an all-reduce on a ring) ...
+  int sum_to_root(double* buf, size_t n, hipStream_t s) {
+    if (!active() || n == 0) return 0;
+#ifdef PPO_BA_TEST_HOOKS
+    if (loop) return loop_reduce(buf, n, 0, s);  // (loopback: every rank receives the sum; only rank 0 reads it)
+#endif
+    return reduce(buf, buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, 0, comm, s) == 0 ? 0 : -1;
+  }
+  // ... and rank 0's bytes go to everybody
+  int bcast_from_root(void* buf, size_t bytes, hipStream_t s) {
+    if (!active() || bytes == 0) return 0;
+#ifdef PPO_BA_TEST_HOOKS
+    if (loop) {
+      if (hipStreamSynchronize(s) != hipSuccess) return -1;
+      LoopGroup& g = *loop;
+      std::unique_lock<std::mutex> lk(g.mu);
+      g.bufs[rank] = static_cast<double*>(buf);
+      const unsigned long long my_gen = g.gen;
+      if (++g.arrived == g.world) {
+        bool ok = true;
+        for (int r = 1; r < g.world; ++r) ok = ok && hipMemcpyAsync(g.bufs[r], g.bufs[0], bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        g.failed = g.failed || !ok;
+        g.arrived = 0;
+        ++g.gen;
+        g.cv.notify_all();
+      } else {
+        g.cv.wait(lk, [&] { return g.gen != my_gen; });
+      }
+      return g.failed ? -1 : 0;
+    }
+#endif
+    return bcast(buf, buf, bytes, /*ncclUint8*/ 1, 0, comm, s) == 0 ? 0 : -1;
   }
   int max(double* buf, size_t n, hipStream_t s) {
     if (!active() || n == 0) return 0;

@@ -578,14 +578,30 @@ int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
     // and lambda on the diagonal are part of its contribution)
     const int nb = g.ld / 64, ntiles = nb * (nb + 1) / 2;
     hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 0);
-    if (s->comm.sum(s->d_pack.p, (size_t)ntiles * 4096 + n, s->stream)) return PPO_BA_ERR_COMM;
-    hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 1);
+    if (s->opt.solve_on_owner) {  // reduce to rank 0, which alone unpacks (and solves: launch_solve)
+      if (s->comm.sum_to_root(s->d_pack.p, (size_t)ntiles * 4096 + n, s->stream)) return PPO_BA_ERR_COMM;
+      if (s->comm.rank == 0) hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 1);
+    } else {
+      if (s->comm.sum(s->d_pack.p, (size_t)ntiles * 4096 + n, s->stream)) return PPO_BA_ERR_COMM;
+      hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 1);
+    }
   }
   return PPO_BA_OK;
 }
 
 // dense SPD solve of S x = bs (LinearSolverDense::solve, linear_solver_dense.h:65-113).  info != 0 <=> not positive.
+int launch_solve_local(ppo_ba_solver* s);
 int launch_solve(ppo_ba_solver* s) {
+  if (s->comm.active() && s->opt.solve_on_owner) {
+    // options.solve_on_owner: rank 0 holds the summed system and solves it; the solution and the factorisation flag go to everybody
+    if (s->comm.rank == 0) RC_TRY(launch_solve_local(s));
+    if (s->comm.bcast_from_root(s->d_xr.p, (size_t)s->g.ld * sizeof(double), s->stream)) return PPO_BA_ERR_COMM;
+    if (s->comm.bcast_from_root(s->d_info.p, sizeof(int), s->stream)) return PPO_BA_ERR_COMM;
+    return PPO_BA_OK;
+  }
+  return launch_solve_local(s);
+}
+int launch_solve_local(ppo_ba_solver* s) {
   const Graph& g = s->g;
   const int n = g.n_red, ld = g.ld;
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
@@ -861,6 +877,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     return PPO_BA_ERR_ARG;
   }
   if (o->world_size < 1 || o->rank < 0 || o->rank >= o->world_size) return PPO_BA_ERR_ARG;
+  if (o->solve_on_owner != 0 && o->solve_on_owner != 1) return PPO_BA_ERR_ARG;
   const auto t_begin = std::chrono::steady_clock::now();
   RC_TRY(validate(p));
   int ndev = 0;
@@ -2080,6 +2097,56 @@ int ppo_ba_time_factor(ppo_ba_handle s, int reps, double* ms_out) {
   *ms_out = (double)total / reps;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  return PPO_BA_OK;
+}
+
+// Sharded runs: average milliseconds of the exchange steps of one solve attempt, each timed alone with HIP events on the library's stream
+// (every rank must call it; the collectives are real).  out[0] pack + ALL-REDUCE of (S, b) + unpack (options.solve_on_owner = 0),
+// out[1] pack + REDUCE to rank 0 + unpack there + broadcast of x and the factorisation flag (solve_on_owner = 1), out[2] the all-reduce of
+// the three trial scalars (chi2, scale, stop vote), out[3] bytes of the packed (S, b).  The contents of S, b and x are garbage afterwards:
+// call ppo_ba_reset() before the next run.
+int ppo_ba_time_collectives(ppo_ba_handle s, int reps, double* out) {
+  if (!s || reps <= 0 || !out) return PPO_BA_ERR_ARG;
+  out[0] = out[1] = out[2] = out[3] = 0.0;
+  if (!s->comm.active()) return PPO_BA_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  const Graph& g = s->g;
+  const int nb = g.ld / 64, ntiles = nb * (nb + 1) / 2;
+  const size_t n = g.ld, count = (size_t)ntiles * 4096 + n;
+  out[3] = (double)count * sizeof(double);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  auto timed = [&](int which, double* ms_out) -> int {
+    float total = 0;
+    for (int i = 0; i < reps + 1; ++i) {
+      HIP_TRY(hipEventRecord(e0, s->stream));
+      if (which < 2) hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 0);
+      if (which == 0) {
+        if (s->comm.sum(s->d_pack.p, count, s->stream)) return PPO_BA_ERR_COMM;
+        hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 1);
+      } else if (which == 1) {
+        if (s->comm.sum_to_root(s->d_pack.p, count, s->stream)) return PPO_BA_ERR_COMM;
+        if (s->comm.rank == 0) hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 1);
+        if (s->comm.bcast_from_root(s->d_xr.p, n * sizeof(double), s->stream)) return PPO_BA_ERR_COMM;
+        if (s->comm.bcast_from_root(s->d_info.p, sizeof(int), s->stream)) return PPO_BA_ERR_COMM;
+      } else {
+        if (s->comm.sum(s->g.acc, 3, s->stream)) return PPO_BA_ERR_COMM;
+      }
+      HIP_TRY(hipEventRecord(e1, s->stream));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      if (i > 0) total += ms;
+    }
+    *ms_out = (double)total / reps;
+    return PPO_BA_OK;
+  };
+  for (int which = 0; which < 3; ++which) RC_TRY(timed(which, &out[which]));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  s->S_is_zero = false;
+  s->lin_valid = false;
   return PPO_BA_OK;
 }
 

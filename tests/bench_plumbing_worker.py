@@ -62,6 +62,11 @@ class StubLib:
     def ppo_ba_overlap_schedule(self, h, fin, n):
         return 0
 
+    def ppo_ba_time_collectives(self, h, reps, out):
+        for i, v in enumerate((0.09, 0.05, 0.02, 5.9e6)):
+            out[i] = v
+        return 0
+
 
 class StubSolver:
     h = None

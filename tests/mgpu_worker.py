@@ -23,6 +23,7 @@ def main():
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     cfg = sys.argv[1] if len(sys.argv) > 1 else "small"
     stop_rank = int(sys.argv[2]) if len(sys.argv) > 2 else -1  # >= 0: that rank raises its stop flag before the run
+    on_owner = int(sys.argv[3]) if len(sys.argv) > 3 else 0    # options.solve_on_owner: reduce to rank 0 + broadcast of x instead of the all-reduce
     P = synth.make_problem(cfg, seed=1)
     lib = B.load_library()
     ident = np.zeros(128, np.uint8)
@@ -31,7 +32,7 @@ def main():
     t = torch.from_numpy(ident).cuda()
     dist.broadcast(t, 0)
     ident = t.cpu().numpy()
-    opt = B.default_options(device_id=local, rank=rank, world_size=world)
+    opt = B.default_options(device_id=local, rank=rank, world_size=world, solve_on_owner=on_owner)
     for i in range(128):
         opt.comm_id[i] = int(ident[i])
     s = B.hip_backend().create(P, opt)

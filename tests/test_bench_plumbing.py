@@ -31,6 +31,9 @@ def test_two_rank_bench_plumbing(tmp_path, cfg, scaling):
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 1 and j["scaling"] == scaling and j["higher_is_better"] is True
     assert j["unit"] == "LM iters/s" and j["dtype"] == "f64" and j["vs_baseline"] is None and "cpu_baseline" not in j
     assert j["config"]["parallelism"] == "landmark-range x2" and "roofline" in j
+    mg = j["config"]["multi_gpu"]  # the exchange steps of one solve attempt, and the other exchange variant beside the one in use
+    assert mg["exchange_in_use"] == "allreduce" and mg["other_exchange"]["exchange"] == "reduce+bcast" and mg["other_exchange"]["lm_iters_per_s"] > 0
+    assert set(mg["us_per_solve_attempt"]) == {"sb_allreduce_incl_pack_unpack", "sb_reduce_to_rank0_plus_bcast_x", "scalar_allreduce", "dense_solve_every_rank"}
     # the stub's rank 1 takes 30 ms per step, rank 0 10 ms: the reported time is the MAX over the ranks (both wait at the barrier)
     assert j["ms_per_step"] >= 29.0, j["ms_per_step"]
     assert abs(j["value"] - 15 * 4 / (j["ms_per_step"] * 4e-3)) <= 1e-6 * j["value"]  # whole-job LM iterations / that time

@@ -32,11 +32,12 @@ def _launch(n, *args):
     return json.loads(line[5:])
 
 
+@pytest.mark.parametrize("on_owner", [0, 1])
 @pytest.mark.parametrize("cfg", ["small", "cfg3"])
-def test_two_rccl_ranks_give_the_single_rank_answer(cfg):
+def test_two_rccl_ranks_give_the_single_rank_answer(cfg, on_owner):
     if _gpus() < 2:
         pytest.skip("needs two GPUs")
-    out = _launch(2, cfg)
+    out = _launch(2, cfg, "-1", str(on_owner))
     r0 = out[0]
     assert all(o["rc"] == 0 for o in out)
     assert all(o["iters"] == r0["iters"] for o in out)  # every rank walks the same schedule

@@ -621,7 +621,8 @@ def test_default_mode_stays_near_the_deterministic_result(oracle, hip):
     assert n_beyond_bar <= 8 and n_sched <= 4, (n_beyond_bar, n_sched)
 
 
-def test_sharded_code_path_with_a_one_rank_rccl_communicator(hip_hooks, monkeypatch):
+@pytest.mark.parametrize("on_owner", [0, 1])
+def test_sharded_code_path_with_a_one_rank_rccl_communicator(hip_hooks, monkeypatch, on_owner):
     """PPO_BA_COMM_SELFTEST=1 makes the library open librccl.so, build a ONE-rank communicator and take every branch of the
     N > 1 path (all-reduce of the pose blocks after each linearisation, of (S, b) per solve attempt, of the chi2 / scale /
     max-diagonal scalars, the landmark gather in read) on a single GPU.  Multi-GPU boxes are not available to these tests;
@@ -632,8 +633,13 @@ def test_sharded_code_path_with_a_one_rank_rccl_communicator(hip_hooks, monkeypa
     ref_stats, ref = s.run(), s.read()
     s.close()
     monkeypatch.setenv("PPO_BA_COMM_SELFTEST", "1")
-    s = hip.create(P, B.default_options())
+    # on_owner = 1: options.solve_on_owner -- ncclReduce of (S, b) to rank 0 + ncclBroadcast of x and the flag instead of the all-reduce
+    s = hip.create(P, B.default_options(solve_on_owner=on_owner))
     st, r = s.run(), s.read()
+    out = np.zeros(4)
+    hip.lib.ppo_ba_time_collectives.argtypes = [C.c_void_p, C.c_int, B.c_dp]
+    assert hip.lib.ppo_ba_time_collectives(s.h, 5, out.ctypes.data_as(B.c_dp)) == 0
+    assert out[0] > 0 and out[1] > 0 and out[2] > 0 and out[3] > 8 * 4096, out  # the three exchange steps, timed alone through RCCL
     s.close()
     assert [(i["trials"], i["accepted"]) for i in st["iters"]] == [(i["trials"], i["accepted"]) for i in ref_stats["iters"]]
     assert abs(st["iters"][-1]["chi2_after"] - ref_stats["iters"][-1]["chi2_after"]) <= 1e-7 * ref_stats["iters"][-1]["chi2_after"]
@@ -673,18 +679,20 @@ def _run_sharded_in_process(hip, P, world, key, **opt):
     return out
 
 
+@pytest.mark.parametrize("on_owner", [0, 1])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("cfg,kw", [("small", dict(seed=1)), ("small", dict(seed=2, stereo_frac=0.3)),
                                     (dict(n_kf=12, n_points=400, n_planes=6, n_cuboids=0), dict(seed=7))])
-def test_landmark_sharding_gives_the_single_rank_answer(hip_hooks, cfg, kw, world):
+def test_landmark_sharding_gives_the_single_rank_answer(hip_hooks, cfg, kw, world, on_owner):
     """The N > 1 path for real: landmark ranges per rank, partial reduced systems summed by a collective, every rank
-    factoring redundantly, landmarks gathered in read -- against the same graph solved by one rank."""
+    factoring redundantly (on_owner = 0) or rank 0 alone factoring and broadcasting the solution (options.solve_on_owner = 1),
+    landmarks gathered in read -- against the same graph solved by one rank."""
     hip = hip_hooks
     P = synth.make_problem(cfg, **kw)
     s = hip.create(P, B.default_options())
     st1, r1 = s.run(), s.read()
     s.close()
-    res = _run_sharded_in_process(hip, P, world, key=1000 + world * 17 + kw["seed"])
+    res = _run_sharded_in_process(hip, P, world, key=1000 + world * 17 + kw["seed"] + 500 * on_owner, solve_on_owner=on_owner)
     for st, r in res:
         assert [(i["trials"], i["accepted"], i["result"]) for i in st["iters"]] == [(i["trials"], i["accepted"], i["result"]) for i in st1["iters"]]
         for a, b in zip(st["iters"], st1["iters"]):
