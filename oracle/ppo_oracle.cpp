@@ -3,15 +3,16 @@
 // Nothing in the product path (libppo_ba.so, the host adapter) links, includes or calls this file.
 //
 // Parity status: the reference cannot be compiled here (Eigen3/OpenCV/PCL/Pangolin absent) and ships no tests for this path,
-// so this restatement is pinned by golden vectors produced by the reference's OWN prebuilt Thirdparty/g2o/lib/libg2o.so
-//   (a) per function: SE3 exp, pose oplus, Huber, projections, the unary OnlyPose edges, and the two binary reprojection edges
-//       through computeError / linearizeOplus / numeric linearizeOplusXi,Xj / constructQuadraticForm -- residual, Jacobians and
-//       H / b blocks agree BIT FOR BIT (oracle/pin_g2o_prebuilt.py -> tests/golden/g2o_prebuilt.json);
-//   (b) as a whole: the library's own SparseOptimizer + OptimizationAlgorithmLevenberg run the two-pass protocol on six
-//       points-only windows and this file follows them with a bit-identical lambda sequence through pass 1
-//       (oracle/pin_g2o_lm.py -> tests/golden/g2o_prebuilt_lm.json);
-// and by analytic known-answer tests.  The custom plane / cuboid edges live only in lib/libORB_SLAM2.so, which does not load
-// here, and BlockSolverX / Eigen::LDLT are header templates: for those parts parity is UNPINNED.
+// so this restatement is pinned by golden vectors produced by the reference's OWN prebuilt binaries, run in the build container:
+//   Thirdparty/g2o/lib/libg2o.so  (oracle/pin_g2o_prebuilt.py, pin_g2o_lm.py, pin_g2o_pose.py)
+//     SE3 exp, pose oplus, Huber, projections, the unary OnlyPose edges, the two binary reprojection edges through computeError /
+//     linearizeOplus / numeric linearizeOplusXi,Xj / constructQuadraticForm -- BIT FOR BIT; the LM loop and the PoseOptimization protocol;
+//   lib/libORB_SLAM2.so  (oracle/orbslam_loader.py + pin_orbslam_prebuilt.py, pin_orbslam_lm.py; round 4)
+//     Plane3D / VertexPlane, VertexCuboid, exptwist_norollpitch and all eight custom edge classes (residual, chi2, numeric Jacobians,
+//     quadratic form), and the complete 5 + classify + 10 optimisation of eleven windows with the reference's own BlockSolverX (Schur
+//     complement) + LinearSolverDense (Eigen LDLT): same trial schedule and outlier levels, lambda bit-identical through pass 1 and the
+//     first reduced solve to 6e-13 on points-only windows (tests/test_orbslam_pin.py, tests/test_orbslam_lm_pin.py);
+// and by analytic known-answer tests.  Nothing on the path is unpinned (oracle/README.md).
 //
 // What is restated, in the reference's own order (paths relative to the reference checkout, G2O =
 // Thirdparty/g2o/g2o):
