@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (pose-only, concurrent windows, phase times): "
                     "used for the rocprofv3 runs so that the kernel statistics hold the headline workload only")
     ap.add_argument("--lin-reps", type=int, default=200)
+    ap.add_argument("--lm-control", type=int, default=0, help="0 (default): the LM decisions by a kernel behind every trial (options.lm_control = PPO_LM_DEVICE), "
+                    "1: by the host after a round trip per trial.  Sharded runs always take the host path")
     ap.add_argument("--solve-on-owner", type=int, default=0, help="N > 1: 1 = reduce (S, b) to rank 0, solve there, broadcast x (options.solve_on_owner)")
     a = ap.parse_args()
 
@@ -194,7 +196,7 @@ def main():
     P = synth.make_problem(a.config, seed=a.seed, with_corners=a.with_corners, world_size=world)  # (cfg5w: 50 000 points per rank)
     weak = isinstance(synth.CONFIGS.get(a.config), dict) and synth.CONFIGS[a.config].get("points_per_rank", False)
     sizes = P.sizes()
-    opt = B.default_options(device_id=local_rank, rank=rank, world_size=world, solver=a.solver, solve_on_owner=a.solve_on_owner if world > 1 else 0)
+    opt = B.default_options(device_id=local_rank, rank=rank, world_size=world, solver=a.solver, solve_on_owner=a.solve_on_owner if world > 1 else 0, lm_control=a.lm_control)
     if world > 1:
         ident = np.zeros(128, np.uint8)
         if rank == 0:
@@ -233,6 +235,22 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # secondary figure: the same workload with the OTHER setting of options.lm_control (single rank; outside the timed region)
+    lm_control = {"in_use": "host" if (a.lm_control or world > 1 or a.solver == 1) else "device"}
+    if world == 1 and not a.no_extras:
+        so_ = B.hip_backend().create(P, B.default_options(device_id=local_rank, solver=a.solver, lm_control=0 if a.lm_control else 1))
+        for _ in range(2):
+            so_.reset(); so_.run()
+        torch.cuda.synchronize()
+        t_o = time.perf_counter()
+        n_o = 0
+        for _ in range(max(5, a.steps // 2)):
+            so_.reset()
+            n_o += so_.run()["n_iters"]
+        dt_o = time.perf_counter() - t_o
+        so_.close()
+        lm_control["other"] = {"lm_control": "device" if a.lm_control else "host", "lm_iters_per_s": n_o / dt_o}
 
     # roofline of the Jacobian/assembly kernel -- k_linearize_all, the ONE fused launch that evaluates residuals and
     # Jacobians of every edge class and writes the block-sparse system (SURVEY.md 8(d) "linearise + assemble") -- timed
@@ -360,6 +378,40 @@ def main():
         analytic = {"lm_iters_per_s": n_it / (t_a1 - t_a0), "k_linearize_all_us": 1e3 * ka_ms.value,
                     "note": "opt-in mode; parity against the numeric oracle: tests/test_parity_gpu.py::test_analytic_jacobians_*"}
         sa.close()
+    # secondary figure, never `value`: the reference's REAL operating point (ICL-sized windows, 157.48 ms per call
+    # published for its CPU path) -- what one call costs all inclusive, a fresh handle per call as in a running SLAM process
+    icl = {}
+    if extras:
+        for label, cfg in (("15kf_800pt_4pl_2cub", dict(n_kf=15, n_points=800, n_planes=4, n_cuboids=2)),
+                           ("30kf_2000pt_10pl_3cub", dict(n_kf=30, n_points=2000, n_planes=10, n_cuboids=3))):
+            Pw = synth.make_problem(cfg, seed=1)
+            ow = B.default_options(device_id=local_rank, solver=a.solver)
+            rows = []
+            for i in range(13):
+                t_0 = time.perf_counter()
+                sw = B.hip_backend().create(Pw, ow)
+                t_1 = time.perf_counter()
+                stw = sw.run()
+                t_2 = time.perf_counter()
+                sw.read()
+                t_3 = time.perf_counter()
+                sw.close()
+                if i >= 3:
+                    rows.append((t_1 - t_0, t_2 - t_1, t_3 - t_2, t_3 - t_0))
+            med = [1e3 * sorted(r[k] for r in rows)[len(rows) // 2] for k in range(4)]
+            icl[label] = {"create_ms": med[0], "run_ms": med[1], "read_ms": med[2], "call_ms": med[3], "lm_iters": stw["n_iters"],
+                          "us_per_lm_iter": 1e3 * med[1] / max(stw["n_iters"], 1)}
+            # ... and repeated runs on ONE handle (reset + run), with the LM decisions on the device (default) and on the host
+            for key, lmc in (("run_ms_repeated_lm_on_device", 0), ("run_ms_repeated_lm_on_host", 1)):
+                sw = B.hip_backend().create(Pw, B.default_options(device_id=local_rank, solver=a.solver, lm_control=lmc))
+                for _ in range(3):
+                    sw.reset(); sw.run()
+                t_0 = time.perf_counter()
+                for _ in range(20):
+                    sw.reset(); sw.run()
+                icl[label][key] = 1e3 * (time.perf_counter() - t_0) / 20
+                sw.close()
+        icl["note"] = "median of 10 calls, a fresh handle per call (create + run + read); the reference publishes 157.48 ms per call for its CPU path on ICL-NUIM"
     # where the device time of one 5+10 call goes (ppo_ba_stats.ms_*, HIP events on the stream, outside the timed region)
     phases = {}
     if extras:
@@ -399,7 +451,7 @@ def main():
                 "factor_solve_ms": fac_ms.value, "schur_reduction": reduction, "parallelism": "landmark-range x%d" % world,
                 "first_create_ms_incl_module_load": create_ms, "steady_state_call_ms": call_ms, "kernels": kernels,
                 "pose_only": pose_only, "device_ms_per_phase_of_one_call": phases,
-                "two_windows_concurrently": concurrent, "analytic_jacobians": analytic, "multi_gpu": multi,
+                "two_windows_concurrently": concurrent, "analytic_jacobians": analytic, "multi_gpu": multi, "icl_sized_windows": icl, "lm_control": lm_control,
             },
             "roofline": {"bound": "hbm", "kernel": "k_linearize_all", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -165,6 +165,8 @@ typedef struct ppo_ba_problem {
   const double* cub3d_huber;   /* [n]     thHuberSE3 itself (not its square root), Optimizer.cc:1793 */
 } ppo_ba_problem;
 
+#define PPO_LM_DEVICE 0
+#define PPO_LM_HOST 1
 typedef struct ppo_ba_options {
   int32_t abi_version;      /* PPO_BA_ABI_VERSION */
   int32_t iters_pass1;      /* 5   Optimizer.cc:2728 */
@@ -200,7 +202,11 @@ typedef struct ppo_ba_options {
   int32_t solve_on_owner;   /* multi-GPU only.  0 (default): the packed (S, b) is ALL-REDUCED and every rank factors it redundantly (no broadcast:
                              * BASELINE.json north_star).  1: (S, b) is REDUCED to rank 0 (half the ring traffic), rank 0 alone factors and solves,
                              * x and the factorisation flag are broadcast.  Same results on every rank either way. */
-  int32_t pad_;
+  int32_t lm_control;       /* where the Levenberg-Marquardt decisions (gain ratio, accept / reject, lambda, nu, the nBad stop;
+                             * optimization_algorithm_levenberg.cpp:102-163) are taken.  PPO_LM_DEVICE (0, default): by a kernel queued behind
+                             * every trial, the host queues the next trial without waiting (single rank, native solver, deterministic = 0,
+                             * verbose = 0; every other configuration takes the host path whatever this says).  PPO_LM_HOST (1): by the host
+                             * after a round trip per trial.  Same arithmetic, same results.  Anything else -> PPO_BA_ERR_ARG */
 } ppo_ba_options;
 
 /* one record per LM iteration (one OptimizationAlgorithmLevenberg::solve call) */

@@ -52,6 +52,7 @@ void hc_corner(const double* pose_qt, const double* c10, const double* K, const 
   const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};
   corner_residual(T, c, K, meas, e);
 }
+double hc_cube(double x) { return cube_rounded_once(x); }
 void hc_cub3d(const double* pose_qt, const double* c10, const double* meas10, double* e) {
   const Pose T{Quat{pose_qt[0], pose_qt[1], pose_qt[2], pose_qt[3]}, Vec3{pose_qt[4], pose_qt[5], pose_qt[6]}};
   const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};

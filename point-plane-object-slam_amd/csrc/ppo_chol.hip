@@ -558,9 +558,10 @@ __device__ __forceinline__ void inv_block_wg(const double* __restrict__ A, int l
 // later launches of an overlapped one; as ONE kernel the pair code's registers (240 against 182) and arguments cost every launch 0.4 us.
 template <bool OV>
 __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info,
-                                                            int inplace_rhs, double* __restrict__ inv, StepOverlap ov) {
+                                                            int inplace_rhs, double* __restrict__ inv, StepOverlap ov, LmGate gate) {
   constexpr int NT = kStepThreads, NI = 2048 / NT;
   __shared__ StepLdsU lds;
+  if (lm_gate_dead(gate)) return;
   double (*const sL)[LP] = lds.a.sL;
   double (*const sB)[LP] = lds.a.sB;
   double (*const sT)[SB][17] = lds.a.sT;
@@ -842,9 +843,10 @@ __device__ __forceinline__ void store_sc1(double* p, double v) { __hip_atomic_st
 constexpr int kBackThreads = 320;  // four compute waves + the polling wave
 constexpr int kRing = 32;          // blocks of x the polling wave may run ahead of the slowest compute wave
 __global__ __launch_bounds__(kBackThreads) void chol_back_all(const double* __restrict__ A, int ld, const double* __restrict__ y, double* x, int* __restrict__ info, int* flags,
-                                                              int nflags, const double* __restrict__ inv) {
+                                                              int nflags, const double* __restrict__ inv, LmGate gate) {
   __shared__ double sL[NB][LP];
   __shared__ double sV[NB];
+  if (lm_gate_dead(gate)) return;
   __shared__ double sXr[kRing][NB];  // x_i as the polling wave saw them, slot i % kRing
   __shared__ int s_seen;             // smallest i with x_i in the ring
   __shared__ int s_prog[4];          // smallest i compute wave w has finished reading
@@ -1074,7 +1076,7 @@ size_t inv_offset(int ld) {
 
 // One launch per panel + one for the backward substitution.  (The one-launch factorisation, ppo_chol_fwd.inc, exists only in the
 // test-hooks build: PPO_BA_CHOL_ONELAUNCH=1 selects it there; DESIGN.md 4.1 has the measurement.)
-int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s, const CholOverlap* ov = nullptr) {
+int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s, const CholOverlap* ov = nullptr, LmGate gate = LmGate{nullptr, 0}) {
   const int nb = ld / NB;
   double* y = ov ? ov->ctx.bs : ws;  // [ld] forward-substituted right-hand side (overlapped reduction: in place, the pair workgroups add to it)
   int* flags = nullptr;
@@ -1116,20 +1118,21 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
       if (PPO_DEV_PROBE("PPO_BA_OVERLAP_EMPTY")) o.chunk_hi = o.chunk_lo;  // timing experiment (WRONG results): the pair workgroups find nothing to do
 #endif
       const dim3 grid(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0) + o.npair_wg + (k > 0 && inv ? 1 : 0));
-      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
-      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
+      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o, gate);
+      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o, gate);
     }
   }
-  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(kBackThreads), 0, s, (const double*)A, ld, (const double*)y, x, info, flags, nflags, (const double*)inv);
+  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(kBackThreads), 0, s, (const double*)A, ld, (const double*)y, x, info, flags, nflags, (const double*)inv, gate);
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
 }
 
 }  // namespace
 
 // A: ld x ld column-major with ld a multiple of 64 (chol_padded_ld), lower triangle valid, pad diagonal = 1.
-int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t stream) {
+int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t stream, LmGate gate) {
   if (ld % NB != 0) return PPO_BA_ERR_ARG;
   if (ld == 0) return PPO_BA_OK;
+  if (gate.epoch_word) return enqueue_all(A, ld, b, x, info, ws, stream, nullptr, gate);
   // Plain launches by default: with ~16 us per panel kernel the host stays ahead of the device and a hipGraph replay only
   // adds its entry/exit boundaries (measured 1826 vs 1834 LM iterations/s); PPO_BA_CHOL_GRAPH=1 selects the captured graph
   // (it paid when the solve was 56 short launches).
@@ -1159,7 +1162,7 @@ int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, 
 int chol_factor_solve_overlapped(double* A, int ld, double* x, int* info, double* ws, const CholOverlap& ov, hipStream_t stream) {
   if (ld % NB != 0 || kStepThreads != 512 || !ov.fin || !ov.cb_start) return PPO_BA_ERR_ARG;
   if (ld == 0) return PPO_BA_OK;
-  return enqueue_all(A, ld, ov.ctx.bs, x, info, ws, stream, &ov);
+  return enqueue_all(A, ld, ov.ctx.bs, x, info, ws, stream, &ov, ov.gate);
 }
 
 // fin[k], k = 0 .. nb: column blocks of S that are final when launch k starts (fin[nb] = nb).  The reduction ahead of the factorisation

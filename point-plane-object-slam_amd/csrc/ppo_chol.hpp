@@ -9,7 +9,8 @@
 namespace ppo {
 // A: ld x ld column-major (ld = chol_padded_ld(n), pad diagonal = 1), lower triangle valid on entry, overwritten by L.  b: right-hand side (left intact;
 // must not alias x), x: solution, workspace: chol_workspace_doubles(n) doubles.  *info (device int) = 0 when A is positive definite, k > 0 when the leading minor of order k is not.
-int chol_factor_solve(double* A, int n, const double* b, double* x, int* info, double* workspace, hipStream_t stream);
+// gate: LM control on the device -- the launches do nothing unless *gate.epoch_word == gate.expect (NULL: always live).
+int chol_factor_solve(double* A, int n, const double* b, double* x, int* info, double* workspace, hipStream_t stream, LmGate gate = LmGate{nullptr, 0});
 // Overlapped reduction (ppo_chol.hip, StepOverlap): only the pair chunks of the first fin[0] 64-column blocks of A have been reduced when this is
 // called; the launches of the factorisation carry the remaining chunks (ordered by column block: cb_start[c] = first chunk of block c, host
 // array of ld / 64 + 1 entries) as extra workgroups that add to A and to the right-hand side ctx.bs, which is solved IN PLACE.
@@ -19,6 +20,7 @@ struct CholOverlap {
   PairChunks pc;
   const int32_t* cb_start;
   const int* fin;
+  LmGate gate;
 };
 int chol_factor_solve_overlapped(double* A, int n, double* x, int* info, double* workspace, const CholOverlap& ov, hipStream_t stream);
 void chol_overlap_schedule(int nb, const int32_t* cb_start, int first_blocks, double share0, double share, int* fin);

@@ -86,6 +86,26 @@ struct State {       // one copy of all estimates
   double* cub;       // [Nc][10] qx qy qz qw tx ty tz sx sy sz
 };
 
+// ---- LM control on the device (ppo_solver.hip, optimize_pipelined; levenberg.cpp:61-164) ----------------------------------------------
+// The damping, the gain-ratio test, nu, the nBad count and the iteration counters live in ONE device record.  k_decide, queued behind the
+// evaluation of every trial state, takes the decision the host used to take after a round trip through mapped memory; the host queues the
+// next trial BEFORE it knows the outcome, on the assumption "accepted, the pass goes on".  Whenever that assumption fails (a rejected trial,
+// a terminated pass, a solver error) k_decide bumps `epoch`: every kernel of a trial carries the epoch it was queued under (Graph::epoch,
+// LmGate) and returns at once when the record has moved on, so the launches queued on the wrong assumption change nothing.
+struct LmCtl {
+  double lambda;    // damping of the NEXT trial (_currentLambda)
+  double chi_cur;   // robust chi2 of the current estimate (currentChi)
+  double ini_chi;   // ... at the start of the running iteration (iniChi)
+  double ni;        // _ni
+  double cubpl;     // constant chi2 term of the cuboid-plane edges
+  double lm_upper, lm_lower;
+  int nbad, qmax, iter, epoch, max_trials, pad_;
+};
+// what k_decide records per trial (doubles; a slot of the device ring, copied to the mapped host ring at the end of a batch of trials)
+enum { REC_CHI2 = 0, REC_SCALE, REC_INFO, REC_LAMBDA, REC_RHO, REC_ACCEPTED, REC_CODE, REC_CHI_BEFORE, REC_CHI_AFTER, REC_TRIALS, REC_ITER,
+       REC_DEAD, REC_LAMBDA_NEXT, REC_NI, REC_NBAD, REC_INI_CHI, REC_EPOCH, REC_QMAX, REC_SEQ = 31, REC_DOUBLES = 32 };
+enum { LM_RETRY = 0, LM_ITER_DONE = 1, LM_TERMINATE = 2, LM_SOLVER_ERROR = 3 };
+
 struct Graph {
   int n_poses, n_points, n_planes, n_cuboids, n_pose_free, n_red, n_lm, n_slots;
   int ld;  // leading dimension of S (n_red rounded up to the Cholesky panel width; pad rows/cols are identity)
@@ -160,6 +180,8 @@ struct Graph {
   int det;           // options.deterministic: every cross-wave accumulation is an INTEGER atomic on a 2^-24 fixed-point image of the
                      // addend (exact, hence independent of the order the atomics arrive in); k_fix_to_double turns the ranges back into doubles
   const double* hb_diag;  // sharded runs, first iteration: diagonal of Hpp summed over ranks (NULL: read it from HB)
+  const LmCtl* ctl;       // LM control on the device: the kernels of a trial read lambda here and do nothing unless ctl->epoch == epoch
+  int epoch;              // (NULL: the host passes lambda and every launch is live)
 #ifdef PPO_BA_TEST_HOOKS
   int dbg;                     // development aid (PPO_BA_LIN_DBG): bit 0 numeric classes skip their scatter, bit 1 plain stores instead of atomics
   unsigned long long* stamps;  // development aid (PPO_BA_LIN_STAMPS): [grid][8] wall-clock stamps of the fused linearisation's workgroups
@@ -170,6 +192,9 @@ struct Graph {
 #else
 #define LIN_STAMP(g_, k_) ((void)0)
 #endif
+
+__device__ __forceinline__ bool lm_dead(const Graph& g) { return g.ctl != nullptr && g.ctl->epoch != g.epoch; }
+__device__ __forceinline__ double lm_lambda(const Graph& g, double host_lambda) { return g.ctl != nullptr ? g.ctl->lambda : host_lambda; }
 
 __device__ __forceinline__ int packed_lower(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
 
@@ -1351,6 +1376,7 @@ struct LinPlan {
 template <bool USE_LDS, bool WITH_CORNERS, bool ANALYTIC = false>
 __global__ __launch_bounds__(256, PPO_LIN_WAVES) PPO_LIN_OCC void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
   extern __shared__ double smem[];
+  if (lm_dead(g)) return;
   int b = blockIdx.x, part = -1;
 #pragma unroll
   for (int oi = 0; oi < LIN_PARTS; ++oi) {
@@ -1390,6 +1416,7 @@ __global__ __launch_bounds__(256, PPO_LIN_WAVES) PPO_LIN_OCC void k_linearize_al
 // residual-only pass of a trial state in ONE launch: numeric edge classes (thread per edge) | points (thread per point)
 __global__ __launch_bounds__(256) void k_chi2_all(Graph g, State st, NumericPlan np, int nb_num, int nb_pts) {
   __shared__ double s_red[4];
+  if (lm_dead(g)) return;
   int b = blockIdx.x;
   if (b >= nb_num) { chi2_points_body(g, st, b - nb_num, nb_pts, s_red); return; }
   if (b < np.nb_plane) { chi2_numeric_body<PlaneModel>(g, st, g.n_pl, false, b); return; }
@@ -1445,6 +1472,114 @@ __global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restri
 
 // the partial sums into acc[0..1] ahead of a reader other than k_publish (fixed-point conversion, sum over ranks)
 __global__ __launch_bounds__(64) void k_fold_acc(double* acc, int det) { fold_acc_parts(acc, det); }
+
+// ---- LM control on the device: the decision behind every trial (OptimizationAlgorithmLevenberg::solve, levenberg.cpp:102-163) -------------
+__global__ void k_ctl_set(LmCtl* ctl, LmCtl v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *ctl = v;
+}
+// One wave.  Reads (chi2, scale) of the trial state and the factorisation flag, takes the accept / reject decision, updates the control
+// record and writes the trial's numbers into its slot of the DEVICE ring of trial records.  `epoch`: the epoch the trial was queued
+// under (a trial that did not run leaves a record that says so).  n_publish > 0 (the last trial of a batch): the records of the last
+// n_publish trials go to the mapped host ring, then the sequence number the host waits for -- ONE hand-over per batch: a kernel that
+// writes host memory holds its successor back until the write has crossed the bus (6 - 10 us, measured as idle queue in front of
+// k_reduce_stage1 with a hand-over per trial; tools/small_window_gap.sh).
+struct DecidePlan {
+  double* rec;    // device ring, kRecSlots x REC_DOUBLES
+  double* host;   // mapped host ring of the same shape, and behind it the sequence word
+  unsigned long long seq;
+  int n_publish;
+};
+constexpr int kRecSlots = 16;
+__global__ __launch_bounds__(64) void k_decide(double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, DecidePlan dp) {
+  const int t = threadIdx.x;
+  double* rec = dp.rec + (dp.seq % kRecSlots) * REC_DOUBLES;
+  const bool dead = ctl->epoch != epoch;
+  if (!dead) fold_acc_parts(acc, 0);
+  __syncthreads();
+  if (t == 0 && dead) {
+    rec[REC_DEAD] = 1.0;
+    rec[REC_SEQ] = (double)dp.seq;
+  }
+  if (t == 0 && !dead) {
+    LmCtl c = *ctl;
+    const int info = *info_p;
+    const double lambda = c.lambda, scale_raw = acc[ACC_SCALE];
+    double currentChi = c.chi_cur;
+    double tempChi = acc[ACC_CHI2] + c.cubpl;
+    const double chi_trial = tempChi;
+    if (info != 0 || !isfinite(scale_raw)) tempChi = 1.7976931348623157e308;  // solver not ok (levenberg.cpp:126-127)
+    double rho = currentChi - tempChi;
+    double scale = scale_raw;
+    if (info != 0) scale = 0;
+    scale += 1e-3;
+    rho /= scale;
+    const bool accepted = rho > 0 && isfinite(tempChi) && info == 0;
+    if (accepted) {
+      double alpha = 1. - cube_rounded_once(2 * rho - 1);
+      alpha = (c.lm_upper < alpha) ? c.lm_upper : alpha;                     // std::min(alpha, upper)
+      const double scaleFactor = (c.lm_lower < alpha) ? alpha : c.lm_lower;  // std::max(lower, alpha)
+      c.lambda *= scaleFactor;
+      c.ni = 2;
+      currentChi = tempChi;
+    } else {
+      c.lambda *= c.ni;
+      c.ni *= 2;
+    }
+    c.qmax++;
+    const int trials = c.qmax;
+    const double chi_before = c.ini_chi;
+    int code;
+    if (info >= (1 << 30)) {
+      code = LM_SOLVER_ERROR;  // the hand-off of the backward substitution timed out: not a "not positive" matrix
+    } else if (rho < 0 && c.qmax < c.max_trials) {
+      code = LM_RETRY;
+    } else {  // the iteration is over (levenberg.cpp:150-163)
+      if (c.qmax == c.max_trials || rho == 0) {
+        code = LM_TERMINATE;
+      } else {
+        if ((c.ini_chi - currentChi) * 1e3 < c.ini_chi) c.nbad++;
+        else c.nbad = 0;
+        code = c.nbad >= 3 ? LM_TERMINATE : LM_ITER_DONE;
+      }
+      c.iter++;
+      c.qmax = 0;
+      c.ini_chi = currentChi;
+    }
+    c.chi_cur = currentChi;
+    if (!(accepted && code == LM_ITER_DONE)) c.epoch++;  // not what the host assumed when it queued the next trials: those launches are dead
+    *ctl = c;
+    rec[REC_CHI2] = chi_trial;
+    rec[REC_SCALE] = scale_raw;
+    rec[REC_INFO] = (double)info;
+    rec[REC_LAMBDA] = lambda;
+    rec[REC_RHO] = rho;
+    rec[REC_ACCEPTED] = accepted ? 1.0 : 0.0;
+    rec[REC_CODE] = (double)code;
+    rec[REC_CHI_BEFORE] = chi_before;
+    rec[REC_CHI_AFTER] = currentChi;
+    rec[REC_TRIALS] = (double)trials;
+    rec[REC_ITER] = (double)c.iter;
+    rec[REC_DEAD] = 0.0;
+    rec[REC_LAMBDA_NEXT] = c.lambda;
+    rec[REC_NI] = c.ni;
+    rec[REC_NBAD] = (double)c.nbad;
+    rec[REC_INI_CHI] = c.ini_chi;
+    rec[REC_EPOCH] = (double)c.epoch;
+    rec[REC_QMAX] = (double)c.qmax;
+    rec[REC_SEQ] = (double)dp.seq;
+  }
+  if (dp.n_publish <= 0) return;
+  __threadfence();
+  __syncthreads();
+  for (int i = t; i < dp.n_publish * REC_DOUBLES; i += 64) {
+    const unsigned long long s = dp.seq - (unsigned long long)(dp.n_publish - 1) + (unsigned long long)(i / REC_DOUBLES);
+    const int at = (int)(s % kRecSlots) * REC_DOUBLES + i % REC_DOUBLES;
+    dp.host[at] = __hip_atomic_load(dp.rec + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dp.host + kRecSlots * REC_DOUBLES), dp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // reset of a solver in ONE launch: up to eight word-granular copies from the pristine device copies made at create, and the
 // zero ranges.  (Seven hipMemcpyAsync / hipMemsetAsync calls took the runtime's blit path: ~15 us of queue idle each.)
@@ -1819,6 +1954,8 @@ __device__ __forceinline__ PairCtx pair_ctx(const Graph& g, double lambda = 0.0)
 template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void k_reduce_stage1(Graph g, double lambda, ReducePlan rp, ZeroPlan zother, PairChunks pc) {
   __shared__ double s_buf[FUSED ? 4 : 1][FUSED ? 21 : 2][65];  // (FUSED: pair workgroups; the cuboid workgroups keep their inverse in its first 81 entries)
+  if (lm_dead(g)) return;
+  lambda = lm_lambda(g, lambda);
   int b = blockIdx.x;
   if (b == 0 && threadIdx.x < 2) g.acc[threadIdx.x] = 0.0;  // chi2 and scale of the trial this reduction leads to
   // (acc[ACC_DETBAD] is NOT cleared here: assemble_body of this very launch may raise it -- k_publish clears it once it is copied out)
@@ -1848,6 +1985,7 @@ __global__ __launch_bounds__(256, 2) void k_reduce_stage1(Graph g, double lambda
 }
 __global__ __launch_bounds__(256) void k_reduce_stage3(Graph g, PairChunks pc, ReducePlan rp) {
   __shared__ double s_buf[4][21][65];
+  if (lm_dead(g)) return;
   const int b = blockIdx.x;
   // the few cuboid workgroups first (a chain of dependent gathers: at the end of the grid they were a 5 us tail behind the pair
   // workgroups); their count is a multiple of 8, so the pair workgroups keep their workgroup -> XCD phase
@@ -2116,6 +2254,8 @@ __global__ __launch_bounds__(256) void k_update_all(Graph g, State cur, State tr
   extern __shared__ double smem[];
   __shared__ double s_red[4];
   __shared__ double sp[54], st[9], sy[9], sx[9];
+  if (lm_dead(g)) return;
+  lambda = lm_lambda(g, lambda);
   int b = blockIdx.x;
   if (b < up.nb_red) { update_reduced_body(g, cur, trial, lambda, b, sp, st, sy, sx); return; }
   b -= up.nb_red;

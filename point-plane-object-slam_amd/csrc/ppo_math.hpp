@@ -40,6 +40,17 @@ struct Cub {
   Vec3 s;  // half extents
 };
 
+// x^3 rounded once (two-term products by FMA): the nearest double to the exact cube.  The reference takes the Levenberg-Marquardt decision
+// on the host with alpha = 1 - pow(2 rho - 1, 3) (levenberg.cpp:131); glibc's pow is within 0.52 ulp of the exact value, i.e. equal to this
+// except for about one argument in a thousand, where it is the neighbouring double (tests/test_lm_control.py).  k_decide (ppo_kernels.hpp).
+PPO_HD double cube_rounded_once(double x) {
+  const double c = x * x * x;
+  const double m = c < 0 ? -c : c;
+  if (!(m < 1.0e300) || !(m > 1.0e-280)) return c;  // (overflow / underflow / NaN: nothing to refine)
+  const double hi = x * x, lo = __builtin_fma(x, x, -hi);
+  const double p = hi * x, pe = __builtin_fma(hi, x, -p);
+  return p + (pe + lo * x);
+}
 PPO_HD Vec3 v3(double x, double y, double z) { return Vec3{x, y, z}; }
 PPO_HD Vec3 operator+(Vec3 a, Vec3 b) { return Vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 PPO_HD Vec3 operator-(Vec3 a, Vec3 b) { return Vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }

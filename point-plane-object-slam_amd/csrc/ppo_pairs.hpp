@@ -21,6 +21,13 @@ struct PairChunks {
   int n_chunks;
 };
 
+// LM control on the device (ppo_kernels.hpp, LmCtl): a launch queued under epoch `expect` does nothing once the record has moved on
+struct LmGate {
+  const int* epoch_word;  // &LmCtl::epoch; NULL: not gated
+  int expect;
+};
+__device__ __forceinline__ bool lm_gate_dead(const LmGate& g) { return g.epoch_word != nullptr && *g.epoch_word != g.expect; }
+
 // What the pair reduction reads and writes (a subset of Graph: the fused launches of the dense factorisation carry only this)
 struct PairCtx {
   const double* linR;  // [ld / 6 + 2][12] rotation + fx, fy, bf at the linearisation point, by reduced column / 6

@@ -92,7 +92,8 @@ struct DevCtx {
   double* h_pinned = nullptr;
   double* h_pinned_dev = nullptr;
 };
-constexpr int kPinnedDoubles = 16;
+constexpr int kRingSlots = 16, kRingSlotDoubles = 32;  // records of the device-side LM control (ppo_kernels.hpp: k_decide), behind the accumulator block
+constexpr int kPinnedDoubles = 16 + kRingSlots * kRingSlotDoubles + 8;  // (+ the sequence word of the ring)
 struct CtxPool {
   std::mutex mu;
   std::vector<DevCtx> free_;

@@ -106,6 +106,13 @@ struct ppo_ba_solver {
   DevBuf<int32_t> d_cub_edge_off, d_cub_edges, d_cub_edge_col, d_cp_cub, d_cp_a, d_cp_b, d_cp_cola, d_cp_colb, d_cp_off;  // cuboid elimination plan
   DevBuf<double> d_cub_Linv, d_cub_Dinv, d_xc;
   DevBuf<int> d_info;
+  // LM control on the device (optimize_pipelined): the record, the epoch the host queues launches under, the sequence number of the
+  // last record asked for (slot ring_seq % kRingSlots of the mapped ring behind h_pinned's accumulator block)
+  DevBuf<LmCtl> d_ctl;
+  DevBuf<double> d_rec;  // device ring of trial records (kRecSlots x REC_DOUBLES), copied to the mapped host ring at the end of a batch
+  int epoch = 0;
+  unsigned long long ring_seq = 0;
+  bool pipeline_ok = false;  // this window / these options take the pipelined path
 #ifdef PPO_BA_TEST_HOOKS
   DevBuf<unsigned long long> d_stamps;  // PPO_BA_LIN_STAMPS (development aid)
   std::string stamp_path;
@@ -282,7 +289,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
   s->d_Wpc.release(); s->d_Dinv.release(); s->d_ul.release();
-  s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release();
+  s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release(); s->d_ctl.release(); s->d_rec.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release(); s->d_pc_lm.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cub_edge_col.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release(); s->d_cp_cola.release(); s->d_cp_colb.release(); s->d_cp_off.release();
@@ -590,6 +597,7 @@ int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
 }
 
 // dense SPD solve of S x = bs (LinearSolverDense::solve, linear_solver_dense.h:65-113).  info != 0 <=> not positive.
+LmGate lm_gate(const ppo_ba_solver* s) { return s->g.ctl ? LmGate{&s->g.ctl->epoch, s->g.epoch} : LmGate{nullptr, 0}; }
 int launch_solve_local(ppo_ba_solver* s);
 int launch_solve(ppo_ba_solver* s) {
   if (s->comm.active() && s->opt.solve_on_owner) {
@@ -606,11 +614,11 @@ int launch_solve_local(ppo_ba_solver* s) {
   const int n = g.n_red, ld = g.ld;
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
     if (s->reduce_overlapped) {
-      CholOverlap ov{pair_ctx_host(g), s->pc, s->cb_start.data(), s->fin.data()};
+      CholOverlap ov{pair_ctx_host(g), s->pc, s->cb_start.data(), s->fin.data(), lm_gate(s)};
       RC_TRY(chol_factor_solve_overlapped(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, ov, s->stream));
       s->reduce_overlapped = false;
     } else {
-      RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs_p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream));
+      RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs_p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream, lm_gate(s)));
     }
   } else {
     HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs_p, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -840,9 +848,166 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
   return 0;
 }
 
+// ---- the same pass with the LM control on the device (ppo_kernels.hpp: LmCtl, k_decide) --------------------------------------------------
+// lm_iteration above waits for (chi2, scale, info) of every trial before it queues the next reduction: the queue runs dry for a host round
+// trip per trial (11 us of a 90 us iteration at 30 keyframes), and the hand-over itself -- a kernel that writes host memory -- holds the
+// next kernel back until the write has crossed the bus.  Here k_decide takes the decision behind the evaluation of the trial state, in
+// device memory, and the host queues a BATCH of trials at once, each on the assumption that the ones before it were accepted and ended
+// their iteration -- the common case, and the only one in which the launches it queues are the right ones (they read lambda from the
+// device record; state and linearisation buffers swap on an accepted trial, so their pointers are the assumption).  When the assumption
+// fails the record's epoch moves on and the launches queued under the old one return at once.  The last k_decide of a batch hands the
+// batch's trial records to the host, which then puts its bookkeeping back to the first trial that went differently, queues what that
+// outcome asks for (a retry of the same iteration, a fresh linearisation) and goes on with a batch of one, doubling while the assumption
+// holds.  The stop flag is read between batches.  Single rank, floating-point accumulation, native solver (ppo_ba_create decides).
+constexpr int kLookahead = 5;  // trials per batch at most (<= kRecSlots)
+struct TrialBook {  // the host-side bookkeeping a queued trial changes
+  int cur, lin_buf;
+  bool lin_clean[2], S_is_zero, reduce_overlapped, have_system;
+};
+TrialBook book_of(const ppo_ba_solver* s) { return TrialBook{s->cur, s->lin_buf, {s->lin_clean[0], s->lin_clean[1]}, s->S_is_zero, s->reduce_overlapped, s->have_system}; }
+void restore_book(ppo_ba_solver* s, const TrialBook& b) {
+  s->cur = b.cur;
+  use_lin_buffer(s, b.lin_buf);
+  s->lin_clean[0] = b.lin_clean[0]; s->lin_clean[1] = b.lin_clean[1];
+  s->S_is_zero = b.S_is_zero; s->reduce_overlapped = b.reduce_overlapped; s->have_system = b.have_system;
+}
+// reduction, solve, update, evaluation of the trial state and the decision: one trial, nothing waited for
+int enqueue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long long* seq_out) {
+  RC_TRY(launch_reduce(s, 0.0, true));  // (lambda: the kernels read the record)
+  RC_TRY(launch_solve(s));
+  s->have_system = true;
+  RC_TRY(launch_update(s, 0.0));
+  if (speculate) RC_TRY(launch_linearize(s, s->cur ^ 1, false, false));  // doubles as the evaluation of the trial state (see lm_iteration)
+  else RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
+  DecidePlan dp{s->d_rec.p, s->h_pinned_dev + 16, ++s->ring_seq, n_publish};
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, s->stream, s->g.acc, (const int*)s->d_info.p, s->d_ctl.p, s->g.epoch, dp);
+  HIP_TRY(hipGetLastError());
+  *seq_out = dp.seq;
+  return PPO_BA_OK;
+}
+int wait_records(ppo_ba_solver* s, unsigned long long seq) {
+  volatile const unsigned long long* w = reinterpret_cast<volatile const unsigned long long*>(s->h_pinned + 16 + kRingSlots * kRingSlotDoubles);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned it = 0; *w != seq; ++it) {
+    if ((it & 1023) == 1023) {
+      if (hipStreamQuery(s->stream) == hipSuccess) break;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+    }
+  }
+  if (*w != seq) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (*w != seq) return PPO_BA_ERR_HIP;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return PPO_BA_OK;
+}
+int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
+  // the head of the pass as lm_iteration does it: linearise the estimate, lambda from the largest diagonal entry (levenberg.cpp:166-180)
+  s->g.ctl = nullptr;
+  RC_TRY(launch_linearize(s));
+  RC_TRY(launch_maxdiag(s));
+  RC_TRY(fetch_acc(s, false, true));
+  LmCtl m{};  // the host's mirror of the record: what the device holds whenever nothing is queued
+  m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+  m.lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
+  m.ni = 2;
+  m.cubpl = s->cubpl_rho_sum;
+  m.lm_upper = s->opt.lm_upper; m.lm_lower = s->opt.lm_lower;
+  m.max_trials = s->opt.lm_max_trials;
+  m.epoch = ++s->epoch;
+  hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
+  s->g.ctl = s->d_ctl.p;
+  s->g.epoch = s->epoch;
+  struct Queued { unsigned long long seq; TrialBook after; bool speculated; };
+  Queued q[kLookahead];
+  int lookahead = kLookahead;
+  if (const char* e = PPO_DEV_ENV("PPO_BA_LOOKAHEAD")) lookahead = std::max(1, std::min(atoi(e), kLookahead));  // (A/B: 1 = a hand-over per trial)
+  const int lookahead_cap = lookahead;
+  bool pass_over = false;  // the pass has ended (iteration count, termination)
+  ppo_ba_iter_stat it{};
+  it.pass = pass;
+  int rc = PPO_BA_OK;
+  auto accept_on_host = [&](bool speculated) {  // discardTop(): the trial state is the estimate, its linearisation the current system
+    s->cur ^= 1;
+    if (speculated) use_lin_buffer(s, s->lin_buf ^ 1);
+  };
+  while (rc == PPO_BA_OK && !pass_over && m.iter < iterations && !stop_now(s)) {
+    // a batch: trial j is queued as if trials 0 .. j - 1 had been accepted and had ended their iterations
+    const int n = std::min(lookahead, iterations - m.iter);
+    for (int j = 0; j < n && rc == PPO_BA_OK; ++j) {
+      if (j > 0) accept_on_host(q[j - 1].speculated);
+      q[j].speculated = m.iter + j + 1 < iterations;
+      rc = enqueue_trial(s, q[j].speculated, j == n - 1 ? n : 0, &q[j].seq);
+      q[j].after = book_of(s);
+    }
+    if (rc != PPO_BA_OK) break;
+    if ((rc = wait_records(s, q[n - 1].seq)) != PPO_BA_OK) break;
+    bool clean = true;
+    for (int j = 0; j < n && clean && rc == PPO_BA_OK; ++j) {
+      const double* r = s->h_pinned + 16 + (q[j].seq % kRingSlots) * kRingSlotDoubles;
+      if (r[REC_SEQ] != (double)q[j].seq || r[REC_DEAD] != 0.0) { rc = PPO_BA_ERR_HIP; break; }  // (a dead trial is never seen before the one that went differently)
+      const int code = (int)r[REC_CODE];
+      const bool accepted = r[REC_ACCEPTED] != 0.0;
+      s->stats.n_trials++;
+      it.iteration = (int)r[REC_ITER] - (code == LM_RETRY || code == LM_SOLVER_ERROR ? 0 : 1);
+      it.chi2_before = r[REC_CHI_BEFORE];
+      it.lambda = r[REC_LAMBDA];
+      it.trials = (int)r[REC_TRIALS];
+      it.accepted = accepted ? 1 : 0;
+      it.chi2_after = r[REC_CHI_AFTER];
+      m.lambda = r[REC_LAMBDA_NEXT]; m.ni = r[REC_NI]; m.nbad = (int)r[REC_NBAD]; m.chi_cur = r[REC_CHI_AFTER]; m.ini_chi = r[REC_INI_CHI];
+      m.iter = (int)r[REC_ITER]; m.qmax = (int)r[REC_QMAX]; m.epoch = (int)r[REC_EPOCH];
+      const bool as_assumed = accepted && code == LM_ITER_DONE;
+      if (as_assumed) {
+        if (j == n - 1) accept_on_host(q[j].speculated);  // (the others: applied when the next trial was queued)
+      } else {
+        // the trials queued behind it did not run: the bookkeeping goes back to "trial j queued, outcome open", then takes j's real outcome
+        clean = false;
+        restore_book(s, q[j].after);
+        s->epoch = m.epoch;  // (k_decide has moved the record on)
+        s->g.epoch = s->epoch;
+        if (accepted) accept_on_host(q[j].speculated);
+      }
+      if (code == LM_SOLVER_ERROR) { rc = PPO_BA_ERR_SOLVER; break; }
+      if (!accepted && (int)r[REC_INFO] != 0 && (rc = launch_chi2(s, s->st[s->cur])) != PPO_BA_OK) break;  // the kept state's per-edge errors back (see lm_iteration)
+      if (code == LM_RETRY) {
+        if (stop_now(s)) {  // the retry loop ends on the stop flag (levenberg.cpp:149): the iteration is over, rejected
+          it.result = 0;
+          if (s->stats.n_iters < PPO_BA_MAX_ITER_STATS) s->stats.iters[s->stats.n_iters] = it;
+          s->stats.n_iters++;
+          pass_over = true;
+        }
+        continue;  // (clean is false: the batch ends here, the next one starts with the retry)
+      }
+      // the iteration is over
+      it.result = code == LM_TERMINATE ? 1 : 0;
+      if (s->stats.n_iters < PPO_BA_MAX_ITER_STATS) s->stats.iters[s->stats.n_iters] = it;
+      s->stats.n_iters++;
+      if (code == LM_TERMINATE) pass_over = true;
+      if (!pass_over && !as_assumed && m.iter < iterations) {
+        // an iteration that ended on a rejected trial without terminating (rho is NaN): the next one starts from a fresh linearisation of
+        // the kept state, as lm_iteration's `fresh` branch does
+        s->g.ctl = nullptr;
+        if ((rc = launch_linearize(s)) != PPO_BA_OK) break;
+        if ((rc = fetch_acc(s, false)) != PPO_BA_OK) break;
+        m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+        hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
+        s->g.ctl = s->d_ctl.p;
+      }
+    }
+    lookahead = clean ? std::min(lookahead_cap, 2 * lookahead) : 1;
+  }
+  // (on an error return launches may still be queued: they are gated or harmless, the caller gives the handle up or resets it)
+  s->g.ctl = nullptr;
+  s->lambda = m.lambda; s->ni = m.ni; s->nBad = m.nbad; s->chi_cur = m.chi_cur;
+  s->lin_valid = false;
+  return rc;
+}
+
 // SparseOptimizer::optimize, sparse_optimizer.cpp:354-419
 int optimize(ppo_ba_solver* s, int pass, int iterations, const volatile uint8_t* stop) {
   if (s->g.n_red == 0) return 0;
+  if (s->pipeline_ok && iterations > 0 && !stop_now(s)) return optimize_pipelined(s, pass, iterations);
   bool ok = true;
   s->lin_valid = false;
   for (int i = 0; i < iterations && !stop_now(s) && ok; ++i) {
@@ -878,6 +1043,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   if (o->world_size < 1 || o->rank < 0 || o->rank >= o->world_size) return PPO_BA_ERR_ARG;
   if (o->solve_on_owner != 0 && o->solve_on_owner != 1) return PPO_BA_ERR_ARG;
+  if (o->lm_control != PPO_LM_DEVICE && o->lm_control != PPO_LM_HOST) return PPO_BA_ERR_ARG;
   const auto t_begin = std::chrono::steady_clock::now();
   RC_TRY(validate(p));
   int ndev = 0;
@@ -1490,7 +1656,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
   ok = ok && s->d_Wpc.alloc(2 * (size_t)(p->n_bbox + n_corner_all) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
-  ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1);
+  ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1) && s->d_ctl.alloc(1) && s->d_rec.alloc((size_t)kRecSlots * REC_DOUBLES);
   if (s->comm.active()) ok = ok && s->d_pack.alloc((size_t)(ld / 64) * (ld / 64 + 1) / 2 * 4096 + ld);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
   ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream) && s->d_cub_edge_col.upload(cub_edge_col, s->stream);
@@ -1613,7 +1779,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_ul); zero(s->d_xr); zero(s->d_cholws);
     zero(s->d_cub_Linv); zero(s->d_cub_Dinv); zero(s->d_xc); zero(s->d_S);
   }
-  static_assert(ACC_N + 3 <= kPinnedDoubles, "mapped host block too small");
+  static_assert(ACC_N + 3 <= 16 && REC_DOUBLES == kRingSlotDoubles && kRecSlots == kRingSlots && kLookahead <= kRecSlots, "mapped host block too small");
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
 
   g.pose_cam = s->d_pose_cam.p; g.pose_col = s->d_pose_col.p; g.pose_free_id = s->d_pose_free_id.p; g.cub_col = s->d_cub_col.p;
@@ -1724,6 +1890,8 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                   
                    96L * Npt + 104L * Npl + 512L * Nc + 272L * nfree + 56L * n_fixed;
   }
+  // LM control on the device (optimize_pipelined): the configurations whose trials are queued without waiting for the host
+  s->pipeline_ok = o->lm_control == PPO_LM_DEVICE && s->solver_kind == PPO_SOLVER_NATIVE && !g.det && !s->comm.active() && !o->verbose;
   t_creating = nullptr;
   *out = s;
   return PPO_BA_OK;

@@ -49,7 +49,7 @@ class COptions(C.Structure):
         ("th_bbox_norm", C.c_double), ("th_corner_norm", C.c_double),
         ("deterministic", C.c_int32), ("solver", C.c_int32), ("eliminate_cuboids", C.c_int32),
         ("device_id", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
-        ("comm_id", C.c_uint8 * 128), ("verbose", C.c_int32), ("th_cub3d_norm", C.c_double), ("solve_on_owner", C.c_int32), ("pad_", C.c_int32),
+        ("comm_id", C.c_uint8 * 128), ("verbose", C.c_int32), ("th_cub3d_norm", C.c_double), ("solve_on_owner", C.c_int32), ("lm_control", C.c_int32),
     ]
 
 

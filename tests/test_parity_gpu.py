@@ -106,12 +106,17 @@ def test_linearisation_matches_oracle(oracle, hip, cfg, kw, elim):
     assert np.linalg.norm(Sh @ xh - bh) <= 1e-8 * np.linalg.norm(bh)
 
 
+# options.lm_control: the LM decisions taken by a kernel behind every trial (default wherever the configuration allows) or by the host
+LM_CONTROL = pytest.mark.parametrize("lm", [0, 1], ids=["lm-on-device", "lm-on-host"])
+
+
+@LM_CONTROL
 @pytest.mark.parametrize("elim", [1, 0])
 @pytest.mark.parametrize("cfg,kw", CASES)
-def test_full_protocol_matches_oracle(oracle, hip, cfg, kw, elim):
+def test_full_protocol_matches_oracle(oracle, hip, cfg, kw, elim, lm):
     """5 LM iterations, outlier classification, 10 more: traces, final estimates, per-edge chi2, levels."""
     P = synth.make_problem(cfg, **kw)
-    so, sh = both(oracle, hip, P, eliminate_cuboids=elim)
+    so, sh = both(oracle, hip, P, eliminate_cuboids=elim, lm_control=lm)
     to, th = so.run(), sh.run()
     assert to["n_reduced"] == th["n_reduced"]
     assert len(to["iters"]) == len(th["iters"])
@@ -223,9 +228,10 @@ def test_zero_noise_graph_stays_put(hip):
     assert st["iters"][0]["chi2_before"] < 1.0
 
 
-def test_stop_flag_aborts_before_and_between(hip):
+@LM_CONTROL
+def test_stop_flag_aborts_before_and_between(hip, lm):
     P = synth.make_problem("small", seed=10)
-    s = hip.create(P, B.default_options())
+    s = hip.create(P, B.default_options(lm_control=lm))
     flag = np.ones(1, np.uint8)
     st = s.run(stop_flag=flag)
     assert s.last_rc == 1 and st["n_iters"] == 0
@@ -291,8 +297,8 @@ def test_full_size_properties(hip, cfg):
     assert np.sqrt(np.mean((r1.pose_qt[:, 4:] - r2.pose_qt[:, 4:]) ** 2)) < 1e-6
 
 
-@pytest.mark.parametrize("det", [0, 1])
-def test_rejected_trials_follow_the_reference_schedule(oracle, hip, det):
+@pytest.mark.parametrize("det,lm", [(0, 0), (0, 1), (1, 0)], ids=["default-lm-on-device", "default-lm-on-host", "deterministic"])
+def test_rejected_trials_follow_the_reference_schedule(oracle, hip, det, lm):
     """A badly initialised graph (20x the usual noise) makes LM reject trials: lambda grows by ni = 2, 4, 8 ..., the kept state's
     system is still in its buffer and the per-iteration trial counts must match the oracle's -- through BOTH passes (30 solve
     attempts for 15 iterations), in the default and in the deterministic mode.  Far from the optimum the 1e-7 noise of the numeric
@@ -303,19 +309,30 @@ def test_rejected_trials_follow_the_reference_schedule(oracle, hip, det):
     oracle's objective evaluated at the device's final state equals its own minimum to 1e-6 (measured 3.5e-8)."""
     import sensitivity as S
     P = synth.make_problem("small", seed=2, noise_scale=20.0)
-    so, sh = both(oracle, hip, P, deterministic=det)
+    so, sh = both(oracle, hip, P, deterministic=det, lm_control=lm)
     to, th = so.run(), sh.run()
     assert sum(i["trials"] for i in to["iters"]) >= len(to["iters"]) + 10 and len(to["iters"]) == 15, "the case no longer exercises rejections in both passes"
     assert [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in to["iters"]] == \
            [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in th["iters"]]
+    # per-iteration bars.  Deterministic mode (reproducible): chi2 2e-4, lambda 3e-2 (measured 4e-5 / 6e-3).  Default mode: the same, or five times
+    # what the ORACLE's own trace moves by on this window when only its rounding changes (its four re-runs: chi2 up to 1.7e-4, lambda 2.3e-2
+    # per iteration) -- the order of the floating-point atomics is one more such change, and in about one run in twenty it is amplified
+    # to 5.5e-4 at an iteration that needed three solve attempts (40 repeats on MI355X, gpurun_out/flaky_a.txt, round 4).
+    runs = S.oracle_runs(oracle, P, B.default_options(), variants=S.VARIANTS)
+    own_chi = own_lam = 0.0
+    for st2, _ in runs[1:]:
+        assert S.schedule(st2) == S.schedule(to)
+        own_chi = max(own_chi, max(abs(a["chi2_after"] - b["chi2_after"]) / abs(a["chi2_after"]) for a, b in zip(to["iters"], st2["iters"])))
+        own_lam = max(own_lam, max(abs(a["lambda_"] - b["lambda_"]) / abs(a["lambda_"]) for a, b in zip(to["iters"], st2["iters"])))
+    bar_chi, bar_lam = (2e-4, 3e-2) if det else (max(2e-4, 5 * own_chi), max(3e-2, 5 * own_lam))
     for a, b in zip(to["iters"], th["iters"]):
-        assert abs(a["chi2_after"] - b["chi2_after"]) <= 2e-4 * abs(a["chi2_after"])
-        assert abs(a["lambda_"] - b["lambda_"]) <= 3e-2 * abs(a["lambda_"])
+        assert abs(a["chi2_after"] - b["chi2_after"]) <= bar_chi * abs(a["chi2_after"]), (a["chi2_after"], b["chi2_after"], bar_chi)
+        assert abs(a["lambda_"] - b["lambda_"]) <= bar_lam * abs(a["lambda_"]), (a["lambda_"], b["lambda_"], bar_lam)
     ro, rh = so.read(), sh.read()
     gap, _, _ = S.optimality_gap(oracle, so, ro, rh)
     assert gap <= 1e-6, gap
     m = S.metrics(ro, rh)
-    oo, _, _ = S.spread(S.oracle_runs(oracle, P, B.default_options(), variants=S.VARIANTS))
+    oo, _, _ = S.spread(runs)
     print("rejected-trials window (det=%d): deviation / oracle spread %s" % (det, {k: "%.1e / %.1e" % (m[k], oo[k]) for k in S.BARS}))
     for k, bar in S.BARS.items():  # inside the bar, or inside what the reference algorithm's own rounding leaves open on this window
         assert m[k] <= max(bar, oo[k]), (k, m[k], oo[k])
@@ -338,13 +355,15 @@ def _not_positive_window():
     return P, dict(lm_tau=1e-5 * 1.1 ** 37.5, lm_max_trials=2)
 
 
+@LM_CONTROL
 @pytest.mark.parametrize("elim", [1, 0])
-def test_failed_factorisation_is_a_rejected_trial(oracle, hip, elim):
+def test_failed_factorisation_is_a_rejected_trial(oracle, hip, elim, lm):
     """The not-positive path (linear_solver_dense.h:108-112 -> levenberg.cpp:110-127: `if (!ok2) tempChi = max` -> rho < 0 -> lambda *= ni,
     pop) on the device: the native Cholesky reports the non-positive pivot (LAPACK-style info), the trial is rejected, lambda follows
     the reference's schedule, the kept state is untouched, and after ten... here two failures the iteration Terminates.  Schedule,
     lambda, chi2 against the oracle; then pass 2 runs on from the kept state."""
     P, kw = _not_positive_window()
+    kw = dict(kw, lm_control=lm)
     so, sh = both(oracle, hip, P, iters_pass2=0, eliminate_cuboids=elim, **kw)
     to, th = so.run(), sh.run()
     sched = [(i["pass_"], i["iteration"], i["trials"], i["accepted"], i["result"]) for i in to["iters"]]
@@ -374,7 +393,8 @@ def test_failed_factorisation_is_a_rejected_trial(oracle, hip, elim):
     so.close(); sh.close()
 
 
-def test_failed_factorisation_leaves_the_kept_states_errors_behind__the_one_deliberate_deviation(oracle, hip):
+@LM_CONTROL
+def test_failed_factorisation_leaves_the_kept_states_errors_behind__the_one_deliberate_deviation(oracle, hip, lm):
     """DESIGN.md section 2 lists ONE deviation of the product from the reference's control flow, and this test pins it.  When a
     factorisation fails the reference still applies `_solver->x()` -- the STALE solution of the last successful solve --, evaluates
     every edge there, and only then pops the vertices (levenberg.cpp:110-146): the edges' stored `_error` (what `e->chi2()` returns
@@ -383,7 +403,7 @@ def test_failed_factorisation_leaves_the_kept_states_errors_behind__the_one_deli
     ENDS in failed factorisations -- which needs lm_max_trials consecutive failures right after a success, i.e. an indefinite
     problem like this one; a positive semi-definite system (every real window: J' W J + lambda I) cannot get there."""
     P, kw = _not_positive_window()
-    so, sh = both(oracle, hip, P, iters_pass2=0, **kw)
+    so, sh = both(oracle, hip, P, iters_pass2=0, lm_control=lm, **kw)
     so.run(); sh.run()
     ro, rh = so.read(), sh.read()
     compare_states(ro, rh)
@@ -403,7 +423,8 @@ def test_failed_factorisation_leaves_the_kept_states_errors_behind__the_one_deli
     so.close(); sh.close(); sk.close()
 
 
-def test_nan_residual_freezes_the_window_like_the_reference(oracle, hip):
+@LM_CONTROL
+def test_nan_residual_freezes_the_window_like_the_reference(oracle, hip, lm):
     """`ominus_ver` divides by |n x n_m| (G2O_Plane3D.h:97-106): a vertical-plane measurement whose normal is PARALLEL to the predicted one
     gives a NaN residual.  In the reference chi2 is then NaN, every comparison on it is false: each LM iteration makes one solve
     attempt, rejects it (`rho > 0` is false), leaves the loop (`rho < 0` is false too), never counts as bad -- 5 + 10 iterations that
@@ -416,7 +437,7 @@ def test_nan_residual_freezes_the_window_like_the_reference(oracle, hip):
     fx = P["pose_fixed"].copy(); fx[ps] = 1; P.set("pose_fixed", fx)
     pc = P["plane_coef"].copy(); pc[pl] = [0, 0, 1, 2]; P.set("plane_coef", pc)
     m = P["pl_meas"].copy().reshape(-1, 4); m[e] = [0, 0, 1, 3]; P.set("pl_meas", m)
-    so, sh = both(oracle, hip, P)
+    so, sh = both(oracle, hip, P, lm_control=lm)
     to, th = so.run(), sh.run()
     assert [(i["pass_"], i["trials"], i["accepted"], i["result"]) for i in to["iters"]] == [(0, 1, 0, 0)] * 5 + [(1, 1, 0, 0)] * 10
     assert [(i["pass_"], i["trials"], i["accepted"], i["result"]) for i in th["iters"]] == [(0, 1, 0, 0)] * 5 + [(1, 1, 0, 0)] * 10

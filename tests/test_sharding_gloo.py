@@ -3,7 +3,8 @@
 What the N > 1 path of libppo_ba.so does per solve attempt (csrc/ppo_solver.hip: launch_reduce / fetch_acc):
   * landmarks are range-partitioned with ppo_ba_partition() (host code of the product library, runs without a GPU);
   * every rank forms the Schur contributions of ITS landmarks, rank 0 additionally adds Hpp + lambda I and the cuboid terms;
-  * ONE sum all-reduce of (S, b_schur) gives every rank the full reduced system, which each rank then factors redundantly;
+  * ONE sum all-reduce of (S, b_schur) gives every rank the full reduced system, which each rank then factors redundantly
+    (options.solve_on_owner = 1: ONE reduce to rank 0, which alone factors, and a broadcast of the solution);
   * the robust chi2 is a sum all-reduce of per-rank partial sums.
 Here the per-rank arithmetic is done by the CPU oracle (test infrastructure) and the collective by gloo, so the test
 checks the decomposition itself: partial systems of disjoint landmark ranges must sum to the unsharded system, identical
@@ -79,13 +80,20 @@ def _worker(rank, world, port, cfg, seed, out_q):
     tchi = torch.tensor([rho.sum()], dtype=torch.float64)
     dist.all_reduce(tchi, op=dist.ReduceOp.SUM)
     x = np.linalg.solve(S_sum, b_sum)
+    # options.solve_on_owner = 1: the same partial systems REDUCED to rank 0 only, rank 0 alone solves, x is broadcast
+    rS, rb = torch.from_numpy(S_part.copy()), torch.from_numpy(b_part.copy())
+    dist.reduce(rS, 0, op=dist.ReduceOp.SUM)
+    dist.reduce(rb, 0, op=dist.ReduceOp.SUM)
+    tx = torch.from_numpy(np.linalg.solve(rS.numpy(), rb.numpy())) if rank == 0 else torch.zeros(n, dtype=torch.float64)
+    dist.broadcast(tx, 0)
+    x_owner = tx.numpy().copy()
     # every rank must hold bit-identical inputs to the (redundant) factorisation
     gathered = [torch.zeros_like(tb) for _ in range(world)]
     dist.all_gather(gathered, tb)
     out_q.put(dict(rank=rank, err_S=float(np.abs(S_sum - S_full).max() / np.abs(S_full).max()),
                    err_b=float(np.abs(b_sum - b_full).max() / np.abs(b_full).max()),
                    same_b=bool(all(torch.equal(g, tb) for g in gathered)),
-                   x=x, share=int(own.sum()), n_mono=int(P["mono_point"].size), mono_chi=float(tchi.item()),
+                   x=x, x_owner=x_owner, share=int(own.sum()), n_mono=int(P["mono_point"].size), mono_chi=float(tchi.item()),
                    ranges=(fp.tolist(), fl.tolist())))
     dist.destroy_process_group()
 
@@ -109,6 +117,9 @@ def test_partial_reduced_systems_sum_to_the_full_one_over_gloo(cfg, seed):
         assert d["err_S"] < 1e-12 and d["err_b"] < 1e-12, d
         assert d["same_b"]
     np.testing.assert_array_equal(res[0]["x"], res[1]["x"])  # identical decisions on every rank
+    # reduce-to-owner + broadcast (options.solve_on_owner): every rank holds rank 0's solution, which is the all-reduce variant's
+    np.testing.assert_array_equal(res[0]["x_owner"], res[1]["x_owner"])
+    assert np.abs(res[0]["x_owner"] - res[0]["x"]).max() <= 1e-9 * np.abs(res[0]["x"]).max()
     assert res[0]["share"] + res[1]["share"] == res[0]["n_mono"]  # every edge is owned exactly once
     assert abs(res[0]["share"] - res[1]["share"]) < 0.25 * res[0]["n_mono"]  # edge-balanced ranges
     assert res[0]["mono_chi"] == res[1]["mono_chi"]
