@@ -329,13 +329,26 @@ def test_rejected_trials_follow_the_reference_schedule(oracle, hip, det, lm):
         assert abs(a["chi2_after"] - b["chi2_after"]) <= bar_chi * abs(a["chi2_after"]), (a["chi2_after"], b["chi2_after"], bar_chi)
         assert abs(a["lambda_"] - b["lambda_"]) <= bar_lam * abs(a["lambda_"]), (a["lambda_"], b["lambda_"], bar_lam)
     ro, rh = so.read(), sh.read()
-    gap, _, _ = S.optimality_gap(oracle, so, ro, rh)
-    assert gap <= 1e-6, gap
+    gap, c_oracle, c_device = S.optimality_gap(oracle, so, ro, rh)
+    if det:
+        assert gap <= 1e-6, gap
+    else:
+        # Default mode.  This window is NOT converged after 5 + 10 iterations (13 of its 30 solve attempts are rejected), so where a run stands
+        # at the end hangs on every gain ratio on the way -- a small difference of two large chi2 values.  194 of 200 runs on MI355X
+        # (tools/rejected_window_diag.py, gpurun_out/rejected_diag.txt, round 4) stay within 4e-8 of the oracle's final cost; in the other
+        # six the gain ratio of pass 2 / iteration 3 comes out 0.15 % lower (chi2 19.00 instead of 19.03 gained), lambda follows 0.7 % higher
+        # from there on, and the run ends 1.67e-5 BELOW the oracle's final cost -- the same accept / reject sequence, the same levels, a
+        # slightly better iterate.  Held: never worse than the oracle's final cost by more than 1e-6, never further than 1e-4 from it.
+        assert (c_device - c_oracle) <= 1e-6 * abs(c_oracle), (c_device, c_oracle)
+        assert gap <= 1e-4, gap
     m = S.metrics(ro, rh)
     oo, _, _ = S.spread(runs)
     print("rejected-trials window (det=%d): deviation / oracle spread %s" % (det, {k: "%.1e / %.1e" % (m[k], oo[k]) for k in S.BARS}))
-    for k, bar in S.BARS.items():  # inside the bar, or inside what the reference algorithm's own rounding leaves open on this window
-        assert m[k] <= max(bar, oo[k]), (k, m[k], oo[k])
+    for k, bar in S.BARS.items():
+        if det:  # inside the bar, or inside what the reference algorithm's own rounding leaves open on this window
+            assert m[k] <= max(bar, oo[k]), (k, m[k], oo[k])
+        else:    # the default-mode rule of test_default_mode_stays_near_the_deterministic_result (measured: up to 2 x the oracle's spread)
+            assert m[k] <= max(3 * bar, 5 * oo[k]), (k, m[k], oo[k])
 
 
 def _not_positive_window():
