@@ -3,6 +3,7 @@
 // oracle.  Not linked into libppo_ba.so and never used by the product path.
 #include "ppo_math.hpp"
 #include "ppo_pose_math.hpp"
+#include "ppo_lm.hpp"
 
 using namespace ppo;
 
@@ -53,6 +54,12 @@ void hc_corner(const double* pose_qt, const double* c10, const double* K, const 
   corner_residual(T, c, K, meas, e);
 }
 double hc_cube(double x) { return cube_rounded_once(x); }
+// the device's LM decision (ppo_lm.hpp).  ctl: lambda chi_cur ini_chi ni cubpl lm_upper lm_lower nbad qmax iter epoch max_trials (doubles), updated in place
+void hc_lm_decide(double* ctl, double chi2_sum, double scale_raw, int info, double* rec) {
+  LmCtl c{ctl[0], ctl[1], ctl[2], ctl[3], ctl[4], ctl[5], ctl[6], (int)ctl[7], (int)ctl[8], (int)ctl[9], (int)ctl[10], (int)ctl[11], 0};
+  lm_decide(c, chi2_sum, scale_raw, info, rec);
+  ctl[0] = c.lambda; ctl[1] = c.chi_cur; ctl[2] = c.ini_chi; ctl[3] = c.ni; ctl[7] = c.nbad; ctl[8] = c.qmax; ctl[9] = c.iter; ctl[10] = c.epoch;
+}
 void hc_cub3d(const double* pose_qt, const double* c10, const double* meas10, double* e) {
   const Pose T{Quat{pose_qt[0], pose_qt[1], pose_qt[2], pose_qt[3]}, Vec3{pose_qt[4], pose_qt[5], pose_qt[6]}};
   const Cub c{Pose{Quat{c10[0], c10[1], c10[2], c10[3]}, Vec3{c10[4], c10[5], c10[6]}}, Vec3{c10[7], c10[8], c10[9]}};

@@ -557,11 +557,14 @@ __device__ __forceinline__ void inv_block_wg(const double* __restrict__ A, int l
 // OV = false: the launch carries no pair workgroups and no tile takes atomic updates (ov is not read) -- the plain factorisation and the
 // later launches of an overlapped one; as ONE kernel the pair code's registers (240 against 182) and arguments cost every launch 0.4 us.
 template <bool OV>
-__global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info,
-                                                            int inplace_rhs, double* __restrict__ inv, StepOverlap ov, LmGate gate) {
+__global__ __launch_bounds__(kStepThreads) void chol_step_t(LmGate gate, double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info,
+                                                            int inplace_rhs, double* __restrict__ inv, StepOverlap ov) {
   constexpr int NT = kStepThreads, NI = 2048 / NT;
   __shared__ StepLdsU lds;
-  if (lm_gate_dead(gate)) return;
+  // LM control on the device: the epoch word is REQUESTED here and looked at only where a workgroup is about to write -- for the column
+  // workgroups (the chain) behind their tile requests, so that its latency hides behind theirs.  (Not gated: the word read is `info`, ignored.)
+  const int gate_seen = *(gate.epoch_word ? gate.epoch_word : const_cast<const int*>(info));
+#define STEP_DEAD() (gate.epoch_word != nullptr && gate_seen != gate.expect)
   double (*const sL)[LP] = lds.a.sL;
   double (*const sB)[LP] = lds.a.sB;
   double (*const sT)[SB][17] = lds.a.sT;
@@ -577,6 +580,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
   const int ncol = 1 + 2 * (m - 1);  // column workgroups of this launch
   const int ninv = (inv != nullptr && upd) ? 1 : 0;
   if (ninv && (int)blockIdx.x == ncol) {
+    if (STEP_DEAD()) return;
     // ---- T and M of the PREVIOUS panel's block for the backward substitution (first behind the column workgroups: the longest of the rest)
     inv_block_wg(A, ld, kp, inv + (size_t)(kp / NB) * kInvDoubles, lds.a);
     return;
@@ -586,11 +590,13 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
   if (OV && (int)blockIdx.x >= ncol + ninv && (int)blockIdx.x < ncol + ninv + npair_wg) {
     // ---- pair workgroup of an overlapped reduction: S -= W_j (D_l + lambda I)^-1 W_i' for chunks of column blocks that are not final yet
     // (right behind the column workgroups in the grid: they are the long ones of the launch's shadow, the trailing tiles fill in)
+    if (STEP_DEAD()) return;
     step_pairs(ov, (int)blockIdx.x - ncol - ninv, lds.pairs);
     return;
   }
   if ((int)blockIdx.x >= ncol + ninv) {
     // ---- trailing tile (bi >= bj >= 1 relative to block k) --------------------------------------------------------------
+    if (STEP_DEAD()) return;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     int t = blockIdx.x - ncol - ninv - npair_wg, bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
@@ -685,6 +691,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
       tp[i] = *reinterpret_cast<const d2*>(&pP[(size_t)c * ld + r]);
     }
     rold = rsrc[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0];  // (for the very end: requested here, not there; unconditional like the others)
+    if (STEP_DEAD()) return;  // (everything above is a request; nothing has been written)
     STAMP(6);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -819,6 +826,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(double* __restrict__
   }
   STAMP(4);
 }
+#undef STEP_DEAD
 
 [[maybe_unused]] constexpr auto chol_step = chol_step_t<false>;  // (tools/chol_probe.hip launches single steps)
 
@@ -1118,8 +1126,8 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
       if (PPO_DEV_PROBE("PPO_BA_OVERLAP_EMPTY")) o.chunk_hi = o.chunk_lo;  // timing experiment (WRONG results): the pair workgroups find nothing to do
 #endif
       const dim3 grid(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0) + o.npair_wg + (k > 0 && inv ? 1 : 0));
-      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o, gate);
-      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o, gate);
+      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, gate, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
+      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, gate, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
     }
   }
   hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(kBackThreads), 0, s, (const double*)A, ld, (const double*)y, x, info, flags, nflags, (const double*)inv, gate);

@@ -25,6 +25,7 @@
 
 #include "ppo_math.hpp"
 #include "ppo_pairs.hpp"
+#include "ppo_lm.hpp"
 #include "ppo_dpp.hpp"
 
 namespace ppo {
@@ -86,27 +87,10 @@ struct State {       // one copy of all estimates
   double* cub;       // [Nc][10] qx qy qz qw tx ty tz sx sy sz
 };
 
-// ---- LM control on the device (ppo_solver.hip, optimize_pipelined; levenberg.cpp:61-164) ----------------------------------------------
-// The damping, the gain-ratio test, nu, the nBad count and the iteration counters live in ONE device record.  k_decide, queued behind the
-// evaluation of every trial state, takes the decision the host used to take after a round trip through mapped memory; the host queues the
-// next trial BEFORE it knows the outcome, on the assumption "accepted, the pass goes on".  Whenever that assumption fails (a rejected trial,
-// a terminated pass, a solver error) k_decide bumps `epoch`: every kernel of a trial carries the epoch it was queued under (Graph::epoch,
-// LmGate) and returns at once when the record has moved on, so the launches queued on the wrong assumption change nothing.
-struct LmCtl {
-  double lambda;    // damping of the NEXT trial (_currentLambda)
-  double chi_cur;   // robust chi2 of the current estimate (currentChi)
-  double ini_chi;   // ... at the start of the running iteration (iniChi)
-  double ni;        // _ni
-  double cubpl;     // constant chi2 term of the cuboid-plane edges
-  double lm_upper, lm_lower;
-  int nbad, qmax, iter, epoch, max_trials, pad_;
-};
-// what k_decide records per trial (doubles; a slot of the device ring, copied to the mapped host ring at the end of a batch of trials)
-enum { REC_CHI2 = 0, REC_SCALE, REC_INFO, REC_LAMBDA, REC_RHO, REC_ACCEPTED, REC_CODE, REC_CHI_BEFORE, REC_CHI_AFTER, REC_TRIALS, REC_ITER,
-       REC_DEAD, REC_LAMBDA_NEXT, REC_NI, REC_NBAD, REC_INI_CHI, REC_EPOCH, REC_QMAX, REC_SEQ = 31, REC_DOUBLES = 32 };
-enum { LM_RETRY = 0, LM_ITER_DONE = 1, LM_TERMINATE = 2, LM_SOLVER_ERROR = 3 };
-
 struct Graph {
+  // (first: inside the kernel-argument registers that are preloaded, so the gate costs one scalar load, not two in a row)
+  const LmCtl* ctl;       // LM control on the device: the kernels of a trial read lambda here and do nothing unless ctl->epoch == epoch
+  int epoch;              // (NULL: the host passes lambda and every launch is live)
   int n_poses, n_points, n_planes, n_cuboids, n_pose_free, n_red, n_lm, n_slots;
   int ld;  // leading dimension of S (n_red rounded up to the Cholesky panel width; pad rows/cols are identity)
   int n_mono, n_stereo, n_pl, n_bbox, n_corner, n_ptcub;
@@ -180,8 +164,6 @@ struct Graph {
   int det;           // options.deterministic: every cross-wave accumulation is an INTEGER atomic on a 2^-24 fixed-point image of the
                      // addend (exact, hence independent of the order the atomics arrive in); k_fix_to_double turns the ranges back into doubles
   const double* hb_diag;  // sharded runs, first iteration: diagonal of Hpp summed over ranks (NULL: read it from HB)
-  const LmCtl* ctl;       // LM control on the device: the kernels of a trial read lambda here and do nothing unless ctl->epoch == epoch
-  int epoch;              // (NULL: the host passes lambda and every launch is live)
 #ifdef PPO_BA_TEST_HOOKS
   int dbg;                     // development aid (PPO_BA_LIN_DBG): bit 0 numeric classes skip their scatter, bit 1 plain stores instead of atomics
   unsigned long long* stamps;  // development aid (PPO_BA_LIN_STAMPS): [grid][8] wall-clock stamps of the fused linearisation's workgroups
@@ -1502,70 +1484,8 @@ __global__ __launch_bounds__(64) void k_decide(double* acc, const int* __restric
   }
   if (t == 0 && !dead) {
     LmCtl c = *ctl;
-    const int info = *info_p;
-    const double lambda = c.lambda, scale_raw = acc[ACC_SCALE];
-    double currentChi = c.chi_cur;
-    double tempChi = acc[ACC_CHI2] + c.cubpl;
-    const double chi_trial = tempChi;
-    if (info != 0 || !isfinite(scale_raw)) tempChi = 1.7976931348623157e308;  // solver not ok (levenberg.cpp:126-127)
-    double rho = currentChi - tempChi;
-    double scale = scale_raw;
-    if (info != 0) scale = 0;
-    scale += 1e-3;
-    rho /= scale;
-    const bool accepted = rho > 0 && isfinite(tempChi) && info == 0;
-    if (accepted) {
-      double alpha = 1. - cube_rounded_once(2 * rho - 1);
-      alpha = (c.lm_upper < alpha) ? c.lm_upper : alpha;                     // std::min(alpha, upper)
-      const double scaleFactor = (c.lm_lower < alpha) ? alpha : c.lm_lower;  // std::max(lower, alpha)
-      c.lambda *= scaleFactor;
-      c.ni = 2;
-      currentChi = tempChi;
-    } else {
-      c.lambda *= c.ni;
-      c.ni *= 2;
-    }
-    c.qmax++;
-    const int trials = c.qmax;
-    const double chi_before = c.ini_chi;
-    int code;
-    if (info >= (1 << 30)) {
-      code = LM_SOLVER_ERROR;  // the hand-off of the backward substitution timed out: not a "not positive" matrix
-    } else if (rho < 0 && c.qmax < c.max_trials) {
-      code = LM_RETRY;
-    } else {  // the iteration is over (levenberg.cpp:150-163)
-      if (c.qmax == c.max_trials || rho == 0) {
-        code = LM_TERMINATE;
-      } else {
-        if ((c.ini_chi - currentChi) * 1e3 < c.ini_chi) c.nbad++;
-        else c.nbad = 0;
-        code = c.nbad >= 3 ? LM_TERMINATE : LM_ITER_DONE;
-      }
-      c.iter++;
-      c.qmax = 0;
-      c.ini_chi = currentChi;
-    }
-    c.chi_cur = currentChi;
-    if (!(accepted && code == LM_ITER_DONE)) c.epoch++;  // not what the host assumed when it queued the next trials: those launches are dead
+    lm_decide(c, acc[ACC_CHI2], acc[ACC_SCALE], *info_p, rec);
     *ctl = c;
-    rec[REC_CHI2] = chi_trial;
-    rec[REC_SCALE] = scale_raw;
-    rec[REC_INFO] = (double)info;
-    rec[REC_LAMBDA] = lambda;
-    rec[REC_RHO] = rho;
-    rec[REC_ACCEPTED] = accepted ? 1.0 : 0.0;
-    rec[REC_CODE] = (double)code;
-    rec[REC_CHI_BEFORE] = chi_before;
-    rec[REC_CHI_AFTER] = currentChi;
-    rec[REC_TRIALS] = (double)trials;
-    rec[REC_ITER] = (double)c.iter;
-    rec[REC_DEAD] = 0.0;
-    rec[REC_LAMBDA_NEXT] = c.lambda;
-    rec[REC_NI] = c.ni;
-    rec[REC_NBAD] = (double)c.nbad;
-    rec[REC_INI_CHI] = c.ini_chi;
-    rec[REC_EPOCH] = (double)c.epoch;
-    rec[REC_QMAX] = (double)c.qmax;
     rec[REC_SEQ] = (double)dp.seq;
   }
   if (dp.n_publish <= 0) return;

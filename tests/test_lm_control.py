@@ -55,6 +55,107 @@ def test_the_device_cube_is_the_correctly_rounded_cube_and_within_one_ulp_of_lib
     assert math.isnan(hc.hc_cube(float("nan")))
 
 
+def _reference_decision(c, chi2_sum, scale_raw, info, libm_pow):
+    """One pass through the body of the do-while of OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:102-149)
+    and, when the loop ends, its tail (:151-163), on a dict of the algorithm's variables.  The product's conventions for a failed
+    factorisation: ok2 = (info == 0 and the scale is finite), scale = 0 then.  Returns (accepted, code)."""
+    ok2 = info == 0 and math.isfinite(scale_raw)
+    temp = chi2_sum + c["cubpl"]
+    if not ok2:
+        temp = sys.float_info.max
+    rho = c["chi_cur"] - temp
+    scale = (scale_raw if info == 0 else 0.0) + 1e-3
+    with np.errstate(all="ignore"):
+        rho = float(np.float64(rho) / np.float64(scale))
+    accepted = rho > 0 and math.isfinite(temp) and info == 0
+    if accepted:
+        alpha = 1.0 - libm_pow(2 * rho - 1, 3.0)
+        alpha = min(alpha, c["upper"])
+        c["lambda"] *= max(c["lower"], alpha)
+        c["ni"] = 2.0
+        c["chi_cur"] = temp
+    else:
+        c["lambda"] *= c["ni"]
+        c["ni"] *= 2
+    c["qmax"] += 1
+    if info >= (1 << 30):
+        return accepted, 3
+    if rho < 0 and c["qmax"] < c["max_trials"]:
+        return accepted, 0  # the loop goes round again
+    if c["qmax"] == c["max_trials"] or rho == 0:
+        code = 2
+    else:
+        if (c["ini_chi"] - c["chi_cur"]) * 1e3 < c["ini_chi"]:
+            c["nbad"] += 1
+        else:
+            c["nbad"] = 0
+        code = 2 if c["nbad"] >= 3 else 1
+    c["iter"] += 1
+    c["qmax"] = 0
+    c["ini_chi"] = c["chi_cur"]
+    return accepted, code
+
+
+def test_the_device_decision_is_the_reference_loop_body():
+    """csrc/ppo_lm.hpp: lm_decide -- the function k_decide runs behind every solve attempt -- compiled for the host, against the restatement
+    above over 20 000 random situations: accepted steps of every quality, rejected ones, rho exactly 0, NaN / infinite chi2 and scale,
+    failed factorisations, the solver-failure flag, the last allowed retry, the third bad iteration.  Everything is compared exactly except
+    lambda behind an accepted step, which may differ by the one ulp glibc's pow is away from the correctly rounded cube."""
+    path = os.path.join(B.PKG_ROOT, "csrc", "libppo_hostcheck.so")
+    if not os.path.exists(path):
+        pytest.skip("libppo_hostcheck.so not built (run __graft_entry__.build())")
+    hc = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    hc.hc_lm_decide.argtypes = [dp, C.c_double, C.c_double, C.c_int, dp]
+    libm = C.CDLL("libm.so.6")
+    libm.pow.restype = C.c_double
+    libm.pow.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(11)
+    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    n_acc = n_one_ulp = 0
+    for case in range(20000):
+        chi = float(np.exp(rng.uniform(1, 12)))
+        kind = rng.integers(0, 12)
+        rel = {0: -rng.uniform(0, 0.5), 1: -rng.uniform(0, 1e-3), 2: -rng.uniform(0, 1e-7), 3: rng.uniform(0, 0.3), 4: rng.uniform(0, 1e-9)}.get(int(kind), -rng.uniform(0, 0.2))
+        cubpl = float(rng.choice([0.0, rng.uniform(0, 50)]))
+        chi2_sum = chi * (1 + rel) - cubpl
+        if kind == 5:
+            chi2_sum = chi - cubpl  # rho == 0 where the subtraction is exact
+        if kind == 6:
+            chi2_sum = float(rng.choice([np.nan, np.inf]))
+        scale = float(np.exp(rng.uniform(-6, 10)))
+        if kind == 7:
+            scale = float(rng.choice([np.nan, np.inf, -1e-3, 0.0]))
+        info = 0
+        if kind == 8:
+            info = int(rng.integers(1, 500))
+        if kind == 9 and rng.random() < 0.2:
+            info = 1 << 30
+        c = dict(chi_cur=chi, ini_chi=chi * (1 + float(rng.choice([0.0, rng.uniform(0, 1e-2), rng.uniform(0, 1e-5)]))), cubpl=cubpl,
+                 ni=float(2 ** rng.integers(1, 8)), upper=2.0 / 3.0, lower=1.0 / 3.0, nbad=int(rng.integers(0, 3)), qmax=int(rng.integers(0, 10)),
+                 iter=int(rng.integers(0, 10)), max_trials=int(rng.choice([10, 10, 2])))
+        c["lambda"] = float(np.exp(rng.uniform(-8, 12)))
+        c["qmax"] = min(c["qmax"], c["max_trials"] - 1)
+        ctl = np.array([c["lambda"], c["chi_cur"], c["ini_chi"], c["ni"], c["cubpl"], c["upper"], c["lower"], c["nbad"], c["qmax"], c["iter"], 7, c["max_trials"]], dtype=np.float64)
+        rec = np.zeros(32)
+        hc.hc_lm_decide(ctl.ctypes.data_as(dp), chi2_sum, scale, info, rec.ctypes.data_as(dp))
+        accepted, code = _reference_decision(c, chi2_sum, scale, info, libm.pow)
+        seen[code] += 1
+        assert (rec[5] != 0) == accepted and int(rec[6]) == code, (case, kind, rec[:8], accepted, code)
+        if accepted:
+            n_acc += 1
+            n_one_ulp += ctl[0] != c["lambda"]
+            assert abs(ctl[0] - c["lambda"]) <= 3e-16 * c["lambda"], (case, ctl[0], c["lambda"])
+        else:
+            assert ctl[0] == c["lambda"], (case, ctl[0], c["lambda"])
+        same = lambda a, b: a == b or (math.isnan(a) and math.isnan(b))
+        assert same(ctl[1], c["chi_cur"]) and same(ctl[2], c["ini_chi"]) and ctl[3] == c["ni"], (case, kind, ctl[:4], c)
+        assert (int(ctl[7]), int(ctl[8]), int(ctl[9])) == (c["nbad"], c["qmax"], c["iter"]), (case, kind, ctl[7:10], c)
+        assert int(ctl[10]) == (7 if (accepted and code == 1) else 8)  # the epoch moves on exactly when the host's assumption fails
+    assert min(seen.values()) >= 50 and n_acc >= 5000, (seen, n_acc)
+    assert n_one_ulp <= n_acc // 100, (n_one_ulp, n_acc)
+
+
 def _hip():
     return B.hip_backend()
 
