@@ -557,14 +557,16 @@ __device__ __forceinline__ void inv_block_wg(const double* __restrict__ A, int l
 // OV = false: the launch carries no pair workgroups and no tile takes atomic updates (ov is not read) -- the plain factorisation and the
 // later launches of an overlapped one; as ONE kernel the pair code's registers (240 against 182) and arguments cost every launch 0.4 us.
 template <bool OV>
-__global__ __launch_bounds__(kStepThreads) void chol_step_t(LmGate gate, double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout, int* __restrict__ info,
-                                                            int inplace_rhs, double* __restrict__ inv, StepOverlap ov) {
+__global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word, int gate_expect, double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout,
+                                                            int* __restrict__ info, int inplace_rhs, double* __restrict__ inv, StepOverlap ov) {
   constexpr int NT = kStepThreads, NI = 2048 / NT;
   __shared__ StepLdsU lds;
   // LM control on the device: the epoch word is REQUESTED here and looked at only where a workgroup is about to write -- for the column
   // workgroups (the chain) behind their tile requests, so that its latency hides behind theirs.  (Not gated: the word read is `info`, ignored.)
-  const int gate_seen = *(gate.epoch_word ? gate.epoch_word : const_cast<const int*>(info));
-#define STEP_DEAD() (gate.epoch_word != nullptr && gate_seen != gate.expect)
+  // (two scalars in front of the argument list, not an LmGate: an aggregate argument ends the kernel-argument preload for everything behind it,
+  //  which put a scalar-load round trip, 0.25 us, at the head of every panel launch)
+  const int gate_seen = *(gate_word ? gate_word : const_cast<const int*>(info));
+#define STEP_DEAD() (gate_word != nullptr && gate_seen != gate_expect)
   double (*const sL)[LP] = lds.a.sL;
   double (*const sB)[LP] = lds.a.sB;
   double (*const sT)[SB][17] = lds.a.sT;
@@ -850,11 +852,11 @@ __device__ __forceinline__ void store_sc1(double* p, double v) { __hip_atomic_st
 
 constexpr int kBackThreads = 320;  // four compute waves + the polling wave
 constexpr int kRing = 32;          // blocks of x the polling wave may run ahead of the slowest compute wave
-__global__ __launch_bounds__(kBackThreads) void chol_back_all(const double* __restrict__ A, int ld, const double* __restrict__ y, double* x, int* __restrict__ info, int* flags,
-                                                              int nflags, const double* __restrict__ inv, LmGate gate) {
+__global__ __launch_bounds__(kBackThreads) void chol_back_all(const int* gate_word, int gate_expect, const double* __restrict__ A, int ld, const double* __restrict__ y, double* x,
+                                                              int* __restrict__ info, int* flags, int nflags, const double* __restrict__ inv) {
   __shared__ double sL[NB][LP];
   __shared__ double sV[NB];
-  if (lm_gate_dead(gate)) return;
+  if (gate_word != nullptr && *gate_word != gate_expect) return;
   __shared__ double sXr[kRing][NB];  // x_i as the polling wave saw them, slot i % kRing
   __shared__ int s_seen;             // smallest i with x_i in the ring
   __shared__ int s_prog[4];          // smallest i compute wave w has finished reading
@@ -1126,11 +1128,11 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
       if (PPO_DEV_PROBE("PPO_BA_OVERLAP_EMPTY")) o.chunk_hi = o.chunk_lo;  // timing experiment (WRONG results): the pair workgroups find nothing to do
 #endif
       const dim3 grid(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0) + o.npair_wg + (k > 0 && inv ? 1 : 0));
-      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, gate, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
-      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, gate, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
+      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
+      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
     }
   }
-  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(kBackThreads), 0, s, (const double*)A, ld, (const double*)y, x, info, flags, nflags, (const double*)inv, gate);
+  hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(kBackThreads), 0, s, gate.epoch_word, gate.expect, (const double*)A, ld, (const double*)y, x, info, flags, nflags, (const double*)inv);
   return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
 }
 
