@@ -400,7 +400,8 @@ def main():
                     rows.append((t_1 - t_0, t_2 - t_1, t_3 - t_2, t_3 - t_0))
             med = [1e3 * sorted(r[k] for r in rows)[len(rows) // 2] for k in range(4)]
             icl[label] = {"create_ms": med[0], "run_ms": med[1], "read_ms": med[2], "call_ms": med[3], "lm_iters": stw["n_iters"],
-                          "us_per_lm_iter": 1e3 * med[1] / max(stw["n_iters"], 1)}
+                          "solve_attempts": stw["n_trials"],  # (> lm_iters: rejected trials, each a complete reduce + solve + evaluate)
+                          "us_per_lm_iter": 1e3 * med[1] / max(stw["n_iters"], 1), "us_per_solve_attempt": 1e3 * med[1] / max(stw["n_trials"], 1)}
             # ... and repeated runs on ONE handle (reset + run), with the LM decisions on the device (default) and on the host
             for key, lmc in (("run_ms_repeated_lm_on_device", 0), ("run_ms_repeated_lm_on_host", 1)):
                 sw = B.hip_backend().create(Pw, B.default_options(device_id=local_rank, solver=a.solver, lm_control=lmc))

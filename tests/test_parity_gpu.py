@@ -317,7 +317,7 @@ def test_rejected_trials_follow_the_reference_schedule(oracle, hip, det, lm):
     # per-iteration bars.  Deterministic mode (reproducible): chi2 2e-4, lambda 3e-2 (measured 4e-5 / 6e-3).  Default mode: the same, or five times
     # what the ORACLE's own trace moves by on this window when only its rounding changes (its four re-runs: chi2 up to 1.7e-4, lambda 2.3e-2
     # per iteration) -- the order of the floating-point atomics is one more such change, and in about one run in twenty it is amplified
-    # to 5.5e-4 at an iteration that needed three solve attempts (40 repeats on MI355X, gpurun_out/flaky_a.txt, round 4).
+    # to 5.5e-4 at an iteration that needed three solve attempts (40 repeats on MI355X, profiles/r04_suite_runs.txt, round 4).
     runs = S.oracle_runs(oracle, P, B.default_options(), variants=S.VARIANTS)
     own_chi = own_lam = 0.0
     for st2, _ in runs[1:]:
@@ -335,7 +335,7 @@ def test_rejected_trials_follow_the_reference_schedule(oracle, hip, det, lm):
     else:
         # Default mode.  This window is NOT converged after 5 + 10 iterations (13 of its 30 solve attempts are rejected), so where a run stands
         # at the end hangs on every gain ratio on the way -- a small difference of two large chi2 values.  194 of 200 runs on MI355X
-        # (tools/rejected_window_diag.py, gpurun_out/rejected_diag.txt, round 4) stay within 4e-8 of the oracle's final cost; in the other
+        # (tools/rejected_window_diag.py, profiles/r04_rejected_window_diag.txt, round 4) stay within 4e-8 of the oracle's final cost; in the other
         # six the gain ratio of pass 2 / iteration 3 comes out 0.15 % lower (chi2 19.00 instead of 19.03 gained), lambda follows 0.7 % higher
         # from there on, and the run ends 1.67e-5 BELOW the oracle's final cost -- the same accept / reject sequence, the same levels, a
         # slightly better iterate.  Held: never worse than the oracle's final cost by more than 1e-6, never further than 1e-4 from it.
