@@ -21,12 +21,12 @@ struct PairChunks {
   int n_chunks;
 };
 
-// LM control on the device (ppo_kernels.hpp, LmCtl): a launch queued under epoch `expect` does nothing once the record has moved on
+// LM control on the device (ppo_lm.hpp, LmCtl): a launch queued under epoch `expect` does nothing once the record has moved on.  (Host-side
+// carrier only: the kernels take the two members as scalar arguments -- an aggregate argument ends the kernel-argument preload.)
 struct LmGate {
   const int* epoch_word;  // &LmCtl::epoch; NULL: not gated
   int expect;
 };
-__device__ __forceinline__ bool lm_gate_dead(const LmGate& g) { return g.epoch_word != nullptr && *g.epoch_word != g.expect; }
 
 // What the pair reduction reads and writes (a subset of Graph: the fused launches of the dense factorisation carry only this)
 struct PairCtx {
