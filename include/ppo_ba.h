@@ -206,7 +206,10 @@ typedef struct ppo_ba_options {
                              * optimization_algorithm_levenberg.cpp:102-163) are taken.  PPO_LM_DEVICE (0, default): by a kernel queued behind
                              * every trial, the host queues the next trial without waiting (single rank, native solver, deterministic = 0,
                              * verbose = 0; every other configuration takes the host path whatever this says).  PPO_LM_HOST (1): by the host
-                             * after a round trip per trial.  Same arithmetic, same results.  Anything else -> PPO_BA_ERR_ARG */
+                             * after a round trip per trial.  Same arithmetic (pow(x, 3) is a correctly rounded cube on the device: one ulp of
+                             * lambda in about one accepted trial in a thousand), same results.  PPO_LM_DEVICE queues up to five solve attempts
+                             * at once: the stop flag of ppo_ba_run is read between such batches, not before every attempt, and a rejected
+                             * trial costs ~12 us more than on the host path.  Anything else -> PPO_BA_ERR_ARG */
 } ppo_ba_options;
 
 /* one record per LM iteration (one OptimizationAlgorithmLevenberg::solve call) */
