@@ -26,6 +26,7 @@
 #include "ppo_chol.hpp"
 #include "ppo_comm.hpp"
 #include "ppo_kernels.hpp"
+#include "ppo_lm_host.hpp"
 #include "ppo_plan.hpp"
 #include "ppo_pool.hpp"
 
@@ -859,11 +860,6 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
 // batch's trial records to the host, which then puts its bookkeeping back to the first trial that went differently, queues what that
 // outcome asks for (a retry of the same iteration, a fresh linearisation) and goes on with a batch of one, doubling while the assumption
 // holds.  The stop flag is read between batches.  Single rank, floating-point accumulation, native solver (ppo_ba_create decides).
-constexpr int kLookahead = 5;  // trials per batch at most (<= kRecSlots)
-struct TrialBook {  // the host-side bookkeeping a queued trial changes
-  int cur, lin_buf;
-  bool lin_clean[2], S_is_zero, reduce_overlapped, have_system;
-};
 TrialBook book_of(const ppo_ba_solver* s) { return TrialBook{s->cur, s->lin_buf, {s->lin_clean[0], s->lin_clean[1]}, s->S_is_zero, s->reduce_overlapped, s->have_system}; }
 void restore_book(ppo_ba_solver* s, const TrialBook& b) {
   s->cur = b.cur;
@@ -872,7 +868,7 @@ void restore_book(ppo_ba_solver* s, const TrialBook& b) {
   s->S_is_zero = b.S_is_zero; s->reduce_overlapped = b.reduce_overlapped; s->have_system = b.have_system;
 }
 // reduction, solve, update, evaluation of the trial state and the decision: one trial, nothing waited for
-int enqueue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long long* seq_out) {
+int queue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long long* seq_out) {
   RC_TRY(launch_reduce(s, 0.0, true));  // (lambda: the kernels read the record)
   RC_TRY(launch_solve(s));
   s->have_system = true;
@@ -885,7 +881,7 @@ int enqueue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long
   *seq_out = dp.seq;
   return PPO_BA_OK;
 }
-int wait_records(ppo_ba_solver* s, unsigned long long seq) {
+int wait_for_records(ppo_ba_solver* s, unsigned long long seq) {
   volatile const unsigned long long* w = reinterpret_cast<volatile const unsigned long long*>(s->h_pinned + 16 + kRingSlots * kRingSlotDoubles);
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned it = 0; *w != seq; ++it) {
@@ -901,6 +897,36 @@ int wait_records(ppo_ba_solver* s, unsigned long long seq) {
   std::atomic_thread_fence(std::memory_order_acquire);
   return PPO_BA_OK;
 }
+// the device interface of lm_pipelined_pass (ppo_lm_host.hpp) on a solver
+struct SolverDev {
+  ppo_ba_solver* s;
+  bool stop() { return stop_now(s); }
+  TrialBook book() { return book_of(s); }
+  void restore(const TrialBook& b) { restore_book(s, b); }
+  void accept(bool speculated) {  // discardTop(): the trial state is the estimate, its linearisation the current system
+    s->cur ^= 1;
+    if (speculated) use_lin_buffer(s, s->lin_buf ^ 1);
+  }
+  int enqueue_trial(bool speculate, int n_publish, unsigned long long* seq) { return queue_trial(s, speculate, n_publish, seq); }
+  int wait_records(unsigned long long seq) { return wait_for_records(s, seq); }
+  const double* record(unsigned long long seq) { return s->h_pinned + 16 + (seq % kRingSlots) * kRingSlotDoubles; }
+  void set_epoch(int e) { s->epoch = e; s->g.epoch = e; }
+  int restore_kept_errors() { return launch_chi2(s, s->st[s->cur]); }
+  int relinearize(LmCtl& m) {
+    s->g.ctl = nullptr;
+    RC_TRY(launch_linearize(s));
+    RC_TRY(fetch_acc(s, false));
+    m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+    hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
+    s->g.ctl = s->d_ctl.p;
+    return PPO_BA_OK;
+  }
+  void count_trial() { s->stats.n_trials++; }
+  void push_stat(const ppo_ba_iter_stat& it) {
+    if (s->stats.n_iters < PPO_BA_MAX_ITER_STATS) s->stats.iters[s->stats.n_iters] = it;
+    s->stats.n_iters++;
+  }
+};
 int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
   // the head of the pass as lm_iteration does it: linearise the estimate, lambda from the largest diagonal entry (levenberg.cpp:166-180)
   s->g.ctl = nullptr;
@@ -918,85 +944,10 @@ int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
   hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
   s->g.ctl = s->d_ctl.p;
   s->g.epoch = s->epoch;
-  struct Queued { unsigned long long seq; TrialBook after; bool speculated; };
-  Queued q[kLookahead];
   int lookahead = kLookahead;
   if (const char* e = PPO_DEV_ENV("PPO_BA_LOOKAHEAD")) lookahead = std::max(1, std::min(atoi(e), kLookahead));  // (A/B: 1 = a hand-over per trial)
-  const int lookahead_cap = lookahead;
-  bool pass_over = false;  // the pass has ended (iteration count, termination)
-  ppo_ba_iter_stat it{};
-  it.pass = pass;
-  int rc = PPO_BA_OK;
-  auto accept_on_host = [&](bool speculated) {  // discardTop(): the trial state is the estimate, its linearisation the current system
-    s->cur ^= 1;
-    if (speculated) use_lin_buffer(s, s->lin_buf ^ 1);
-  };
-  while (rc == PPO_BA_OK && !pass_over && m.iter < iterations && !stop_now(s)) {
-    // a batch: trial j is queued as if trials 0 .. j - 1 had been accepted and had ended their iterations
-    const int n = std::min(lookahead, iterations - m.iter);
-    for (int j = 0; j < n && rc == PPO_BA_OK; ++j) {
-      if (j > 0) accept_on_host(q[j - 1].speculated);
-      q[j].speculated = m.iter + j + 1 < iterations;
-      rc = enqueue_trial(s, q[j].speculated, j == n - 1 ? n : 0, &q[j].seq);
-      q[j].after = book_of(s);
-    }
-    if (rc != PPO_BA_OK) break;
-    if ((rc = wait_records(s, q[n - 1].seq)) != PPO_BA_OK) break;
-    bool clean = true;
-    for (int j = 0; j < n && clean && rc == PPO_BA_OK; ++j) {
-      const double* r = s->h_pinned + 16 + (q[j].seq % kRingSlots) * kRingSlotDoubles;
-      if (r[REC_SEQ] != (double)q[j].seq || r[REC_DEAD] != 0.0) { rc = PPO_BA_ERR_HIP; break; }  // (a dead trial is never seen before the one that went differently)
-      const int code = (int)r[REC_CODE];
-      const bool accepted = r[REC_ACCEPTED] != 0.0;
-      s->stats.n_trials++;
-      it.iteration = (int)r[REC_ITER] - (code == LM_RETRY || code == LM_SOLVER_ERROR ? 0 : 1);
-      it.chi2_before = r[REC_CHI_BEFORE];
-      it.lambda = r[REC_LAMBDA];
-      it.trials = (int)r[REC_TRIALS];
-      it.accepted = accepted ? 1 : 0;
-      it.chi2_after = r[REC_CHI_AFTER];
-      m.lambda = r[REC_LAMBDA_NEXT]; m.ni = r[REC_NI]; m.nbad = (int)r[REC_NBAD]; m.chi_cur = r[REC_CHI_AFTER]; m.ini_chi = r[REC_INI_CHI];
-      m.iter = (int)r[REC_ITER]; m.qmax = (int)r[REC_QMAX]; m.epoch = (int)r[REC_EPOCH];
-      const bool as_assumed = accepted && code == LM_ITER_DONE;
-      if (as_assumed) {
-        if (j == n - 1) accept_on_host(q[j].speculated);  // (the others: applied when the next trial was queued)
-      } else {
-        // the trials queued behind it did not run: the bookkeeping goes back to "trial j queued, outcome open", then takes j's real outcome
-        clean = false;
-        restore_book(s, q[j].after);
-        s->epoch = m.epoch;  // (k_decide has moved the record on)
-        s->g.epoch = s->epoch;
-        if (accepted) accept_on_host(q[j].speculated);
-      }
-      if (code == LM_SOLVER_ERROR) { rc = PPO_BA_ERR_SOLVER; break; }
-      if (!accepted && (int)r[REC_INFO] != 0 && (rc = launch_chi2(s, s->st[s->cur])) != PPO_BA_OK) break;  // the kept state's per-edge errors back (see lm_iteration)
-      if (code == LM_RETRY) {
-        if (stop_now(s)) {  // the retry loop ends on the stop flag (levenberg.cpp:149): the iteration is over, rejected
-          it.result = 0;
-          if (s->stats.n_iters < PPO_BA_MAX_ITER_STATS) s->stats.iters[s->stats.n_iters] = it;
-          s->stats.n_iters++;
-          pass_over = true;
-        }
-        continue;  // (clean is false: the batch ends here, the next one starts with the retry)
-      }
-      // the iteration is over
-      it.result = code == LM_TERMINATE ? 1 : 0;
-      if (s->stats.n_iters < PPO_BA_MAX_ITER_STATS) s->stats.iters[s->stats.n_iters] = it;
-      s->stats.n_iters++;
-      if (code == LM_TERMINATE) pass_over = true;
-      if (!pass_over && !as_assumed && m.iter < iterations) {
-        // an iteration that ended on a rejected trial without terminating (rho is NaN): the next one starts from a fresh linearisation of
-        // the kept state, as lm_iteration's `fresh` branch does
-        s->g.ctl = nullptr;
-        if ((rc = launch_linearize(s)) != PPO_BA_OK) break;
-        if ((rc = fetch_acc(s, false)) != PPO_BA_OK) break;
-        m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
-        hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
-        s->g.ctl = s->d_ctl.p;
-      }
-    }
-    lookahead = clean ? std::min(lookahead_cap, 2 * lookahead) : 1;
-  }
+  SolverDev dev{s};
+  const int rc = lm_pipelined_pass(dev, pass, iterations, m, lookahead);  // (ppo_lm_host.hpp: the batch loop, also run on the CPU against a simulated device)
   // (on an error return launches may still be queued: they are gated or harmless, the caller gives the handle up or resets it)
   s->g.ctl = nullptr;
   s->lambda = m.lambda; s->ni = m.ni; s->nBad = m.nbad; s->chi_cur = m.chi_cur;

@@ -156,6 +156,19 @@ def test_the_device_decision_is_the_reference_loop_body():
     assert n_one_ulp <= n_acc // 100, (n_one_ulp, n_acc)
 
 
+def test_batch_queueing_against_a_simulated_device(tmp_path):
+    """tests/lm_pipeline_test.cpp: the host loop of the device-side LM control (csrc/ppo_lm_host.hpp -- the code ppo_solver.hip runs) over a
+    simulated device that executes queued solve attempts through lm_decide, turns attempts queued under an outdated epoch into no-ops and
+    checks that every LIVE attempt was queued on the true bookkeeping; 4 000 random scripts of accepted / marginal / rejected / NaN /
+    failed-factorisation / no-change outcomes, iteration statistics against a serial walk through levenberg.cpp:61-164; the stop flag."""
+    import subprocess
+    exe = tmp_path / "lm_pipeline_test"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unknown-pragmas", os.path.join(HERE, "lm_pipeline_test.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "lm_pipeline_test ok" in out.stdout, out.stdout + out.stderr
+    print(out.stdout.strip())
+
+
 def _hip():
     return B.hip_backend()
 
