@@ -1037,6 +1037,8 @@ __global__ __launch_bounds__(kBackThreads) void chol_back_all(const int* gate_wo
   STAMPB(31);
 }
 
+#include "ppo_chol_small.inc"  // chol_small: n <= 192 in one launch of one workgroup, the matrix in LDS
+
 struct GraphKey {
   double* A;
   const double* b;
@@ -1086,8 +1088,13 @@ size_t inv_offset(int ld) {
 
 // One launch per panel + one for the backward substitution.  (The one-launch factorisation, ppo_chol_fwd.inc, exists only in the
 // test-hooks build: PPO_BA_CHOL_ONELAUNCH=1 selects it there; DESIGN.md 4.1 has the measurement.)
-int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s, const CholOverlap* ov = nullptr, LmGate gate = LmGate{nullptr, 0}) {
+int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s, const CholOverlap* ov = nullptr, LmGate gate = LmGate{nullptr, 0}, int n_active = -1) {
   const int nb = ld / NB;
+  if (chol_small_applies(ld, n_active) && (!ov || ov->fin[0] >= nb)) {  // (an overlapped reduction must have left nothing for the panel launches to carry)
+    const int n = (n_active > 0 && n_active <= ld) ? n_active : ld;
+    hipLaunchKernelGGL(chol_small, dim3(1), dim3(kSmallThreads), 0, s, gate.epoch_word, gate.expect, (const double*)A, ld, n, ov ? (const double*)ov->ctx.bs : b, x, info);
+    return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
+  }
   double* y = ov ? ov->ctx.bs : ws;  // [ld] forward-substituted right-hand side (overlapped reduction: in place, the pair workgroups add to it)
   int* flags = nullptr;
   int nflags = 0;
@@ -1139,10 +1146,10 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
 }  // namespace
 
 // A: ld x ld column-major with ld a multiple of 64 (chol_padded_ld), lower triangle valid, pad diagonal = 1.
-int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t stream, LmGate gate) {
+int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t stream, LmGate gate, int n_active) {
   if (ld % NB != 0) return PPO_BA_ERR_ARG;
   if (ld == 0) return PPO_BA_OK;
-  if (gate.epoch_word) return enqueue_all(A, ld, b, x, info, ws, stream, nullptr, gate);
+  if (gate.epoch_word || chol_small_applies(ld, n_active)) return enqueue_all(A, ld, b, x, info, ws, stream, nullptr, gate, n_active);
   // Plain launches by default: with ~16 us per panel kernel the host stays ahead of the device and a hipGraph replay only
   // adds its entry/exit boundaries (measured 1826 vs 1834 LM iterations/s); PPO_BA_CHOL_GRAPH=1 selects the captured graph
   // (it paid when the solve was 56 short launches).
@@ -1169,10 +1176,22 @@ int chol_factor_solve(double* A, int ld, const double* b, double* x, int* info, 
 }
 
 // The overlapped variant: S's column blocks [fin[0], nb) are still being reduced by pair workgroups inside the first launches.
-int chol_factor_solve_overlapped(double* A, int ld, double* x, int* info, double* ws, const CholOverlap& ov, hipStream_t stream) {
+int chol_factor_solve_overlapped(double* A, int ld, double* x, int* info, double* ws, const CholOverlap& ov, hipStream_t stream, int n_active) {
   if (ld % NB != 0 || kStepThreads != 512 || !ov.fin || !ov.cb_start) return PPO_BA_ERR_ARG;
   if (ld == 0) return PPO_BA_OK;
-  return enqueue_all(A, ld, ov.ctx.bs, x, info, ws, stream, &ov, ov.gate);
+  return enqueue_all(A, ld, ov.ctx.bs, x, info, ws, stream, &ov, ov.gate, n_active);
+}
+
+// The one-launch solve of small systems (ppo_chol_small.inc) handles up to 192 unknowns; it is USED where it is the faster of the two
+// (tools/chol_small_check.hip on MI355X, us per solve, one launch | panel path): n = 16: 7 | 18.5, 48: 14 | 18.5, 64: 17 | 18.5, 84: 27 | 31.5,
+// 96: 27 | 31.5, 128: 37 | 31.5, 174: 55 | 45, 192: 62 | 45 -- one compute unit's FP64 matrix rate (44 ns per v_mfma_f64_16x16x4 and SIMD,
+// measured) bounds the trailing updates of the first tile columns once n > 100.  PPO_BA_CHOL_SMALL (test-hooks build): 0 keeps every window on
+// the panel path, N > 0 moves the crossover to N unknowns (<= 192) -- so that both paths stay covered by the same tests.
+bool chol_small_applies(int ld, int n_active) {
+  const char* e = PPO_DEV_ENV("PPO_BA_CHOL_SMALL");  // (read on every call in the test-hooks build: a test switches it; the product build has no environment)
+  const int limit = e ? std::max(0, std::min(atoi(e), 192)) : 96;
+  const int n = (n_active > 0 && n_active <= ld) ? n_active : ld;
+  return ld > 0 && ld <= 192 && n <= limit;
 }
 
 // fin[k], k = 0 .. nb: column blocks of S that are final when launch k starts (fin[nb] = nb).  The reduction ahead of the factorisation

@@ -616,10 +616,10 @@ int launch_solve_local(ppo_ba_solver* s) {
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
     if (s->reduce_overlapped) {
       CholOverlap ov{pair_ctx_host(g), s->pc, s->cb_start.data(), s->fin.data(), lm_gate(s)};
-      RC_TRY(chol_factor_solve_overlapped(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, ov, s->stream));
+      RC_TRY(chol_factor_solve_overlapped(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, ov, s->stream, n));
       s->reduce_overlapped = false;
     } else {
-      RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs_p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream, lm_gate(s)));
+      RC_TRY(chol_factor_solve(s->d_S.p, ld, s->d_bs_p, s->d_xr.p, s->d_info.p, s->d_cholws.p, s->stream, lm_gate(s), n));
     }
   } else {
     HIP_TRY(hipMemcpyAsync(s->d_xr.p, s->d_bs_p, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -1826,9 +1826,13 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       if (e[0] == '0' && e[1] == 0) enabled = false;
       else std::sscanf(e, "%d,%lf,%lf,%d,%d", &first_blocks, &share0, &share, &min_chunks, &min_nb);
     }
-    if (enabled && nb >= std::max(2, min_nb) && (int)s->cb_start.size() == nb + 1 && s->cb_start[nb] == s->pc.n_chunks && s->pc.n_chunks >= std::max(1, min_chunks)) {
+    // round 5: a small system (ppo_chol.hip: chol_small_applies) is solved by ONE launch with the matrix in LDS (ppo_chol_small.inc): no panel launches to hide pair
+    // chunks in, so the WHOLE reduction rides in stage 1's launch (fin[0] = nb: what the fused first stage already does for the first column block)
+    const bool small = s->solver_kind == PPO_SOLVER_NATIVE && chol_small_applies(s->g.ld, s->g.n_red);
+    if (small) min_nb = 1;
+    if (enabled && nb >= std::max(small ? 1 : 2, min_nb) && (int)s->cb_start.size() == nb + 1 && s->cb_start[nb] == s->pc.n_chunks && s->pc.n_chunks >= std::max(1, min_chunks)) {
       s->fin.assign(nb + 1, nb);
-      chol_overlap_schedule(nb, s->cb_start.data(), first_blocks, share0, share, s->fin.data());
+      if (!small) chol_overlap_schedule(nb, s->cb_start.data(), first_blocks, share0, share, s->fin.data());
     }
   }
   // algorithmic bytes of one linearisation, SURVEY.md 8(d)

@@ -178,6 +178,50 @@ def test_native_cholesky_matches_rocsolver_and_oracle_ldlt(oracle_lib, hip, cfg,
     assert np.abs(xo - x).max() <= 1e-8 * np.abs(xo).max()
 
 
+@pytest.mark.parametrize("n_kf", [3, 4, 6, 9, 12, 15, 17, 23, 30, 33])
+def test_one_launch_solve_of_small_systems_against_the_panel_path(hip_hooks, monkeypatch, n_kf):
+    """Reduced systems of at most 192 unknowns can be solved by ONE launch with the matrix in one compute unit (csrc/ppo_chol_small.inc; the product uses
+    it up to 96 unknowns, where it is the faster path).  The same reduced system through that kernel (PPO_BA_CHOL_SMALL=192: wherever it can run) and
+    through the panel path (=0), both against numpy on the matrix the library hands out; then a complete 5 + 10 run on either path."""
+    P = synth.make_problem(dict(n_kf=n_kf, n_points=60 * n_kf, n_planes=min(4, n_kf), n_cuboids=2 if n_kf > 3 else 0), seed=20 + n_kf)
+    xs, runs = {}, {}
+    for mode in ("192", "0"):
+        monkeypatch.setenv("PPO_BA_CHOL_SMALL", mode)
+        s = hip_hooks.create(P, B.default_options(solver=2))
+        n = C.c_int32()
+        hip_hooks.lib.ppo_ba_debug_set_lambda(s.h, C.c_double(2.0))
+        hip_hooks.lib.ppo_ba_debug_reduced(s.h, None, None, None, C.byref(n))
+        n = n.value
+        assert n == 6 * (n_kf - 1)
+        S, b, x = np.zeros((n, n)), np.zeros(n), np.zeros(n)
+        assert hip_hooks.lib.ppo_ba_debug_reduced(s.h, dptr(S), dptr(b), dptr(x), None) == 0
+        assert np.all(np.isfinite(x)) and np.linalg.norm(S @ x - b) <= 1e-9 * np.linalg.norm(b)
+        assert np.abs(x - np.linalg.solve(S, b)).max() <= 1e-9 * np.abs(x).max()
+        xs[mode] = x
+        s.reset()
+        runs[mode] = (s.run(), s.read())
+        s.close()
+    assert np.abs(xs["192"] - xs["0"]).max() <= 1e-10 * np.abs(xs["0"]).max()
+    (ta, ra), (tb, rb) = runs["192"], runs["0"]
+    assert [i["trials"] for i in ta["iters"]] == [i["trials"] for i in tb["iters"]]
+    assert abs(ta["iters"][-1]["chi2_after"] - tb["iters"][-1]["chi2_after"]) <= 1e-6 * tb["iters"][-1]["chi2_after"]
+    compare_states(rb, ra)
+
+
+def test_one_launch_solve_reports_a_matrix_that_is_not_positive(hip_hooks, monkeypatch):
+    """levenberg.cpp:126-127 treats a failed LDLT as a rejected trial; the one-launch kernel must raise the same flag as the panel path: the
+    indefinite window of the failed-factorisation tests below walks the same schedule on either path."""
+    P, kw = _not_positive_window()
+    stats = {}
+    for mode in ("192", "0"):
+        monkeypatch.setenv("PPO_BA_CHOL_SMALL", mode)
+        s = hip_hooks.create(P, B.default_options(solver=2, **kw))
+        stats[mode] = s.run()
+        s.close()
+    sched = lambda t: [(i["trials"], i["accepted"], i["result"]) for i in t["iters"]]
+    assert sched(stats["192"]) == sched(stats["0"]) and sched(stats["0"])[:2] == [(1, 1, 0), (2, 0, 1)]
+
+
 def test_native_cholesky_beyond_the_resident_chain(hip):
     """A window with more 64-column blocks (34) than workgroups of the backward substitution fit on the one XCD they all run on (32): the chain
     must make progress with part of it resident (its head is the first workgroup dispatched) and its ring of x blocks must wrap.  Native

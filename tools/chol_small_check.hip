@@ -1,0 +1,124 @@
+// chol_small_check.hip -- development probe (not part of the product): the one-launch solve of small systems (csrc/ppo_chol_small.inc)
+// against a host Cholesky on random SPD matrices of every size class, and its time next to the per-panel path (argv[1] = "panels":
+// PPO_BA_CHOL_SMALL=0 of the test-hooks build).  Build + run: tools/run_chol_small_check.sh
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define PPO_BA_TEST_HOOKS 1
+__device__ long long g_ss[8 * 64];
+#ifndef NO_STAMPS
+#define STAMPS(slot) do { if ((threadIdx.x & 63) == 0) g_ss[(threadIdx.x >> 6) * 64 + (slot)] = wall_clock64(); } while (0)
+#endif
+#include "../point-plane-object-slam_amd/csrc/ppo_chol.hip"
+
+static bool host_solve(int n, int ld, const std::vector<double>& A, const std::vector<double>& b, std::vector<double>& x) {
+  std::vector<long double> L((size_t)n * n, 0.0L), y(n);
+  for (int j = 0; j < n; ++j) {
+    long double d = A[(size_t)j * ld + j];
+    for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(d > 0)) return false;
+    d = sqrtl(d);
+    L[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      long double v = A[(size_t)j * ld + i];
+      for (int k = 0; k < j; ++k) v -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = v / d;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    long double v = b[i];
+    for (int k = 0; k < i; ++k) v -= L[(size_t)i * n + k] * y[k];
+    y[i] = v / L[(size_t)i * n + i];
+  }
+  x.assign(n, 0.0);
+  for (int i = n - 1; i >= 0; --i) {
+    long double v = y[i];
+    for (int k = i + 1; k < n; ++k) v -= L[(size_t)k * n + i] * (long double)x[k];
+    x[i] = (double)(v / L[(size_t)i * n + i]);
+  }
+  return true;
+}
+
+static int run(int n, bool panels, int reps, int bad_at = -1) {
+  const int ld = ppo::chol_padded_ld(n);
+  std::vector<double> A((size_t)ld * ld, 0.0), b(ld, 0.0);
+  srand(1000 + n);
+  for (int c = 0; c < n; ++c)
+    for (int r = c; r < n; ++r) A[(size_t)c * ld + r] = (r == c) ? 6.0 + (rand() % 100) * 0.05 : ((rand() % 2001) - 1000) * 2e-5 * (1.0 + 6.0 / (1 + (r - c)));
+  for (int c = 0; c < ld; ++c)
+    for (int r = 0; r < c; ++r) A[(size_t)c * ld + r] = NAN;  // the upper triangle is nobody's business
+  if (bad_at >= 0) A[(size_t)bad_at * ld + bad_at] = -1.0;
+  for (int c = n; c < ld; ++c) A[(size_t)c * ld + c] = 1.0;
+  for (int r = 0; r < n; ++r) b[r] = 1.0 + 0.01 * (r % 17) - 0.3 * (r % 3);
+  double *dA, *dA0, *dx, *db, *dws; int* dinfo;
+  const size_t wsn = ppo::chol_workspace_doubles(n);
+  hipMalloc((void**)&dA, A.size() * 8); hipMalloc((void**)&dA0, A.size() * 8); hipMalloc((void**)&dx, ld * 8); hipMalloc((void**)&db, ld * 8);
+  hipMalloc((void**)&dws, wsn * 8); hipMalloc((void**)&dinfo, 4);
+  hipMemset(dws, 0, wsn * 8);
+  hipMemcpy(dA0, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(db, b.data(), ld * 8, hipMemcpyHostToDevice);
+  hipStream_t s; hipStreamCreate(&s);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  double best = 1e30, sum = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
+    hipEventRecord(e0, s);
+    ppo::chol_factor_solve(dA, ld, db, dx, dinfo, dws, s, ppo::LmGate{nullptr, 0}, n);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms * 1e3 < best) best = ms * 1e3;
+    if (rep) sum += ms * 1e3;
+  }
+  std::vector<double> x(ld), xh;
+  int info = -1;
+  hipMemcpy(x.data(), dx, ld * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
+  int fail = 0;
+  if (bad_at >= 0) {
+    printf("n %3d %-9s: leading minor %d not positive -> info %d %s\n", n, panels ? "panels" : "one launch", bad_at + 1, info, info == bad_at + 1 ? "ok" : "WRONG");
+    fail = info != bad_at + 1;
+  } else {
+    const bool ok = host_solve(n, ld, A, b, xh);
+    double emax = 0, xmax = 0, pad = 0;
+    for (int i = 0; i < n; ++i) { emax = fmax(emax, fabs(x[i] - xh[i])); xmax = fmax(xmax, fabs(xh[i])); }
+    for (int i = n; i < ld; ++i) pad = fmax(pad, fabs(x[i]));
+    fail = !ok || info != 0 || !(emax <= 1e-11 * xmax) || pad != 0.0;
+    printf("n %3d (ld %3d) %-9s: best %.1f us, mean %.1f us, info %d, max |x - x_host| / max |x| %.2e, pad %.1e %s\n", n, ld, panels ? "panels" : "one launch", best,
+           sum / (reps - 1), info, emax / xmax, pad, fail ? "WRONG" : "ok");
+  }
+  hipFree(dA); hipFree(dA0); hipFree(dx); hipFree(db); hipFree(dws); hipFree(dinfo);
+  return fail;
+}
+
+int main(int argc, char** argv) {
+  const bool panels = argc > 1 && argv[1][0] == 'p';
+  setenv("PPO_BA_CHOL_SMALL", panels ? "0" : "1", 1);
+  int fails = 0;
+  const int sizes[] = {1, 6, 15, 16, 17, 30, 48, 64, 65, 84, 96, 100, 128, 129, 150, 174, 176, 177, 180, 186, 191, 192};
+  for (int n : sizes) fails += run(n, panels, 8);
+  const int bads[][2] = {{84, 0}, {84, 37}, {174, 173}, {192, 100}, {30, 16}};
+  for (auto& bd : bads) fails += run(bd[0], panels, 2, bd[1]);
+#ifndef NO_STAMPS
+  if (!panels) {
+    for (int n : {96, 192}) {
+      run(n, false, 3);
+      static long long st[8 * 64];
+      hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ss), sizeof(st));
+      const long long t0 = st[0];
+      const int nt = (n + 15) / 16;
+      auto us = [&](int w, int slot) { return (st[w * 64 + slot] - t0) * 0.01; };
+      printf("timeline n = %d (us since the first barrier): column 0 in LDS wave 0 %.2f, owner 1 %.2f, wave 4 %.2f\n", n, us(0, 1), us(1, 1), us(4, 1));
+      for (int k = 0; k < nt; ++k)
+        printf("  k %2d: potf2 %.2f .. %.2f | owner 1 / owner 7: S(k-1) done %.2f %.2f, potf seen %.2f %.2f, near done %.2f %.2f, P2 done %.2f %.2f | y_k %.2f\n", k, us(0, 4 + 4 * k), us(0, 5 + 4 * k),
+               us(1, 4 + 4 * k), us(7, 4 + 4 * k), us(1, 5 + 4 * k), us(7, 5 + 4 * k), us(1, 6 + 4 * k), us(7, 6 + 4 * k), us(1, 7 + 4 * k), us(7, 7 + 4 * k), us(4, 6 + 4 * k));
+      for (int w : {1, 2, 3, 5, 6, 7}) printf("  S(0) owner wave %d: p2 seen %.2f | after pairs %.2f %.2f %.2f %.2f %.2f | slot 10 %.2f | rhs rows %.2f\n", w, us(w, 52), us(w, 53), us(w, 54), us(w, 55), us(w, 56), us(w, 57), us(w, 58), us(w, 59));
+      printf("  G formed %.2f | backward done %.2f | x written %.2f\n", us(0, 60), us(0, 61), us(0, 62));
+    }
+  }
+#endif
+  printf("%s\n", fails ? "FAILED" : "all ok");
+  return fails ? 1 : 0;
+}
