@@ -31,6 +31,15 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden and a version script: the entry points declared here (and in ppo_pose.h) are its ONLY dynamic
+ * symbols, so that it can be loaded into a process that already holds g2o, Eigen, OpenCV and other ROCm libraries (no rocprim, STL or
+ * ppo:: instantiation of this library can interpose on, or be interposed by, theirs). */
+#if defined(__GNUC__)
+#define PPO_API __attribute__((visibility("default")))
+#else
+#define PPO_API
+#endif
+
 #define PPO_BA_ABI_VERSION 2  /* 2: the 9-D camera-object edge (cub3d_*), th_cub3d_norm */
 
 /* return codes: 0 ok, <0 error, >0 early termination */
@@ -206,7 +215,7 @@ typedef struct ppo_ba_options {
                              * optimization_algorithm_levenberg.cpp:102-163) are taken.  PPO_LM_DEVICE (0, default): by a kernel queued behind
                              * every trial, the host queues the next trial without waiting (single rank, native solver, deterministic = 0,
                              * verbose = 0; every other configuration takes the host path whatever this says).  PPO_LM_HOST (1): by the host
-                             * after a round trip per trial.  Same arithmetic (pow(x, 3) is a correctly rounded cube on the device: one ulp of
+                             * after a round trip per trial.  Same arithmetic (pow(x, 3) is a cube within one ulp on the device: one ulp of
                              * lambda in about one accepted trial in a thousand), same results.  PPO_LM_DEVICE queues up to five solve attempts
                              * at once: the stop flag of ppo_ba_run is read between such batches, not before every attempt, and a rejected
                              * trial costs ~12 us more than on the host path.  Anything else -> PPO_BA_ERR_ARG */
@@ -263,38 +272,38 @@ typedef struct ppo_ba_result {
 
 typedef struct ppo_ba_solver* ppo_ba_handle;
 
-int ppo_ba_version(void);
-const char* ppo_ba_strerror(int code);
+PPO_API int ppo_ba_version(void);
+PPO_API const char* ppo_ba_strerror(int code);
 
 /* fills *o with the reference's constants (the comments on ppo_ba_options) */
-void ppo_ba_default_options(ppo_ba_options* o);
+PPO_API void ppo_ba_default_options(ppo_ba_options* o);
 
 /* validate + copy + upload once.  Fails with PPO_BA_ERR_HIP when no gfx950 device is usable.
  * Host threads: the flattening passes run on a process-wide worker team of min(hardware threads - 1, 7) threads, started on first
  * use and asleep between calls; the environment variable PPO_BA_HOST_THREADS=n caps the total (1: the calling thread only). */
-int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handle* out);
+PPO_API int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handle* out);
 
 /* pass 1, outlier classification, pass 2.  stop_flag (may be NULL) is polled before the start,
  * between the passes, before every LM iteration and every LM trial, like g2o's _forceStopFlag. */
-int ppo_ba_run(ppo_ba_handle h, const volatile uint8_t* stop_flag, ppo_ba_stats* stats);
+PPO_API int ppo_ba_run(ppo_ba_handle h, const volatile uint8_t* stop_flag, ppo_ba_stats* stats);
 
-int ppo_ba_read(ppo_ba_handle h, ppo_ba_result* r);
+PPO_API int ppo_ba_read(ppo_ba_handle h, ppo_ba_result* r);
 
-void ppo_ba_destroy(ppo_ba_handle h); /* NULL-safe */
+PPO_API void ppo_ba_destroy(ppo_ba_handle h); /* NULL-safe */
 
 /* -- measurement and test hooks (not part of the reference seam) ---------------------------------- */
 
 /* Re-upload the initial estimates and reset edge levels / robust kernels, so that run() can be timed
  * repeatedly on one handle with inputs already resident in HBM. */
-int ppo_ba_reset(ppo_ba_handle h);
+PPO_API int ppo_ba_reset(ppo_ba_handle h);
 
 /* One linearisation of the current state: fills the block-sparse system and returns sum(rho0).
  * Used by bench.py to time the Jacobian/assembly kernels in isolation and by the parity tests. */
-int ppo_ba_linearize(ppo_ba_handle h, double* robust_chi2);
+PPO_API int ppo_ba_linearize(ppo_ba_handle h, double* robust_chi2);
 
 /* Time `reps` back-to-back launches of the linearise/assemble kernel group with HIP events on the
  * library's own stream; returns average milliseconds per linearisation in *ms. */
-int ppo_ba_time_linearize(ppo_ba_handle h, int reps, double* ms);
+PPO_API int ppo_ba_time_linearize(ppo_ba_handle h, int reps, double* ms);
 
 /* Time ONE kernel of the path alone: `reps` back-to-back launches between two HIP events on the library's own
  * stream; *ms = average per launch (agrees with rocprofv3's average duration up to the inter-launch gap),
@@ -309,16 +318,16 @@ enum {
   PPO_BA_KERNEL_CHI2_POINTS = 5,
   PPO_BA_KERNEL_LINEARIZE_ALL = 6 /* the fused linearisation launch of the product path (no zeroing) */
 };
-int ppo_ba_time_kernel(ppo_ba_handle h, int which, int reps, double* ms, int64_t* bytes);
+PPO_API int ppo_ba_time_kernel(ppo_ba_handle h, int which, int reps, double* ms, int64_t* bytes);
 
 /* Sharded runs (every rank calls it): average milliseconds of the exchange steps of ONE solve attempt, each timed alone with HIP events:
  * out[0] pack + all-reduce of (S, b) + unpack, out[1] pack + reduce to rank 0 + unpack there + broadcast of x and the flag
  * (options.solve_on_owner), out[2] the all-reduce of the three trial scalars, out[3] bytes of the packed (S, b).  Zeros on a single rank.
  * S, b, x hold garbage afterwards: ppo_ba_reset() before the next run. */
-int ppo_ba_time_collectives(ppo_ba_handle h, int reps, double* out);
+PPO_API int ppo_ba_time_collectives(ppo_ba_handle h, int reps, double* out);
 
 /* Time `reps` factorisations of the current reduced system (HIP events); average ms in *ms. */
-int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
+PPO_API int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
 
 /* The Schur reduction of windows with enough panels is OVERLAPPED with the dense factorisation (csrc/ppo_chol.hip): only the
  * pose-pair chunks of the first column blocks of the reduced matrix are reduced ahead of it, the first panel launches carry the rest.
@@ -326,26 +335,26 @@ int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
  * number of column blocks that are final when launch k starts (fin[0]: reduced ahead of the factorisation); 0 when the reduction of this
  * window is not overlapped (few panels, deterministic mode, sharded runs, the rocSOLVER backend).  ppo_ba_time_factor() times the dense
  * solve ALONE, after a complete reduction. */
-int ppo_ba_overlap_schedule(ppo_ba_handle h, int32_t* fin, int32_t n);
+PPO_API int ppo_ba_overlap_schedule(ppo_ba_handle h, int32_t* fin, int32_t n);
 /* The schedule rule itself (host only, no GPU needed): for n_blocks 64-column blocks whose pose-pair chunks start at first_chunk[c]
  * (n_blocks + 1 entries, non-decreasing), fin[0 .. n_blocks] as ppo_ba_create would choose it with `first_blocks` blocks reduced ahead and at
  * most share0 / share of all chunks carried by launch 0 / by every later launch.  Guarantees: fin is non-decreasing, fin[k] >= min(n_blocks,
  * k + 1) (the column workgroups of launch k only read final blocks), fin[n_blocks] = n_blocks. */
-int ppo_ba_overlap_plan(int32_t n_blocks, const int32_t* first_chunk, int32_t first_blocks, double share0, double share, int32_t* fin);
+PPO_API int ppo_ba_overlap_plan(int32_t n_blocks, const int32_t* first_chunk, int32_t first_blocks, double share0, double share, int32_t* fin);
 
 /* Re-linearise the current state and build the reduced system for the damping set with
  * ppo_ba_debug_set_lambda(): S is n*n column-major (returned symmetric), b the Schur right-hand side, x the
  * solution of S x = b.  n = ppo_ba_stats.n_reduced.  Any pointer may be NULL. */
-int ppo_ba_debug_set_lambda(ppo_ba_handle h, double lambda);
-int ppo_ba_debug_reduced(ppo_ba_handle h, double* S, double* b, double* x, int32_t* n);
+PPO_API int ppo_ba_debug_set_lambda(ppo_ba_handle h, double lambda);
+PPO_API int ppo_ba_debug_reduced(ppo_ba_handle h, double* S, double* b, double* x, int32_t* n);
 
 /* Graph dump / replay (host only, no device needed).  ppo_ba_problem_save() writes every array of the
  * problem to one binary file (layout in csrc/ppo_io.cpp); ppo_ba_problem_load() returns a problem that owns its arrays and
  * must be released with ppo_ba_problem_free().  A maintainer of the reference calls save() next to ppo_ba_create() to
  * capture real local-BA windows; tools/replay.py runs a capture through the solver (and, where built, the oracle). */
-int ppo_ba_problem_save(const ppo_ba_problem* problem, const char* path);
-int ppo_ba_problem_load(const char* path, ppo_ba_problem** problem);
-void ppo_ba_problem_free(ppo_ba_problem* problem);
+PPO_API int ppo_ba_problem_save(const ppo_ba_problem* problem, const char* path);
+PPO_API int ppo_ba_problem_load(const char* path, ppo_ba_problem** problem);
+PPO_API void ppo_ba_problem_free(ppo_ba_problem* problem);
 
 /* End-of-run text exports in the reference's formats (src/System.cc:402-494; the second half of SURVEY.md 8(f) N3).  Host only.
  *   tum:     one line per keyframe "timestamp tx ty tz qx qy qz qw" -- camera centre and camera-to-world rotation of the
@@ -353,27 +362,34 @@ void ppo_ba_problem_free(ppo_ba_problem* problem);
  *   cuboids: "class x y z roll pitch yaw sx sy sz" = cuboid::toMinimalVector (include/g2o_cuboid.h:143-162), fixed, 6 decimals;
  *            class_names may be NULL ("object")
  *   planes:  "index a b c d" as float32, fixed, 6 decimals */
-int ppo_ba_export_tum(const char* path, int32_t n, const double* timestamps, const double* pose_qt);
-int ppo_ba_export_cuboids(const char* path, int32_t n, const char* const* class_names, const double* cuboid_qt, const double* cuboid_scale);
-int ppo_ba_export_planes(const char* path, int32_t n, const double* plane_coef);
+PPO_API int ppo_ba_export_tum(const char* path, int32_t n, const double* timestamps, const double* pose_qt);
+PPO_API int ppo_ba_export_cuboids(const char* path, int32_t n, const char* const* class_names, const double* cuboid_qt, const double* cuboid_scale);
+PPO_API int ppo_ba_export_planes(const char* path, int32_t n, const double* plane_coef);
 
 /* ppo_ba_destroy() keeps device blocks, streams and the mapped host block of the solver in a process-wide cache so that
  * the next ppo_ba_create() -- one per local-BA call in the reference -- does not pay for ~60 allocations again (capped at
  * 4 GiB).  This call returns everything cached to the driver; live solvers are not affected. */
-int ppo_ba_release_cached(void);
+PPO_API int ppo_ba_release_cached(void);
+
+/* Pays the process-wide first-use costs up front: loading the library's code objects onto `device`, the stream and the mapped host block, the host
+ * team, the block cache (~155 ms on MI355X, otherwise part of the FIRST ppo_ba_create of the process -- i.e. of the first local bundle
+ * adjustment of a SLAM run, src/LocalMapping.cc:100).  Runs one tiny window with every vertex / edge class and one pose-only frame through the
+ * public entry points.  Call once, e.g. from System's constructor next to where the threads are spawned (src/System.cc:95-119).
+ * Returns PPO_BA_OK or the negative code of the step that failed; calling it again is harmless (a few hundred microseconds). */
+PPO_API int ppo_ba_warmup(int device);
 
 /* Algorithmic bytes of one linearisation (SURVEY.md 8(d) formula) for the problem in h. */
-int64_t ppo_ba_linearize_bytes(ppo_ba_handle h);
+PPO_API int64_t ppo_ba_linearize_bytes(ppo_ba_handle h);
 
 /* Host-only helpers (no GPU needed). */
 /* sizeof() of the ABI structs as THIS library was compiled: 0 ppo_ba_problem, 1 ppo_ba_options, 2 ppo_ba_stats, 3 ppo_ba_result,
  * 4 ppo_ba_iter_stat; -1 otherwise.  A binding (ctypes, cgo ...) compares its own mirror against it instead of trusting a count. */
-int64_t ppo_ba_sizeof(int32_t which);
+PPO_API int64_t ppo_ba_sizeof(int32_t which);
 /* Range-partition landmarks (points then planes) into world_size contiguous edge-balanced ranges:
  * fills first_point[world_size+1], first_plane[world_size+1]. */
-int ppo_ba_partition(const ppo_ba_problem* p, int32_t world_size, int32_t* first_point, int32_t* first_plane);
+PPO_API int ppo_ba_partition(const ppo_ba_problem* p, int32_t world_size, int32_t* first_point, int32_t* first_plane);
 /* 128-byte RCCL unique id for ppo_ba_options.comm_id (call on rank 0, broadcast to the others). */
-int ppo_ba_comm_unique_id(uint8_t id[128]);
+PPO_API int ppo_ba_comm_unique_id(uint8_t id[128]);
 
 #ifdef __cplusplus
 }

@@ -72,10 +72,17 @@ typedef struct ppo_pose_result {
   ppo_pose_stats* stats;        /* [n_frames] */
 } ppo_pose_result;
 
-void ppo_pose_default_options(ppo_pose_options* o);
+#ifndef PPO_API
+#if defined(__GNUC__)
+#define PPO_API __attribute__((visibility("default")))
+#else
+#define PPO_API
+#endif
+#endif
+PPO_API void ppo_pose_default_options(ppo_pose_options* o);
 
 /* returns PPO_BA_OK or a negative PPO_BA_ERR_* code */
-int ppo_pose_optimize(const ppo_pose_problem* p, const ppo_pose_options* o, ppo_pose_result* r);
+PPO_API int ppo_pose_optimize(const ppo_pose_problem* p, const ppo_pose_options* o, ppo_pose_result* r);
 
 #ifdef __cplusplus
 }

@@ -629,6 +629,9 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     if (tid >= 256) return;  // loader waves
     v4d acc[2][2] = {};
     quadrant_product(sP, sQ, wr, wc, li, lk, acc);
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND)
+    quadrant_product(sP, sQ, wr, wc, li, lk, acc);  // (a pair launch's trailing tiles take a rank-128 update)
+#endif
     if (atomic_out) {  // (16 lanes -> 16 consecutive rows of one column: one cache line per quarter wave)
 #pragma unroll
       for (int jc = 0; jc < 2; ++jc)
@@ -692,6 +695,15 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
       tb[i] = *reinterpret_cast<const d2*>(&pB[(size_t)c * ld + r]);
       tp[i] = *reinterpret_cast<const d2*>(&pP[(size_t)c * ld + r]);
     }
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND) && PPO_CHOL_EXPERIMENT_PAIR_BOUND == 3
+    d2 tx[2 * NI];  // (timing experiment: what a real pair launch must also pull through this CU -- block row k+1's tile and its previous-panel rows, 64 KB)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = tid + NT * i, c = p >> 5, r = 2 * (p & 31);
+      tx[i] = *reinterpret_cast<const d2*>(&pB[(size_t)c * ld + r]);
+      tx[NI + i] = *reinterpret_cast<const d2*>(&pP[(size_t)c * ld + r]);
+    }
+#endif
     rold = rsrc[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0];  // (for the very end: requested here, not there; unconditional like the others)
     if (STEP_DEAD()) return;  // (everything above is a request; nothing has been written)
     STAMP(6);
@@ -715,10 +727,35 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
       sB[r + 1][c] = tb[i].y;
       *reinterpret_cast<d2*>(&sP[c][r]) = tp[i];
     }
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND) && PPO_CHOL_EXPERIMENT_PAIR_BOUND == 3
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {  // (they have to land somewhere: over the own half, wrong results)
+      const int p = tid + NT * i, c = p >> 5, r = 2 * (p & 31);
+      *reinterpret_cast<d2*>(&sP[c][r]) = tx[i] + tx[NI + i];
+    }
+#endif
   }
   __syncthreads();
   if (tid >= 256) return;  // loader waves
   STAMP(1);
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND)
+  // (timing experiment of tools/run_chol_experiments.sh, WRONG results: two panels per launch with the second panel's inputs "faked local" -- the
+  //  workgroup walks the whole chain of a panel a second time on what lies in LDS, nothing more is loaded or stored: the UPPER BOUND of what a
+  //  pair launch can save, i.e. one launch boundary + prologue + epilogue per pair.  PPO_CHOL_EXPERIMENT_PAIR_BOUND=2 also puts the redundant
+  //  work of a real pair design into the shadow of the first chain: block row k+1's update and substitution, here as the own-half jobs run
+  //  three times over.)
+#pragma unroll 1
+  for (int pair_rep = 0; pair_rep < 2; ++pair_rep) {
+  if (pair_rep == 1) {
+    if (updc) tile_update1(sL, wave, 0, wave == 0, sQ, sQ);
+    __syncthreads();
+  }
+#define PPO_PAIR_SIDE_LOOP for (int side_rep = 0; side_rep < ((PPO_CHOL_EXPERIMENT_PAIR_BOUND >= 2 && pair_rep == 0) ? 3 : 1); ++side_rep)
+#define PPO_PAIR_D (PPO_CHOL_EXPERIMENT_PAIR_BOUND != 3 || side_rep == 0)  // (=3: only the own-row jobs are redundant, the diagonal block's are not)
+#else
+#define PPO_PAIR_SIDE_LOOP
+#define PPO_PAIR_D true
+#endif
 #pragma unroll
   for (int kk = 0; kk < NB / SB; ++kk) {
     const int o = kk * SB;
@@ -729,24 +766,24 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
 #if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_NO_SIDE)  // (timing experiment: wrong results, the register factorisations without the MFMA jobs in their shadow)
     } else if (true) {
 #endif
-    } else if (kk == 0) {
-      if (updc) tile_update1(sL, wave, 1, wave == 1, sQ, sQ);  // D(1,1) D(2,1) D(3,1): what the next factorisation needs
+    } else PPO_PAIR_SIDE_LOOP if (kk == 0) {
+      if (updc && PPO_PAIR_D) tile_update1(sL, wave, 1, wave == 1, sQ, sQ);  // D(1,1) D(2,1) D(3,1): what the next factorisation needs
       if (uo) tile_update1(sB, r0t, wave - 1, false, sP, sQ);
     } else if (kk == 1) {
       // (first: the three tiles of the diagonal block that block column 0 still owes an update and that the factorisation running now does
       //  not read -- (2,2) (3,2) (3,3); as part of the update round behind potf2(0) they made it two rounds of matrix instructions, 0.64 us
       //  of the chain instead of 0.28)
       if (wave == 1) {
-        mfma_sub_16(sL, 3 * SB, 3 * SB, sL, 3 * SB, sL, 3 * SB, 0);
+        if (PPO_PAIR_D) mfma_sub_16(sL, 3 * SB, 3 * SB, sL, 3 * SB, sL, 3 * SB, 0);
         if (uo) tile_update1(sB, r0t, 3, false, sP, sQ);
         if (own) solve_rows<0>(sB, r0t, sL, sT);
       } else if (wave == 2) {
-        mfma_sub_16(sL, 2 * SB, 2 * SB, sL, 2 * SB, sL, 2 * SB, 0);
-        if (updc) tile_update1(sL, 2, 2, true, sQ, sQ);
+        if (PPO_PAIR_D) mfma_sub_16(sL, 2 * SB, 2 * SB, sL, 2 * SB, sL, 2 * SB, 0);
+        if (updc && PPO_PAIR_D) tile_update1(sL, 2, 2, true, sQ, sQ);
         if (uo) tile_update1(sB, r1t, 0, false, sP, sQ);
       } else {
-        mfma_sub_16(sL, 3 * SB, 2 * SB, sL, 3 * SB, sL, 2 * SB, 0);
-        if (updc) tile_update1(sL, 3, 2, false, sQ, sQ);
+        if (PPO_PAIR_D) mfma_sub_16(sL, 3 * SB, 2 * SB, sL, 3 * SB, sL, 2 * SB, 0);
+        if (updc && PPO_PAIR_D) tile_update1(sL, 3, 2, false, sQ, sQ);
         if (uo) tile_update1(sB, r1t, 1, false, sP, sQ);
       }
     } else if (kk == 2) {
@@ -754,11 +791,10 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
         if (uo) tile_update1(sB, r1t, 2, false, sP, sQ);
         if (own) solve_rows<1>(sB, r0t, sL, sT);
       } else if (wave == 2) {
-        if (updc) tile_update1(sL, 3, 3, true, sQ, sQ);
+        if (updc && PPO_PAIR_D) tile_update1(sL, 3, 3, true, sQ, sQ);
         if (uo) tile_update1(sB, r1t, 3, false, sP, sQ);
       } else {
-        solve_rhs_row(sB, 0, sL, sT);
-        solve_rhs_row(sB, 1, sL, sT);
+        if (PPO_PAIR_D) { solve_rhs_row(sB, 0, sL, sT); solve_rhs_row(sB, 1, sL, sT); }
       }
     } else {
       if (wave == 1) {
@@ -766,7 +802,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
       } else if (wave == 2) {
         if (own) solve_rows<2>(sB, r0t, sL, sT);
       } else {
-        solve_rhs_row(sB, 2, sL, sT);
+        if (PPO_PAIR_D) solve_rhs_row(sB, 2, sL, sT);
       }
     }
     STAMP1(28 + kk);
@@ -787,6 +823,14 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     __syncthreads();
     STAMP(9 + 2 * kk);
   }
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND)
+  if (pair_rep == 0) {  // the first panel's last substitution steps, before the second chain starts
+    if (own && wave < 2) solve_rows<3>(sB, wave == 0 ? r0t : r1t, sL, sT);
+    if (wave == 3) solve_rhs_row(sB, NB / SB - 1, sL, sT);
+    __syncthreads();
+  }
+  }
+#endif
   const int bad = sBad;
   STAMP(2);
   if (own && wave < 2) solve_rows<3>(sB, wave == 0 ? r0t : r1t, sL, sT);
@@ -1117,7 +1161,11 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
   } else
 #endif
   {
+#if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND)
+    for (int k = 0; k < nb; k += 2) {  // (timing experiment: one launch per PAIR of panels, each walking two chains)
+#else
     for (int k = 0; k < nb; ++k) {
+#endif
       const int k0 = k * NB;
       const int m = nb - k;  // column workgroups: 1 (diagonal) + 2 per block row below (row halves); then the trailing tiles
       StepOverlap o = step_no_overlap(nb);

@@ -226,6 +226,20 @@ __device__ __forceinline__ void fold_acc_parts(double* acc, int det) {
   p[0] = 0.0;
   p[1] = 0.0;
 }
+// the same inside the launch whose workgroups are still adding elsewhere (lm_tail): the partial sums are read and cleared with device-scope
+// operations, at the memory side where the atomics that formed them were performed
+__device__ __forceinline__ void fold_acc_parts_coherent(double* acc) {
+  const int t = threadIdx.x & 63;
+  double* p = acc + ACC_N + t * kAccPartStride;
+  double c = __hip_atomic_load(&p[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sc = __hip_atomic_load(&p[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); sc += __shfl_down(sc, off, 64); }
+  if (t == 0) {
+    __hip_atomic_store(&acc[ACC_CHI2], __hip_atomic_load(&acc[ACC_CHI2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&acc[ACC_SCALE], __hip_atomic_load(&acc[ACC_SCALE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(&p[0], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&p[1], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void lds_wave_fence() {  // make this wave's LDS writes visible to its own other lanes
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1341,6 +1355,99 @@ using CornerModel = CubProjModelT<true>;
 // cost ~12 us per linearisation (tools/gap_report.py).  All parts share one dynamic LDS allocation.
 // The launch holds more waves than the chip has slots (6 000 against 4 096 at the BASELINE size), so the ORDER of the parts in the
 // grid is a scheduling decision: longest-running workgroups first (tools/lin_stamps.py prints every part's timeline).
+// ---- LM control on the device: the decision behind every trial (OptimizationAlgorithmLevenberg::solve, levenberg.cpp:102-163) -------------
+__global__ void k_ctl_set(LmCtl* ctl, LmCtl v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *ctl = v;
+}
+// One wave.  Reads (chi2, scale) of the trial state and the factorisation flag, takes the accept / reject decision, updates the control
+// record and writes the trial's numbers into its slot of the DEVICE ring of trial records.  `epoch`: the epoch the trial was queued
+// under (a trial that did not run leaves a record that says so).  n_publish > 0 (the last trial of a batch): the records of the last
+// n_publish trials go to the mapped host ring, then the sequence number the host waits for -- ONE hand-over per batch: a kernel that
+// writes host memory holds its successor back until the write has crossed the bus (6 - 10 us, measured as idle queue in front of
+// k_reduce_stage1 with a hand-over per trial; tools/small_window_gap.sh).
+struct DecidePlan {
+  double* rec;    // device ring, kRecSlots x REC_DOUBLES
+  double* host;   // mapped host ring of the same shape, and behind it the sequence word
+  unsigned long long seq;
+  int n_publish;
+};
+constexpr int kRecSlots = 16;
+// the body, by ONE wave (t = its lane): k_decide's, and (round 5) the tail of the launch that evaluates the trial state
+template <bool COHERENT = false>
+__device__ __forceinline__ void decide_wave(int t, double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, const DecidePlan& dp) {
+  double* rec = dp.rec + (dp.seq % kRecSlots) * REC_DOUBLES;
+  const bool dead = __hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
+  if (!dead) {
+    if (COHERENT) fold_acc_parts_coherent(acc);
+    else fold_acc_parts(acc, 0);
+  }
+  __threadfence();
+  __builtin_amdgcn_wave_barrier();
+  if (t == 0 && dead) {
+    rec[REC_DEAD] = 1.0;
+    rec[REC_SEQ] = (double)dp.seq;
+  }
+  if (t == 0 && !dead) {
+    LmCtl c = *ctl;
+    lm_decide(c, __hip_atomic_load(&acc[ACC_CHI2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&acc[ACC_SCALE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), *info_p, rec);
+    *ctl = c;
+    rec[REC_SEQ] = (double)dp.seq;
+  }
+  if (dp.n_publish <= 0) return;
+  __threadfence();
+  __builtin_amdgcn_wave_barrier();
+  for (int i = t; i < dp.n_publish * REC_DOUBLES; i += 64) {
+    const unsigned long long s = dp.seq - (unsigned long long)(dp.n_publish - 1) + (unsigned long long)(i / REC_DOUBLES);
+    const int at = (int)(s % kRecSlots) * REC_DOUBLES + i % REC_DOUBLES;
+    dp.host[at] = __hip_atomic_load(dp.rec + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence_system();
+  __builtin_amdgcn_wave_barrier();
+  if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dp.host + kRecSlots * REC_DOUBLES), dp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void k_decide(double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, DecidePlan dp) {
+  decide_wave(threadIdx.x, acc, info_p, ctl, epoch, dp);
+}
+// The decision as the TAIL of the launch that evaluates the trial state (k_linearize_all on a speculated trial, k_chi2_all otherwise) instead of
+// a 5 us launch of its own behind it: the workgroup that finishes LAST runs decide_wave.  "Last" through two levels of arrival counters
+// (64 + 1, zero between launches: a launch of 1 500 workgroups would otherwise queue 1 500 atomics on one address at its very end).  Every
+// workgroup's sums are in memory before its ticket is drawn (barrier, then a device-scope release fence by the thread that draws it).
+struct DecideTail {
+  DecidePlan dp;
+  const int* info;
+  LmCtl* ctl;
+  int* cnt;  // [65]; NULL: no tail (the host takes the decisions, or k_decide follows)
+};
+__device__ __forceinline__ void lm_tail(const Graph& g, const DecideTail& dt) {
+  if (dt.cnt == nullptr) return;
+  __shared__ int s_last;
+  // What the decision reads of this launch are SUMS -- device-scope atomics, performed at the memory side, complete once acknowledged.  So every
+  // wave waits for its own memory operations (a workgroup-scope release: s_waitcnt, no cache maintenance), the barrier collects the waves, and
+  // the ticket is drawn.  A device-scope release fence per workgroup instead (an L2 write-back each, 1 500 times per launch) cost 33 us per
+  // LM iteration at the BASELINE size -- six times what the separate launch of k_decide costs.  The last workgroup reads the sums with
+  // device-scope loads (fold_acc_parts_coherent).
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int G = (int)gridDim.x, p = (int)blockIdx.x & 63, expect = (G + 63 - p) >> 6;
+    int last = 0;
+    if (atomicAdd(&dt.cnt[p], 1) == expect - 1) {
+      __hip_atomic_store(&dt.cnt[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every workgroup of this part has drawn: nobody touches the counter again before the next launch)
+      if (atomicAdd(&dt.cnt[64], 1) == min(G, 64) - 1) {
+        __hip_atomic_store(&dt.cnt[64], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 64) decide_wave<true>((int)threadIdx.x, g.acc, dt.info, dt.ctl, g.epoch, dt.dp);
+}
+// a launch that finds its epoch gone still owes the host the trial's (dead) record
+__device__ __forceinline__ void lm_tail_dead(const Graph& g, const DecideTail& dt) {
+  if (dt.cnt != nullptr && blockIdx.x == 0 && threadIdx.x < 64) decide_wave((int)threadIdx.x, g.acc, dt.info, dt.ctl, g.epoch, dt.dp);
+}
+
 #ifndef PPO_LIN_WAVES
 #define PPO_LIN_WAVES 3  // waves per SIMD the fused linearisation is compiled for (register budget 512 / this): 120 VGPRs, nothing spills,
                         // 4 waves per SIMD resident
@@ -1356,9 +1463,12 @@ struct LinPlan {
 #define PPO_LIN_OCC
 #endif
 template <bool USE_LDS, bool WITH_CORNERS, bool ANALYTIC = false>
-__global__ __launch_bounds__(256, PPO_LIN_WAVES) PPO_LIN_OCC void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta) {
+__global__ __launch_bounds__(256, PPO_LIN_WAVES) PPO_LIN_OCC void k_linearize_all(Graph g, State st, LinPlan lp, PoseChunks pc, double delta, DecideTail tail) {
   extern __shared__ double smem[];
-  if (lm_dead(g)) return;
+  if (lm_dead(g)) {
+    lm_tail_dead(g, tail);
+    return;
+  }
   int b = blockIdx.x, part = -1;
 #pragma unroll
   for (int oi = 0; oi < LIN_PARTS; ++oi) {
@@ -1394,20 +1504,22 @@ __global__ __launch_bounds__(256, PPO_LIN_WAVES) PPO_LIN_OCC void k_linearize_al
     case LIN_POINTS: LIN_STAMP(g, 0); lin_points_body<USE_LDS>(g, st, b, lp.nb[LIN_POINTS], smem + 8, smem); LIN_STAMP(g, 4); break;
     default: break;
   }
+  lm_tail(g, tail);
 }
 // residual-only pass of a trial state in ONE launch: numeric edge classes (thread per edge) | points (thread per point)
-__global__ __launch_bounds__(256) void k_chi2_all(Graph g, State st, NumericPlan np, int nb_num, int nb_pts) {
+__global__ __launch_bounds__(256) void k_chi2_all(Graph g, State st, NumericPlan np, int nb_num, int nb_pts, DecideTail tail) {
   __shared__ double s_red[4];
-  if (lm_dead(g)) return;
+  if (lm_dead(g)) {
+    lm_tail_dead(g, tail);
+    return;
+  }
   int b = blockIdx.x;
-  if (b >= nb_num) { chi2_points_body(g, st, b - nb_num, nb_pts, s_red); return; }
-  if (b < np.nb_plane) { chi2_numeric_body<PlaneModel>(g, st, g.n_pl, false, b); return; }
-  b -= np.nb_plane;
-  if (b < np.nb_bbox) { chi2_numeric_body<BboxModel>(g, st, g.n_bbox, false, b); return; }
-  b -= np.nb_bbox;
-  if (b < np.nb_corner) { chi2_numeric_body<CornerModel>(g, st, g.n_corner, true, b); return; }
-  b -= np.nb_corner;
-  chi2_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, b);
+  if (b >= nb_num) chi2_points_body(g, st, b - nb_num, nb_pts, s_red);
+  else if (b < np.nb_plane) chi2_numeric_body<PlaneModel>(g, st, g.n_pl, false, b);
+  else if ((b -= np.nb_plane) < np.nb_bbox) chi2_numeric_body<BboxModel>(g, st, g.n_bbox, false, b);
+  else if ((b -= np.nb_bbox) < np.nb_corner) chi2_numeric_body<CornerModel>(g, st, g.n_corner, true, b);
+  else chi2_numeric_body<PtCubModel>(g, st, g.n_ptcub, false, b - np.nb_corner);
+  lm_tail(g, tail);
 }
 
 // Hands the accumulator block and the factorisation flag to the host through mapped, coherent host memory: payload first,
@@ -1454,52 +1566,6 @@ __global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restri
 
 // the partial sums into acc[0..1] ahead of a reader other than k_publish (fixed-point conversion, sum over ranks)
 __global__ __launch_bounds__(64) void k_fold_acc(double* acc, int det) { fold_acc_parts(acc, det); }
-
-// ---- LM control on the device: the decision behind every trial (OptimizationAlgorithmLevenberg::solve, levenberg.cpp:102-163) -------------
-__global__ void k_ctl_set(LmCtl* ctl, LmCtl v) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *ctl = v;
-}
-// One wave.  Reads (chi2, scale) of the trial state and the factorisation flag, takes the accept / reject decision, updates the control
-// record and writes the trial's numbers into its slot of the DEVICE ring of trial records.  `epoch`: the epoch the trial was queued
-// under (a trial that did not run leaves a record that says so).  n_publish > 0 (the last trial of a batch): the records of the last
-// n_publish trials go to the mapped host ring, then the sequence number the host waits for -- ONE hand-over per batch: a kernel that
-// writes host memory holds its successor back until the write has crossed the bus (6 - 10 us, measured as idle queue in front of
-// k_reduce_stage1 with a hand-over per trial; tools/small_window_gap.sh).
-struct DecidePlan {
-  double* rec;    // device ring, kRecSlots x REC_DOUBLES
-  double* host;   // mapped host ring of the same shape, and behind it the sequence word
-  unsigned long long seq;
-  int n_publish;
-};
-constexpr int kRecSlots = 16;
-__global__ __launch_bounds__(64) void k_decide(double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, DecidePlan dp) {
-  const int t = threadIdx.x;
-  double* rec = dp.rec + (dp.seq % kRecSlots) * REC_DOUBLES;
-  const bool dead = ctl->epoch != epoch;
-  if (!dead) fold_acc_parts(acc, 0);
-  __syncthreads();
-  if (t == 0 && dead) {
-    rec[REC_DEAD] = 1.0;
-    rec[REC_SEQ] = (double)dp.seq;
-  }
-  if (t == 0 && !dead) {
-    LmCtl c = *ctl;
-    lm_decide(c, acc[ACC_CHI2], acc[ACC_SCALE], *info_p, rec);
-    *ctl = c;
-    rec[REC_SEQ] = (double)dp.seq;
-  }
-  if (dp.n_publish <= 0) return;
-  __threadfence();
-  __syncthreads();
-  for (int i = t; i < dp.n_publish * REC_DOUBLES; i += 64) {
-    const unsigned long long s = dp.seq - (unsigned long long)(dp.n_publish - 1) + (unsigned long long)(i / REC_DOUBLES);
-    const int at = (int)(s % kRecSlots) * REC_DOUBLES + i % REC_DOUBLES;
-    dp.host[at] = __hip_atomic_load(dp.rec + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __threadfence_system();
-  __syncthreads();
-  if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dp.host + kRecSlots * REC_DOUBLES), dp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 // reset of a solver in ONE launch: up to eight word-granular copies from the pristine device copies made at create, and the
 // zero ranges.  (Seven hipMemcpyAsync / hipMemsetAsync calls took the runtime's blit path: ~15 us of queue idle each.)

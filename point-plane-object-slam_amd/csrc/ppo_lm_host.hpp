@@ -35,8 +35,13 @@ struct TrialBook {
 //
 // m: the host's mirror of the device record at entry (iteration 0 of the pass set up: lambda, chi2 of the estimate, epoch); at exit what the
 // device holds.  lookahead_cap: 1 ... kLookahead.  Returns PPO_BA_OK or an error code.
+// back_off_for_the_pass (round 5; the product's choice): after the first batch of a pass that did not go as assumed -- a rejected trial, a
+// termination -- every further batch of that pass is ONE attempt.  Rejections come in runs (a damping that is too small stays too small for a
+// few attempts), and every attempt queued behind a rejected one is ~25 launches that find their epoch gone (~12 us): doubling back up to five lost
+// 4 % on a 15-keyframe window that rejects a quarter of its trials (profiles/r04_lm_control.txt), a batch of one costs what the host path costs.
+// false: the round-4 rule (one attempt after a miss, then doubling while the assumption holds).
 template <class Dev>
-int lm_pipelined_pass(Dev& dev, int pass, int iterations, LmCtl& m, int lookahead_cap) {
+int lm_pipelined_pass(Dev& dev, int pass, int iterations, LmCtl& m, int lookahead_cap, bool back_off_for_the_pass = true) {
   struct Queued { unsigned long long seq; TrialBook after; bool speculated; };
   Queued q[kLookahead];
   lookahead_cap = std::max(1, std::min(lookahead_cap, kLookahead));
@@ -101,6 +106,7 @@ int lm_pipelined_pass(Dev& dev, int pass, int iterations, LmCtl& m, int lookahea
         if ((rc = dev.relinearize(m)) != PPO_BA_OK) break;
       }
     }
+    if (!clean && back_off_for_the_pass) lookahead_cap = 1;
     lookahead = clean ? std::min(lookahead_cap, 2 * lookahead) : 1;
   }
   return rc;

@@ -110,6 +110,9 @@ struct ppo_ba_solver {
   // LM control on the device (optimize_pipelined): the record, the epoch the host queues launches under, the sequence number of the
   // last record asked for (slot ring_seq % kRingSlots of the mapped ring behind h_pinned's accumulator block)
   DevBuf<LmCtl> d_ctl;
+  DevBuf<int> d_tailcnt;    // [65 (+ pad)] arrival counters of the decide tail (ppo_kernels.hpp: lm_tail), zero between launches
+  DecideTail tail{};        // armed by queue_trial: the next evaluation launch (k_linearize_all / k_chi2_all) carries the LM decision as its tail
+  bool tail_armed = false;
   DevBuf<double> d_rec;  // device ring of trial records (kRecSlots x REC_DOUBLES), copied to the mapped host ring at the end of a batch
   int epoch = 0;
   unsigned long long ring_seq = 0;
@@ -290,7 +293,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
   s->d_Wpc.release(); s->d_Dinv.release(); s->d_ul.release();
-  s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release(); s->d_ctl.release(); s->d_rec.release();
+  s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release(); s->d_ctl.release(); s->d_rec.release(); s->d_tailcnt.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release(); s->d_pc_lm.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cub_edge_col.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release(); s->d_cp_cola.release(); s->d_cp_colb.release(); s->d_cp_off.release();
@@ -471,6 +474,8 @@ int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st) {
   }
   int grid = 0;
   for (int i = 0; i < LIN_PARTS; ++i) grid += lp.nb[i];
+  const DecideTail tl = (s->tail_armed && grid > 0) ? s->tail : DecideTail{};
+  if (grid > 0) s->tail_armed = false;
 #ifdef PPO_BA_TEST_HOOKS
   if (const char* path = PPO_DEV_ENV("PPO_BA_LIN_STAMPS")) {  // development aid: wall-clock stamps of every workgroup of the LAST launch
     if (!s->d_stamps.p && grid > 0 && s->d_stamps.alloc((size_t)grid * 8)) s->g.stamps = s->d_stamps.p;
@@ -484,15 +489,15 @@ int launch_linearize_kernel(ppo_ba_solver* s, const Graph& g, const State& st) {
     const dim3 gd(grid), bd(256);
     const double dl = s->opt.numeric_delta;
     if (ana) {  // (the point-cuboid edges stay numeric in this mode)
-      if (s->use_lds_lin && cor) hipLaunchKernelGGL((k_linearize_all<true, true, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl);
-      else if (s->use_lds_lin) hipLaunchKernelGGL((k_linearize_all<true, false, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl);
-      else if (cor) hipLaunchKernelGGL((k_linearize_all<false, true, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl);
-      else hipLaunchKernelGGL((k_linearize_all<false, false, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl);
+      if (s->use_lds_lin && cor) hipLaunchKernelGGL((k_linearize_all<true, true, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl, tl);
+      else if (s->use_lds_lin) hipLaunchKernelGGL((k_linearize_all<true, false, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl, tl);
+      else if (cor) hipLaunchKernelGGL((k_linearize_all<false, true, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl, tl);
+      else hipLaunchKernelGGL((k_linearize_all<false, false, true>), gd, bd, s->lin_lds_bytes, s->stream, g, st, lp, s->posec, dl, tl);
     } else
-    if (s->use_lds_lin && cor) hipLaunchKernelGGL((k_linearize_all<true, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
-    else if (s->use_lds_lin) hipLaunchKernelGGL((k_linearize_all<true, false>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
-    else if (cor) hipLaunchKernelGGL((k_linearize_all<false, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
-    else hipLaunchKernelGGL((k_linearize_all<false, false>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta);
+    if (s->use_lds_lin && cor) hipLaunchKernelGGL((k_linearize_all<true, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta, tl);
+    else if (s->use_lds_lin) hipLaunchKernelGGL((k_linearize_all<true, false>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta, tl);
+    else if (cor) hipLaunchKernelGGL((k_linearize_all<false, true>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta, tl);
+    else hipLaunchKernelGGL((k_linearize_all<false, false>), dim3(grid), dim3(256), s->lin_lds_bytes, s->stream, g, st, lp, s->posec, s->opt.numeric_delta, tl);
   }
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
@@ -510,7 +515,11 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
   }
   const int nb_num = np.nb_plane + np.nb_bbox + np.nb_corner + np.nb_ptcub;
   const int nb_pts = npts > 0 ? std::min(nblk((long)kLanesPerPoint * npts, 256), 4 * s->n_cu) : 0;
-  if (nb_num + nb_pts > 0) hipLaunchKernelGGL(k_chi2_all, dim3(nb_num + nb_pts), dim3(256), 0, s->stream, g, st, np, nb_num, nb_pts);
+  if (nb_num + nb_pts > 0) {
+    const DecideTail tl = s->tail_armed ? s->tail : DecideTail{};
+    s->tail_armed = false;
+    hipLaunchKernelGGL(k_chi2_all, dim3(nb_num + nb_pts), dim3(256), 0, s->stream, g, st, np, nb_num, nb_pts, tl);
+  }
   if (g.det) s->acc_fixed = true;
   HIP_TRY(hipGetLastError());
   return PPO_BA_OK;
@@ -873,10 +882,23 @@ int queue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long l
   RC_TRY(launch_solve(s));
   s->have_system = true;
   RC_TRY(launch_update(s, 0.0));
+  // round 5 experiment: the decision as the tail of the launch that evaluates the trial state (ppo_kernels.hpp: lm_tail) instead of k_decide as a
+  // launch of its own (5 us of every trace).
+  const DecidePlan dp{s->d_rec.p, s->h_pinned_dev + 16, ++s->ring_seq, n_publish};
+  // Measured (profiles/r05_decide_tail.txt): NEUTRAL -- 15 KF 0.822 / 0.836 ms per call with the tail against 0.822 / 0.847 with the launch, 30 KF
+  // 1.240 / 1.247 against 1.254 / 1.209, BASELINE size 2 771 against 2 785 LM iterations/s: a 5 us kernel between two long ones costs the queue
+  // next to nothing, and the tail holds every workgroup of the evaluation until its atomics are acknowledged.  So the separate launch, whose
+  // ordering needs no argument beyond the kernel boundary, stays the product path; PPO_BA_DECIDE_TAIL=1 (test-hooks build) selects the tail.
+  const char* const tail_env = PPO_DEV_ENV("PPO_BA_DECIDE_TAIL");  // (read per trial in the test-hooks build: a test switches it)
+  const bool tail_off = !(tail_env && tail_env[0] == '1');
+  s->tail = DecideTail{dp, (const int*)s->d_info.p, s->d_ctl.p, s->d_tailcnt.p};
+  s->tail_armed = !tail_off;
   if (speculate) RC_TRY(launch_linearize(s, s->cur ^ 1, false, false));  // doubles as the evaluation of the trial state (see lm_iteration)
   else RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
-  DecidePlan dp{s->d_rec.p, s->h_pinned_dev + 16, ++s->ring_seq, n_publish};
-  hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, s->stream, s->g.acc, (const int*)s->d_info.p, s->d_ctl.p, s->g.epoch, dp);
+  if (s->tail_armed || tail_off) {
+    s->tail_armed = false;
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, s->stream, s->g.acc, (const int*)s->d_info.p, s->d_ctl.p, s->g.epoch, dp);
+  }
   HIP_TRY(hipGetLastError());
   *seq_out = dp.seq;
   return PPO_BA_OK;
@@ -884,13 +906,18 @@ int queue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long l
 int wait_for_records(ppo_ba_solver* s, unsigned long long seq) {
   volatile const unsigned long long* w = reinterpret_cast<volatile const unsigned long long*>(s->h_pinned + 16 + kRingSlots * kRingSlotDoubles);
   const auto t0 = std::chrono::steady_clock::now();
+  bool timed_out = false;
   for (unsigned it = 0; *w != seq; ++it) {
+    __builtin_ia32_pause();  // (a batch is up to five LM iterations long: leave the core's other hardware thread its issue slots)
     if ((it & 1023) == 1023) {
       if (hipStreamQuery(s->stream) == hipSuccess) break;
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { timed_out = true; break; }
     }
   }
   if (*w != seq) {
+    // a batch that has not reported after 5 s is a hung kernel, not a slow one (the longest window the tests know takes 30 ms): an error, not
+    // an unbounded wait inside the caller's thread
+    if (timed_out) return PPO_BA_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (*w != seq) return PPO_BA_ERR_HIP;
   }
@@ -918,6 +945,7 @@ struct SolverDev {
     RC_TRY(fetch_acc(s, false));
     m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
     hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
+    HIP_TRY(hipGetLastError());
     s->g.ctl = s->d_ctl.p;
     return PPO_BA_OK;
   }
@@ -942,6 +970,7 @@ int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
   m.max_trials = s->opt.lm_max_trials;
   m.epoch = ++s->epoch;
   hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
+  HIP_TRY(hipGetLastError());
   s->g.ctl = s->d_ctl.p;
   s->g.epoch = s->epoch;
   int lookahead = kLookahead;
@@ -1607,7 +1636,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
   ok = ok && s->d_Wpc.alloc(2 * (size_t)(p->n_bbox + n_corner_all) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
-  ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1) && s->d_ctl.alloc(1) && s->d_rec.alloc((size_t)kRecSlots * REC_DOUBLES);
+  ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1) && s->d_ctl.alloc(1) && s->d_rec.alloc((size_t)kRecSlots * REC_DOUBLES) && s->d_tailcnt.alloc(80);
   if (s->comm.active()) ok = ok && s->d_pack.alloc((size_t)(ld / 64) * (ld / 64 + 1) / 2 * 4096 + ld);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
   ok = ok && s->d_cub_edge_off.upload(cub_edge_off, s->stream) && s->d_cub_edges.upload(cub_edges, s->stream) && s->d_cub_edge_col.upload(cub_edge_col, s->stream);
@@ -1732,6 +1761,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   static_assert(ACC_N + 3 <= 16 && REC_DOUBLES == kRingSlotDoubles && kRecSlots == kRingSlots && kLookahead <= kRecSlots, "mapped host block too small");
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
+  (void)hipMemsetAsync(s->d_tailcnt.p, 0, 80 * sizeof(int), s->stream);
 
   g.pose_cam = s->d_pose_cam.p; g.pose_col = s->d_pose_col.p; g.pose_free_id = s->d_pose_free_id.p; g.cub_col = s->d_cub_col.p;
   g.point_fixed = s->d_point_fixed.p; g.cub_flags = s->d_cub_flags.p; g.cub_fixedscale = s->d_cub_fixedscale.p;
@@ -2237,7 +2267,18 @@ int ppo_ba_time_collectives(ppo_ba_handle s, int reps, double* out) {
   const int nb = g.ld / 64, ntiles = nb * (nb + 1) / 2;
   const size_t n = g.ld, count = (size_t)ntiles * 4096 + n;
   out[3] = (double)count * sizeof(double);
-  hipEvent_t e0, e1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct Guard {  // every exit: the events go back, and the handle knows that S, b, x hold garbage (a following time_factor / debug call must rebuild them)
+    ppo_ba_solver* s;
+    hipEvent_t *a, *b;
+    ~Guard() {
+      if (*a) (void)hipEventDestroy(*a);
+      if (*b) (void)hipEventDestroy(*b);
+      s->S_is_zero = false;
+      s->lin_valid = false;
+      s->have_system = false;
+    }
+  } guard{s, &e0, &e1};
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   auto timed = [&](int which, double* ms_out) -> int {
@@ -2266,10 +2307,6 @@ int ppo_ba_time_collectives(ppo_ba_handle s, int reps, double* out) {
     return PPO_BA_OK;
   };
   for (int which = 0; which < 3; ++which) RC_TRY(timed(which, &out[which]));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  s->S_is_zero = false;
-  s->lin_valid = false;
   return PPO_BA_OK;
 }
 

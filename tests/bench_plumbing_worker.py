@@ -38,6 +38,12 @@ class StubLib:
         C.memmove(out, ID, 128)
         return 0
 
+    class _Fn:  # (bench.py sets restype / argtypes on the entry point before calling it)
+        def __call__(self, device):
+            return 0
+
+    ppo_ba_warmup = _Fn()
+
     def ppo_ba_time_linearize(self, h, reps, ms):
         _set(ms, 0.03)
         return 0

@@ -27,6 +27,32 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), "libppo_ba.so does not export " + n
 
 
+def test_the_c_abi_is_the_only_dynamic_symbol_set():
+    """The library is loaded into a process that already holds g2o, Eigen, OpenCV and possibly other ROCm libraries: nothing but the entry points of
+    include/ppo_ba.h and include/ppo_pose.h may be a dynamic symbol (csrc/ppo_ba.map; -fvisibility=hidden) -- no rocprim trampoline, no ppo:: function,
+    no weak STL instantiation that could interpose on, or be interposed by, the host's."""
+    import subprocess
+    declared = set(declared_functions())
+    pose = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "ppo_pose.h")).read(), flags=re.S)
+    declared |= set(re.findall(r"\b(ppo_pose_[a-z_0-9]+)\s*\(", pose))
+    for name in ("libppo_ba.so", "libppo_ba_test.so"):
+        path = os.path.join(REPO, "point-plane-object-slam_amd", "csrc", name)
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+        assert exported == declared, (name, sorted(exported ^ declared))
+
+
+def test_warmup_fails_loudly_without_a_gpu():
+    """ppo_ba_warmup goes through ppo_ba_create: no device, no silent success."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = B.load_library()
+    lib.ppo_ba_warmup.restype = C.c_int
+    lib.ppo_ba_warmup.argtypes = [C.c_int]
+    assert lib.ppo_ba_warmup(0) == -4  # PPO_BA_ERR_HIP
+
+
 def test_version_and_strerror():
     lib = B.load_library()
     assert lib.ppo_ba_version() == 2  # 2: the 9-D camera-object edge (cub3d_*)

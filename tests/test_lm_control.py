@@ -245,9 +245,33 @@ def test_device_control_survives_reset_and_repeated_runs():
 
 
 @pytest.mark.gpu
+def test_decision_as_the_tail_of_the_evaluation_launch_gives_the_same_run(monkeypatch):
+    """Round-5 experiment kept behind PPO_BA_DECIDE_TAIL=1 of the test-hooks build (csrc/ppo_kernels.hpp: lm_tail -- the workgroup that finishes
+    last takes the LM decision instead of k_decide as a launch of its own; measured neutral, profiles/r05_decide_tail.txt): same schedule, same
+    lambda, same final state as the separate launch, on windows that accept everything and on one that rejects trials."""
+    hooks = B.hip_backend(test_hooks=True)
+    cases = [synth.make_problem("small", seed=1), synth.make_problem(dict(n_kf=30, n_points=2000, n_planes=10, n_cuboids=3), seed=1)]
+    Pbad = synth.make_problem(dict(n_kf=15, n_points=800, n_planes=4, n_cuboids=2), seed=1)  # (bench.py's window with four rejected trials)
+    cases.append(Pbad)
+    for P in cases:
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("PPO_BA_DECIDE_TAIL", mode)
+            s = hooks.create(P, B.default_options(lm_control=0))
+            out[mode] = (s.run(), s.read())
+            s.close()
+        (ta, ra), (tb, rb) = out["0"], out["1"]
+        assert [(i["trials"], i["accepted"], i["result"]) for i in ta["iters"]] == [(i["trials"], i["accepted"], i["result"]) for i in tb["iters"]]
+        for ia, ib in zip(ta["iters"], tb["iters"]):
+            assert abs(ia["lambda"] - ib["lambda"]) <= 1e-6 * abs(ia["lambda"]) and abs(ia["chi2_after"] - ib["chi2_after"]) <= 1e-6 * abs(ia["chi2_after"])
+        assert np.abs(ra.pose_qt - rb.pose_qt).max() < 1e-6
+
+
+@pytest.mark.gpu
 def test_stop_flag_raised_during_the_run_ends_it_between_trials():
-    """The flag is polled before every trial is queued; raised from another thread mid-run it ends the call with PPO_BA_ABORTED (1) or,
-    when the run was already over, PPO_BA_OK -- and the estimates are those of a completed trial either way (finite, chi2 not above the start)."""
+    """With lm_control = host the flag is polled before every trial is queued; with the LM decisions on the device (the default) between BATCHES of up
+    to five queued solve attempts (include/ppo_ba.h: a flag raised mid-batch lets that batch finish -- g2o checks it before every retry,
+    levenberg.cpp:149).  Raised from another thread mid-run it ends the call with PPO_BA_ABORTED (1) or, when the run was already over, PPO_BA_OK -- and the estimates are those of a completed trial either way (finite, chi2 not above the start)."""
     import threading
     import time
     hip = _hip()

@@ -208,6 +208,24 @@ def test_one_launch_solve_of_small_systems_against_the_panel_path(hip_hooks, mon
     compare_states(rb, ra)
 
 
+def test_warmup_entry_point(hip):
+    """ppo_ba_warmup (include/ppo_ba.h; INTEGRATION.md: one line in System's constructor): succeeds, may be called again, and a create right after it
+    costs what a steady-state create does (the first-use costs -- module load, stream, mapped block, host team -- are not left for it)."""
+    import time
+    hip.lib.ppo_ba_warmup.restype = C.c_int
+    hip.lib.ppo_ba_warmup.argtypes = [C.c_int]
+    assert hip.lib.ppo_ba_warmup(0) == 0
+    t0 = time.perf_counter()
+    assert hip.lib.ppo_ba_warmup(0) == 0
+    assert time.perf_counter() - t0 < 0.05
+    P = synth.make_problem("small", seed=1)
+    t0 = time.perf_counter()
+    s = hip.create(P, B.default_options())
+    dt = time.perf_counter() - t0
+    s.close()
+    assert dt < 0.02, dt
+
+
 def test_one_launch_solve_reports_a_matrix_that_is_not_positive(hip_hooks, monkeypatch):
     """levenberg.cpp:126-127 treats a failed LDLT as a rejected trial; the one-launch kernel must raise the same flag as the panel path: the
     indefinite window of the failed-factorisation tests below walks the same schedule on either path."""

@@ -8,3 +8,6 @@ for flags in ${CHOL_FLAGS:-"" "-DPPO_CHOL_EXPERIMENT_NO_LOOKAHEAD" "-DPPO_CHOL_E
   echo "== flags: $flags"
   timeout 120 /tmp/chol_check panels 2>&1 | grep -E "^n (1194|1644| 600)"
 done
+# round 5: the pair bound -- CHOL_FLAGS='"" "-DPPO_CHOL_EXPERIMENT_PAIR_BOUND=1" "-DPPO_CHOL_EXPERIMENT_PAIR_BOUND=2"' tools/run_chol_experiments.sh
+# (=1: two panel chains per launch, nothing more loaded or stored: the upper bound of what two panels per launch can save;
+#  =2: the same with the redundant block-row work of a real pair design in the shadow of the first chain)
