@@ -133,13 +133,8 @@ class RefRun:
                        float(A["cub3d_huber"][i]))
             assert addE(self.optimizer.ctypes.data, e.ctypes.data)
             self.edges["cub3d"].append(("cuboid3d", e))
-        # ---- Optimizer.cc:2108-2113: BlockSolverX(LinearSolverDense) + OptimizationAlgorithmLevenberg ----
-        ls = self.linear_solver = O.aligned(0x80)  # operator new(0x78) at the compiled call site
-        u64(ls)[0] = R.vtable(LSD)
-        ls.view(np.uint8)[0x8] = 1       # _reset(true)
-        ls.view(np.int32)[0x68 // 4] = 2  # Eigen::LDLT m_sign(ZeroSign); everything else zero
-        bs = self.solver = O.aligned(0x100)  # operator new(0xd8)
-        R.fn(BSX + "::BlockSolver(g2o::LinearSolver<Eigen::Matrix<double, -1, -1, 0, -1, -1> >*)", vp, vp)(bs.ctypes.data, ls.ctypes.data)
+        self._make_solver()
+        bs = self.solver
         self._install_log_trampolines()
         self.algo = O.aligned(0x100)     # operator new(0x90)
         R.fn("g2o::OptimizationAlgorithmLevenberg::OptimizationAlgorithmLevenberg(g2o::Solver*)", vp, vp)(self.algo.ctypes.data, bs.ctypes.data)
@@ -148,6 +143,18 @@ class RefRun:
         self.f_optimize = R.fn("g2o::SparseOptimizer::optimize(int, bool)", vp, C.c_int, C.c_bool, restype=C.c_int)
         self.f_chi2 = R.fn("g2o::SparseOptimizer::activeRobustChi2() const", vp, restype=C.c_double)
         self.f_errors = R.fn("g2o::SparseOptimizer::computeActiveErrors()", vp)
+
+    def _make_solver(self):
+        """Optimizer.cc:2108-2113: BlockSolverX(LinearSolverDense) (oracle/pin_orbslam_63.py overrides it with the solvers of
+        LocalBundleAdjustment, Optimizer.cc:516-520)."""
+        O, R = self.O, self.W.R
+        u64 = O.u64
+        ls = self.linear_solver = O.aligned(0x80)  # operator new(0x78) at the compiled call site
+        u64(ls)[0] = R.vtable(LSD)
+        ls.view(np.uint8)[0x8] = 1       # _reset(true)
+        ls.view(np.int32)[0x68 // 4] = 2  # Eigen::LDLT m_sign(ZeroSign); everything else zero
+        bs = self.solver = O.aligned(0x100)  # operator new(0xd8)
+        R.fn(BSX + "::BlockSolver(g2o::LinearSolver<Eigen::Matrix<double, -1, -1, 0, -1, -1> >*)", vp, vp)(bs.ctypes.data, ls.ctypes.data)
 
     def _install_log_trampolines(self):
         """A copy of BlockSolverX's vtable whose buildSystem / solve / setLambda slots log and then call the reference's function."""
