@@ -263,8 +263,10 @@ def test_decision_as_the_tail_of_the_evaluation_launch_gives_the_same_run(monkey
         (ta, ra), (tb, rb) = out["0"], out["1"]
         assert [(i["trials"], i["accepted"], i["result"]) for i in ta["iters"]] == [(i["trials"], i["accepted"], i["result"]) for i in tb["iters"]]
         for ia, ib in zip(ta["iters"], tb["iters"]):
-            assert abs(ia["lambda"] - ib["lambda"]) <= 1e-6 * abs(ia["lambda"]) and abs(ia["chi2_after"] - ib["chi2_after"]) <= 1e-6 * abs(ia["chi2_after"])
-        assert np.abs(ra.pose_qt - rb.pose_qt).max() < 1e-6
+            # (two default-mode runs: the arrival order of the atomics moves chi2 by ~1e-9 and lambda -- a function of the gain ratio -- by up to 1e-3;
+            #  the tolerances are those of test_device_and_host_control_walk_the_same_schedule at unit noise)
+            assert abs(ia["lambda_"] - ib["lambda_"]) <= 1e-3 * abs(ia["lambda_"]) and abs(ia["chi2_after"] - ib["chi2_after"]) <= 1e-6 * abs(ia["chi2_after"])
+        assert np.abs(ra.pose_qt - rb.pose_qt).max() < 1e-5
 
 
 @pytest.mark.gpu
