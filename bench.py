@@ -250,7 +250,7 @@ def main():
     # atomics), which the tests hold to the deterministic result.  So: the deterministic mode's own rate on this workload, and how far the timed
     # default-mode run ended from it, per quantity of BASELINE.md's bar.
     deterministic_mode = None
-    if world == 1:
+    if world == 1 and not a.no_extras:
         r_def = solver.read()
         sd_ = B.hip_backend().create(P, B.default_options(device_id=local_rank, solver=a.solver, deterministic=1))
         for _ in range(2):
