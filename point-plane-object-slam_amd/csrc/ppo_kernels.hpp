@@ -1574,6 +1574,23 @@ struct CopyPlan {
   const uint32_t* src[8];
   unsigned long long n[8];  // 32-bit words
 };
+// the small uploads of ppo_ba_create in ONE launch: every item is copied from page-locked host memory (read over the bus by the kernel itself) to its
+// device block; 16-byte words, then the tail bytes.  One workgroup column per item (blockIdx.y), so that 60 items of a few KB do not queue behind
+// each other's bus round trips.
+struct GatherPlan {
+  static constexpr int kItems = 56;
+  void* dst[kItems];
+  const void* src[kItems];
+  unsigned int bytes[kItems];
+};
+__global__ __launch_bounds__(256) void k_gather_uploads(GatherPlan gp) {
+  const int r = blockIdx.y;
+  const size_t n = gp.bytes[r], n16 = n / 16;
+  const uint4* s16 = static_cast<const uint4*>(gp.src[r]);
+  uint4* d16 = static_cast<uint4*>(gp.dst[r]);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d16[i] = s16[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 15)) static_cast<unsigned char*>(gp.dst[r])[n16 * 16 + threadIdx.x] = static_cast<const unsigned char*>(gp.src[r])[n16 * 16 + threadIdx.x];
+}
 __global__ __launch_bounds__(256) void k_reset(CopyPlan cp, ZeroPlan zp) {
   const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
 #pragma unroll

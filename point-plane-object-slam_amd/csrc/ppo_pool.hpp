@@ -224,6 +224,14 @@ struct Stage {
     open = m.open;
     if (open >= 0) blocks[open].used = m.open_used;
   }
+  // [p, p + bytes) lies in a page-locked block of this arena (device-readable as it is: hipHostMalloc memory is mapped into the device's address space)
+  bool owns_pinned(const void* p, size_t bytes) {
+    const char* c = static_cast<const char*>(p);
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Block& b : blocks)
+      if (b.pinned && c >= b.p && c + bytes <= b.p + b.used) return true;
+    return false;
+  }
   void release() { rewind(Mark{0, -1, 0}); }
 };
 inline thread_local Stage* t_stage = nullptr;  // the arena SVec allocations of this thread go to (set by StageScope)
@@ -402,6 +410,18 @@ class HostTeam {
   bool stop_ = false;
 };
 
+// Uploads of ppo_ba_create, batched (round 5).  An ICL-sized window is ~60 arrays of a few KB each: as one hipMemcpyAsync per array the host spent
+// 0.2 ms of a 0.5 ms create in the runtime's copy path.  While a batch is open on this thread, DevBuf::upload only RECORDS (destination, source,
+// bytes) for sources that lie in the page-locked staging arena; the owner flushes the list with ONE gather kernel that reads the staging
+// memory directly (ppo_solver.hip: flush_uploads -> k_gather_uploads) before the first kernel that reads any of the destinations.  Large arrays
+// (> kMaxItemBytes: at the BASELINE size the copy engine is the better path) and sources outside the arena take hipMemcpyAsync as before.
+struct UploadBatch {
+  struct Item { void* dst; const void* src; size_t bytes; };
+  static constexpr size_t kMaxItemBytes = 1u << 20;
+  std::vector<Item> items;
+};
+inline thread_local UploadBatch* t_upload_batch = nullptr;
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -421,7 +441,12 @@ struct DevBuf {
   bool upload(const V& h, hipStream_t s) {
     if (!alloc(h.size())) return false;
     if (h.empty()) return true;
-    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess;
+    const size_t bytes = h.size() * sizeof(T);
+    if (t_upload_batch && bytes <= UploadBatch::kMaxItemBytes && t_stage && t_stage->owns_pinned(h.data(), bytes)) {
+      t_upload_batch->items.push_back(UploadBatch::Item{p, h.data(), bytes});
+      return true;
+    }
+    return hipMemcpyAsync(p, h.data(), bytes, hipMemcpyHostToDevice, s) == hipSuccess;
   }
   void release() {  // the owner has synchronised its streams (free_all)
     if (p) g_pool.put(p, cap_bytes, dev);

@@ -1007,6 +1007,33 @@ int optimize(ppo_ba_solver* s, int pass, int iterations, const volatile uint8_t*
 }  // namespace
 
 // ================================================================================================
+// the recorded small uploads of this thread's open batch (ppo_pool.hpp: UploadBatch) in as few launches of k_gather_uploads as their number needs
+static int flush_uploads(hipStream_t stream) {
+  UploadBatch* const b = t_upload_batch;
+  if (!b || b->items.empty()) return PPO_BA_OK;
+  for (size_t at = 0; at < b->items.size(); at += GatherPlan::kItems) {
+    GatherPlan gp{};
+    const int n = (int)std::min<size_t>(GatherPlan::kItems, b->items.size() - at);
+    size_t largest = 0;
+    for (int i = 0; i < n; ++i) {
+      const UploadBatch::Item& it = b->items[at + i];
+      gp.dst[i] = it.dst; gp.src[i] = it.src; gp.bytes[i] = (unsigned int)it.bytes;
+      largest = std::max(largest, it.bytes);
+    }
+    const int bx = (int)std::max<size_t>(1, std::min<size_t>(16, (largest / 16 + 255) / 256));
+    hipLaunchKernelGGL(k_gather_uploads, dim3(bx, n), dim3(256), 0, stream, gp);
+  }
+  b->items.clear();
+  HIP_TRY(hipGetLastError());
+  return PPO_BA_OK;
+}
+struct UploadBatchScope {  // opens a batch on this thread.  Whatever is still recorded when the scope ends is DROPPED: that is a failure path of
+  UploadBatch batch;       // ppo_ba_create (its device blocks are on their way back to the pool); the success path flushes explicitly
+  UploadBatch* prev;
+  UploadBatchScope() : prev(t_upload_batch) { t_upload_batch = &batch; }
+  ~UploadBatchScope() { t_upload_batch = prev; }
+};
+
 static thread_local ppo_ba_solver* t_creating = nullptr;  // the solver ppo_ba_create is building on this thread
 
 extern "C" {
@@ -1164,10 +1191,14 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   // The device builder wins at every size measured (tools/small_window_times.py, profiles/r03_small_windows.txt: create 0.47 vs 0.51 ms at
   // 15 keyframes / 2 900 edges, 0.59 vs 0.89 at 30 / 9 500 -- the ICL-sized windows the reference really runs --, 0.75 vs 1.40 at 50 / 24 800),
   // so every window whose edge lists arrive sorted by point takes it; the host builder remains for unsorted input.
+  // (round 5, with the uploads batched: at 15 KF / 2 900 edges the two builders are now level -- 0.35 / 0.40 ms host against 0.39 / 0.38 device in two
+  //  runs --, from 30 KF on the device builder wins as before: 0.45 against 0.76)
   const long dev_plan_min = PPO_DEV_ENV("PPO_BA_DEV_PLAN_MIN") ? atol(PPO_DEV_ENV("PPO_BA_DEV_PLAN_MIN")) : 0;
   const bool dev_plan = mono_sorted && stereo_sorted && (long)p->n_mono + p->n_stereo >= dev_plan_min && !PPO_DEV_ENV("PPO_BA_HOST_PLAN");
 
   mark("csr sort");
+  // round 5: the small uploads from here on are recorded and go up in one gather launch each time a kernel is about to read them (flush_uploads)
+  UploadBatchScope upload_batch;
   // ---- host threads for the plans below -------------------------------------------------------------------------------
   // Everything from here to the uploads is counting / bucketing over the ~4e5 edges and ~9e5 landmark pose pairs of a
   // BASELINE-size window.  It runs on a few threads over contiguous, ascending unit ranges, so every bucket keeps the order
@@ -1529,6 +1560,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   if (!dev_plan) {
     ok = ok && s->d_monoP_src.upload(monoP_src, s->stream) && s->d_stereoP_src.upload(stereoP_src, s->stream);
     if (ok && n_monoP + n_stereoP > 0)
+      if (flush_uploads(s->stream) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
       hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(n_monoP, n_stereoP), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
                          s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)n_monoP, s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)n_stereoP);
   }
@@ -1668,6 +1700,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (!ok) return fail(PPO_BA_ERR_NOMEM);
     const SlotInputs sin{s->d_mo_off.p, s->d_st_off.p, d_raw_mono_pose.p, d_raw_stereo_pose.p, d_pl_off.p, d_pl_perm.p, d_pl_pose.p, s->d_pose_col.p, s->d_point_fixed.p,
                          Npt, Npl, p->n_mono, p->n_stereo};
+    if (flush_uploads(s->stream) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
     hipLaunchKernelGGL(k_plan_slot_gather, dim3(nblk(g.n_lm + 1, 256)), dim3(256), 0, s->stream, sin, d_seg.p, d_seg_cnt.p);
     if (!plan_exclusive_scan(plan_scratch, d_seg_cnt.p, d_slot_off_lm.p, (size_t)g.n_lm + 1, s->stream)) return fail(PPO_BA_ERR_NOMEM);
     hipLaunchKernelGGL(k_plan_slot_compact, dim3(nblk(std::max(g.n_lm, 1), 256)), dim3(256), 0, s->stream, sin, d_seg.p, d_slot_off_lm.p, d_slot_col_lm.p, d_slot_lm_lm.p, d_counts.p);
@@ -1700,6 +1733,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
         return fail(PPO_BA_ERR_NOMEM);
     }
     if (n_monoP + n_stereoP > 0)
+      if (flush_uploads(s->stream) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
       hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(n_monoP, n_stereoP), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
                          s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)n_monoP, s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)n_stereoP);
     // Schur pair plan
@@ -1752,16 +1786,35 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (hipMemcpyAsync(h_n_chunks + 1, d_counts.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(PPO_BA_ERR_HIP);
     s->pc = PairChunks{s->d_pc_start.p, s->d_pc_colj.p, s->d_pc_coli.p, s->d_pc_sj.p, s->d_pc_si.p, s->d_pc_lm.p, 0};  // (n_chunks: after the synchronisation below)
   }
+  if (flush_uploads(s->stream) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
   mark("hipMalloc + H2D enqueue");
   if (!ok) return fail(PPO_BA_ERR_NOMEM);
   {  // blocks come from the cache with stale contents: the work arrays that are only partially written start from zero
-    auto zero = [&](auto& b) { if (b.p && b.n) (void)hipMemsetAsync(b.p, 0, b.n * sizeof(*b.p), s->stream); };
+    // (round 5: two launches of k_zero_ranges instead of eleven hipMemsetAsync -- each of those took the runtime's blit path, k_reset's comment)
+    ZeroPlan zp{};
+    int nz = 0;
+    auto flush_zero = [&]() {
+      if (nz == 0) return;
+      size_t total = 0;
+      for (int i = 0; i < nz; ++i) total += zp.n[i];
+      hipLaunchKernelGGL(k_zero_ranges, dim3(std::max(1, std::min(nblk((long)total / 2, 256), 2 * s->n_cu))), dim3(256), 0, s->stream, zp);
+      zp = ZeroPlan{};
+      nz = 0;
+    };
+    auto zero = [&](DevBuf<double>& b) {
+      if (!(b.p && b.n)) return;
+      zp.p[nz] = b.p; zp.n[nz] = b.n;
+      if (++nz == 6) flush_zero();
+    };
     zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_ul); zero(s->d_xr); zero(s->d_cholws);
     zero(s->d_cub_Linv); zero(s->d_cub_Dinv); zero(s->d_xc); zero(s->d_S);
+    static_assert(sizeof(int) * 2 == sizeof(double), "the two int blocks below are cleared as doubles");
+    zp.p[nz] = reinterpret_cast<double*>(s->d_tailcnt.p); zp.n[nz] = 40;  // 80 ints
+    if (++nz == 6) flush_zero();
+    flush_zero();
   }
   static_assert(ACC_N + 3 <= 16 && REC_DOUBLES == kRingSlotDoubles && kRecSlots == kRingSlots && kLookahead <= kRecSlots, "mapped host block too small");
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
-  (void)hipMemsetAsync(s->d_tailcnt.p, 0, 80 * sizeof(int), s->stream);
 
   g.pose_cam = s->d_pose_cam.p; g.pose_col = s->d_pose_col.p; g.pose_free_id = s->d_pose_free_id.p; g.cub_col = s->d_cub_col.p;
   g.point_fixed = s->d_point_fixed.p; g.cub_flags = s->d_cub_flags.p; g.cub_fixedscale = s->d_cub_fixedscale.p;
@@ -1961,16 +2014,32 @@ int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
   SVec<uint32_t> hmf(g.n_mono), hsf(g.n_stereo);
   SVec<PlaneEdge> hp(g.n_pl);
   SVec<CubEdge> hb(g.n_bbox), hc(g.n_corner);
-  if (s->state_doubles) HIP_TRY(hipMemcpyAsync(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  // (round 5: the small ones -- every one of them on an ICL-sized window -- come down in ONE launch of the copy kernel writing the page-locked staging
+  //  memory directly, instead of up to seven hipMemcpyAsync; arrays above UploadBatch::kMaxItemBytes keep the copy engine)
+  UploadBatch down;
+  auto fetch = [&](void* dst, const void* src, size_t bytes) -> int {
+    if (bytes == 0) return PPO_BA_OK;
+    if (bytes <= UploadBatch::kMaxItemBytes && s->stage->owns_pinned(dst, bytes)) { down.items.push_back(UploadBatch::Item{dst, src, bytes}); return PPO_BA_OK; }
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+    return PPO_BA_OK;
+  };
+  if (s->state_doubles) RC_TRY(fetch(hs.data(), s->d_state[s->cur].p, s->state_doubles * sizeof(double)));
   // (only what the caller's non-NULL pointers ask for crosses the bus: the per-edge chi2 block is the largest part of a read)
   const bool want_chi = r->mono_chi2 || r->stereo_chi2 || r->pl_chi2 || r->bbox_chi2 || r->bbox_errnorm || r->corner_chi2 || r->corner_errnorm || r->ptcub_chi2 ||
                         r->cub3d_chi2 || r->cub3d_errnorm;
-  if (chi.size() && want_chi) HIP_TRY(hipMemcpyAsync(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  if (g.n_mono && r->mono_level) HIP_TRY(hipMemcpyAsync(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-  if (g.n_stereo && r->stereo_level) HIP_TRY(hipMemcpyAsync(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-  if (g.n_pl) HIP_TRY(hipMemcpyAsync(hp.data(), s->d_pl.p, hp.size() * sizeof(PlaneEdge), hipMemcpyDeviceToHost, s->stream));
-  if (g.n_bbox) HIP_TRY(hipMemcpyAsync(hb.data(), s->d_bbox.p, hb.size() * sizeof(CubEdge), hipMemcpyDeviceToHost, s->stream));
-  if (g.n_corner) HIP_TRY(hipMemcpyAsync(hc.data(), s->d_corner.p, hc.size() * sizeof(CubEdge), hipMemcpyDeviceToHost, s->stream));
+  if (chi.size() && want_chi) RC_TRY(fetch(chi.data(), s->d_chi2_all.p, chi.size() * sizeof(double)));
+  if (g.n_mono && r->mono_level) RC_TRY(fetch(hmf.data(), s->d_mono_flags.p, hmf.size() * sizeof(uint32_t)));
+  if (g.n_stereo && r->stereo_level) RC_TRY(fetch(hsf.data(), s->d_stereo_flags.p, hsf.size() * sizeof(uint32_t)));
+  if (g.n_pl) RC_TRY(fetch(hp.data(), s->d_pl.p, hp.size() * sizeof(PlaneEdge)));
+  if (g.n_bbox) RC_TRY(fetch(hb.data(), s->d_bbox.p, hb.size() * sizeof(CubEdge)));
+  if (g.n_corner) RC_TRY(fetch(hc.data(), s->d_corner.p, hc.size() * sizeof(CubEdge)));
+  {
+    UploadBatch* const prev = t_upload_batch;
+    t_upload_batch = &down;
+    const int rc = flush_uploads(s->stream);
+    t_upload_batch = prev;
+    if (rc != PPO_BA_OK) return rc;
+  }
   HIP_TRY(hipStreamSynchronize(s->stream));
   State h = make_state(hs.data(), Np, Npt, Npl, Nc);
   if (s->comm.active()) {
