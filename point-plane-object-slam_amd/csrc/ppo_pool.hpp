@@ -39,6 +39,27 @@ struct DevPool {
       if (b / 4 * q >= bytes) return b / 4 * q;
     return b * 2;
   }
+  // A slab per device that ppo_ba_warmup() reserves (round 5): a miss of the cache is then a pointer bump instead of a hipMalloc (~0.1 ms each -- 60 of
+  // them made the first create of a BASELINE-size window 8 ms after the warm-up had already paid for everything else).  Blocks carved from the slab
+  // go through the same size-class free lists as every other block; they are never handed to hipFree one by one: the slab goes back as a whole once
+  // nobody holds a block of it (trim, i.e. ppo_ba_release_cached).
+  struct Slab { char* base = nullptr; size_t cap = 0, used = 0, outstanding = 0; };
+  std::map<int, Slab> slabs_;
+  Slab* slab_of(const void* p, int dev) {  // (mu held)
+    auto it = slabs_.find(dev);
+    if (it == slabs_.end() || !it->second.base) return nullptr;
+    const char* c = static_cast<const char*>(p);
+    return (c >= it->second.base && c < it->second.base + it->second.cap) ? &it->second : nullptr;
+  }
+  bool reserve(int dev, size_t bytes) {
+    std::lock_guard<std::mutex> lk(mu);
+    Slab& sl = slabs_[dev];
+    if (sl.base) return true;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    sl.base = static_cast<char*>(p); sl.cap = bytes; sl.used = 0; sl.outstanding = 0;
+    return true;
+  }
   void* get(size_t bytes, int dev, size_t* got) {
     const size_t b = bucket(bytes);
     *got = b;
@@ -49,6 +70,14 @@ struct DevPool {
         void* p = it->second.back();
         it->second.pop_back();
         cached -= b;
+        if (Slab* sl = slab_of(p, dev)) ++sl->outstanding;
+        return p;
+      }
+      auto st = slabs_.find(dev);
+      if (st != slabs_.end() && st->second.base && st->second.used + b <= st->second.cap) {
+        void* p = st->second.base + st->second.used;
+        st->second.used += b;  // (size classes are multiples of 1 KiB: every block stays 1 KiB-aligned)
+        ++st->second.outstanding;
         return p;
       }
     }
@@ -62,7 +91,9 @@ struct DevPool {
   void put(void* p, size_t b, int dev) {
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (cached + b <= kMaxCached) {
+      Slab* const sl = slab_of(p, dev);
+      if (sl) --sl->outstanding;
+      if (cached + b <= kMaxCached || sl) {  // (a slab block cannot go anywhere else)
         free_[{dev, b}].push_back(p);
         cached += b;
         return;
@@ -76,10 +107,17 @@ struct DevPool {
     for (auto& kv : free_)
       for (void* p : kv.second) {
         chol_release(static_cast<double*>(p));
-        (void)hipFree(p);
+        if (!slab_of(p, kv.first.first)) (void)hipFree(p);
       }
     free_.clear();
     cached = 0;
+    for (auto& kv : slabs_) {  // a slab nobody holds a block of goes back to the driver; one that is in use only forgets its free blocks' space
+      Slab& sl = kv.second;
+      if (sl.base && sl.outstanding == 0) {
+        (void)hipFree(sl.base);
+        sl = Slab{};
+      }
+    }
   }
 };
 inline DevPool g_pool;

@@ -1034,6 +1034,17 @@ struct UploadBatchScope {  // opens a batch on this thread.  Whatever is still r
   ~UploadBatchScope() { t_upload_batch = prev; }
 };
 
+// ppo_ba_warmup (ppo_warmup.cpp): 512 MiB of device memory reserved for the block cache of `device` (hidden symbol: not part of the C ABI)
+namespace ppo {
+int pool_reserve(int device) {
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return PPO_BA_ERR_HIP;
+  const bool ok = g_pool.reserve(device, (size_t)512 << 20);
+  (void)hipSetDevice(prev);
+  return ok ? PPO_BA_OK : PPO_BA_ERR_NOMEM;
+}
+}  // namespace ppo
+
 static thread_local ppo_ba_solver* t_creating = nullptr;  // the solver ppo_ba_create is building on this thread
 
 extern "C" {

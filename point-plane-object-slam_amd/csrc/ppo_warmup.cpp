@@ -14,6 +14,10 @@
 #include "../../include/ppo_ba.h"
 #include "../../include/ppo_pose.h"
 
+namespace ppo {
+int pool_reserve(int device);  // ppo_solver.hip: a slab for the device block cache, so that the first create of every new size is pointer bumps, not hipMallocs
+}
+
 extern "C" int ppo_ba_warmup(int device) {
   const int NP = 4, NPT = 24;
   const double fx = 500, fy = 500, cx = 320, cy = 240, bf = 40;
@@ -72,6 +76,7 @@ extern "C" int ppo_ba_warmup(int device) {
   P.n_ptcub = 1; P.ptcub_cuboid = pc_cub; P.ptcub_offsets = pc_off; P.ptcub_points = pc_pts; P.ptcub_margin_ratio = pc_ratio; P.ptcub_info = pc_info;
   P.n_cubpl = 1; P.cubpl_cuboid = cp_cub; P.cubpl_plane = cp_pl; P.cubpl_meas = cp_meas; P.cubpl_info = cp_info; P.cubpl_huber = cp_hub;
 
+  (void)ppo::pool_reserve(device);  // (failure is not an error: the cache then grows by hipMalloc as before)
   ppo_ba_options O;
   ppo_ba_default_options(&O);
   O.device_id = device;

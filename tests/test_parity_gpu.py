@@ -224,6 +224,21 @@ def test_warmup_entry_point(hip):
     dt = time.perf_counter() - t0
     s.close()
     assert dt < 0.02, dt
+    # the warm-up reserves a slab for the device block cache (csrc/ppo_pool.hpp): blocks carved from it live in the same free lists; giving the cache
+    # back while a solver holds such blocks, and again when nobody does, must leave a working library behind
+    a = hip.create(P, B.default_options())
+    assert hip.lib.ppo_ba_release_cached() == 0
+    ta = a.run()
+    a.close()
+    assert hip.lib.ppo_ba_release_cached() == 0
+    b = hip.create(P, B.default_options())
+    tb = b.run()
+    b.close()
+    assert [i["trials"] for i in ta["iters"]] == [i["trials"] for i in tb["iters"]]
+    assert hip.lib.ppo_ba_warmup(0) == 0  # (reserves again)
+    c = hip.create(synth.make_problem(dict(n_kf=40, n_points=3000, n_planes=10, n_cuboids=4), seed=3), B.default_options())
+    assert c.run()["n_iters"] > 0
+    c.close()
 
 
 def test_one_launch_solve_reports_a_matrix_that_is_not_positive(hip_hooks, monkeypatch):
