@@ -217,13 +217,13 @@ def test_warmup_entry_point(hip):
     assert hip.lib.ppo_ba_warmup(0) == 0
     t0 = time.perf_counter()
     assert hip.lib.ppo_ba_warmup(0) == 0
-    assert time.perf_counter() - t0 < 0.05
+    assert time.perf_counter() - t0 < 0.1  # (wall clock on a shared box: generous -- the first call pays ~150 ms)
     P = synth.make_problem("small", seed=1)
     t0 = time.perf_counter()
     s = hip.create(P, B.default_options())
     dt = time.perf_counter() - t0
     s.close()
-    assert dt < 0.02, dt
+    assert dt < 0.05, dt  # (0.4 ms typical; 155 ms is what a create pays without the warm-up -- the bound only has to tell these apart)
     # the warm-up reserves a slab for the device block cache (csrc/ppo_pool.hpp): blocks carved from it live in the same free lists; giving the cache
     # back while a solver holds such blocks, and again when nobody does, must leave a working library behind
     a = hip.create(P, B.default_options())
