@@ -44,7 +44,7 @@ struct DevPool {
   // them made the first create of a BASELINE-size window 8 ms after the warm-up had already paid for everything else).  Blocks carved from the slab
   // go through the same size-class free lists as every other block; they are never handed to hipFree one by one: the slab goes back as a whole once
   // nobody holds a block of it (trim, i.e. ppo_ba_release_cached).
-  struct Slab { char* base = nullptr; size_t cap = 0, used = 0, outstanding = 0; };
+  struct Slab { char* base = nullptr; size_t cap = 0, used = 0, outstanding = 0; bool owned = true; };
   std::map<int, Slab> slabs_;
   Slab* slab_of(const void* p, int dev) {  // (mu held)
     auto it = slabs_.find(dev);
@@ -60,6 +60,12 @@ struct DevPool {
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
     sl.base = static_cast<char*>(p); sl.cap = bytes; sl.used = 0; sl.outstanding = 0;
     return true;
+  }
+  // (tests/pool_test.cpp: the slab bookkeeping on the CPU, over an address range nobody dereferences and nobody frees)
+  void reserve_external(int dev, void* base, size_t bytes) {
+    std::lock_guard<std::mutex> lk(mu);
+    Slab& sl = slabs_[dev];
+    sl.base = static_cast<char*>(base); sl.cap = bytes; sl.used = 0; sl.outstanding = 0; sl.owned = false;
   }
   void* get(size_t bytes, int dev, size_t* got) {
     const size_t b = bucket(bytes);
@@ -115,7 +121,7 @@ struct DevPool {
     for (auto& kv : slabs_) {  // a slab nobody holds a block of goes back to the driver; one that is in use only forgets its free blocks' space
       Slab& sl = kv.second;
       if (sl.base && sl.outstanding == 0) {
-        (void)hipFree(sl.base);
+        if (sl.owned) (void)hipFree(sl.base);
         sl = Slab{};
       }
     }
