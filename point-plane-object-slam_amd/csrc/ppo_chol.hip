@@ -429,10 +429,39 @@ __host__ __device__ inline StepOverlap step_no_overlap(int nb) {
   return o;
 }
 
+// ---- deterministic mode (options.deterministic): the reduction's sums are INTEGERS ---------------------------------------------------------
+// Every sum of the reduction that crosses a wave (assembly of H_pp + lambda I, the pair chunks, the cuboid terms) is an integer atomic on a 2^-24
+// fixed-point image of the addend (ppo_kernels.hpp: fixed_add), so its result does not depend on the order the atomics arrive in.  Those sums live
+// in a SECOND array of the shape of A (Afix, with bfix behind it); A itself only ever receives the factorisation's own writes, which are plain
+// stores in a fixed order.  The consumer converts on load: the first launch that finds a column block FINAL (all its pair chunks reduced:
+// block < fin[k]) adds the converted image to what the trailing updates have left in A so far ("fold"), and the very first touch of a tile -- launch
+// 0 for block column 0 and the right-hand side, launch 1 for everything else -- does not read A at all, so A needs no clearing between solves.
+// The overlapped reduction therefore works unchanged in this mode (integer adds commute with everything), no tile takes atomic updates, and no
+// conversion launch stands between the reduction and the factorisation.
+struct StepFix {
+  const long long* Afix;  // [ld][ld] column-major, lower triangle; NULL: floating-point accumulation (nothing below applies)
+  const long long* bfix;  // [ld]
+  double* detbad;         // raised by a pair workgroup whose addend does not fit the fixed-point range
+  int fold_lo, fold_hi;   // column blocks [fold_lo, fold_hi) are folded by this launch
+};
+constexpr double kStepFixScale = 16777216.0, kStepFixInv = 1.0 / 16777216.0;  // (= kFixScale / kFixInv of ppo_kernels.hpp)
+__device__ __forceinline__ double fix2d(long long v) { return (double)v * kStepFixInv; }
+__device__ __forceinline__ d2 fix2d2(const long long* p) {
+  const longlong2 v = *reinterpret_cast<const longlong2*>(p);
+  return d2v(fix2d(v.x), fix2d(v.y));
+}
+
 // (not inlined: as part of chol_step's body the pair code -- 234 VGPRs, 60 scalar registers of keyframe data -- pushed the column
 //  workgroups' prologue into scratch memory)
 __device__ __forceinline__ void step_pairs(const StepOverlap& ov, int bid, double (*s_buf)[21][65]) {
   schur_pairs_body<kStepThreads / 64, false>(ov.ctx, ov.pc, ov.chunk_lo, ov.chunk_hi, bid, ov.npair_wg, s_buf, [](double* p, double v) { atomicAdd(p, v); });
+}
+// deterministic mode: ov.ctx.S / ov.ctx.bs point at the fixed-point arrays
+__device__ __forceinline__ void step_pairs_fixed(const StepOverlap& ov, double* detbad, int bid, double (*s_buf)[21][65]) {
+  schur_pairs_body<kStepThreads / 64, false>(ov.ctx, ov.pc, ov.chunk_lo, ov.chunk_hi, bid, ov.npair_wg, s_buf, [detbad](double* p, double v) {
+    if (!(fabs(v) < 4.0e11)) { *detbad = 1.0; return; }
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn(v * kStepFixScale));
+  });
 }
 
 // ---- explicit inverses for the backward substitution ---------------------------------------------------------------------------
@@ -556,9 +585,13 @@ __device__ __forceinline__ void inv_block_wg(const double* __restrict__ A, int l
 
 // OV = false: the launch carries no pair workgroups and no tile takes atomic updates (ov is not read) -- the plain factorisation and the
 // later launches of an overlapped one; as ONE kernel the pair code's registers (240 against 182) and arguments cost every launch 0.4 us.
-template <bool OV>
+// FX (deterministic mode, StepFix): 0 floating-point accumulation; 1 the trailing tiles and the right-hand-side rows of the column blocks
+// [fx.fold_lo, fx.fold_hi) fold their fixed-point image in, pair workgroups add integers; 2 also the column workgroups' own column block (k0 / 64) is
+// in that range -- a variant of its own because its extra requests sit in the prologue of the chain (launches 0 and 1 always, later ones only when
+// the schedule runs at its minimum fin[k - 1] == k).
+template <bool OV, int FX = 0>
 __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word, int gate_expect, double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout,
-                                                            int* __restrict__ info, int inplace_rhs, double* __restrict__ inv, StepOverlap ov) {
+                                                            int* __restrict__ info, int inplace_rhs, double* __restrict__ inv, StepOverlap ov, StepFix fx) {
   constexpr int NT = kStepThreads, NI = 2048 / NT;
   __shared__ StepLdsU lds;
   // LM control on the device: the epoch word is REQUESTED here and looked at only where a workgroup is about to write -- for the column
@@ -593,7 +626,8 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     // ---- pair workgroup of an overlapped reduction: S -= W_j (D_l + lambda I)^-1 W_i' for chunks of column blocks that are not final yet
     // (right behind the column workgroups in the grid: they are the long ones of the launch's shadow, the trailing tiles fill in)
     if (STEP_DEAD()) return;
-    step_pairs(ov, (int)blockIdx.x - ncol - ninv, lds.pairs);
+    if constexpr (FX != 0) step_pairs_fixed(ov, fx.detbad, (int)blockIdx.x - ncol - ninv, lds.pairs);
+    else step_pairs(ov, (int)blockIdx.x - ncol - ninv, lds.pairs);
     return;
   }
   if ((int)blockIdx.x >= ncol + ninv) {
@@ -606,11 +640,31 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     const int r0 = k0 + NB + bi * NB, c0 = k0 + NB + bj * NB;
     const int cblk = c0 / NB;  // column block of the tile
     bool atomic_out = false;  // pair workgroups of this launch may be adding to it
-    if constexpr (OV) atomic_out = cblk >= ov.atomic_lo && cblk <= ov.atomic_hi;
+    if constexpr (OV && FX == 0) atomic_out = cblk >= ov.atomic_lo && cblk <= ov.atomic_hi;  // (FX: they add to Afix, A is this workgroup's alone)
     d2 tp[NI], tq[NI];
     load_tile_nt<NT>(&A[(size_t)kp * ld + r0], ld, tp);
     load_tile_nt<NT>(&A[(size_t)kp * ld + c0], ld, tq);
     double cold[2][2][4] = {};  // old values of the output quadrant, fetched while the panel tiles land (compute waves)
+    if constexpr (FX != 0) {
+      // launch 1 is the first touch of every trailing tile: what lies in A is left over from the previous solve and is not read
+      const bool first = k0 == NB, fold = cblk >= fx.fold_lo && cblk < fx.fold_hi;
+      if (tid < 256 && !first) {
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+          for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) cold[jc][ir][reg] = A[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li];
+      }
+      if (tid < 256 && fold) {
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+          for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) cold[jc][ir][reg] += fix2d(fx.Afix[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li]);
+      }
+    } else
     if (tid < 256 && !atomic_out) {
 #pragma unroll
       for (int jc = 0; jc < 2; ++jc)
@@ -688,12 +742,36 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     STAMP(16);
     load_tile_nt<NT>(pQ, ld, tq);
     STAMP(17);
-    const double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
+    double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
 #pragma unroll
     for (int i = 0; i < NI / 2; ++i) {  // the own half: 32 rows x 64 columns, 16 d2 per column
       const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
       tb[i] = *reinterpret_cast<const d2*>(&pB[(size_t)c * ld + r]);
       tp[i] = *reinterpret_cast<const d2*>(&pP[(size_t)c * ld + r]);
+    }
+    if constexpr (FX == 2) {
+      // deterministic mode, this launch folds its own column block: the fixed-point images of the diagonal tile and of the own half (and of this
+      // block's right-hand-side rows).  Launches 0 and 1 are the first touch of their column block -- A's stale contents are dropped.
+      const bool first = k0 <= NB;
+      const long long* fC = &fx.Afix[(size_t)k0 * ld + k0];
+      const long long* fB = own ? &fx.Afix[(size_t)k0 * ld + row0] : fC;
+      d2 fd[NI], fb[NI / 2];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int p = tid + NT * i;
+        fd[i] = fix2d2(&fC[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
+      }
+#pragma unroll
+      for (int i = 0; i < NI / 2; ++i) {
+        const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
+        fb[i] = fix2d2(&fB[(size_t)c * ld + r]);
+      }
+      const double rf = (tid < NB) ? fix2d(fx.bfix[k0 + tid]) : 0.0;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) td[i] = first ? fd[i] : td[i] + fd[i];
+#pragma unroll
+      for (int i = 0; i < NI / 2; ++i) tb[i] = first ? fb[i] : tb[i] + fb[i];
+      rv = (k0 == 0) ? rf : rv + rf;
     }
 #if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND) && PPO_CHOL_EXPERIMENT_PAIR_BOUND == 3
     d2 tx[2 * NI];  // (timing experiment: what a real pair launch must also pull through this CU -- block row k+1's tile and its previous-panel rows, 64 KB)
@@ -705,6 +783,12 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     }
 #endif
     rold = rsrc[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0];  // (for the very end: requested here, not there; unconditional like the others)
+    if constexpr (FX != 0) {
+      // the right-hand-side rows of block k + b: launch 0 is their first touch; folded with their column block
+      const int rblk = row0 / NB;
+      if (k0 == 0) rold = 0.0;
+      if (own && rblk >= fx.fold_lo && rblk < fx.fold_hi) rold += fix2d(fx.bfix[row0 + 32 * half + ((tid & 255) >> 3)]);
+    }
     if (STEP_DEAD()) return;  // (everything above is a request; nothing has been written)
     STAMP(6);
 #pragma unroll
@@ -866,7 +950,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     sacc += __shfl_xor(sacc, 2, 64);
     sacc += __shfl_xor(sacc, 4, 64);
     if ((tid & 7) == 0) {
-      if (inplace_rhs) atomicAdd(&rhs[row0 + myrow], -sacc);  // (overlapped reduction: the pair workgroups may be adding to this row too)
+      if (FX == 0 && inplace_rhs) atomicAdd(&rhs[row0 + myrow], -sacc);  // (overlapped reduction: the pair workgroups may be adding to this row too)
       else rhs[row0 + myrow] = rold - sacc;
     }
   }
@@ -1132,14 +1216,18 @@ size_t inv_offset(int ld) {
 
 // One launch per panel + one for the backward substitution.  (The one-launch factorisation, ppo_chol_fwd.inc, exists only in the
 // test-hooks build: PPO_BA_CHOL_ONELAUNCH=1 selects it there; DESIGN.md 4.1 has the measurement.)
-int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s, const CholOverlap* ov = nullptr, LmGate gate = LmGate{nullptr, 0}, int n_active = -1) {
+int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double* ws, hipStream_t s, const CholOverlap* ov = nullptr, LmGate gate = LmGate{nullptr, 0}, int n_active = -1,
+                const CholFixed* fixed = nullptr) {
   const int nb = ld / NB;
   if (chol_small_applies(ld, n_active) && (!ov || ov->fin[0] >= nb)) {  // (an overlapped reduction must have left nothing for the panel launches to carry)
     const int n = (n_active > 0 && n_active <= ld) ? n_active : ld;
-    hipLaunchKernelGGL(chol_small, dim3(1), dim3(kSmallThreads), 0, s, gate.epoch_word, gate.expect, (const double*)A, ld, n, ov ? (const double*)ov->ctx.bs : b, x, info);
+    if (fixed) hipLaunchKernelGGL(chol_small<true>, dim3(1), dim3(kSmallThreads), 0, s, gate.epoch_word, gate.expect, reinterpret_cast<const double*>(fixed->Afix), ld, n, reinterpret_cast<const double*>(fixed->bfix), x, info);
+    else hipLaunchKernelGGL(chol_small<false>, dim3(1), dim3(kSmallThreads), 0, s, gate.epoch_word, gate.expect, (const double*)A, ld, n, ov ? (const double*)ov->ctx.bs : b, x, info);
     return hipGetLastError() == hipSuccess ? PPO_BA_OK : PPO_BA_ERR_HIP;
   }
-  double* y = ov ? ov->ctx.bs : ws;  // [ld] forward-substituted right-hand side (overlapped reduction: in place, the pair workgroups add to it)
+  // [ld] forward-substituted right-hand side (overlapped reduction: in place, the pair workgroups add to it; deterministic mode: the pair workgroups add to
+  // bfix, y is the factorisation's own -- the workspace)
+  double* y = (ov && !fixed) ? ov->ctx.bs : ws;
   int* flags = nullptr;
   int nflags = 0;
   // T_k and M_k of every block but the last (inv_block_wg -> chol_back_all), at the end of the workspace
@@ -1183,8 +1271,25 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
       if (PPO_DEV_PROBE("PPO_BA_OVERLAP_EMPTY")) o.chunk_hi = o.chunk_lo;  // timing experiment (WRONG results): the pair workgroups find nothing to do
 #endif
       const dim3 grid(1 + 2 * (m - 1) + (k > 0 ? m * (m - 1) / 2 : 0) + o.npair_wg + (k > 0 && inv ? 1 : 0));
-      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
-      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o);
+      if (fixed) {
+        // deterministic mode: launch k folds the column blocks that are final by now and have not been folded yet -- [done, fin[k]) with
+        // done = 0, 1, fin[k - 1] for k = 0, 1, >= 2 (launch 0 touches block column 0 only, every later launch every block >= k).  Nothing is
+        // overlapped (ov == NULL): every block is final from the start.
+        const int fin_k = ov ? ov->fin[k] : nb, fin_km1 = (ov && k > 0) ? ov->fin[k - 1] : nb;
+        StepFix fx{fixed->Afix, fixed->bfix, fixed->detbad, k == 0 ? 0 : (k == 1 ? 1 : fin_km1), k == 0 ? 1 : fin_k};
+        const bool fold_own = k >= fx.fold_lo && k < fx.fold_hi;
+        if (o.npair_wg > 0) {
+          if (fold_own) hipLaunchKernelGGL((chol_step_t<true, 2>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx);
+          else hipLaunchKernelGGL((chol_step_t<true, 1>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx);
+        } else {
+          if (fold_own) hipLaunchKernelGGL((chol_step_t<false, 2>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx);
+          else hipLaunchKernelGGL((chol_step_t<false, 1>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx);
+        }
+        continue;
+      }
+      const StepFix nofx{nullptr, nullptr, nullptr, 0, 0};
+      if (o.npair_wg > 0) hipLaunchKernelGGL(chol_step_t<true>, grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o, nofx);
+      else hipLaunchKernelGGL(chol_step_t<false>, grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, ov ? y : b, y, x, info, ov ? 1 : 0, inv, o, nofx);
     }
   }
   hipLaunchKernelGGL(chol_back_all, dim3(nb * 8), dim3(kBackThreads), 0, s, gate.epoch_word, gate.expect, (const double*)A, ld, (const double*)y, x, info, flags, nflags, (const double*)inv);
@@ -1228,6 +1333,14 @@ int chol_factor_solve_overlapped(double* A, int ld, double* x, int* info, double
   if (ld % NB != 0 || kStepThreads != 512 || !ov.fin || !ov.cb_start) return PPO_BA_ERR_ARG;
   if (ld == 0) return PPO_BA_OK;
   return enqueue_all(A, ld, ov.ctx.bs, x, info, ws, stream, &ov, ov.gate, n_active);
+}
+
+// Deterministic mode (StepFix): the system was summed as fixed-point integers into fixed.Afix / fixed.bfix; A is the factorisation's own array and
+// needs no initialisation.  ov (may be NULL): an overlapped reduction whose pair workgroups add to the fixed-point arrays (ov->ctx.S == Afix).
+int chol_factor_solve_fixed(double* A, int ld, double* x, int* info, double* ws, const CholFixed& fixed, const CholOverlap* ov, LmGate gate, hipStream_t stream, int n_active) {
+  if (ld % NB != 0 || kStepThreads != 512 || !fixed.Afix || !fixed.bfix || (ov && (!ov->fin || !ov->cb_start))) return PPO_BA_ERR_ARG;
+  if (ld == 0) return PPO_BA_OK;
+  return enqueue_all(A, ld, nullptr, x, info, ws, stream, ov, gate, n_active, &fixed);
 }
 
 // The one-launch solve of small systems (ppo_chol_small.inc) handles up to 192 unknowns; it is USED where it is the faster of the two

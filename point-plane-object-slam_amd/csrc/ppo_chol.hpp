@@ -27,6 +27,15 @@ struct CholOverlap {
   LmGate gate;
 };
 int chol_factor_solve_overlapped(double* A, int n, double* x, int* info, double* workspace, const CholOverlap& ov, hipStream_t stream, int n_active = -1);
+// Deterministic mode (options.deterministic): the reduction summed the system as 2^-24 fixed-point integers into Afix (the shape of A, lower triangle,
+// pad diagonal = 1.0 in fixed point) and bfix; the factorisation converts on load and writes A, which needs NO initialisation (ppo_chol.hip: StepFix).
+// ov (may be NULL): an overlapped reduction as above whose pair workgroups add integers: ov->ctx.S / ov->ctx.bs are Afix / bfix seen as double*.
+struct CholFixed {
+  const long long* Afix;
+  const long long* bfix;
+  double* detbad;  // device word raised when an addend does not fit the fixed-point range (ACC_DETBAD)
+};
+int chol_factor_solve_fixed(double* A, int n, double* x, int* info, double* workspace, const CholFixed& fixed, const CholOverlap* ov, LmGate gate, hipStream_t stream, int n_active = -1);
 void chol_overlap_schedule(int nb, const int32_t* cb_start, int first_blocks, double share0, double share, int* fin);
 size_t chol_workspace_doubles(int n);
 int chol_padded_ld(int n);   // leading dimension the native solver needs (multiple of the panel width)

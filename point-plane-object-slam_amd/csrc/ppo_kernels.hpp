@@ -164,6 +164,11 @@ struct Graph {
   int det;           // options.deterministic: every cross-wave accumulation is an INTEGER atomic on a 2^-24 fixed-point image of the
                      // addend (exact, hence independent of the order the atomics arrive in); k_fix_to_double turns the ranges back into doubles
   const double* hb_diag;  // sharded runs, first iteration: diagonal of Hpp summed over ranks (NULL: read it from HB)
+  // deterministic mode with the LM control on the device: a linearisation that RUNS (its epoch is live) leaves its tag here; the decide launch
+  // behind it converts the ranges it summed into back to doubles only when it finds that tag (k_decide_fix) -- a launch that found its epoch gone
+  // has written nothing, and its target buffer may hold an earlier linearisation that is doubles already
+  unsigned long long* lin_tag_word;
+  unsigned long long lin_tag;
 #ifdef PPO_BA_TEST_HOOKS
   int dbg;                     // development aid (PPO_BA_LIN_DBG): bit 0 numeric classes skip their scatter, bit 1 plain stores instead of atomics
   unsigned long long* stamps;  // development aid (PPO_BA_LIN_STAMPS): [grid][8] wall-clock stamps of the fused linearisation's workgroups
@@ -1373,13 +1378,15 @@ struct DecidePlan {
 };
 constexpr int kRecSlots = 16;
 // the body, by ONE wave (t = its lane): k_decide's, and (round 5) the tail of the launch that evaluates the trial state
-template <bool COHERENT = false>
+// DET (deterministic mode): chi2 and the scale of the gain ratio were summed as fixed-point integers -- folded as integers, converted here; an addend
+// that did not fit (ACC_DETBAD) makes the trial's system unusable: reported like a factorisation that failed (what lm_iteration does on the host).
+template <bool COHERENT = false, bool DET = false>
 __device__ __forceinline__ void decide_wave(int t, double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, const DecidePlan& dp) {
   double* rec = dp.rec + (dp.seq % kRecSlots) * REC_DOUBLES;
   const bool dead = __hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
   if (!dead) {
     if (COHERENT) fold_acc_parts_coherent(acc);
-    else fold_acc_parts(acc, 0);
+    else fold_acc_parts(acc, DET ? 1 : 0);
   }
   __threadfence();
   __builtin_amdgcn_wave_barrier();
@@ -1389,7 +1396,17 @@ __device__ __forceinline__ void decide_wave(int t, double* acc, const int* __res
   }
   if (t == 0 && !dead) {
     LmCtl c = *ctl;
-    lm_decide(c, __hip_atomic_load(&acc[ACC_CHI2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&acc[ACC_SCALE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), *info_p, rec);
+    double chi = __hip_atomic_load(&acc[ACC_CHI2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sc = __hip_atomic_load(&acc[ACC_SCALE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int info = *info_p;
+    if constexpr (DET) {
+      chi = (double)__double_as_longlong(chi) * kFixInv;
+      sc = (double)__double_as_longlong(sc) * kFixInv;
+      if (acc[ACC_DETBAD] != 0.0) {
+        if (info < (1 << 30)) info = 1 << 29;
+        acc[ACC_DETBAD] = 0.0;  // handed over; armed again for the next trial
+      }
+    }
+    lm_decide(c, chi, sc, info, rec);
     *ctl = c;
     rec[REC_SEQ] = (double)dp.seq;
   }
@@ -1407,6 +1424,31 @@ __device__ __forceinline__ void decide_wave(int t, double* acc, const int* __res
 }
 __global__ __launch_bounds__(64) void k_decide(double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, DecidePlan dp) {
   decide_wave(threadIdx.x, acc, info_p, ctl, epoch, dp);
+}
+// Deterministic mode.  Workgroup 0 decides; the others turn the ranges the trial's (speculated) linearisation summed into -- H_pp | H_cc, the planes' D /
+// b_l / W: fixed-point integers -- back into doubles, in the shadow of the decision, so that the mode needs no conversion launch of its own.  They act
+// only when the linearisation in front of this launch left ITS tag (Graph::lin_tag): a linearisation that found its epoch gone wrote nothing and its target
+// may hold an earlier linearisation that is doubles already.  (Not gated by the epoch itself: workgroup 0 may be moving it at this very moment; a
+// converted linearisation of a trial that ends up rejected is simply never read.)
+struct DecideFix {
+  const unsigned long long* tag_word;
+  unsigned long long tag;
+  double* p[4];
+  unsigned long long n[4];
+};
+__global__ __launch_bounds__(256) void k_decide_fix(double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, DecidePlan dp, DecideFix df) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) decide_wave<false, true>(threadIdx.x, acc, info_p, ctl, epoch, dp);
+    return;
+  }
+  if (*df.tag_word != df.tag) return;
+  const size_t t0 = (size_t)(blockIdx.x - 1) * 256 + threadIdx.x, stride = (size_t)(gridDim.x - 1) * 256;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double* p = df.p[q];
+    const size_t n = df.n[q];
+    for (size_t i = t0; i < n; i += stride) p[i] = (double)__double_as_longlong(p[i]) * kFixInv;
+  }
 }
 // The decision as the TAIL of the launch that evaluates the trial state (k_linearize_all on a speculated trial, k_chi2_all otherwise) instead of
 // a 5 us launch of its own behind it: the workgroup that finishes LAST runs decide_wave.  "Last" through two levels of arrival counters
@@ -1469,6 +1511,7 @@ __global__ __launch_bounds__(256, PPO_LIN_WAVES) PPO_LIN_OCC void k_linearize_al
     lm_tail_dead(g, tail);
     return;
   }
+  if (g.lin_tag_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *g.lin_tag_word = g.lin_tag;  // (deterministic + device LM control: this launch is live)
   int b = blockIdx.x, part = -1;
 #pragma unroll
   for (int oi = 0; oi < LIN_PARTS; ++oi) {
@@ -1612,6 +1655,11 @@ __global__ __launch_bounds__(256) void k_fix_to_double(ZeroPlan zp) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
       p[i] = (double)__double_as_longlong(p[i]) * kFixInv;
   }
+}
+
+// the same out of place: the reduced system summed into the fixed-point array -> doubles in S (consumers other than the native solver, which converts on load)
+__global__ __launch_bounds__(256) void k_fix_to_double_copy(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (double)__double_as_longlong(src[i]) * kFixInv;
 }
 
 // max |H_jj| over every active diagonal (computeLambdaInit, levenberg.cpp:166-180)

@@ -24,6 +24,17 @@
 
 namespace ppo {
 
+// one spin-wait hint for the host's polling loops (the host side is plain C++: nothing here may assume an x86 host)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
+}
+
 // Device memory comes from a process-wide cache of freed blocks (size-bucketed, per device): a SLAM process creates and
 // destroys one solver per local-BA call, and ~60 hipMalloc + hipFree pairs cost ~9 ms per call against ~10 ms of solve.
 // Blocks keep their addresses while cached, so the captured Cholesky launch graph of a recurring window shape is reused too.
@@ -44,7 +55,7 @@ struct DevPool {
   // them made the first create of a BASELINE-size window 8 ms after the warm-up had already paid for everything else).  Blocks carved from the slab
   // go through the same size-class free lists as every other block; they are never handed to hipFree one by one: the slab goes back as a whole once
   // nobody holds a block of it (trim, i.e. ppo_ba_release_cached).
-  struct Slab { char* base = nullptr; size_t cap = 0, used = 0, outstanding = 0; bool owned = true; };
+  struct Slab { char* base = nullptr; size_t cap = 0, used = 0, outstanding = 0; bool owned = true, keep = false; };
   std::map<int, Slab> slabs_;
   Slab* slab_of(const void* p, int dev) {  // (mu held)
     auto it = slabs_.find(dev);
@@ -53,12 +64,22 @@ struct DevPool {
     return (c >= it->second.base && c < it->second.base + it->second.cap) ? &it->second : nullptr;
   }
   bool reserve(int dev, size_t bytes) {
-    std::lock_guard<std::mutex> lk(mu);
-    Slab& sl = slabs_[dev];
-    if (sl.base) return true;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (slabs_[dev].base) return true;
+    }
+    // (the allocation itself outside the lock: half a gigabyte takes the driver milliseconds, and every create / destroy of the process takes `mu`)
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
-    sl.base = static_cast<char*>(p); sl.cap = bytes; sl.used = 0; sl.outstanding = 0;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      Slab& sl = slabs_[dev];
+      if (!sl.base) {
+        sl.base = static_cast<char*>(p); sl.cap = bytes; sl.used = 0; sl.outstanding = 0; sl.owned = true;
+        return true;
+      }
+    }
+    (void)hipFree(p);  // somebody else reserved meanwhile
     return true;
   }
   // (tests/pool_test.cpp: the slab bookkeeping on the CPU, over an address range nobody dereferences and nobody frees)
@@ -111,16 +132,29 @@ struct DevPool {
   }
   void trim() {
     std::lock_guard<std::mutex> lk(mu);
-    for (auto& kv : free_)
-      for (void* p : kv.second) {
-        chol_release(static_cast<double*>(p));
-        if (!slab_of(p, kv.first.first)) (void)hipFree(p);
-      }
-    free_.clear();
-    cached = 0;
-    for (auto& kv : slabs_) {  // a slab nobody holds a block of goes back to the driver; one that is in use only forgets its free blocks' space
+    // A slab nobody holds a block of goes back to the driver as a whole (with it every free block carved from it).  A slab that is still in use
+    // KEEPS its free blocks in their size-class lists: its bump pointer cannot be rewound while blocks are out, so forgetting them would lose
+    // their space until the last holder lets go.
+    for (auto& kv : slabs_) {
       Slab& sl = kv.second;
-      if (sl.base && sl.outstanding == 0) {
+      sl.keep = sl.base && sl.outstanding != 0;
+    }
+    size_t kept = 0;
+    for (auto& kv : free_) {
+      std::vector<void*> stay;
+      for (void* p : kv.second) {
+        Slab* const sl = slab_of(p, kv.first.first);
+        if (sl && sl->keep) { stay.push_back(p); kept += kv.first.second; continue; }
+        chol_release(static_cast<double*>(p));
+        if (!sl) (void)hipFree(p);
+      }
+      kv.second.swap(stay);
+    }
+    for (auto it = free_.begin(); it != free_.end();) it = it->second.empty() ? free_.erase(it) : std::next(it);
+    cached = kept;
+    for (auto& kv : slabs_) {
+      Slab& sl = kv.second;
+      if (sl.base && !sl.keep) {
         if (sl.owned) (void)hipFree(sl.base);
         sl = Slab{};
       }
@@ -388,13 +422,7 @@ class HostTeam {
  private:
   static constexpr int kSpin = 600;  // x ~40 ns.  (Kept short: a container with a CPU quota pays for every spinning thread, and long spins
                                      // of 15 workers were measured as multi-millisecond throttling stalls inside ppo_ba_create.)
-  static void relax() {
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#else
-    std::this_thread::yield();
-#endif
-  }
+  static void relax() { cpu_relax(); }
   struct Job {
     std::function<void(int)> call;
     int n = 0, next = 0;            // (mu_)

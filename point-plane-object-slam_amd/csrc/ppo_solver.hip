@@ -95,6 +95,15 @@ struct ppo_ba_solver {
   DevBuf<double> d_arena;     // HB | HC | acc | D | bl | W ; a prefix is zeroed before every linearisation
   DevBuf<double> d_Wpc, d_Dinv, d_ul, d_S, d_xr, d_cholws;
   double* d_bs_p = nullptr;  // = d_S.p + ld * ld
+  // deterministic mode: the reduction sums S and b as 2^-24 fixed-point integers into a second array of the same shape (ppo_chol.hip: StepFix).  The
+  // native solver converts on load (fix_pending: the system in d_Sfix has not been turned into doubles -- launch_solve_local takes the fixed path);
+  // every other consumer (rocSOLVER, the sum over ranks, the debug hooks) gets a conversion launch into d_S.  S_is_zero then speaks of d_Sfix.
+  DevBuf<double> d_Sfix;
+  double* d_bsfix_p = nullptr;
+  bool fix_pending = false;
+  unsigned long long lin_tag = 0;  // deterministic + pipelined: tag of the last linearisation launch (k_decide_fix converts its ranges, see queue_trial)
+  DevBuf<double> d_lin_tag;        // (one 8-byte word)
+  DecideFix pending_fix{};         // ... and the ranges that launch summed into
   DevBuf<double> d_pack;     // sharded runs: lower-triangle tiles of S + b, contiguous, for the all-reduce
   DevBuf<int32_t> d_pc_start, d_pc_colj, d_pc_coli, d_pc_sj, d_pc_si, d_pc_lm;  // pose-pair chunks of the Schur accumulation
   PairChunks pc{};
@@ -117,6 +126,7 @@ struct ppo_ba_solver {
   int epoch = 0;
   unsigned long long ring_seq = 0;
   bool pipeline_ok = false;  // this window / these options take the pipelined path
+  bool poisoned = false;     // a batch of the pipelined path never reported (wait_for_records): unusable until ppo_ba_reset()
 #ifdef PPO_BA_TEST_HOOKS
   DevBuf<unsigned long long> d_stamps;  // PPO_BA_LIN_STAMPS (development aid)
   std::string stamp_path;
@@ -293,7 +303,7 @@ void free_all(ppo_ba_solver* s) {
   s->d_pl0.release(); s->d_bbox0.release(); s->d_corner0.release();
   s->d_chi2_all.release(); s->d_state[0].release(); s->d_state[1].release(); s->d_init.release(); s->d_arena.release();
   s->d_Wpc.release(); s->d_Dinv.release(); s->d_ul.release();
-  s->d_S.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release(); s->d_ctl.release(); s->d_rec.release(); s->d_tailcnt.release();
+  s->d_S.release(); s->d_Sfix.release(); s->d_lin_tag.release(); s->d_pack.release(); s->d_xr.release(); s->d_cholws.release(); s->d_info.release(); s->d_ctl.release(); s->d_rec.release(); s->d_tailcnt.release();
   s->d_pc_start.release(); s->d_pc_colj.release(); s->d_pc_coli.release(); s->d_pc_sj.release(); s->d_pc_si.release(); s->d_pc_lm.release();
   s->d_po_start.release(); s->d_po_end.release(); s->d_po_pose.release(); s->d_W.release();
   s->d_cub_edge_off.release(); s->d_cub_edges.release(); s->d_cub_edge_col.release(); s->d_cp_cub.release(); s->d_cp_a.release(); s->d_cp_b.release(); s->d_cp_cola.release(); s->d_cp_colb.release(); s->d_cp_off.release();
@@ -393,6 +403,7 @@ int reset_device(ppo_ba_solver* s) {
   s->ran = false;
   s->have_system = false;
   HIP_TRY(hipStreamSynchronize(s->stream));
+  s->poisoned = false;  // (the stream has drained: whatever a timed-out batch had left queued is done, the next pass sets a fresh epoch)
   return PPO_BA_OK;
 }
 
@@ -420,7 +431,7 @@ void use_lin_buffer(ppo_ba_solver* s, int buf) {
 // Linearise state `which_state` (default: the current estimate) into the buffer that is not current.  commit: that buffer becomes the
 // current one right away (the linearisation of the kept / initial state); otherwise the caller switches once the trial is accepted.
 // zero_acc: the chi2 / scale accumulators start from zero too (not for the speculated linearisation: the scale of the update is in there).
-int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool commit = true, bool zero_acc = true) {
+int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool commit = true, bool zero_acc = true, bool defer_fix = false) {
   const State& st = s->st[which_state < 0 ? s->cur : which_state];
   const int target = s->lin_buf ^ 1;
   if (!s->lin_clean[target] || zero_acc) {
@@ -430,11 +441,19 @@ int launch_linearize(ppo_ba_solver* s, int which_state = -1, bool commit = true,
   }
   Graph g = s->g;
   point_graph_at(g, s->lb[target]);
+  if (g.det && defer_fix) {  // (queue_trial: the decide launch behind this one converts, if this one runs)
+    g.lin_tag_word = reinterpret_cast<unsigned long long*>(s->d_lin_tag.p);
+    g.lin_tag = ++s->lin_tag;
+  }
   RC_TRY(launch_linearize_kernel(s, g, st));
   s->lin_clean[target] = false;
   if (g.det) {  // the ranges the launch summed into (H_pp | H_cc, the planes' D / b_l / W) back to doubles
     const ZeroPlan zp = linearize_zero_plan(s, target, false);
-    hipLaunchKernelGGL(k_fix_to_double, dim3(std::max(1, std::min(nblk((long)zero_plan_doubles(zp), 256), 2 * s->n_cu))), dim3(256), 0, s->stream, zp);
+    if (defer_fix) {
+      s->pending_fix = DecideFix{g.lin_tag_word, g.lin_tag, {zp.p[0], zp.p[1], zp.p[2], zp.p[3]}, {zp.n[0], zp.n[1], zp.n[2], zp.n[3]}};
+    } else {
+      hipLaunchKernelGGL(k_fix_to_double, dim3(std::max(1, std::min(nblk((long)zero_plan_doubles(zp), 256), 2 * s->n_cu))), dim3(256), 0, s->stream, zp);
+    }
     s->acc_fixed = true;
   }
   if (commit) use_lin_buffer(s, target);
@@ -526,16 +545,25 @@ int launch_chi2(ppo_ba_solver* s, const State& st) {
 }
 
 // reduced system for `lambda` into S (lower triangle) / bs      (block_solver.hpp:354-439)
+// (deterministic mode: the array the reduction sums into is the fixed-point one)
+Graph reduce_graph(const ppo_ba_solver* s) {
+  Graph g = s->g;
+  if (g.det) { g.S = s->d_Sfix.p; g.bs = s->d_bsfix_p; }
+  return g;
+}
 int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
-  const Graph& g = s->g;
+  const Graph g = reduce_graph(s);
   // Overlapped reduction (ppo_chol.hip): only the pair chunks of the first column blocks of S are reduced here, the launches of the
-  // factorisation carry the rest.  (One rank, floating-point accumulation, native solver, and a caller that goes straight on to launch_solve.)
-  s->reduce_overlapped = allow_overlap && !s->fin.empty() && s->solver_kind == PPO_SOLVER_NATIVE && !g.det && !s->comm.active();
+  // factorisation carry the rest.  (One rank, native solver, and a caller that goes straight on to launch_solve.  Round 6: also in deterministic
+  // mode -- integer sums commute with everything, the factorisation converts on load.)
+  const bool to_native = allow_overlap && s->solver_kind == PPO_SOLVER_NATIVE && !s->comm.active();
+  s->reduce_overlapped = to_native && !s->fin.empty();
+  s->fix_pending = to_native && g.det;
   const size_t n = g.ld;
   if (!s->S_is_zero) {  // (normally k_update_all of the previous trial has cleared S and b already)
     ZeroPlan zp{};
-    zp.p[0] = s->d_S.p; zp.n[0] = n * n;
-    zp.p[1] = s->d_bs_p; zp.n[1] = n;
+    zp.p[0] = g.S; zp.n[0] = n * n;
+    zp.p[1] = g.bs; zp.n[1] = n;
     hipLaunchKernelGGL(k_zero_ranges, dim3(4 * s->n_cu), dim3(256), 0, s->stream, zp);
   }
   s->S_is_zero = false;
@@ -584,10 +612,10 @@ int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
   if (fuse_a) hipLaunchKernelGGL(k_reduce_stage1<true>, grid1, dim3(256), 0, s->stream, g, lambda, rp, zother, s->pc);
   else hipLaunchKernelGGL(k_reduce_stage1<false>, grid1, dim3(256), 0, s->stream, g, lambda, rp, zother, s->pc);
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
-  if (g.det) {  // S and b were summed as fixed-point integers (assembly, pair chunks, cuboid terms): back to doubles before anybody factors them
-    ZeroPlan zp{};
-    zp.p[0] = s->d_S.p; zp.n[0] = n * n + n;
-    hipLaunchKernelGGL(k_fix_to_double, dim3(2 * s->n_cu), dim3(256), 0, s->stream, zp);
+  if (g.det && !s->fix_pending) {
+    // S and b were summed as fixed-point integers (assembly, pair chunks, cuboid terms).  The native solver converts on load (launch_solve_local);
+    // for everybody else -- rocSOLVER, the sum over ranks, the debug hooks -- they become doubles in d_S here
+    hipLaunchKernelGGL(k_fix_to_double_copy, dim3(2 * s->n_cu), dim3(256), 0, s->stream, (const double*)s->d_Sfix.p, s->d_S.p, n * n + n);
   }
   HIP_TRY(hipGetLastError());
   if (s->comm.active()) {
@@ -623,7 +651,13 @@ int launch_solve_local(ppo_ba_solver* s) {
   const Graph& g = s->g;
   const int n = g.n_red, ld = g.ld;
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
-    if (s->reduce_overlapped) {
+    if (s->fix_pending) {  // deterministic mode: the system lies in d_Sfix as fixed-point integers, the factorisation converts on load
+      const CholFixed fixed{reinterpret_cast<const long long*>(s->d_Sfix.p), reinterpret_cast<const long long*>(s->d_bsfix_p), s->g.acc + ACC_DETBAD};
+      CholOverlap ov{pair_ctx_host(reduce_graph(s)), s->pc, s->cb_start.data(), s->fin.data(), lm_gate(s)};
+      RC_TRY(chol_factor_solve_fixed(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, fixed, s->reduce_overlapped ? &ov : nullptr, lm_gate(s), s->stream, n));
+      s->reduce_overlapped = false;
+      s->fix_pending = false;
+    } else if (s->reduce_overlapped) {
       CholOverlap ov{pair_ctx_host(g), s->pc, s->cb_start.data(), s->fin.data(), lm_gate(s)};
       RC_TRY(chol_factor_solve_overlapped(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, ov, s->stream, n));
       s->reduce_overlapped = false;
@@ -649,7 +683,7 @@ int launch_update(ppo_ba_solver* s, double lambda) {
   up.nb_red = g.n_cuboids + nblk(g.n_poses, 256);
   up.nb_lm = nl > 0 ? nblk((long)PPO_UPD_LPP * nl, 256) : 0;
   up.nb_zero = nb * (nb + 1) / 2;
-  up.S = s->d_S.p; up.bs = s->d_bs_p; up.ld = g.ld;
+  up.S = g.det ? s->d_Sfix.p : s->d_S.p; up.bs = g.det ? s->d_bsfix_p : s->d_bs_p; up.ld = g.ld;  // (what the next reduction sums into)
   if (const char* e = PPO_DEV_PROBE("PPO_BA_UPDATE_PROBE")) {  // timing experiments (WRONG results): parts of the update launch left out -- 'l' landmarks, 'z' clearing of S
     if (strchr(e, 'l')) up.nb_lm = 0;
     if (strchr(e, 'z')) up.nb_zero = 0;
@@ -890,11 +924,21 @@ int queue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long l
   // next to nothing, and the tail holds every workgroup of the evaluation until its atomics are acknowledged.  So the separate launch, whose
   // ordering needs no argument beyond the kernel boundary, stays the product path; PPO_BA_DECIDE_TAIL=1 (test-hooks build) selects the tail.
   const char* const tail_env = PPO_DEV_ENV("PPO_BA_DECIDE_TAIL");  // (read per trial in the test-hooks build: a test switches it)
-  const bool tail_off = !(tail_env && tail_env[0] == '1');
+  const bool tail_off = s->g.det || !(tail_env && tail_env[0] == '1');     // (deterministic mode: the decide launch also carries the conversion of the linearisation's ranges)
   s->tail = DecideTail{dp, (const int*)s->d_info.p, s->d_ctl.p, s->d_tailcnt.p};
   s->tail_armed = !tail_off;
-  if (speculate) RC_TRY(launch_linearize(s, s->cur ^ 1, false, false));  // doubles as the evaluation of the trial state (see lm_iteration)
+  s->pending_fix = DecideFix{reinterpret_cast<const unsigned long long*>(s->d_lin_tag.p), 0, {}, {}};
+  if (speculate) RC_TRY(launch_linearize(s, s->cur ^ 1, false, false, true));  // doubles as the evaluation of the trial state (see lm_iteration)
   else RC_TRY(launch_chi2(s, s->st[s->cur ^ 1]));
+  if (s->g.det) {
+    // round 6: the deterministic mode on the pipelined path.  chi2 and scale are folded and converted by the decide wave itself, the ranges of the
+    // linearisation by the other workgroups of its launch: the same number of launches per trial as the floating-point mode.
+    const DecideFix& df = s->pending_fix;
+    const size_t nconv = df.n[0] + df.n[1] + df.n[2] + df.n[3];
+    const int nwg = nconv ? std::max(1, std::min(nblk((long)nconv, 1024), s->n_cu)) : 0;
+    hipLaunchKernelGGL(k_decide_fix, dim3(1 + nwg), dim3(256), 0, s->stream, s->g.acc, (const int*)s->d_info.p, s->d_ctl.p, s->g.epoch, dp, df);
+    s->acc_fixed = false;  // (consumed: the next reduction clears the sums)
+  } else
   if (s->tail_armed || tail_off) {
     s->tail_armed = false;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, s->stream, s->g.acc, (const int*)s->d_info.p, s->d_ctl.p, s->g.epoch, dp);
@@ -908,18 +952,27 @@ int wait_for_records(ppo_ba_solver* s, unsigned long long seq) {
   const auto t0 = std::chrono::steady_clock::now();
   bool timed_out = false;
   for (unsigned it = 0; *w != seq; ++it) {
-    __builtin_ia32_pause();  // (a batch is up to five LM iterations long: leave the core's other hardware thread its issue slots)
+    cpu_relax();  // (a batch is up to five LM iterations long: leave the core's other hardware thread its issue slots)
     if ((it & 1023) == 1023) {
       if (hipStreamQuery(s->stream) == hipSuccess) break;
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { timed_out = true; break; }
     }
   }
+  if (*w != seq && timed_out) {
+    // Not there after 5 s of spinning.  The longest batch the tests know takes 30 ms, but a GPU shared with other processes, a profiler that
+    // serialises launches or a debugger can make a healthy batch that slow: one bounded recovery -- sleep-poll the stream for another 25 s --
+    // before the batch is declared hung.  (Bounded: the caller's thread is never parked in an unbounded hipStreamSynchronize.)
+    const auto t1 = std::chrono::steady_clock::now();
+    while (*w != seq && hipStreamQuery(s->stream) == hipErrorNotReady && std::chrono::steady_clock::now() - t1 < std::chrono::seconds(25))
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    timed_out = *w != seq && hipStreamQuery(s->stream) == hipErrorNotReady;
+  }
   if (*w != seq) {
-    // a batch that has not reported after 5 s is a hung kernel, not a slow one (the longest window the tests know takes 30 ms): an error, not
-    // an unbounded wait inside the caller's thread
-    if (timed_out) return PPO_BA_ERR_HIP;
+    // Launches that write the mapped ring and the control record may still be queued: the handle's sequence numbers and epoch are out of step
+    // with the device from here on.  It is marked unusable -- run / read fail until ppo_ba_reset() has drained the stream and re-armed it.
+    if (timed_out) { s->poisoned = true; return PPO_BA_ERR_HIP; }
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (*w != seq) return PPO_BA_ERR_HIP;
+    if (*w != seq) { s->poisoned = true; return PPO_BA_ERR_HIP; }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   return PPO_BA_OK;
@@ -943,6 +996,7 @@ struct SolverDev {
     s->g.ctl = nullptr;
     RC_TRY(launch_linearize(s));
     RC_TRY(fetch_acc(s, false));
+    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) return PPO_BA_ERR_NONFINITE;
     m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
     hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
     HIP_TRY(hipGetLastError());
@@ -961,6 +1015,7 @@ int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
   RC_TRY(launch_linearize(s));
   RC_TRY(launch_maxdiag(s));
   RC_TRY(fetch_acc(s, false, true));
+  if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) return PPO_BA_ERR_NONFINITE;  // (as lm_iteration: the committed state's system is incomplete, nothing to fall back to)
   LmCtl m{};  // the host's mirror of the record: what the device holds whenever nothing is queued
   m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
   m.lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
@@ -1589,10 +1644,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_monoP.alloc(n_monoP) && s->d_stereoP.alloc(n_stereoP);
   if (!dev_plan) {
     ok = ok && s->d_monoP_src.upload(monoP_src, s->stream) && s->d_stereoP_src.upload(stereoP_src, s->stream);
-    if (ok && n_monoP + n_stereoP > 0)
+    if (ok && n_monoP + n_stereoP > 0) {
       if (flush_uploads(s->stream) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
       hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(n_monoP, n_stereoP), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
                          s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)n_monoP, s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)n_stereoP);
+    }
   }
 
   mark("  flags");
@@ -1698,6 +1754,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   ok = ok && s->d_po_start.upload(po_start, s->stream) && s->d_po_end.upload(po_end, s->stream) && s->d_po_pose.upload(po_pose, s->stream);
   s->posec = PoseChunks{s->d_po_start.p, s->d_po_end.p, s->d_po_pose.p, (int)po_pose.size()};
   ok = ok && s->d_Wpc.alloc(2 * (size_t)(p->n_bbox + n_corner_all) * 54) && s->d_Dinv.alloc(nD) && s->d_ul.alloc(nbl);
+  if (o->deterministic) ok = ok && s->d_Sfix.alloc((size_t)ld * ld + ld) && s->d_lin_tag.alloc(2);
   ok = ok && s->d_S.alloc((size_t)ld * ld + ld) && s->d_xr.alloc(ld) && s->d_info.alloc(1) && s->d_ctl.alloc(1) && s->d_rec.alloc((size_t)kRecSlots * REC_DOUBLES) && s->d_tailcnt.alloc(80);
   if (s->comm.active()) ok = ok && s->d_pack.alloc((size_t)(ld / 64) * (ld / 64 + 1) / 2 * 4096 + ld);  // S, then b right behind it: ONE all-reduce when sharded
   ok = ok && s->d_cholws.alloc(chol_workspace_doubles(ncol));
@@ -1762,10 +1819,11 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       if (!plan_sort_positions(plan_scratch, d_pose_key.p, d_pose_key_out.p, reinterpret_cast<uint32_t*>(type == 0 ? s->d_monoP_src.p : s->d_stereoP_src.p), (size_t)n, pose_bits, s->stream))
         return fail(PPO_BA_ERR_NOMEM);
     }
-    if (n_monoP + n_stereoP > 0)
+    if (n_monoP + n_stereoP > 0) {
       if (flush_uploads(s->stream) != PPO_BA_OK) return fail(PPO_BA_ERR_HIP);
       hipLaunchKernelGGL(k_expand_pose_major, dim3(std::min(nblk((long)std::max(n_monoP, n_stereoP), 256), 4 * s->n_cu)), dim3(256), 0, s->stream,
                          s->d_mono.p, s->d_monoP_src.p, s->d_monoP.p, (int)n_monoP, s->d_stereo.p, s->d_stereoP_src.p, s->d_stereoP.p, (int)n_stereoP);
+    }
     // Schur pair plan
     OwnedLandmarks own{Npt, g.pt_first, g.pt_last - g.pt_first, g.plane_first, (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first)};
     long n_pairs = 0;  // (upper bound: every edge of a landmark a slot; the device knows the exact number, positions past it sort to the end)
@@ -1837,7 +1895,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
       if (++nz == 6) flush_zero();
     };
     zero(s->d_Wpc); zero(s->d_Dinv); zero(s->d_ul); zero(s->d_xr); zero(s->d_cholws);
-    zero(s->d_cub_Linv); zero(s->d_cub_Dinv); zero(s->d_xc); zero(s->d_S);
+    zero(s->d_cub_Linv); zero(s->d_cub_Dinv); zero(s->d_xc); zero(s->d_S); zero(s->d_Sfix); zero(s->d_lin_tag);
     static_assert(sizeof(int) * 2 == sizeof(double), "the two int blocks below are cleared as doubles");
     zp.p[nz] = reinterpret_cast<double*>(s->d_tailcnt.p); zp.n[nz] = 40;  // 80 ints
     if (++nz == 6) flush_zero();
@@ -1886,7 +1944,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   }
   g.cub_edge_off = s->d_cub_edge_off.p; g.cub_edges = s->d_cub_edges.p; g.cub_edge_col = s->d_cub_edge_col.p; g.cp_cub = s->d_cp_cub.p; g.cp_a = s->d_cp_a.p; g.cp_b = s->d_cp_b.p; g.cp_cola = s->d_cp_cola.p; g.cp_colb = s->d_cp_colb.p; g.cp_off = s->d_cp_off.p;
   g.n_cub_pairs = (int)cp_cub.size(); g.cub_Linv = s->d_cub_Linv.p; g.cub_Dinv = s->d_cub_Dinv.p; g.xc = s->d_xc.p;
-  g.Dinv = s->d_Dinv.p; g.ul = s->d_ul.p; s->d_bs_p = s->d_S.p + (size_t)ld * ld; g.S = s->d_S.p; g.bs = s->d_bs_p; g.xr = s->d_xr.p;
+  g.Dinv = s->d_Dinv.p; g.ul = s->d_ul.p; s->d_bs_p = s->d_S.p + (size_t)ld * ld; s->d_bsfix_p = s->d_Sfix.p ? s->d_Sfix.p + (size_t)ld * ld : nullptr; g.S = s->d_S.p; g.bs = s->d_bs_p; g.xr = s->d_xr.p;
   s->st[0] = make_state(s->d_state[0].p, Np, Npt, Npl, Nc);
   s->st[1] = make_state(s->d_state[1].p, Np, Npt, Npl, Nc);
 
@@ -1959,7 +2017,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
                    96L * Npt + 104L * Npl + 512L * Nc + 272L * nfree + 56L * n_fixed;
   }
   // LM control on the device (optimize_pipelined): the configurations whose trials are queued without waiting for the host
-  s->pipeline_ok = o->lm_control == PPO_LM_DEVICE && s->solver_kind == PPO_SOLVER_NATIVE && !g.det && !s->comm.active() && !o->verbose;
+  s->pipeline_ok = o->lm_control == PPO_LM_DEVICE && s->solver_kind == PPO_SOLVER_NATIVE && !s->comm.active() && !o->verbose;
   t_creating = nullptr;
   *out = s;
   return PPO_BA_OK;
@@ -1983,6 +2041,7 @@ int ppo_ba_reset(ppo_ba_handle s) {
 // Optimizer.cc:2723-2838
 int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stats) {
   if (!s) return PPO_BA_ERR_ARG;
+  if (s->poisoned) return PPO_BA_ERR_HIP;  // (a batch of an earlier run never reported: ppo_ba_reset() first)
   HIP_TRY(hipSetDevice(s->device));
   const int n_red = s->stats.n_reduced;
   std::memset(&s->stats, 0, sizeof(s->stats));
@@ -2033,6 +2092,7 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
 
 int ppo_ba_read(ppo_ba_handle s, ppo_ba_result* r) try {
   if (!s || !r) return PPO_BA_ERR_ARG;
+  if (s->poisoned) return PPO_BA_ERR_HIP;
   HIP_TRY(hipSetDevice(s->device));
   StageScope stage_scope(s->stage, true);  // the staging vectors below are gone (and their memory reusable) when read returns
   const Graph& g = s->g;
@@ -2457,7 +2517,7 @@ int ppo_ba_overlap_plan(int32_t n_blocks, const int32_t* first_chunk, int32_t fi
 
 int ppo_ba_overlap_schedule(ppo_ba_handle s, int32_t* fin, int32_t n) {
   if (!s) return PPO_BA_ERR_ARG;
-  if (s->fin.empty() || s->solver_kind != PPO_SOLVER_NATIVE || s->g.det || s->comm.active()) return 0;
+  if (s->fin.empty() || s->solver_kind != PPO_SOLVER_NATIVE || s->comm.active()) return 0;
   for (int k = 0; fin && k < n && k < (int)s->fin.size(); ++k) fin[k] = s->fin[k];
   return s->g.ld / 64;
 }

@@ -40,14 +40,14 @@ int main() {
   CHECK(pool.slabs_[dev].outstanding == held.size() - 1);
   void* again = pool.get(66000, dev, &got);  // same class as 70 000
   CHECK(again == held[2].first && got == held[2].second && pool.slabs_[dev].used == expect_used && pool.slabs_[dev].outstanding == held.size());
-  // giving the cache back while blocks are held: the slab stays (its free blocks are forgotten, the held ones remain valid)
+  // giving the cache back while blocks are held: the slab stays AND keeps its free blocks in their size-class lists (its bump pointer
+  // cannot be rewound while blocks are out: forgetting them would lose their space until the last holder lets go)
   pool.put(held[0].first, held[0].second, dev);
   pool.trim();
-  CHECK(pool.slabs_[dev].base == base && pool.slabs_[dev].outstanding == held.size() - 1 && pool.cached == 0);
+  CHECK(pool.slabs_[dev].base == base && pool.slabs_[dev].outstanding == held.size() - 1 && pool.cached == held[0].second);
   void* fresh = pool.get(1000, dev, &got);
-  CHECK(fresh == base + expect_used);  // (not the forgotten block: carved behind everything that was ever handed out)
-  expect_used += got;
-  held[0] = {fresh, got};
+  CHECK(fresh == held[0].first && got == held[0].second && pool.slabs_[dev].used == expect_used && pool.cached == 0);  // the kept block, not a new carve
+  CHECK(pool.slabs_[dev].outstanding == held.size());
   // a request the slab cannot hold falls through to hipMalloc (no device here: nullptr), the slab is untouched
   void* big = pool.get(cap, dev, &got);
   CHECK(big == nullptr && pool.slabs_[dev].used == expect_used);

@@ -103,9 +103,13 @@ def check_against_reference_run(backend, case, tol_lambda, tol_chi2, gate=1.0, t
         return st, r
     fs = R["final_state"]
     ref_pose, ref_pt = np.array(fs["pose_qt"]), np.array(fs["point_xyz"])
-    # BASELINE.md section 2, parity gate
-    assert np.sqrt(np.mean(np.sum((r.pose_qt[:, 4:] - ref_pose[:, 4:]) ** 2, axis=1))) < 1e-5 * gate
-    assert max(quat_angle(a[:4], b[:4]) for a, b in zip(r.pose_qt, ref_pose)) < 1e-5 * gate
+    # BASELINE.md section 2, parity gate (translation 1e-5 m, rotation 1e-6 rad, points 1e-5 m, planes 1e-6, cuboids 1e-5).
+    # gate=None: the caller holds the STATE to its own rule (sensitivity.BARS + the oracle-spread excuse); the per-edge chi2 below still is checked here.
+    state_gate = gate is not None
+    gate = 1.0 if gate is None else gate
+    if state_gate:
+        assert np.sqrt(np.mean(np.sum((r.pose_qt[:, 4:] - ref_pose[:, 4:]) ** 2, axis=1))) < 1e-5 * gate
+        assert max(quat_angle(a[:4], b[:4]) for a, b in zip(r.pose_qt, ref_pose)) < 1e-6 * gate
     # points: where pass 2 determines them (two active observations: >= 4 residual rows for 3 unknowns)
     P = case["problem"]
     n_mono = len(P.get("mono_point", []))
@@ -116,13 +120,14 @@ def check_against_reference_run(backend, case, tol_lambda, tol_chi2, gate=1.0, t
     np.add.at(nrows, E[lvl == 0], rows[lvl == 0])
     well = nrows >= 4
     assert well.sum() >= 8
-    assert np.sqrt(np.mean(np.sum((r.point_xyz[well] - ref_pt[well]) ** 2, axis=1))) < 1e-5 * gate
-    if len(fs["plane_coef"]):
-        assert np.abs(r.plane_coef - np.array(fs["plane_coef"])).max() < 1e-6 * gate
-    if len(fs["cuboid_qt"]):
-        assert np.abs(r.cuboid_qt[:, 4:] - np.array(fs["cuboid_qt"])[:, 4:]).max() < 1e-5 * gate
-        assert max(quat_angle(a[:4], b[:4]) for a, b in zip(r.cuboid_qt, np.array(fs["cuboid_qt"]))) < 1e-5 * gate
-        assert np.abs(r.cuboid_scale - np.array(fs["cuboid_scale"])).max() < 1e-5 * gate
+    if state_gate:
+        assert np.sqrt(np.mean(np.sum((r.point_xyz[well] - ref_pt[well]) ** 2, axis=1))) < 1e-5 * gate
+        if len(fs["plane_coef"]):
+            assert np.abs(r.plane_coef - np.array(fs["plane_coef"])).max() < 1e-6 * gate
+        if len(fs["cuboid_qt"]):
+            assert np.abs(r.cuboid_qt[:, 4:] - np.array(fs["cuboid_qt"])[:, 4:]).max() < 1e-5 * gate
+            assert max(quat_angle(a[:4], b[:4]) for a, b in zip(r.cuboid_qt, np.array(fs["cuboid_qt"]))) < 1e-5 * gate
+            assert np.abs(r.cuboid_scale - np.array(fs["cuboid_scale"])).max() < 1e-5 * gate
     # per-edge chi2 of the custom edges at the final state (active edges).  Bar: a bbox residual of ~10 px with Omega = 0.49 turns a
     # state deviation of 1e-5 m (the gate above; f / z ~ 160 px per metre) into 2 e Omega de ~ 1.6e-2 of chi2 -- 1e-3 of the
     # largest chi2 (~50) is the tighter of the two statements
@@ -224,7 +229,7 @@ def test_hip_follows_the_reference_run(oracle, hip, k):
     1.2e-5 against a spread of 1.5e-5; everything else is inside the bar, the largest ratio 0.74 on a rotation)."""
     import sensitivity as S
     case = CASES[k]
-    _, r = check_against_reference_run(hip, case, tol_lambda=1e-3, tol_chi2=1e-4, marginal_floor=1e-6, options=dict(deterministic=1), gate=3.0)
+    _, r = check_against_reference_run(hip, case, tol_lambda=1e-3, tol_chi2=1e-4, marginal_floor=1e-6, options=dict(deterministic=1), gate=None)
     P = problem_of(case)
     ref = ReferenceState(case["result"]["final_state"], r)
     m = S.metrics(ref, r, S.determined_points(P, r))

@@ -164,8 +164,8 @@ int main() {
   printf("info %d max residual %.3e\n", info, rmax);
   // phase stamps of column workgroup 1 of the second step (update of panel 0 fused with the factorisation of panel 1)
   hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (n / 64 - 1)), dim3(ppo::kStepThreads), 0, s, (const int*)nullptr, 0, dA, n, 0, db, dws, dx, dinfo, 0, (double*)nullptr, ppo::step_no_overlap(n / 64));
-  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (m - 1) + m * (m - 1) / 2), dim3(ppo::kStepThreads), 0, s, (const int*)nullptr, 0, dA, n, 64, db, dws, dx, dinfo, 0, (double*)nullptr, ppo::step_no_overlap(n / 64)); }
+  hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (n / 64 - 1)), dim3(ppo::kStepThreads), 0, s, (const int*)nullptr, 0, dA, n, 0, db, dws, dx, dinfo, 0, (double*)nullptr, ppo::step_no_overlap(n / 64), ppo::StepFix{nullptr, nullptr, nullptr, 0, 0});
+  { const int m = n / 64 - 1; hipLaunchKernelGGL(ppo::chol_step, dim3(1 + 2 * (m - 1) + m * (m - 1) / 2), dim3(ppo::kStepThreads), 0, s, (const int*)nullptr, 0, dA, n, 64, db, dws, dx, dinfo, 0, (double*)nullptr, ppo::step_no_overlap(n / 64), ppo::StepFix{nullptr, nullptr, nullptr, 0, 0}); }
   hipStreamSynchronize(s);
   long long st[48];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
