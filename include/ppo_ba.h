@@ -193,10 +193,11 @@ typedef struct ppo_ba_options {
   double chi2_plane_vp;     /* 200 */
   double th_bbox_norm;      /* thHuberBbox2d, compared with |e| (not chi2) Optimizer.cc:2774 */
   double th_corner_norm;    /* thHuberConer2d Optimizer.cc:2783 */
-  int32_t deterministic;    /* 0 (default): cross-wave sums are floating-point atomics (run-to-run differences ~1e-9 in chi2, DESIGN.md
-                             * section 6).  1: the same atomics add 2^-24 fixed-point INTEGERS (exact, hence independent of arrival
-                             * order): two runs on the same device and build give bit-identical results; ~10 % slower.
-                             * Any other value -> PPO_BA_ERR_ARG */
+  int32_t deterministic;    /* 1 (default since round 6): every sum that crosses a wave adds 2^-24 fixed-point INTEGERS (exact, hence independent
+                             * of the order the atomics arrive in): two runs on the same device and build give bit-identical results, like the
+                             * single-threaded reference.  This is the mode every strict parity test runs and the mode bench.py times.
+                             * 0: the same sums as floating-point atomics (run-to-run differences ~1e-9 in chi2 that flat directions of a
+                             * window amplify); ~1 % faster at the BASELINE size.  Any other value -> PPO_BA_ERR_ARG */
   int32_t solver;           /* PPO_SOLVER_* */
   int32_t eliminate_cuboids; /* 1 (default): cuboids are Schur-eliminated too and the dense system is poses only --
                               * the same linear solve as the reference (which keeps them dense, Optimizer.cc:2172),
@@ -213,7 +214,7 @@ typedef struct ppo_ba_options {
                              * x and the factorisation flag are broadcast.  Same results on every rank either way. */
   int32_t lm_control;       /* where the Levenberg-Marquardt decisions (gain ratio, accept / reject, lambda, nu, the nBad stop;
                              * optimization_algorithm_levenberg.cpp:102-163) are taken.  PPO_LM_DEVICE (0, default): by a kernel queued behind
-                             * every trial, the host queues the next trial without waiting (single rank, native solver, deterministic = 0,
+                             * every trial, the host queues the next trial without waiting (single rank, native solver,
                              * verbose = 0; every other configuration takes the host path whatever this says).  PPO_LM_HOST (1): by the host
                              * after a round trip per trial.  Same arithmetic (pow(x, 3) is a cube within one ulp on the device: one ulp of
                              * lambda in about one accepted trial in a thousand), same results.  PPO_LM_DEVICE queues up to five solve attempts
@@ -333,7 +334,7 @@ PPO_API int ppo_ba_time_factor(ppo_ba_handle h, int reps, double* ms);
  * pose-pair chunks of the first column blocks of the reduced matrix are reduced ahead of it, the first panel launches carry the rest.
  * Returns the number of 64-column blocks (= panel launches) of this window's dense system and fills fin[k], k < min(n, blocks + 1), with the
  * number of column blocks that are final when launch k starts (fin[0]: reduced ahead of the factorisation); 0 when the reduction of this
- * window is not overlapped (few panels, deterministic mode, sharded runs, the rocSOLVER backend).  ppo_ba_time_factor() times the dense
+ * window is not overlapped (few panels, sharded runs, the rocSOLVER backend).  ppo_ba_time_factor() times the dense
  * solve ALONE, after a complete reduction. */
 PPO_API int ppo_ba_overlap_schedule(ppo_ba_handle h, int32_t* fin, int32_t n);
 /* The schedule rule itself (host only, no GPU needed): for n_blocks 64-column blocks whose pose-pair chunks start at first_chunk[c]

@@ -459,7 +459,7 @@ __device__ __forceinline__ void step_pairs(const StepOverlap& ov, int bid, doubl
 // deterministic mode: ov.ctx.S / ov.ctx.bs point at the fixed-point arrays
 __device__ __forceinline__ void step_pairs_fixed(const StepOverlap& ov, double* detbad, int bid, double (*s_buf)[21][65]) {
   schur_pairs_body<kStepThreads / 64, false>(ov.ctx, ov.pc, ov.chunk_lo, ov.chunk_hi, bid, ov.npair_wg, s_buf, [detbad](double* p, double v) {
-    if (!(fabs(v) < 4.0e11)) { *detbad = 1.0; return; }
+    if (!(fabs(v) < 4.0e11)) { *detbad = 1.0; return; }  // (ppo_kernels.hpp: fixed_add -- an entry of S or b that does not fit: ACC_DETRANGE, the system is not usable)
     atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn(v * kStepFixScale));
   });
 }
@@ -587,8 +587,9 @@ __device__ __forceinline__ void inv_block_wg(const double* __restrict__ A, int l
 // later launches of an overlapped one; as ONE kernel the pair code's registers (240 against 182) and arguments cost every launch 0.4 us.
 // FX (deterministic mode, StepFix): 0 floating-point accumulation; 1 the trailing tiles and the right-hand-side rows of the column blocks
 // [fx.fold_lo, fx.fold_hi) fold their fixed-point image in, pair workgroups add integers; 2 also the column workgroups' own column block (k0 / 64) is
-// in that range -- a variant of its own because its extra requests sit in the prologue of the chain (launches 0 and 1 always, later ones only when
-// the schedule runs at its minimum fin[k - 1] == k).
+// in that range -- a variant of its own because its extra requests sit in the prologue of the chain (only when the schedule runs at its minimum
+// fin[k - 1] == k); 3 launches 0 and 1: the own column block is folded AND this is its first touch -- the diagonal tile and the own half are
+// requested from the fixed-point array INSTEAD of A (the same number of requests in the prologue as a plain step).
 template <bool OV, int FX = 0>
 __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word, int gate_expect, double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout,
                                                             int* __restrict__ info, int inplace_rhs, double* __restrict__ inv, StepOverlap ov, StepFix fx) {
@@ -738,7 +739,18 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     const double* pB = own ? &A[(size_t)k0 * ld + row0] : pC;
     const double* pP = uo ? &A[(size_t)kp * ld + row0] : pC;  // L[k+b][k-1]
     STAMP(15);
-    load_tile_nt<NT>(pC, ld, td);
+    [[maybe_unused]] longlong2 fd[NI], fb[NI / 2];  // (FX >= 2: fixed-point images of the diagonal tile and of the own half, converted behind the requests)
+    const long long* fC = FX >= 2 ? &fx.Afix[(size_t)k0 * ld + k0] : nullptr;
+    const long long* fB = FX >= 2 ? (own ? &fx.Afix[(size_t)k0 * ld + row0] : fC) : nullptr;
+    if constexpr (FX == 3) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int p = tid + NT * i;
+        fd[i] = *reinterpret_cast<const longlong2*>(&fC[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
+      }
+    } else {
+      load_tile_nt<NT>(pC, ld, td);
+    }
     STAMP(16);
     load_tile_nt<NT>(pQ, ld, tq);
     STAMP(17);
@@ -746,32 +758,31 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
 #pragma unroll
     for (int i = 0; i < NI / 2; ++i) {  // the own half: 32 rows x 64 columns, 16 d2 per column
       const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
-      tb[i] = *reinterpret_cast<const d2*>(&pB[(size_t)c * ld + r]);
+      if constexpr (FX == 3) fb[i] = *reinterpret_cast<const longlong2*>(&fB[(size_t)c * ld + r]);
+      else tb[i] = *reinterpret_cast<const d2*>(&pB[(size_t)c * ld + r]);
       tp[i] = *reinterpret_cast<const d2*>(&pP[(size_t)c * ld + r]);
     }
     if constexpr (FX == 2) {
       // deterministic mode, this launch folds its own column block: the fixed-point images of the diagonal tile and of the own half (and of this
-      // block's right-hand-side rows).  Launches 0 and 1 are the first touch of their column block -- A's stale contents are dropped.
-      const bool first = k0 <= NB;
-      const long long* fC = &fx.Afix[(size_t)k0 * ld + k0];
-      const long long* fB = own ? &fx.Afix[(size_t)k0 * ld + row0] : fC;
-      d2 fd[NI], fb[NI / 2];
+      // block's right-hand-side rows) on top of what the trailing updates have left in A
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int p = tid + NT * i;
-        fd[i] = fix2d2(&fC[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
+        fd[i] = *reinterpret_cast<const longlong2*>(&fC[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
       }
 #pragma unroll
       for (int i = 0; i < NI / 2; ++i) {
         const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
-        fb[i] = fix2d2(&fB[(size_t)c * ld + r]);
+        fb[i] = *reinterpret_cast<const longlong2*>(&fB[(size_t)c * ld + r]);
       }
+    }
+    if constexpr (FX >= 2) {
       const double rf = (tid < NB) ? fix2d(fx.bfix[k0 + tid]) : 0.0;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) td[i] = first ? fd[i] : td[i] + fd[i];
+      for (int i = 0; i < NI; ++i) td[i] = FX == 3 ? d2v(fix2d(fd[i].x), fix2d(fd[i].y)) : td[i] + d2v(fix2d(fd[i].x), fix2d(fd[i].y));
 #pragma unroll
-      for (int i = 0; i < NI / 2; ++i) tb[i] = first ? fb[i] : tb[i] + fb[i];
-      rv = (k0 == 0) ? rf : rv + rf;
+      for (int i = 0; i < NI / 2; ++i) tb[i] = FX == 3 ? d2v(fix2d(fb[i].x), fix2d(fb[i].y)) : tb[i] + d2v(fix2d(fb[i].x), fix2d(fb[i].y));
+      rv = (k0 == 0) ? rf : rv + rf;  // (launch 0 is the first touch of the right-hand side)
     }
 #if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND) && PPO_CHOL_EXPERIMENT_PAIR_BOUND == 3
     d2 tx[2 * NI];  // (timing experiment: what a real pair launch must also pull through this CU -- block row k+1's tile and its previous-panel rows, 64 KB)
@@ -784,10 +795,12 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
 #endif
     rold = rsrc[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0];  // (for the very end: requested here, not there; unconditional like the others)
     if constexpr (FX != 0) {
-      // the right-hand-side rows of block k + b: launch 0 is their first touch; folded with their column block
+      // the right-hand-side rows of block k + b: launch 0 is their first touch; folded with their column block.  (The request is unconditional like
+      // every other of this prologue: a load under an `if` makes the compiler drain the requests in front of it first.)
       const int rblk = row0 / NB;
+      const double rf = fix2d(fx.bfix[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0]);
       if (k0 == 0) rold = 0.0;
-      if (own && rblk >= fx.fold_lo && rblk < fx.fold_hi) rold += fix2d(fx.bfix[row0 + 32 * half + ((tid & 255) >> 3)]);
+      if (own && rblk >= fx.fold_lo && rblk < fx.fold_hi) rold += rf;
     }
     if (STEP_DEAD()) return;  // (everything above is a request; nothing has been written)
     STAMP(6);
@@ -1277,14 +1290,18 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
         // overlapped (ov == NULL): every block is final from the start.
         const int fin_k = ov ? ov->fin[k] : nb, fin_km1 = (ov && k > 0) ? ov->fin[k - 1] : nb;
         StepFix fx{fixed->Afix, fixed->bfix, fixed->detbad, k == 0 ? 0 : (k == 1 ? 1 : fin_km1), k == 0 ? 1 : fin_k};
-        const bool fold_own = k >= fx.fold_lo && k < fx.fold_hi;
+        const int mode = (k >= fx.fold_lo && k < fx.fold_hi) ? (k <= 1 ? 3 : 2) : 1;  // (launches 0 and 1 always fold their own block, as its first touch)
+#define PPO_STEP_FX(OV_, FX_) hipLaunchKernelGGL((chol_step_t<OV_, FX_>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx)
         if (o.npair_wg > 0) {
-          if (fold_own) hipLaunchKernelGGL((chol_step_t<true, 2>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx);
-          else hipLaunchKernelGGL((chol_step_t<true, 1>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx);
+          if (mode == 3) PPO_STEP_FX(true, 3);
+          else if (mode == 2) PPO_STEP_FX(true, 2);
+          else PPO_STEP_FX(true, 1);
         } else {
-          if (fold_own) hipLaunchKernelGGL((chol_step_t<false, 2>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx);
-          else hipLaunchKernelGGL((chol_step_t<false, 1>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx);
+          if (mode == 3) PPO_STEP_FX(false, 3);
+          else if (mode == 2) PPO_STEP_FX(false, 2);
+          else PPO_STEP_FX(false, 1);
         }
+#undef PPO_STEP_FX
         continue;
       }
       const StepFix nofx{nullptr, nullptr, nullptr, 0, 0};

@@ -33,7 +33,7 @@ int chol_factor_solve_overlapped(double* A, int n, double* x, int* info, double*
 struct CholFixed {
   const long long* Afix;
   const long long* bfix;
-  double* detbad;  // device word raised when an addend does not fit the fixed-point range (ACC_DETBAD)
+  double* detbad;  // device word raised by an addend that is not finite or does not fit the fixed-point range (ACC_DETRANGE: the system is not usable)
 };
 int chol_factor_solve_fixed(double* A, int n, double* x, int* info, double* workspace, const CholFixed& fixed, const CholOverlap* ov, LmGate gate, hipStream_t stream, int n_active = -1);
 void chol_overlap_schedule(int nb, const int32_t* cb_start, int first_blocks, double share0, double share, int* fin);

@@ -45,6 +45,7 @@ void ppo_ba_default_options(ppo_ba_options* o) {
   o->th_cub3d_norm = 900.0;  /* thHuberSE3, src/Parameters.cc:65 */
   o->solve_on_owner = 0;
   o->lm_control = PPO_LM_DEVICE;
+  o->deterministic = 1;  /* round 6: the bit-reproducible mode is the default (within 1 % of the floating-point atomics) */
   o->solver = PPO_SOLVER_AUTO;
   o->eliminate_cuboids = 1;
   o->world_size = 1;

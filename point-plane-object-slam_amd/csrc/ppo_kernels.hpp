@@ -73,11 +73,12 @@ struct PtCubEdge {
 };
 
 enum { F_ACTIVE = 1u, F_ROBUST = 2u };
-enum { ACC_CHI2 = 0, ACC_SCALE = 1, ACC_STOP = 2, ACC_MAXDIAG = 3, ACC_DETBAD = 4, ACC_N = 8 };  // ACC_STOP: sharded runs, the ranks' stop votes (summed)
+enum { ACC_CHI2 = 0, ACC_SCALE = 1, ACC_STOP = 2, ACC_MAXDIAG = 3, ACC_DETBAD = 4, ACC_DETRANGE = 5, ACC_N = 8 };  // ACC_STOP: sharded runs, the ranks' stop votes (summed)
 // chi2 and the gain-ratio scale are sums over ALL workgroups of a launch: 1 300 atomics on one address retire one after the other and
 // were 4 us of the 31 us fused linearisation (PPO_BA_LIN_DBG=4).  Workgroups add to one of kAccParts partial sums, 128 bytes apart,
 // behind the accumulator block; whoever reads the block folds them in first (fold_acc_parts: k_publish, k_fold_acc).
 constexpr int kAccParts = 64, kAccPartStride = 16, ACC_TOTAL = ACC_N + kAccParts * kAccPartStride;
+static_assert(ACC_N == 8 && kAccParts == 64 && kAccPartStride == 16, "fixed_add tells a chi2 term by its address inside the accumulator block");
 
 struct State {       // one copy of all estimates
   double* pose_qt;   // [Np][7]
@@ -195,17 +196,27 @@ __device__ __forceinline__ double wave_sum(double v) {
 // In deterministic mode the same atomics add INTEGERS: the addend is rounded to a multiple of 2^-24 and added as a 64-bit
 // two's-complement number, which is exact and therefore order-independent; the accumulation ranges are converted back to
 // doubles by k_fix_to_double before anybody reads them.  Range +-5.5e11 (the largest entries, diagonal of H_pp / S, are ~1e9),
-// resolution 6e-8 absolute, i.e. <= 1e-15 of the norm of the matrices that are factored; an addend that is not finite or out
-// of range raises ACC_DETBAD (reported like a failed factorisation) instead of being added.
+// resolution 6e-8 absolute, i.e. <= 1e-15 of the norm of the matrices that are factored.  An addend that cannot be represented is left out and
+// flagged.  A NON-FINITE term of chi2 raises ACC_DETBAD: the sum would be NaN in the reference's arithmetic and is treated as NaN by whoever reads
+// the flag (chi2 of the estimate NaN: the window freezes exactly as it does in the reference, levenberg.cpp:113-149 with every comparison on NaN
+// false).  Every other term that does not fit -- finite and out of range, or a non-finite entry of a matrix, a right-hand side or the scale of the
+// gain ratio -- raises ACC_DETRANGE: the system is not usable, reported like a factorisation that failed (what a NaN in S is to the reference's
+// LDLT, linear_solver_dense.h:108-112).
 constexpr double kFixScale = 16777216.0, kFixInv = 1.0 / 16777216.0;
-__device__ __forceinline__ void fixed_add(double* p, double v, double* bad) {
-  if (!(fabs(v) < 4.0e11)) { *bad = 1.0; return; }
+constexpr int kAccPartsFirst = 8;  // (= ACC_N, declared below with the partial sums)
+__device__ __forceinline__ void fixed_add(double* p, double v, double* acc) {  // acc: the accumulator block (flags; and p inside it <=> a chi2 / scale term)
+  if (!(fabs(v) < 4.0e11)) {
+    const long off = p - acc;
+    const bool chi2_term = off >= kAccPartsFirst && off < kAccPartsFirst + 64 * 16 && ((off - kAccPartsFirst) & 15) == ACC_CHI2;  // (kAccParts x kAccPartStride)
+    acc[(chi2_term && !isfinite(v)) ? ACC_DETBAD : ACC_DETRANGE] = 1.0;
+    return;
+  }
   atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn(v * kFixScale));
 }
 #ifdef PPO_BA_TEST_HOOKS  // PPO_BA_LIN_DBG bit 1: plain (racy) stores instead of atomics -- timing experiments only
-#define acc_add(g_, p_, v_) do { if ((g_).det) fixed_add((p_), (v_), &(g_).acc[ACC_DETBAD]); else if ((g_).dbg & 2) *(p_) = (v_); else atomicAdd((p_), (v_)); } while (0)
+#define acc_add(g_, p_, v_) do { if ((g_).det) fixed_add((p_), (v_), (g_).acc); else if ((g_).dbg & 2) *(p_) = (v_); else atomicAdd((p_), (v_)); } while (0)
 #else
-#define acc_add(g_, p_, v_) do { if ((g_).det) fixed_add((p_), (v_), &(g_).acc[ACC_DETBAD]); else atomicAdd((p_), (v_)); } while (0)
+#define acc_add(g_, p_, v_) do { if ((g_).det) fixed_add((p_), (v_), (g_).acc); else atomicAdd((p_), (v_)); } while (0)
 #endif
 
 // where this workgroup (wave) adds its share of acc[which], which = ACC_CHI2 or ACC_SCALE
@@ -1401,9 +1412,13 @@ __device__ __forceinline__ void decide_wave(int t, double* acc, const int* __res
     if constexpr (DET) {
       chi = (double)__double_as_longlong(chi) * kFixInv;
       sc = (double)__double_as_longlong(sc) * kFixInv;
-      if (acc[ACC_DETBAD] != 0.0) {
+      if (acc[ACC_DETRANGE] != 0.0) {  // a finite addend out of the fixed-point range: the trial's system is not usable
         if (info < (1 << 30)) info = 1 << 29;
-        acc[ACC_DETBAD] = 0.0;  // handed over; armed again for the next trial
+        acc[ACC_DETRANGE] = 0.0;  // handed over; armed again for the next trial
+      }
+      if (acc[ACC_DETBAD] != 0.0) {  // a non-finite addend: the trial state's chi2 is NaN in the reference's arithmetic
+        chi = __builtin_nan("");
+        acc[ACC_DETBAD] = 0.0;
       }
     }
     lm_decide(c, chi, sc, info, rec);
@@ -1599,7 +1614,7 @@ __global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restri
   __syncthreads();
   double v = 0.0;
   if (t < ACC_N) { v = acc[t]; host[t] = v; }
-  if (t == ACC_DETBAD) acc[t] = 0.0;  // deterministic mode: "an addend did not fit" has been handed over; armed again for the next launches
+  if (t == ACC_DETBAD || t == ACC_DETRANGE) acc[t] = 0.0;  // deterministic mode: "an addend did not fit" has been handed over; armed again for the next launches
   if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
   __threadfence_system();
   __syncthreads();
@@ -2273,6 +2288,7 @@ __global__ __launch_bounds__(256) void k_pack_lower_tiles(double* __restrict__ S
   if (b == ntiles) {  // the right-hand side rides behind the tiles
     for (int i = threadIdx.x; i < ld; i += 256) {
       if (dir == 0) pack[(size_t)ntiles * 4096 + i] = bs[i];
+      else if (dir == 2) pack[(size_t)ntiles * 4096 + i] = (double)__double_as_longlong(bs[i]) * kFixInv;
       else bs[i] = pack[(size_t)ntiles * 4096 + i];
     }
     return;
@@ -2284,7 +2300,10 @@ __global__ __launch_bounds__(256) void k_pack_lower_tiles(double* __restrict__ S
   for (int i = threadIdx.x; i < 64 * 32; i += 256) {
     const int c = i >> 5, r2 = i & 31;
     if (dir == 0) dst[i] = tile[(size_t)c * (ld / 2) + r2];
-    else tile[(size_t)c * (ld / 2) + r2] = dst[i];
+    else if (dir == 2) {  // deterministic mode: S / bs are the fixed-point arrays -- converted while they are packed (no conversion launch in front of the collective)
+      const double2 v = tile[(size_t)c * (ld / 2) + r2];
+      dst[i] = make_double2((double)__double_as_longlong(v.x) * kFixInv, (double)__double_as_longlong(v.y) * kFixInv);
+    } else tile[(size_t)c * (ld / 2) + r2] = dst[i];
   }
 }
 

@@ -612,9 +612,9 @@ int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
   if (fuse_a) hipLaunchKernelGGL(k_reduce_stage1<true>, grid1, dim3(256), 0, s->stream, g, lambda, rp, zother, s->pc);
   else hipLaunchKernelGGL(k_reduce_stage1<false>, grid1, dim3(256), 0, s->stream, g, lambda, rp, zother, s->pc);
   if (rp.nb_pairs + rp.nb_cubschur > 0) hipLaunchKernelGGL(k_reduce_stage3, dim3(rp.nb_pairs + rp.nb_cubschur), dim3(256), 0, s->stream, g, s->pc, rp);
-  if (g.det && !s->fix_pending) {
+  if (g.det && !s->fix_pending && !s->comm.active()) {
     // S and b were summed as fixed-point integers (assembly, pair chunks, cuboid terms).  The native solver converts on load (launch_solve_local);
-    // for everybody else -- rocSOLVER, the sum over ranks, the debug hooks -- they become doubles in d_S here
+    // for rocSOLVER and the debug hooks they become doubles in d_S here (sharded runs: while they are packed for the collective, below)
     hipLaunchKernelGGL(k_fix_to_double_copy, dim3(2 * s->n_cu), dim3(256), 0, s->stream, (const double*)s->d_Sfix.p, s->d_S.p, n * n + n);
   }
   HIP_TRY(hipGetLastError());
@@ -622,7 +622,8 @@ int launch_reduce(ppo_ba_solver* s, double lambda, bool allow_overlap = false) {
     // ONE collective per solve attempt: the lower-triangle tiles of S and b, packed (the owner's identity on the padding
     // and lambda on the diagonal are part of its contribution)
     const int nb = g.ld / 64, ntiles = nb * (nb + 1) / 2;
-    hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 0);
+    if (g.det) hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_Sfix.p, s->d_bsfix_p, s->d_pack.p, g.ld, 2);
+    else hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 0);
     if (s->opt.solve_on_owner) {  // reduce to rank 0, which alone unpacks (and solves: launch_solve)
       if (s->comm.sum_to_root(s->d_pack.p, (size_t)ntiles * 4096 + n, s->stream)) return PPO_BA_ERR_COMM;
       if (s->comm.rank == 0) hipLaunchKernelGGL(k_pack_lower_tiles, dim3(ntiles + 1), dim3(256), 0, s->stream, s->d_S.p, s->d_bs_p, s->d_pack.p, g.ld, 1);
@@ -652,7 +653,7 @@ int launch_solve_local(ppo_ba_solver* s) {
   const int n = g.n_red, ld = g.ld;
   if (s->solver_kind == PPO_SOLVER_NATIVE) {
     if (s->fix_pending) {  // deterministic mode: the system lies in d_Sfix as fixed-point integers, the factorisation converts on load
-      const CholFixed fixed{reinterpret_cast<const long long*>(s->d_Sfix.p), reinterpret_cast<const long long*>(s->d_bsfix_p), s->g.acc + ACC_DETBAD};
+      const CholFixed fixed{reinterpret_cast<const long long*>(s->d_Sfix.p), reinterpret_cast<const long long*>(s->d_bsfix_p), s->g.acc + ACC_DETRANGE};
       CholOverlap ov{pair_ctx_host(reduce_graph(s)), s->pc, s->cb_start.data(), s->fin.data(), lm_gate(s)};
       RC_TRY(chol_factor_solve_fixed(s->d_S.p, ld, s->d_xr.p, s->d_info.p, s->d_cholws.p, fixed, s->reduce_overlapped ? &ov : nullptr, lm_gate(s), s->stream, n));
       s->reduce_overlapped = false;
@@ -716,7 +717,7 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linea
     HIP_TRY(hipMemcpyAsync(s->g.acc + ACC_STOP, s->h_pinned + ACC_N + 2, sizeof(double), hipMemcpyHostToDevice, s->stream));
     if (s->comm.sum(s->g.acc, 3, s->stream)) return PPO_BA_ERR_COMM;
     if (with_maxdiag && s->comm.max(s->g.acc + ACC_MAXDIAG, 1, s->stream)) return PPO_BA_ERR_COMM;
-    if (s->g.det && s->comm.sum(s->g.acc + ACC_DETBAD, 1, s->stream)) return PPO_BA_ERR_COMM;  // every rank must see every rank's flag
+    if (s->g.det && s->comm.sum(s->g.acc + ACC_DETBAD, 2, s->stream)) return PPO_BA_ERR_COMM;  // every rank must see every rank's flags (ACC_DETBAD, ACC_DETRANGE)
   }
   (void)zero_for_next_linearize;  // (the linearisation targets are double-buffered: nothing to clear behind the hand-over any more)
   ZeroPlan zp{};
@@ -773,6 +774,27 @@ int launch_maxdiag(ppo_ba_solver* s) {
 
 bool stop_requested(const volatile uint8_t* f) { return f && *f; }
 
+// Deterministic mode, chi2 of the ESTIMATE is NaN (a non-finite addend of its linearisation was left out of the integer sums and flagged,
+// ACC_DETBAD).  In the reference every comparison on a NaN chi2 is false (levenberg.cpp:113-149): each iteration makes one solve attempt,
+// rejects it (`rho > 0` is false), leaves the retry loop (`rho < 0` is false too), is never counted as bad, and lambda *= ni, ni *= 2 -- the
+// window is FROZEN for the rest of the pass, nothing moves, the stored per-edge errors stay the estimate's.  That outcome is produced here
+// without queueing the solves whose results would be thrown away (in the floating-point mode the NaN simply flows through the kernels).
+void frozen_iteration(ppo_ba_solver* s, int pass, int iteration) {
+  ppo_ba_iter_stat it{};
+  it.pass = pass;
+  it.iteration = iteration;
+  it.trials = 1;
+  it.accepted = 0;
+  it.result = 0;
+  it.chi2_before = it.chi2_after = std::numeric_limits<double>::quiet_NaN();
+  it.lambda = s->lambda;
+  s->lambda *= s->ni;
+  s->ni *= 2;
+  s->stats.n_trials++;
+  if (s->stats.n_iters < PPO_BA_MAX_ITER_STATS) s->stats.iters[s->stats.n_iters] = it;
+  s->stats.n_iters++;
+}
+
 // OptimizationAlgorithmLevenberg::solve, levenberg.cpp:61-164.  Returns <0 error, 0 OK, 1 Terminate.
 //
 // Host/device pipelining: the only value the host must see per trial is (chi2, scale, info) of the trial state.  While
@@ -790,10 +812,11 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
   double currentChi;
   if (fresh || iteration == 0) {
     RC_TRY(fetch_acc(s, false, iteration == 0));
-    // deterministic mode: an addend of THIS linearisation (the committed state) did not fit the fixed-point range -- its system is
+    // deterministic mode: a finite addend of THIS linearisation (the committed state) did not fit the fixed-point range -- its system is
     // incomplete and there is no earlier state to fall back to
-    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) return PPO_BA_ERR_NONFINITE;
     currentChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) currentChi = std::numeric_limits<double>::quiet_NaN();  // (a non-finite term of chi2: NaN in the reference's arithmetic -- frozen, below)
+    else if (s->g.det && s->h_pinned[ACC_DETRANGE] != 0.0) return PPO_BA_ERR_NONFINITE;
   } else {
     currentChi = s->chi_cur;  // computeActiveErrors of the state the previous trial produced (levenberg.cpp:72-75)
   }
@@ -804,6 +827,11 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     s->lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
     s->ni = 2;
     s->nBad = 0;
+  }
+  if (s->g.det && std::isnan(currentChi)) {  // frozen window (see frozen_iteration): the caller records the iteration
+    s->lin_valid = true;  // (the estimate does not move: its linearisation stays the current system)
+    s->chi_cur = currentChi;
+    return 2;
   }
   double rho = 0;
   int qmax = 0;
@@ -844,8 +872,9 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     // A hand-off of the backward substitution that timed out (chol_back_all's spin cap, info = 1 << 30) is a SOLVER FAILURE, not a
     // "not positive" matrix: it must not be retried with a larger lambda as if the reference's LDLT had rejected the system.
     if (info >= (1 << 30)) return PPO_BA_ERR_SOLVER;
-    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) info = 1 << 29;  // an addend that was not finite / out of the fixed-point range: the system is not usable
+    if (s->g.det && s->h_pinned[ACC_DETRANGE] != 0.0) info = 1 << 29;  // a finite addend out of the fixed-point range: the system is not usable
     double tempChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) tempChi = std::numeric_limits<double>::quiet_NaN();  // a non-finite addend: the trial's chi2 is NaN (k_decide_fix does the same)
     if (info != 0 || !std::isfinite(s->h_pinned[ACC_SCALE])) tempChi = std::numeric_limits<double>::max();  // solver not ok (:126-127)
     rho = currentChi - tempChi;
     double scale = s->h_pinned[ACC_SCALE];
@@ -996,8 +1025,9 @@ struct SolverDev {
     s->g.ctl = nullptr;
     RC_TRY(launch_linearize(s));
     RC_TRY(fetch_acc(s, false));
-    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) return PPO_BA_ERR_NONFINITE;
     m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+    if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) m.chi_cur = m.ini_chi = std::numeric_limits<double>::quiet_NaN();
+    else if (s->g.det && s->h_pinned[ACC_DETRANGE] != 0.0) return PPO_BA_ERR_NONFINITE;
     hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
     HIP_TRY(hipGetLastError());
     s->g.ctl = s->d_ctl.p;
@@ -1015,7 +1045,15 @@ int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
   RC_TRY(launch_linearize(s));
   RC_TRY(launch_maxdiag(s));
   RC_TRY(fetch_acc(s, false, true));
-  if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) return PPO_BA_ERR_NONFINITE;  // (as lm_iteration: the committed state's system is incomplete, nothing to fall back to)
+  if (s->g.det && s->h_pinned[ACC_DETBAD] == 0.0 && s->h_pinned[ACC_DETRANGE] != 0.0) return PPO_BA_ERR_NONFINITE;  // (as lm_iteration: the committed state's system is incomplete, nothing to fall back to)
+  if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) {  // chi2 of the estimate is NaN: the window is frozen for this pass (frozen_iteration)
+    s->lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
+    s->ni = 2;
+    s->nBad = 0;
+    for (int i = 0; i < iterations && !stop_now(s); ++i) frozen_iteration(s, pass, i);
+    s->lin_valid = false;
+    return PPO_BA_OK;
+  }
   LmCtl m{};  // the host's mirror of the record: what the device holds whenever nothing is queued
   m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
   m.lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
@@ -1051,6 +1089,7 @@ int optimize(ppo_ba_solver* s, int pass, int iterations, const volatile uint8_t*
     it.iteration = i;
     const int res = lm_iteration(s, i, i + 1 < iterations, stop, it);
     if (res < 0) return res;
+    if (res == 2) { frozen_iteration(s, pass, i); continue; }
     it.result = res;
     ok = (res == 0);
     if (s->stats.n_iters < PPO_BA_MAX_ITER_STATS) s->stats.iters[s->stats.n_iters] = it;
@@ -2486,6 +2525,13 @@ int ppo_ba_debug_reduced(ppo_ba_handle s, double* S, double* b, double* x, int32
     HIP_TRY(hipMemcpy(tmp.data(), s->d_S.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int c = 0; c < n; ++c)
       for (int r = c; r < n; ++r) S[(size_t)c * n + r] = S[(size_t)r * n + c] = tmp[(size_t)c * ld + r];
+    if (s->g.det) {
+      // deterministic mode: a term that is not finite or does not fit is LEFT OUT of the integer sums and flagged (ACC_DETRANGE: the system is not
+      // usable, every trial on it is rejected like a failed factorisation).  The matrix handed out says the same thing the floating-point sums would.
+      double flags[2] = {0.0, 0.0};
+      HIP_TRY(hipMemcpy(flags, s->g.acc + ACC_DETBAD, sizeof(flags), hipMemcpyDeviceToHost));
+      if (flags[1] != 0.0 && n > 0) S[0] = std::numeric_limits<double>::quiet_NaN();
+    }
   }
   if (b) HIP_TRY(hipMemcpy(b, s->d_bs_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   if (x) {

@@ -51,10 +51,12 @@ extern "C" int ppo_ba_warmup(int device) {
         m_info.push_back(1.0); m_hub.push_back(std::sqrt(5.991));
       }
     }
-  // one plane z = 5 seen from two keyframes, one cuboid in front of the cameras with one edge of every class
-  const double plane[4] = {0.0, 0.0, 1.0, -5.0};
+  // one plane near z = 5 seen from two keyframes, one cuboid in front of the cameras with one edge of every class.  (The plane is tilted off the z axis:
+  // a normal EXACTLY along z sits on the pole of the azimuth / elevation chart of G2O_Plane3D.h:66-72, where the reference's delta = 1e-9 central
+  // differences are a jump of pi over 2e-9 -- entries of 1e20 that the default, fixed-point mode refuses as out of range.)
+  const double plane[4] = {0.06, 0.03, 1.0, -5.0};
   const int32_t pl_plane[2] = {0, 0}, pl_pose[2] = {1, 2};
-  const double pl_meas[8] = {0.0, 0.0, 1.0, -5.02, 0.0, 0.01, 1.0, -4.98}, pl_info[6] = {100, 100, 100, 100, 100, 100}, pl_hub[2] = {10.0, 10.0};
+  const double pl_meas[8] = {0.06, 0.03, 1.0, -5.02, 0.05, 0.04, 1.0, -4.98}, pl_info[6] = {100, 100, 100, 100, 100, 100}, pl_hub[2] = {10.0, 10.0};
   const double cub_qt[7] = {0, 0, 0, 1, 0.2, 0.1, 5.0}, cub_sc[3] = {0.5, 0.4, 0.3};
   const double K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
   const int32_t bb_pose[1] = {1}, bb_cub[1] = {0};

@@ -330,7 +330,7 @@ def default_options(**over):
     o.numeric_delta, o.jacobian_mode = 1e-9, 0
     o.chi2_mono, o.chi2_stereo, o.chi2_plane, o.chi2_plane_vp = 5.991, 7.815, 500.0, 200.0
     o.th_bbox_norm, o.th_corner_norm, o.th_cub3d_norm = 80.0, 10.0, 900.0
-    o.deterministic, o.solver, o.eliminate_cuboids = 0, 0, 1
+    o.deterministic, o.solver, o.eliminate_cuboids = 1, 0, 1
     o.device_id, o.rank, o.world_size, o.verbose = 0, 0, 1, 0
     for k, v in over.items():
         setattr(o, k, v)

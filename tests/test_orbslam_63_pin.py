@@ -107,18 +107,20 @@ def test_oracle_lambda_and_trial_schedule_match_the_reference_in_every_round(ora
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", range(len(WINDOWS)), ids=W_IDS)
 def test_hip_follows_the_reference_local_bundle_adjustment(hip, k):
-    """The product (deterministic mode: no run-to-run component) against the reference's own LocalBundleAdjustment-shaped run: schedule, lambda, chi2 per
+    """The product (default = deterministic mode: no run-to-run component, LM decisions on the device) against the reference's own LocalBundleAdjustment-shaped run: schedule, lambda, chi2 per
     iteration up to the first marginal one, levels, final chi2, final state at BASELINE.md's bar."""
     TL.check_against_reference_run(hip, WINDOWS[k], tol_lambda=1e-3, tol_chi2=1e-4, marginal_floor=1e-6, options=dict(deterministic=1))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", range(len(WINDOWS)), ids=W_IDS)
-def test_hip_default_mode_with_the_lm_decisions_on_the_device_follows_the_reference_schedule(hip, k):
-    """the strict comparison above runs deterministic = 1, i.e. with the LM decisions on the HOST.  The same windows in the default mode
-    -- k_decide behind every trial, batches queued ahead -- must walk the reference's trial schedule (accept / reject sequence, lambda, chi2) up to the
-    first marginal iteration, classify the same edges and end at the same cost."""
-    TL.check_against_reference_run(hip, WINDOWS[k], tol_lambda=1e-3, tol_chi2=1e-4, marginal_floor=1e-6, options=dict(lm_control=0), states=False, tol_final_chi2=3e-6)
+@pytest.mark.parametrize("opts", [dict(deterministic=1, lm_control=1), dict(deterministic=0, lm_control=0), dict(deterministic=0, lm_control=1)],
+                         ids=["deterministic-lm-on-host", "atomics-lm-on-device", "atomics-lm-on-host"])
+def test_hip_other_modes_follow_the_reference_schedule(hip, k, opts):
+    """The strict comparison above runs the default mode (round 6: deterministic sums, k_decide behind every trial, batches queued ahead).  The same
+    windows with the LM decisions on the host, and in the floating-point-atomics mode with either control, must walk the reference's trial schedule
+    (accept / reject sequence, lambda, chi2) up to the first marginal iteration, classify the same edges and end at the same cost."""
+    TL.check_against_reference_run(hip, WINDOWS[k], tol_lambda=1e-3, tol_chi2=1e-4, marginal_floor=1e-6, options=opts, states=False, tol_final_chi2=3e-6)
 
 
 @pytest.mark.gpu

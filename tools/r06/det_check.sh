@@ -8,9 +8,11 @@ python bench.py --no-cpu-baseline --steps 10 2>gpurun_out/r06_det_check_bench.er
 import sys, json
 j = json.loads(sys.stdin.read())
 d = j['config'].get('deterministic_mode') or {}
-print('default %.0f it/s (%.4f ms/iter) | deterministic %.0f it/s (%.4f ms/iter) ratio %.3f | lin %.1f us | factor %.3f ms' % (
-    j['value'], j['config']['ms_per_lm_iter'], d.get('lm_iters_per_s', 0), d.get('ms_per_lm_iter', 0), d.get('lm_iters_per_s', 0) / j['value'],
+o = d.get('floating_point_atomics_mode') or {}
+print('value (deterministic, default) %.0f it/s (%.4f ms/iter) | atomics mode %.0f it/s | det/atomics %.3f | lin %.1f us | factor %.3f ms' % (
+    j['value'], j['config']['ms_per_lm_iter'], o.get('lm_iters_per_s', 0), j['value'] / max(o.get('lm_iters_per_s', 1), 1),
     j['roofline']['launch_ms'] * 1e3, j['config']['factor_solve_ms']))
-print('default-vs-det deviation', d.get('default_run_deviation_from_it'))
+print('atomics-vs-det deviation', o.get('its_run_deviation_from_the_timed_run'))
+print('icl', j['config'].get('icl_sized_windows'))
 "
 tail -5 gpurun_out/r06_det_check_bench.err
