@@ -218,8 +218,9 @@ typedef struct ppo_ba_options {
                              * verbose = 0; every other configuration takes the host path whatever this says).  PPO_LM_HOST (1): by the host
                              * after a round trip per trial.  Same arithmetic (pow(x, 3) is a cube within one ulp on the device: one ulp of
                              * lambda in about one accepted trial in a thousand), same results.  PPO_LM_DEVICE queues up to five solve attempts
-                             * at once: the stop flag of ppo_ba_run is read between such batches, not before every attempt, and a rejected
-                             * trial costs ~12 us more than on the host path.  Anything else -> PPO_BA_ERR_ARG */
+                             * at once; the stop flag of ppo_ba_run is still honoured before every attempt (round 6: the device reads a mirror of it
+                             * before every decision and cancels what is queued behind, levenberg.cpp:149); a rejected trial costs ~12 us more than
+                             * on the host path.  Anything else -> PPO_BA_ERR_ARG */
 } ppo_ba_options;
 
 /* one record per LM iteration (one OptimizationAlgorithmLevenberg::solve call) */

@@ -307,6 +307,10 @@ __device__ __forceinline__ PlaneC load_plane(const double* p) { return PlaneC{p[
 // Camera table of a workgroup: R, t (12) and fx, fy, cx, cy of every keyframe, 16 doubles each, into LDS.  Eight loads per thread are
 // issued before the first store (sixteen measure the same): written as one load + one store per trip the loop waited for memory 13 times in a row
 // (200 keyframes, 256 threads) before the workgroup could touch its first edge.
+#ifndef PPO_CAM_ROW
+#define PPO_CAM_ROW 17  // doubles per keyframe row of the table in LDS: 16 used + 1 of padding.  Lanes gather WHOLE rows by keyframe index; with 128-byte rows every row starts in one of two bank groups (SQ_WAIT_INST_LDS 18 % of the wave cycles of k_update_all).  Measured (tools/r06/ab_libs.sh): k_linearize_all 27.5 -> 24.9 us, k_update_all 18.8 -> 18.2 with 17 (18: 25.0 / 18.2, 20: 25.3 / 18.4)
+#endif
+constexpr int kCamRow = PPO_CAM_ROW;
 __device__ __forceinline__ void stage_camera_table(double* smem, const double* __restrict__ pose_rt, const double* __restrict__ pose_cam, int n_poses) {
   const int n = n_poses * 16;
   for (int base = threadIdx.x; base < n; base += 8 * 256) {
@@ -319,7 +323,7 @@ __device__ __forceinline__ void stage_camera_table(double* smem, const double* _
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (base + 256 * k < n) smem[base + 256 * k] = v[k];
+      if (base + 256 * k < n) smem[((base + 256 * k) >> 4) * kCamRow + ((base + 256 * k) & 15)] = v[k];
   }
 }
 
@@ -350,7 +354,7 @@ __device__ __forceinline__ void lin_points_body(const Graph& g, const State& st,
       const MonoEdge ed = g.mono[e];
       Mat3 R; Vec3 t; double fx, fy, cx, cy;
       if (USE_LDS) {
-        const double* c = &smem[ed.pose * 16];
+        const double* c = &smem[ed.pose * kCamRow];
 #pragma unroll
         for (int k = 0; k < 9; ++k) R.a[k] = c[k];
         t = v3(c[9], c[10], c[11]); fx = c[12]; fy = c[13]; cx = c[14]; cy = c[15];
@@ -1386,6 +1390,7 @@ struct DecidePlan {
   double* host;   // mapped host ring of the same shape, and behind it the sequence word
   unsigned long long seq;
   int n_publish;
+  const double* host_stop;  // mapped host word: the host's mirror of the caller's stop flag, read before EVERY decision (round 6; NULL: not looked at)
 };
 constexpr int kRecSlots = 16;
 // the body, by ONE wave (t = its lane): k_decide's, and (round 5) the tail of the launch that evaluates the trial state
@@ -1394,6 +1399,9 @@ constexpr int kRecSlots = 16;
 template <bool COHERENT = false, bool DET = false>
 __device__ __forceinline__ void decide_wave(int t, double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, const DecidePlan& dp) {
   double* rec = dp.rec + (dp.seq % kRecSlots) * REC_DOUBLES;
+  // the stop flag (levenberg.cpp:149 reads terminate() before every retry): requested first -- a read over the bus, ~1.5 us -- and looked at last, behind the
+  // folds and the decision, which take as long
+  const double host_stop = dp.host_stop != nullptr ? __hip_atomic_load(dp.host_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
   const bool dead = __hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
   if (!dead) {
     if (COHERENT) fold_acc_parts_coherent(acc);
@@ -1422,6 +1430,7 @@ __device__ __forceinline__ void decide_wave(int t, double* acc, const int* __res
       }
     }
     lm_decide(c, chi, sc, info, rec);
+    if (host_stop != 0.0) lm_decide_stop(c, epoch, rec);
     *ctl = c;
     rec[REC_SEQ] = (double)dp.seq;
   }
@@ -2190,8 +2199,8 @@ __device__ __forceinline__ void backsub_body(const Graph& g, const State& cur, c
           const MonoEdge ed = g.mono[e];
           const int col = g.pose_col[ed.pose];
           if (col < 0) continue;
-          const double* rt = USE_LDS ? &smem[ed.pose * 16] : &cur.pose_rt[ed.pose * 12];
-          const double* cm = USE_LDS ? &smem[ed.pose * 16 + 12] : &g.pose_cam[ed.pose * 5];
+          const double* rt = USE_LDS ? &smem[ed.pose * kCamRow] : &cur.pose_rt[ed.pose * 12];
+          const double* cm = USE_LDS ? &smem[ed.pose * kCamRow + 12] : &g.pose_cam[ed.pose * 5];
           Mat3 R;
 #pragma unroll
           for (int q = 0; q < 9; ++q) R.a[q] = rt[q];
@@ -2318,6 +2327,14 @@ struct UpdatePlan {
   double* S;
   double* bs;
   int ld;
+#ifdef PPO_BA_TEST_HOOKS
+  // round 6, timing experiment PPO_BA_FUSE_BOUND=1 (results stay right): the first fuse_lin_blocks landmark workgroups ALSO run the landmark side of the
+  // linearisation on the trial state behind their back-substitution -- into the linearisation buffer nobody reads (fD / fbl), without the chi2 atomics --,
+  // i.e. what a fused "update + landmark-major linearisation" launch would make them do.  The duration of THIS launch next to the duration of the fused
+  // linearisation without its landmark part (PPO_BA_LIN_PARTS=15) bounds what that fusion can gain.
+  int fuse_lin_blocks;
+  double *fD, *fbl;
+#endif
 };
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void k_update_all(Graph g, State cur, State trial, double lambda, UpdatePlan up) {
@@ -2329,7 +2346,19 @@ __global__ __launch_bounds__(256) void k_update_all(Graph g, State cur, State tr
   int b = blockIdx.x;
   if (b < up.nb_red) { update_reduced_body(g, cur, trial, lambda, b, sp, st, sy, sx); return; }
   b -= up.nb_red;
-  if (b < up.nb_lm) { backsub_body<USE_LDS, PPO_UPD_LPP>(g, cur, trial, lambda, b, smem, s_red); return; }
+  if (b < up.nb_lm) {
+    backsub_body<USE_LDS, PPO_UPD_LPP>(g, cur, trial, lambda, b, smem, s_red);
+#ifdef PPO_BA_TEST_HOOKS
+    if (b < up.fuse_lin_blocks) {
+      __syncthreads();
+      Graph g2 = g;
+      g2.D = up.fD; g2.bl = up.fbl;
+      g2.dbg |= 4;  // (no chi2 atomics: the real linearisation behind this launch owns the sums)
+      lin_points_body<USE_LDS>(g2, trial, b, up.fuse_lin_blocks, smem, s_red);
+    }
+#endif
+    return;
+  }
   b -= up.nb_lm;
   // zero one 64x64 tile of the lower triangle of S (tile index b -> (bi >= bj)); the last workgroup also clears b
   int bi = 0;

@@ -23,7 +23,7 @@ struct LmCtl {
 };
 // what k_decide records per trial (doubles; a slot of the device ring, copied to the mapped host ring at the end of a batch of trials)
 enum { REC_CHI2 = 0, REC_SCALE, REC_INFO, REC_LAMBDA, REC_RHO, REC_ACCEPTED, REC_CODE, REC_CHI_BEFORE, REC_CHI_AFTER, REC_TRIALS, REC_ITER,
-       REC_DEAD, REC_LAMBDA_NEXT, REC_NI, REC_NBAD, REC_INI_CHI, REC_EPOCH, REC_QMAX, REC_SEQ = 31, REC_DOUBLES = 32 };
+       REC_DEAD, REC_LAMBDA_NEXT, REC_NI, REC_NBAD, REC_INI_CHI, REC_EPOCH, REC_QMAX, REC_STOPPED, REC_SEQ = 31, REC_DOUBLES = 32 };
 enum { LM_RETRY = 0, LM_ITER_DONE = 1, LM_TERMINATE = 2, LM_SOLVER_ERROR = 3 };
 
 
@@ -94,6 +94,17 @@ PPO_HD void lm_decide(LmCtl& c, double chi2_sum, double scale_raw, int info, dou
   rec[REC_INI_CHI] = c.ini_chi;
   rec[REC_EPOCH] = (double)c.epoch;
   rec[REC_QMAX] = (double)c.qmax;
+  rec[REC_STOPPED] = 0.0;
+}
+
+// The caller's stop flag was up when this attempt was decided (k_decide reads its mirror in mapped host memory before EVERY decision, as
+// levenberg.cpp:149 and sparse_optimizer.cpp:375 read terminate() before every retry and every iteration): nothing queued behind this attempt may
+// run -- the epoch moves on if the decision itself has not moved it -- and the record says so; the host ends the pass at this attempt.
+// `epoch_in`: the epoch the attempt ran under.
+PPO_HD void lm_decide_stop(LmCtl& c, int epoch_in, double* rec) {
+  if (c.epoch == epoch_in) c.epoch++;
+  rec[REC_EPOCH] = (double)c.epoch;
+  rec[REC_STOPPED] = 1.0;
 }
 
 }  // namespace ppo

@@ -76,7 +76,9 @@ int lm_pipelined_pass(Dev& dev, int pass, int iterations, LmCtl& m, int lookahea
       it.chi2_after = r[REC_CHI_AFTER];
       m.lambda = r[REC_LAMBDA_NEXT]; m.ni = r[REC_NI]; m.nbad = (int)r[REC_NBAD]; m.chi_cur = r[REC_CHI_AFTER]; m.ini_chi = r[REC_INI_CHI];
       m.iter = (int)r[REC_ITER]; m.qmax = (int)r[REC_QMAX]; m.epoch = (int)r[REC_EPOCH];
-      const bool as_assumed = accepted && code == LM_ITER_DONE;
+      // (round 6) the device saw the stop flag when it decided this attempt (lm_decide_stop): everything queued behind it is dead, the pass ends here
+      const bool stopped = r[REC_STOPPED] != 0.0;
+      const bool as_assumed = accepted && code == LM_ITER_DONE && !stopped;
       if (as_assumed) {
         if (j == n - 1) dev.accept(q[j].speculated);  // (the others: applied when the next attempt was queued)
       } else {
@@ -89,7 +91,7 @@ int lm_pipelined_pass(Dev& dev, int pass, int iterations, LmCtl& m, int lookahea
       if (code == LM_SOLVER_ERROR) { rc = PPO_BA_ERR_SOLVER; break; }
       if (!accepted && (int)r[REC_INFO] != 0 && (rc = dev.restore_kept_errors()) != PPO_BA_OK) break;
       if (code == LM_RETRY) {
-        if (dev.stop()) {  // the retry loop ends on the stop flag (levenberg.cpp:149): the iteration is over, rejected
+        if (stopped || dev.stop()) {  // the retry loop ends on the stop flag (levenberg.cpp:149): the iteration is over, rejected
           it.result = 0;
           dev.push_stat(it);
           pass_over = true;
@@ -99,7 +101,7 @@ int lm_pipelined_pass(Dev& dev, int pass, int iterations, LmCtl& m, int lookahea
       // the iteration is over
       it.result = code == LM_TERMINATE ? 1 : 0;
       dev.push_stat(it);
-      if (code == LM_TERMINATE) pass_over = true;
+      if (code == LM_TERMINATE || stopped) pass_over = true;
       if (!pass_over && !as_assumed && m.iter < iterations) {
         // an iteration that ended on a rejected attempt without terminating (rho is NaN): the next one starts from a fresh linearisation of
         // the kept state, as lm_iteration's `fresh` branch does

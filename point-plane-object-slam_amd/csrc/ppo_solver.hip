@@ -690,6 +690,13 @@ int launch_update(ppo_ba_solver* s, double lambda) {
     if (strchr(e, 'z')) up.nb_zero = 0;
     if (strchr(e, 'r')) up.nb_red = 0;  // ('r': cuboids and poses)
   }
+#ifdef PPO_BA_TEST_HOOKS
+  if (PPO_DEV_ENV("PPO_BA_FUSE_BOUND")) {  // round 6 timing experiment (ppo_kernels.hpp: UpdatePlan::fuse_lin_blocks); the extra work lands in the buffer that is not current
+    const int npts = g.pt_last - g.pt_first;
+    up.fuse_lin_blocks = npts > 0 ? std::min(up.nb_lm, std::min(nblk((long)PPO_LIN_LPP * npts, 256), 4 * s->n_cu)) : 0;
+    up.fD = s->lb[s->lin_buf ^ 1].D; up.fbl = s->lb[s->lin_buf ^ 1].bl;
+  }
+#endif
   const int grid = up.nb_red + up.nb_lm + up.nb_zero;
   if (s->use_lds) hipLaunchKernelGGL(k_update_all<true>, dim3(grid), dim3(256), s->lds_bytes, s->stream, g, cur, tr, lambda, up);
   else hipLaunchKernelGGL(k_update_all<false>, dim3(grid), dim3(256), 0, s->stream, g, cur, tr, lambda, up);
@@ -932,6 +939,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
 // batch's trial records to the host, which then puts its bookkeeping back to the first trial that went differently, queues what that
 // outcome asks for (a retry of the same iteration, a fresh linearisation) and goes on with a batch of one, doubling while the assumption
 // holds.  The stop flag is read between batches.  Single rank, floating-point accumulation, native solver (ppo_ba_create decides).
+constexpr int kStopMirror = ACC_N + 3;  // slot of the mapped host block that mirrors the caller's stop flag for the device (mirror_stop_flag, below)
 TrialBook book_of(const ppo_ba_solver* s) { return TrialBook{s->cur, s->lin_buf, {s->lin_clean[0], s->lin_clean[1]}, s->S_is_zero, s->reduce_overlapped, s->have_system}; }
 void restore_book(ppo_ba_solver* s, const TrialBook& b) {
   s->cur = b.cur;
@@ -947,7 +955,7 @@ int queue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long l
   RC_TRY(launch_update(s, 0.0));
   // round 5 experiment: the decision as the tail of the launch that evaluates the trial state (ppo_kernels.hpp: lm_tail) instead of k_decide as a
   // launch of its own (5 us of every trace).
-  const DecidePlan dp{s->d_rec.p, s->h_pinned_dev + 16, ++s->ring_seq, n_publish};
+  const DecidePlan dp{s->d_rec.p, s->h_pinned_dev + 16, ++s->ring_seq, n_publish, s->h_pinned_dev + kStopMirror};
   // Measured (profiles/r05_decide_tail.txt): NEUTRAL -- 15 KF 0.822 / 0.836 ms per call with the tail against 0.822 / 0.847 with the launch, 30 KF
   // 1.240 / 1.247 against 1.254 / 1.209, BASELINE size 2 771 against 2 785 LM iterations/s: a 5 us kernel between two long ones costs the queue
   // next to nothing, and the tail holds every workgroup of the evaluation until its atomics are acknowledged.  So the separate launch, whose
@@ -976,12 +984,22 @@ int queue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long l
   *seq_out = dp.seq;
   return PPO_BA_OK;
 }
+// The caller's stop flag is a byte in ordinary host memory; the device reads its MIRROR in the mapped block (slot kStopMirror), which the host keeps
+// up to date while it waits for a batch (it spins there anyway): k_decide looks at it before every decision, so a flag raised mid-batch ends the pass at
+// the attempt that is being evaluated -- as levenberg.cpp:149 does -- instead of at the end of the batch (up to five attempts, ~1.8 ms at the BASELINE size).
+inline void mirror_stop_flag(ppo_ba_solver* s) {
+  if (s->stop_ptr && *s->stop_ptr) {
+    volatile double* m = s->h_pinned + kStopMirror;
+    if (*m == 0.0) *m = 1.0;
+  }
+}
 int wait_for_records(ppo_ba_solver* s, unsigned long long seq) {
   volatile const unsigned long long* w = reinterpret_cast<volatile const unsigned long long*>(s->h_pinned + 16 + kRingSlots * kRingSlotDoubles);
   const auto t0 = std::chrono::steady_clock::now();
   bool timed_out = false;
   for (unsigned it = 0; *w != seq; ++it) {
     cpu_relax();  // (a batch is up to five LM iterations long: leave the core's other hardware thread its issue slots)
+    if ((it & 15) == 15) mirror_stop_flag(s);
     if ((it & 1023) == 1023) {
       if (hipStreamQuery(s->stream) == hipSuccess) break;
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { timed_out = true; break; }
@@ -1040,6 +1058,7 @@ struct SolverDev {
   }
 };
 int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
+  s->h_pinned[kStopMirror] = stop_now(s) ? 1.0 : 0.0;  // (the mirror the device reads: see wait_for_records)
   // the head of the pass as lm_iteration does it: linearise the estimate, lambda from the largest diagonal entry (levenberg.cpp:166-180)
   s->g.ctl = nullptr;
   RC_TRY(launch_linearize(s));
@@ -1940,7 +1959,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
     if (++nz == 6) flush_zero();
     flush_zero();
   }
-  static_assert(ACC_N + 3 <= 16 && REC_DOUBLES == kRingSlotDoubles && kRecSlots == kRingSlots && kLookahead <= kRecSlots, "mapped host block too small");
+  static_assert(ACC_N + 4 <= 16 && REC_DOUBLES == kRingSlotDoubles && kRecSlots == kRingSlots && kLookahead <= kRecSlots, "mapped host block too small");
   (void)hipMemsetAsync(s->d_info.p, 0, sizeof(int), s->stream);
 
   g.pose_cam = s->d_pose_cam.p; g.pose_col = s->d_pose_col.p; g.pose_free_id = s->d_pose_free_id.p; g.cub_col = s->d_cub_col.p;
@@ -1988,7 +2007,7 @@ int ppo_ba_create(const ppo_ba_problem* p, const ppo_ba_options* o, ppo_ba_handl
   s->st[1] = make_state(s->d_state[1].p, Np, Npt, Npl, Nc);
 
   // LDS plan for k_lin_points: camera table + pose-block accumulators
-  s->lds_bytes = (int)((size_t)Np * 16 * sizeof(double));
+  s->lds_bytes = (int)((size_t)Np * kCamRow * sizeof(double));
   s->use_lds = s->lds_bytes <= 150 * 1024;
   if (s->use_lds && s->lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute((const void*)k_lin_points<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes) != hipSuccess ||

@@ -55,6 +55,7 @@ struct SimDevice {
   std::vector<Outcome> script;
   size_t next = 0;
   int stop_after_polls = -1, polls = 0;
+  int stop_at_live = -1;  // round 6: the flag goes up while live attempt number stop_at_live is evaluated -- the device's decide step sees it (REC_STOPPED), the host from then on
   // what came out
   std::vector<ppo_ba_iter_stat> stats;
   int n_trials = 0, n_dead = 0, n_live = 0, n_kept_error_passes = 0, n_relinearize = 0;
@@ -66,7 +67,7 @@ struct SimDevice {
     b.S_is_zero = true;                  // the update clears S behind the backward substitution
     if (speculate) b.lin_clean[b.lin_buf ^ 1] = false;  // the trial state is linearised into it
   }
-  bool stop() { ++polls; return stop_after_polls >= 0 && polls > stop_after_polls; }
+  bool stop() { ++polls; return (stop_after_polls >= 0 && polls > stop_after_polls) || (stop_at_live >= 0 && n_live > stop_at_live); }
   TrialBook book() { return host; }
   void restore(const TrialBook& b) { host = b; }
   void accept(bool speculated) { host.cur ^= 1; if (speculated) host.lin_buf ^= 1; }
@@ -98,6 +99,7 @@ struct SimDevice {
       int info;
       realise(script[next++], ctl.chi_cur, ctl.cubpl, &chi2_sum, &scale, &info);
       lm_decide(ctl, chi2_sum, scale, info, rec);
+      if (stop_at_live >= 0 && n_live >= stop_at_live) lm_decide_stop(ctl, e.tag, rec);  // (what k_decide does when the mirror of the flag is up)
       rec[REC_SEQ] = (double)e.seq;
       if (rec[REC_ACCEPTED] != 0.0) {  // the trial state is the estimate now; its linearisation (if there is one) the current system
         truth.cur ^= 1;
@@ -269,8 +271,23 @@ int main() {
     CHECK(dev.stats.size() <= 10);
     for (size_t i = 0; i < dev.stats.size(); ++i) CHECK(dev.stats[i].iteration == (int)i && dev.stats[i].chi2_after <= dev.stats[i].chi2_before);
   }
+  // round 6: the flag goes up MID-BATCH, while some live attempt is being evaluated: the device's decision sees it, nothing behind that attempt runs (no
+  // live attempt after it), and the host's report ends with that attempt
+  for (g_script = 11000; g_script < 11500; ++g_script) {
+    SimDevice dev;
+    for (int i = 0; i < 200; ++i) dev.script.push_back(Outcome{U(rng) < 0.3 ? 2 : 0, U(rng)});
+    LmCtl m{};
+    m.lambda = 1e-3; m.chi_cur = m.ini_chi = 5000.0; m.ni = 2; m.lm_upper = 2.0 / 3.0; m.lm_lower = 1.0 / 3.0; m.max_trials = 10; m.epoch = 3;
+    dev.ctl = m; dev.host_epoch = 3;
+    dev.stop_at_live = (int)(U(rng) * 12);
+    CHECK(lm_pipelined_pass(dev, 0, 10, m, kLookahead) == PPO_BA_OK);
+    CHECK(dev.pending.empty() && dev.host.cur == dev.truth.cur && dev.host.lin_buf == dev.truth.lin_buf && dev.host_epoch == dev.ctl.epoch);
+    CHECK(dev.n_live <= dev.stop_at_live + 1);  // the attempt that saw the flag is the last one that ran
+    CHECK(dev.n_trials == dev.n_live && dev.stats.size() <= 10);
+    for (size_t i = 0; i < dev.stats.size(); ++i) CHECK(dev.stats[i].iteration == (int)i && dev.stats[i].chi2_after <= dev.stats[i].chi2_before);
+  }
   std::printf("lm_pipeline_test ok: 4000 scripted passes, %ld live and %ld dead solve attempts, %ld rejected trials, %ld terminated iterations, %ld fresh linearisations, "
-              "%ld kept-state error passes (dead attempts with the round-4 doubling rule: %ld); 500 passes with the stop flag\n", live_total, dead_total, rejected_total, terminated, relin_total, kept_total,
+              "%ld kept-state error passes (dead attempts with the round-4 doubling rule: %ld); 500 passes with the stop flag between batches, 500 with the flag seen by the device mid-batch\n", live_total, dead_total, rejected_total, terminated, relin_total, kept_total,
               dead_by_policy[0]);
   return 0;
 }

@@ -1,4 +1,5 @@
-"""Development aid: the random-window comparison of tests/test_parity_gpu.py in numbers, for the deterministic and the default mode.
+"""Development aid: the random-window comparison of tests/test_parity_gpu.py in numbers, for the deterministic mode (the default since round 6: what
+bench.py times) and the opt-in floating-point-atomics mode ("def" in the keys below: it WAS the default until round 5).
 Per window: schedule equal?, optimality gap vs the oracle's own variant gap, which BASELINE.md quantities are outside the bar and what the
 oracle's own spread is there, and how far the default mode is from the deterministic result.   python tools/strict_sweep.py [n] [first_seed]"""
 import importlib.util, os, sys
@@ -67,4 +68,4 @@ for seed in range(s0, s0 + n):
         print("seed %d sched_det=%s sched_def_vs_det=%s gap %.1e own %.1e | det out %s unexcused %s | def-vs-det %s far %s" % (
             seed, same, same_def, gap, own_gap, {k: "%.1e(own %.1e)" % (m[k], oo[k]) for k in out}, unex, {k: "%.1e" % md[k] for k in S.BARS if md[k] >= S.BARS[k]}, far))
     so.close()
-print("totals", tot, "worst default-vs-deterministic / bar", {k: "%.2f" % v for k, v in worst_ratio.items()})
+print("totals", tot, "worst atomics-vs-deterministic / bar", {k: "%.2f" % v for k, v in worst_ratio.items()})
