@@ -446,11 +446,14 @@ def main():
                 t_3 = time.perf_counter()
                 sw.close()
                 if i >= 3:
-                    rows.append((t_1 - t_0, t_2 - t_1, t_3 - t_2, t_3 - t_0))
-            med = [1e3 * sorted(r[k] for r in rows)[len(rows) // 2] for k in range(4)]
-            icl[label] = {"create_ms": med[0], "run_ms": med[1], "read_ms": med[2], "call_ms": med[3], "lm_iters": stw["n_iters"],
+                    rows.append((t_1 - t_0, t_2 - t_1, t_3 - t_2, t_3 - t_0, 1e-3 * sw.c_ms["create"], 1e-3 * sw.c_ms["run"], 1e-3 * sw.c_ms["read"]))
+            med = [1e3 * sorted(r[k] for r in rows)[len(rows) // 2] for k in range(7)]
+            # create / run / read: INSIDE the C calls (what the adapter in Optimizer.cc pays; examples/replay.cpp measures the same from C++:
+            # profiles/r06_icl_from_cpp.txt); *_with_harness: the same calls with this script's ctypes marshalling of ~60 arrays around them
+            icl[label] = {"create_ms": med[4], "run_ms": med[5], "read_ms": med[6], "call_ms": med[4] + med[5] + med[6],
+                          "create_ms_with_harness": med[0], "read_ms_with_harness": med[2], "call_ms_with_harness": med[3], "lm_iters": stw["n_iters"],
                           "solve_attempts": stw["n_trials"],  # (> lm_iters: rejected trials, each a complete reduce + solve + evaluate)
-                          "us_per_lm_iter": 1e3 * med[1] / max(stw["n_iters"], 1), "us_per_solve_attempt": 1e3 * med[1] / max(stw["n_trials"], 1)}
+                          "us_per_lm_iter": 1e3 * med[5] / max(stw["n_iters"], 1), "us_per_solve_attempt": 1e3 * med[5] / max(stw["n_trials"], 1)}
             # ... and repeated runs on ONE handle (reset + run), with the LM decisions on the device (default) and on the host
             for key, lmc in (("run_ms_repeated_lm_on_device", 0), ("run_ms_repeated_lm_on_host", 1)):
                 sw = B.hip_backend().create(Pw, B.default_options(device_id=local_rank, solver=a.solver, lm_control=lmc))

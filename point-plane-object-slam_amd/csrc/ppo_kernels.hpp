@@ -170,6 +170,8 @@ struct Graph {
   // has written nothing, and its target buffer may hold an earlier linearisation that is doubles already
   unsigned long long* lin_tag_word;
   unsigned long long lin_tag;
+  int lin_raw;  // deterministic mode: the accumulation ranges of the linearisation this launch reads still hold fixed-point integers (their conversion
+                // rides in the publish launch behind: k_publish_fix) -- k_maxdiag converts what it reads
 #ifdef PPO_BA_TEST_HOOKS
   int dbg;                     // development aid (PPO_BA_LIN_DBG): bit 0 numeric classes skip their scatter, bit 1 plain stores instead of atomics
   unsigned long long* stamps;  // development aid (PPO_BA_LIN_STAMPS): [grid][8] wall-clock stamps of the fused linearisation's workgroups
@@ -1631,6 +1633,37 @@ __global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restri
   if (gridDim.x > 1 && t < ACC_N) acc[t] = 0.0;
 }
 
+// Deterministic mode, one rank (round 6): the hand-over itself folds the INTEGER partial sums of chi2 and of the scale and converts them, and the other
+// workgroups of its launch turn the ranges a linearisation in front of it summed into back into doubles (DecideFix; tag_word == NULL: unconditionally) --
+// the k_fold_acc + two k_fix_to_double launches this mode used to put in front of every hand-over are gone.
+__global__ __launch_bounds__(256) void k_publish_fix(double* acc, const int* __restrict__ info, double* host, unsigned long long seq, DecideFix df) {
+  const int t = threadIdx.x;
+  if (blockIdx.x > 0) {
+    if (df.tag_word != nullptr && *df.tag_word != df.tag) return;
+    const size_t t0 = (size_t)(blockIdx.x - 1) * 256 + t, stride = (size_t)(gridDim.x - 1) * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double* p = df.p[q];
+      const size_t n = df.n[q];
+      for (size_t i = t0; i < n; i += stride) p[i] = (double)__double_as_longlong(p[i]) * kFixInv;
+    }
+    return;
+  }
+  if (t < 64) fold_acc_parts(acc, 1);  // (lane 0 leaves the integer totals in acc[0..1] ...)
+  if (t == 0) {                        // (... and converts them: chi2, scale)
+    acc[ACC_CHI2] = (double)__double_as_longlong(acc[ACC_CHI2]) * kFixInv;
+    acc[ACC_SCALE] = (double)__double_as_longlong(acc[ACC_SCALE]) * kFixInv;
+  }
+  __threadfence();
+  __syncthreads();
+  if (t < ACC_N) host[t] = acc[t];
+  if (t == ACC_DETBAD || t == ACC_DETRANGE) acc[t] = 0.0;  // handed over; armed again for the next launches
+  if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + ACC_N + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the partial sums into acc[0..1] ahead of a reader other than k_publish (fixed-point conversion, sum over ranks)
 __global__ __launch_bounds__(64) void k_fold_acc(double* acc, int det) { fold_acc_parts(acc, det); }
 
@@ -1697,15 +1730,18 @@ __global__ __launch_bounds__(256) void k_maxdiag(Graph g) {
   __shared__ double s_m[4];
   const int nl_owned = (g.pt_last - g.pt_first) + (g.plane_last - g.plane_first);
   const int n = max(max(g.n_pose_free * 6, g.n_cuboids * 9), nl_owned * 3);
+  // (g.lin_raw: H_pp | H_cc and the PLANES' D were summed as fixed-point integers and have not been converted yet; the points' D are plain stores)
+  auto summed = [&](const double* p) { return g.lin_raw ? (double)__double_as_longlong(*p) * kFixInv : *p; };
   double m = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (i < g.n_pose_free * 6) m = fmax(m, fabs(g.hb_diag ? g.hb_diag[i] : g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)]));
-    if (i < g.n_cuboids * 9 && g.owns_reduced) m = fmax(m, fabs(g.HC[(size_t)(i / 9) * 54 + packed_lower(i % 9, i % 9)]));
+    if (i < g.n_pose_free * 6) m = fmax(m, fabs(g.hb_diag ? g.hb_diag[i] : summed(&g.HB[(size_t)(i / 6) * 27 + packed_lower(i % 6, i % 6)])));
+    if (i < g.n_cuboids * 9 && g.owns_reduced) m = fmax(m, fabs(summed(&g.HC[(size_t)(i / 9) * 54 + packed_lower(i % 9, i % 9)])));
     if (i < nl_owned * 3) {
       const int k = i / 3, a = i % 3;
       const int l = k < (g.pt_last - g.pt_first) ? g.pt_first + k : g.n_points + g.plane_first + (k - (g.pt_last - g.pt_first));
       const bool fixed = l < g.n_points && g.point_fixed[l];
-      if (!fixed) m = fmax(m, fabs(g.D[(size_t)l * 6 + (a == 0 ? 0 : (a == 1 ? 3 : 5))]));
+      const double* d = &g.D[(size_t)l * 6 + (a == 0 ? 0 : (a == 1 ? 3 : 5))];
+      if (!fixed) m = fmax(m, fabs(l >= g.n_points ? summed(d) : *d));
     }
   }
   for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));

@@ -709,6 +709,19 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 // bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
 // can be queued behind the copy before the host blocks on it.
 int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false) {
+  if (s->g.det && s->acc_fixed && !s->comm.active()) {
+    // deterministic mode, one rank (round 6): ONE launch folds the integer sums, converts chi2 / scale, hands them over -- and its other workgroups
+    // convert the ranges of a linearisation whose conversion was deferred to here (launch_linearize(..., defer_fix): s->pending_fix)
+    DecideFix df = s->pending_fix;
+    df.tag_word = nullptr;  // (the host queued that linearisation unconditionally: it ran)
+    const size_t nconv = df.n[0] + df.n[1] + df.n[2] + df.n[3];
+    const int nwg = nconv ? std::max(1, std::min(nblk((long)nconv, 1024), s->n_cu)) : 0;
+    hipLaunchKernelGGL(k_publish_fix, dim3(1 + nwg), dim3(256), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, df);
+    s->pending_fix = DecideFix{};
+    s->acc_fixed = false;
+    (void)zero_for_next_linearize; (void)with_maxdiag;
+    return PPO_BA_OK;
+  }
   if ((s->g.det && s->acc_fixed) || s->comm.active())  // the workgroups' partial sums into acc[0..1] (otherwise k_publish does it itself)
     hipLaunchKernelGGL(k_fold_acc, dim3(1), dim3(64), 0, s->stream, s->g.acc, (s->g.det && s->acc_fixed) ? 1 : 0);
   if (s->g.det && s->acc_fixed) {  // chi2 and scale -> doubles (before they are summed over ranks / published)
@@ -767,6 +780,7 @@ int fetch_acc(ppo_ba_solver* s, bool with_info, bool with_maxdiag = false) {
 // ranks).  Sharded runs keep Hpp as per-rank partial sums, so its diagonal is summed over ranks first (d_xr is free here).
 int launch_maxdiag(ppo_ba_solver* s) {
   Graph g = s->g;
+  g.lin_raw = (g.det && (s->pending_fix.n[0] + s->pending_fix.n[1] + s->pending_fix.n[2] + s->pending_fix.n[3]) > 0) ? 1 : 0;  // (conversion deferred to the publish launch)
   const long npd = (long)g.n_pose_free * 6;
   if (s->comm.active() && npd > 0) {
     hipLaunchKernelGGL(k_hb_diag, dim3(nblk(npd, 256)), dim3(256), 0, s->stream, g, s->d_xr.p);
@@ -810,9 +824,10 @@ void frozen_iteration(ppo_ba_solver* s, int pass, int iteration) {
 // `may_speculate` is false on the last iteration of a pass (the outlier classification or the caller comes next).
 int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const volatile uint8_t* stop, ppo_ba_iter_stat& it) {
   const bool fresh = !s->lin_valid;
+  const bool defer = s->g.det && !s->comm.active();  // (deterministic, one rank: the conversions ride in the hand-over launch, fetch_acc_enqueue)
   if (fresh) {
     phase_mark(s, PH_LIN);
-    RC_TRY(launch_linearize(s));
+    RC_TRY(launch_linearize(s, -1, true, true, defer));
     phase_mark(s, PH_OTHER);
   }
   if (iteration == 0) RC_TRY(launch_maxdiag(s));
@@ -861,7 +876,7 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
     static const bool chi2_pass = []() { const char* e = PPO_DEV_ENV("PPO_BA_CHI2_PASS"); return e && e[0] == '1'; }();
     if (speculated && !chi2_pass) {
       phase_mark(s, PH_LIN);
-      RC_TRY(launch_linearize(s, s->cur ^ 1, false, false));  // (into the other buffer, which the reduction above has cleared)
+      RC_TRY(launch_linearize(s, s->cur ^ 1, false, false, defer));  // (into the other buffer, which the reduction above has cleared)
       RC_TRY(fetch_acc_enqueue(s, true, false));
     } else {
       phase_mark(s, PH_CHI2);
@@ -974,6 +989,7 @@ int queue_trial(ppo_ba_solver* s, bool speculate, int n_publish, unsigned long l
     const size_t nconv = df.n[0] + df.n[1] + df.n[2] + df.n[3];
     const int nwg = nconv ? std::max(1, std::min(nblk((long)nconv, 1024), s->n_cu)) : 0;
     hipLaunchKernelGGL(k_decide_fix, dim3(1 + nwg), dim3(256), 0, s->stream, s->g.acc, (const int*)s->d_info.p, s->d_ctl.p, s->g.epoch, dp, df);
+    s->pending_fix = DecideFix{};
     s->acc_fixed = false;  // (consumed: the next reduction clears the sums)
   } else
   if (s->tail_armed || tail_off) {
@@ -1041,7 +1057,7 @@ struct SolverDev {
   int restore_kept_errors() { return launch_chi2(s, s->st[s->cur]); }
   int relinearize(LmCtl& m) {
     s->g.ctl = nullptr;
-    RC_TRY(launch_linearize(s));
+    RC_TRY(launch_linearize(s, -1, true, true, s->g.det != 0));
     RC_TRY(fetch_acc(s, false));
     m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
     if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) m.chi_cur = m.ini_chi = std::numeric_limits<double>::quiet_NaN();
@@ -1061,7 +1077,7 @@ int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
   s->h_pinned[kStopMirror] = stop_now(s) ? 1.0 : 0.0;  // (the mirror the device reads: see wait_for_records)
   // the head of the pass as lm_iteration does it: linearise the estimate, lambda from the largest diagonal entry (levenberg.cpp:166-180)
   s->g.ctl = nullptr;
-  RC_TRY(launch_linearize(s));
+  RC_TRY(launch_linearize(s, -1, true, true, s->g.det != 0));  // (deterministic mode: converted by the hand-over launch of fetch_acc)
   RC_TRY(launch_maxdiag(s));
   RC_TRY(fetch_acc(s, false, true));
   if (s->g.det && s->h_pinned[ACC_DETBAD] == 0.0 && s->h_pinned[ACC_DETRANGE] != 0.0) return PPO_BA_ERR_NONFINITE;  // (as lm_iteration: the committed state's system is incomplete, nothing to fall back to)

@@ -6,6 +6,7 @@ fallback: if the HIP library is missing, loading fails loudly.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -269,21 +270,28 @@ class _Backend:
     def create(self, problem, options):
         h = C.c_void_p()
         ps = problem.as_struct()
+        t0 = time.perf_counter()
         rc = self._create(C.byref(ps), C.byref(options), C.byref(h))
+        c_ms = 1e3 * (time.perf_counter() - t0)
         if rc != 0:
             raise RuntimeError("%screate failed: %d" % (self.prefix, rc))
-        return Solver(self, h, problem)
+        s = Solver(self, h, problem)
+        s.c_ms["create"] = c_ms  # (inside the C call: what a C++ caller pays -- the ctypes marshalling around it is this harness's, not the library's)
+        return s
 
 
 class Solver:
     def __init__(self, backend, handle, problem):
         self.backend, self.h, self.problem = backend, handle, problem
         self.sizes = problem.sizes()
+        self.c_ms = {}  # milliseconds inside the last C call of each kind (create / run / read)
 
     def run(self, stop_flag=None):
         st = CStats()
         sf = stop_flag.ctypes.data_as(c_bp) if stop_flag is not None else None
+        t0 = time.perf_counter()
         rc = self.backend._run(self.h, sf, C.byref(st))
+        self.c_ms["run"] = 1e3 * (time.perf_counter() - t0)
         if rc < 0:
             raise RuntimeError("%srun failed: %d" % (self.backend.prefix, rc))
         self.last_rc = rc
@@ -292,7 +300,9 @@ class Solver:
     def read(self):
         r = Result(self.sizes)
         rs = r.as_struct()
+        t0 = time.perf_counter()
         rc = self.backend._read(self.h, C.byref(rs))
+        self.c_ms["read"] = 1e3 * (time.perf_counter() - t0)
         if rc != 0:
             raise RuntimeError("%sread failed: %d" % (self.backend.prefix, rc))
         return r
