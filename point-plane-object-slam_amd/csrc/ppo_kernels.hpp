@@ -1401,36 +1401,53 @@ constexpr int kRecSlots = 16;
 template <bool COHERENT = false, bool DET = false>
 __device__ __forceinline__ void decide_wave(int t, double* acc, const int* __restrict__ info_p, LmCtl* ctl, int epoch, const DecidePlan& dp) {
   double* rec = dp.rec + (dp.seq % kRecSlots) * REC_DOUBLES;
-  // the stop flag (levenberg.cpp:149 reads terminate() before every retry): requested first -- a read over the bus, ~1.5 us -- and looked at last, behind the
-  // folds and the decision, which take as long
+  // EVERYTHING the decision reads is requested here, side by side -- the epoch, the 64 partial sums, the totals in front of them, the flags, the control
+  // record, and the stop flag's mirror over the bus (levenberg.cpp:149 reads terminate() before every retry) -- and folded in registers: one memory round
+  // trip in front of the decision instead of four in a row with a device-scope fence between them (round 6: 5.3 -> 3.x us per decision).
   const double host_stop = dp.host_stop != nullptr ? __hip_atomic_load(dp.host_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
-  const bool dead = __hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
-  if (!dead) {
-    if (COHERENT) fold_acc_parts_coherent(acc);
-    else fold_acc_parts(acc, DET ? 1 : 0);
+  LmCtl c = *ctl;  // (every lane the same record: one request; its epoch member decides whether this attempt is live)
+  int info = *info_p;
+  [[maybe_unused]] const double f_range = acc[ACC_DETRANGE], f_bad = acc[ACC_DETBAD];
+  const bool dead = c.epoch != epoch;
+  double chi = 0.0, sc = 0.0;
+  if constexpr (COHERENT) {  // (the tail of the evaluation launch: other workgroups' atomics were performed at the memory side -- device-scope operations, folded in memory)
+    if (!dead) fold_acc_parts_coherent(acc);
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+    chi = __hip_atomic_load(&acc[ACC_CHI2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sc = __hip_atomic_load(&acc[ACC_SCALE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    double* part = acc + ACC_N + (t & 63) * kAccPartStride;
+    const double p0 = part[0], p1 = part[1], b0 = (t == 0) ? acc[ACC_CHI2] : 0.0, b1 = (t == 0) ? acc[ACC_SCALE] : 0.0;
+    if constexpr (DET) {
+      long long c = __double_as_longlong(p0) + __double_as_longlong(b0), q = __double_as_longlong(p1) + __double_as_longlong(b1);  // (integers: any order)
+      for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); q += __shfl_down(q, off, 64); }
+      chi = (double)c * kFixInv;
+      sc = (double)q * kFixInv;
+    } else {
+      double c = p0, q = p1;  // (the order of fold_acc_parts: the partial sums by a shuffle tree, then onto the total)
+      for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); q += __shfl_down(q, off, 64); }
+      chi = b0 + c;
+      sc = b1 + q;
+    }
+    if (!dead) { part[0] = 0.0; part[1] = 0.0; }  // (what fold_acc_parts leaves behind: the partial sums cleared)
   }
-  __threadfence();
-  __builtin_amdgcn_wave_barrier();
   if (t == 0 && dead) {
     rec[REC_DEAD] = 1.0;
     rec[REC_SEQ] = (double)dp.seq;
   }
   if (t == 0 && !dead) {
-    LmCtl c = *ctl;
-    double chi = __hip_atomic_load(&acc[ACC_CHI2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sc = __hip_atomic_load(&acc[ACC_SCALE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int info = *info_p;
     if constexpr (DET) {
-      chi = (double)__double_as_longlong(chi) * kFixInv;
-      sc = (double)__double_as_longlong(sc) * kFixInv;
-      if (acc[ACC_DETRANGE] != 0.0) {  // a finite addend out of the fixed-point range: the trial's system is not usable
+      if (f_range != 0.0) {  // a term that does not fit the fixed-point range, or a non-finite entry of a matrix: the trial's system is not usable
         if (info < (1 << 30)) info = 1 << 29;
         acc[ACC_DETRANGE] = 0.0;  // handed over; armed again for the next trial
       }
-      if (acc[ACC_DETBAD] != 0.0) {  // a non-finite addend: the trial state's chi2 is NaN in the reference's arithmetic
+      if (f_bad != 0.0) {  // a non-finite term of chi2: the trial state's chi2 is NaN in the reference's arithmetic
         chi = __builtin_nan("");
         acc[ACC_DETBAD] = 0.0;
       }
     }
+    if constexpr (!COHERENT) { acc[ACC_CHI2] = chi; acc[ACC_SCALE] = sc; }  // (as fold_acc_parts: the totals, as doubles, for whoever looks afterwards)
     lm_decide(c, chi, sc, info, rec);
     if (host_stop != 0.0) lm_decide_stop(c, epoch, rec);
     *ctl = c;
