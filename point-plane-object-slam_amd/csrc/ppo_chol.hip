@@ -432,17 +432,19 @@ __host__ __device__ inline StepOverlap step_no_overlap(int nb) {
 // ---- deterministic mode (options.deterministic): the reduction's sums are INTEGERS ---------------------------------------------------------
 // Every sum of the reduction that crosses a wave (assembly of H_pp + lambda I, the pair chunks, the cuboid terms) is an integer atomic on a 2^-24
 // fixed-point image of the addend (ppo_kernels.hpp: fixed_add), so its result does not depend on the order the atomics arrive in.  Those sums live
-// in a SECOND array of the shape of A (Afix, with bfix behind it); A itself only ever receives the factorisation's own writes, which are plain
-// stores in a fixed order.  The consumer converts on load: the first launch that finds a column block FINAL (all its pair chunks reduced:
-// block < fin[k]) adds the converted image to what the trailing updates have left in A so far ("fold"), and the very first touch of a tile -- launch
-// 0 for block column 0 and the right-hand side, launch 1 for everything else -- does not read A at all, so A needs no clearing between solves.
-// The overlapped reduction therefore works unchanged in this mode (integer adds commute with everything), no tile takes atomic updates, and no
-// conversion launch stands between the reduction and the factorisation.
+// in a SECOND array of the shape of A (Afix, with bfix behind it).  A column block is OPEN for launch k while pair workgroups may still add to it
+// (block >= fin[k]): the trailing update of an open tile is added to Afix as well -- the factorisation's own terms rounded to the same 2^-24 grid,
+// integer atomics, still exact and order-free -- so that everything an open block has received lies in ONE place.  The first launch that finds the
+// block final FOLDS it: the workgroup that owns a tile takes conv(Afix) as the tile's value (it never reads A: A needs no clearing between solves),
+// applies its update and stores doubles into A; from then on the block lives in A like in the floating-point mode.  One load per tile in every launch,
+// whatever the schedule.  (A first version kept the trailing updates of open tiles in A and added conv(Afix) on top at the fold: a launch that folded
+// its own column block then requested both arrays in the prologue of the chain -- every launch of a schedule that runs at its minimum fin[k] = k + 1,
+// 7 of the 10 launches at the 100-keyframe BASELINE configuration: 4 526 against 4 750 LM iterations/s in the floating-point mode.)
 struct StepFix {
   const long long* Afix;  // [ld][ld] column-major, lower triangle; NULL: floating-point accumulation (nothing below applies)
   const long long* bfix;  // [ld]
   double* detbad;         // raised by a pair workgroup whose addend does not fit the fixed-point range
-  int fold_lo, fold_hi;   // column blocks [fold_lo, fold_hi) are folded by this launch
+  int fold_lo, fold_hi;   // column blocks [fold_lo, fold_hi) are folded by this launch; blocks >= fold_hi are open (updates go to Afix / bfix), blocks < fold_lo live in A
 };
 constexpr double kStepFixScale = 16777216.0, kStepFixInv = 1.0 / 16777216.0;  // (= kFixScale / kFixInv of ppo_kernels.hpp)
 // (v * 2^-24 rounded once, as (double)v * 2^-24 is -- written as hi * 2^8 + lo * 2^-24 in ONE fused multiply-add: four instructions instead of the five
@@ -587,11 +589,11 @@ __device__ __forceinline__ void inv_block_wg(const double* __restrict__ A, int l
 
 // OV = false: the launch carries no pair workgroups and no tile takes atomic updates (ov is not read) -- the plain factorisation and the
 // later launches of an overlapped one; as ONE kernel the pair code's registers (240 against 182) and arguments cost every launch 0.4 us.
-// FX (deterministic mode, StepFix): 0 floating-point accumulation; 1 the trailing tiles and the right-hand-side rows of the column blocks
-// [fx.fold_lo, fx.fold_hi) fold their fixed-point image in, pair workgroups add integers; 2 also the column workgroups' own column block (k0 / 64) is
-// in that range -- a variant of its own because its extra requests sit in the prologue of the chain (only when the schedule runs at its minimum
-// fin[k - 1] == k); 3 launches 0 and 1: the own column block is folded AND this is its first touch -- the diagonal tile and the own half are
-// requested from the fixed-point array INSTEAD of A (the same number of requests in the prologue as a plain step).
+// FX (deterministic mode, StepFix): 0 floating-point accumulation; 1 trailing tiles and right-hand-side rows are open / folded / in A by their column
+// block (runtime ranges), pair workgroups add integers, the column workgroups' own block (k0 / 64) lives in A already; 3 the own column block is
+// folded by THIS launch (launches 0 and 1 always; later ones when the schedule runs at its minimum fin[k - 1] == k): the diagonal tile, the own half
+// and the block's right-hand-side rows are requested from the fixed-point arrays INSTEAD of A -- the same number of requests in the prologue of the
+// chain as a plain step.
 template <bool OV, int FX = 0>
 __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word, int gate_expect, double* __restrict__ A, int ld, int k0, const double* rhs_in, double* rhs, double* xout,
                                                             int* __restrict__ info, int inplace_rhs, double* __restrict__ inv, StepOverlap ov, StepFix fx) {
@@ -648,24 +650,27 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     load_tile_nt<NT>(&A[(size_t)kp * ld + r0], ld, tp);
     load_tile_nt<NT>(&A[(size_t)kp * ld + c0], ld, tq);
     double cold[2][2][4] = {};  // old values of the output quadrant, fetched while the panel tiles land (compute waves)
+    [[maybe_unused]] bool open_out = false;  // deterministic mode: the tile's column block is still open -- its update goes to Afix as integers
     if constexpr (FX != 0) {
-      // launch 1 is the first touch of every trailing tile: what lies in A is left over from the previous solve and is not read
-      const bool first = k0 == NB, fold = cblk >= fx.fold_lo && cblk < fx.fold_hi;
-      if (tid < 256 && !first) {
+      open_out = cblk >= fx.fold_hi;
+      const bool fold = !open_out && cblk >= fx.fold_lo;
+      if (tid < 256 && !open_out) {  // a folded tile starts from conv(Afix) (A is not read: nothing of the previous solve survives), a tile in A from A
+        // (ONE stream of sixteen requests from a base chosen once -- written as `fold ? fix2d(Afix[at]) : A[at]` the compiler made it sixteen branches, each
+        //  with its own load and its own wait: sixteen memory round trips in a row, 14.4 us for a launch whose chain takes 13.2)
+        const long long* const src = fold ? fx.Afix : reinterpret_cast<const long long*>(A);
+        long long raw[2][2][4];
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc)
 #pragma unroll
           for (int ir = 0; ir < 2; ++ir)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) cold[jc][ir][reg] = A[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li];
-      }
-      if (tid < 256 && fold) {
+            for (int reg = 0; reg < 4; ++reg) raw[jc][ir][reg] = src[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li];
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc)
 #pragma unroll
           for (int ir = 0; ir < 2; ++ir)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) cold[jc][ir][reg] += fix2d(fx.Afix[(size_t)(c0 + wc + 16 * jc + lk + 4 * reg) * ld + r0 + wr + 16 * ir + li]);
+            for (int reg = 0; reg < 4; ++reg) cold[jc][ir][reg] = fold ? fix2d(raw[jc][ir][reg]) : __longlong_as_double(raw[jc][ir][reg]);
       }
     } else
     if (tid < 256 && !atomic_out) {
@@ -689,6 +694,25 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
 #if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND)
     quadrant_product(sP, sQ, wr, wc, li, lk, acc);  // (a pair launch's trailing tiles take a rank-128 update)
 #endif
+    if constexpr (FX != 0) {
+      if (open_out) {  // (the same 2^-24 grid as every other term of the open block: exact integer adds, any order)
+        unsigned long long* const Ai = reinterpret_cast<unsigned long long*>(const_cast<long long*>(fx.Afix));
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+          for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int c = wc + 16 * jc + lk + 4 * reg, r = wr + 16 * ir + li;
+              const double v = -acc[jc][ir][reg];
+              if (bi != bj || r >= c) {
+                if (!(fabs(v) < 4.0e11)) *fx.detbad = 1.0;
+                else atomicAdd(&Ai[(size_t)(c0 + c) * ld + r0 + r], (unsigned long long)__double2ll_rn(v * kStepFixScale));
+              }
+            }
+        return;
+      }
+    }
     if (atomic_out) {  // (16 lanes -> 16 consecutive rows of one column: one cache line per quarter wave)
 #pragma unroll
       for (int jc = 0; jc < 2; ++jc)
@@ -729,6 +753,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
   // step 0 takes the right-hand side from rhs_in (the caller's b stays intact), later steps continue in rhs
   const double* rsrc = (k0 == 0) ? rhs_in : rhs;
   double rold = 0.0;  // the right-hand-side entry this thread updates at the end (threads 8 r of a row-half workgroup)
+  [[maybe_unused]] bool rhs_open = false;  // (deterministic mode: its row block is still open -- the update goes to bfix as an integer)
   {
     // Everything is requested unconditionally and back to back (what is not needed aliases the diagonal tile): with the
     // loads under `if`s the compiler drained each group before issuing the next, four memory round trips in a row.
@@ -741,9 +766,9 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     const double* pB = own ? &A[(size_t)k0 * ld + row0] : pC;
     const double* pP = uo ? &A[(size_t)kp * ld + row0] : pC;  // L[k+b][k-1]
     STAMP(15);
-    [[maybe_unused]] longlong2 fd[NI], fb[NI / 2];  // (FX >= 2: fixed-point images of the diagonal tile and of the own half, converted behind the requests)
-    const long long* fC = FX >= 2 ? &fx.Afix[(size_t)k0 * ld + k0] : nullptr;
-    const long long* fB = FX >= 2 ? (own ? &fx.Afix[(size_t)k0 * ld + row0] : fC) : nullptr;
+    [[maybe_unused]] longlong2 fd[NI], fb[NI / 2];  // (FX == 3: fixed-point images of the diagonal tile and of the own half, converted behind the requests)
+    const long long* fC = FX == 3 ? &fx.Afix[(size_t)k0 * ld + k0] : nullptr;
+    const long long* fB = FX == 3 ? (own ? &fx.Afix[(size_t)k0 * ld + row0] : fC) : nullptr;
     if constexpr (FX == 3) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -756,7 +781,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     STAMP(16);
     load_tile_nt<NT>(pQ, ld, tq);
     STAMP(17);
-    double rv = (tid < NB) ? rsrc[k0 + tid] : 0.0;
+    double rv = (tid < NB) ? (FX == 3 ? fix2d(fx.bfix[k0 + tid]) : rsrc[k0 + tid]) : 0.0;
 #pragma unroll
     for (int i = 0; i < NI / 2; ++i) {  // the own half: 32 rows x 64 columns, 16 d2 per column
       const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
@@ -764,27 +789,11 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
       else tb[i] = *reinterpret_cast<const d2*>(&pB[(size_t)c * ld + r]);
       tp[i] = *reinterpret_cast<const d2*>(&pP[(size_t)c * ld + r]);
     }
-    if constexpr (FX == 2) {
-      // deterministic mode, this launch folds its own column block: the fixed-point images of the diagonal tile and of the own half (and of this
-      // block's right-hand-side rows) on top of what the trailing updates have left in A
+    if constexpr (FX == 3) {  // the own column block is folded here: everything it has received lies in the fixed-point arrays
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int p = tid + NT * i;
-        fd[i] = *reinterpret_cast<const longlong2*>(&fC[(size_t)(p >> 5) * ld + 2 * (p & 31)]);
-      }
+      for (int i = 0; i < NI; ++i) td[i] = d2v(fix2d(fd[i].x), fix2d(fd[i].y));
 #pragma unroll
-      for (int i = 0; i < NI / 2; ++i) {
-        const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
-        fb[i] = *reinterpret_cast<const longlong2*>(&fB[(size_t)c * ld + r]);
-      }
-    }
-    if constexpr (FX >= 2) {
-      const double rf = (tid < NB) ? fix2d(fx.bfix[k0 + tid]) : 0.0;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) td[i] = FX == 3 ? d2v(fix2d(fd[i].x), fix2d(fd[i].y)) : td[i] + d2v(fix2d(fd[i].x), fix2d(fd[i].y));
-#pragma unroll
-      for (int i = 0; i < NI / 2; ++i) tb[i] = FX == 3 ? d2v(fix2d(fb[i].x), fix2d(fb[i].y)) : tb[i] + d2v(fix2d(fb[i].x), fix2d(fb[i].y));
-      rv = (k0 == 0) ? rf : rv + rf;  // (launch 0 is the first touch of the right-hand side)
+      for (int i = 0; i < NI / 2; ++i) tb[i] = d2v(fix2d(fb[i].x), fix2d(fb[i].y));
     }
 #if defined(PPO_BA_TEST_HOOKS) && defined(PPO_CHOL_EXPERIMENT_PAIR_BOUND) && PPO_CHOL_EXPERIMENT_PAIR_BOUND == 3
     d2 tx[2 * NI];  // (timing experiment: what a real pair launch must also pull through this CU -- block row k+1's tile and its previous-panel rows, 64 KB)
@@ -797,12 +806,13 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
 #endif
     rold = rsrc[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0];  // (for the very end: requested here, not there; unconditional like the others)
     if constexpr (FX != 0) {
-      // the right-hand-side rows of block k + b: launch 0 is their first touch; folded with their column block.  (The request is unconditional like
-      // every other of this prologue: a load under an `if` makes the compiler drain the requests in front of it first.)
+      // the right-hand-side rows of block k + b follow their column block: open -> the update is added to bfix as an integer; folded by this launch ->
+      // they start from conv(bfix); else they live in `rhs`.  (The bfix request is unconditional like every other of this prologue: a load under an `if`
+      // makes the compiler drain the requests in front of it first.)
       const int rblk = row0 / NB;
       const double rf = fix2d(fx.bfix[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0]);
-      if (k0 == 0) rold = 0.0;
-      if (own && rblk >= fx.fold_lo && rblk < fx.fold_hi) rold += rf;
+      rhs_open = own && rblk >= fx.fold_hi;
+      if (own && !rhs_open && rblk >= fx.fold_lo) rold = rf;
     }
     if (STEP_DEAD()) return;  // (everything above is a request; nothing has been written)
     STAMP(6);
@@ -965,7 +975,14 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     sacc += __shfl_xor(sacc, 2, 64);
     sacc += __shfl_xor(sacc, 4, 64);
     if ((tid & 7) == 0) {
-      if (FX == 0 && inplace_rhs) atomicAdd(&rhs[row0 + myrow], -sacc);  // (overlapped reduction: the pair workgroups may be adding to this row too)
+      if constexpr (FX != 0) {
+        if (rhs_open) {
+          if (!(fabs(sacc) < 4.0e11)) *fx.detbad = 1.0;
+          else atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<long long*>(fx.bfix)) + row0 + myrow, (unsigned long long)__double2ll_rn(-sacc * kStepFixScale));
+        } else {
+          rhs[row0 + myrow] = rold - sacc;
+        }
+      } else if (inplace_rhs) atomicAdd(&rhs[row0 + myrow], -sacc);  // (overlapped reduction: the pair workgroups may be adding to this row too)
       else rhs[row0 + myrow] = rold - sacc;
     }
   }
@@ -1292,15 +1309,13 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
         // overlapped (ov == NULL): every block is final from the start.
         const int fin_k = ov ? ov->fin[k] : nb, fin_km1 = (ov && k > 0) ? ov->fin[k - 1] : nb;
         StepFix fx{fixed->Afix, fixed->bfix, fixed->detbad, k == 0 ? 0 : (k == 1 ? 1 : fin_km1), k == 0 ? 1 : fin_k};
-        const int mode = (k >= fx.fold_lo && k < fx.fold_hi) ? (k <= 1 ? 3 : 2) : 1;  // (launches 0 and 1 always fold their own block, as its first touch)
+        const int mode = (k >= fx.fold_lo && k < fx.fold_hi) ? 3 : 1;  // (launches 0 and 1 always fold their own block; later ones when fin[k - 1] == k)
 #define PPO_STEP_FX(OV_, FX_) hipLaunchKernelGGL((chol_step_t<OV_, FX_>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx)
         if (o.npair_wg > 0) {
           if (mode == 3) PPO_STEP_FX(true, 3);
-          else if (mode == 2) PPO_STEP_FX(true, 2);
           else PPO_STEP_FX(true, 1);
         } else {
           if (mode == 3) PPO_STEP_FX(false, 3);
-          else if (mode == 2) PPO_STEP_FX(false, 2);
           else PPO_STEP_FX(false, 1);
         }
 #undef PPO_STEP_FX

@@ -234,7 +234,9 @@ def test_one_launch_solve_of_small_systems_against_the_panel_path(hip_hooks, mon
         s.reset()
         runs[mode] = (s.run(), s.read())
         s.close()
-    assert np.abs(xs["192"] - xs["0"]).max() <= 1e-10 * np.abs(xs["0"]).max()
+    # (deterministic mode: on the panel path the trailing updates of column blocks that are still open go to the fixed-point array -- rounded to its 2^-24 grid like
+    #  every other term there, csrc/ppo_chol.hip: StepFix -- which the one-launch kernel, with nothing open, does not do: measured 1.2e-10 / 2.0e-10 at 174 / 192 unknowns)
+    assert np.abs(xs["192"] - xs["0"]).max() <= (1e-9 if det else 1e-10) * np.abs(xs["0"]).max()
     (ta, ra), (tb, rb) = runs["192"], runs["0"]
     assert [i["trials"] for i in ta["iters"]] == [i["trials"] for i in tb["iters"]]
     assert abs(ta["iters"][-1]["chi2_after"] - tb["iters"][-1]["chi2_after"]) <= 1e-6 * tb["iters"][-1]["chi2_after"]
