@@ -441,8 +441,8 @@ __host__ __device__ inline StepOverlap step_no_overlap(int nb) {
 // its own column block then requested both arrays in the prologue of the chain -- every launch of a schedule that runs at its minimum fin[k] = k + 1,
 // 7 of the 10 launches at the 100-keyframe BASELINE configuration: 4 526 against 4 750 LM iterations/s in the floating-point mode.)
 struct StepFix {
-  const long long* Afix;  // [ld][ld] column-major, lower triangle; NULL: floating-point accumulation (nothing below applies)
-  const long long* bfix;  // [ld]
+  const long long* Afix;  // [ld][ld] column-major, lower triangle; NULL: floating-point accumulation (nothing below applies).  (The kernel takes both
+  const long long* bfix;  // [ld]  arrays through its preloaded `rhs_in` argument -- bfix == Afix + ld * ld --, these two members document the launch.)
   double* detbad;         // raised by a pair workgroup whose addend does not fit the fixed-point range
   int fold_lo, fold_hi;   // column blocks [fold_lo, fold_hi) are folded by this launch; blocks >= fold_hi are open (updates go to Afix / bfix), blocks < fold_lo live in A
 };
@@ -599,6 +599,12 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
                                                             int* __restrict__ info, int inplace_rhs, double* __restrict__ inv, StepOverlap ov, StepFix fx) {
   constexpr int NT = kStepThreads, NI = 2048 / NT;
   __shared__ StepLdsU lds;
+  // deterministic mode: the fixed-point arrays arrive through `rhs_in` (unused there: the right-hand side starts from bfix) -- one of the kernel arguments
+  // that are PRELOADED into scalar registers; as members of the StepFix aggregate at the end of the list they cost the column workgroups of a folding
+  // launch a scalar-load round trip in front of their first tile request (measured +1.4 us on a launch whose chain is the launch: 14.5 against 13.2 us).
+  // bfix lies right behind Afix (ld * ld entries), as b lies behind S.
+  [[maybe_unused]] const long long* const fxA = FX != 0 ? reinterpret_cast<const long long*>(rhs_in) : nullptr;
+  [[maybe_unused]] const long long* const fxb = FX != 0 ? fxA + (size_t)ld * ld : nullptr;
   // LM control on the device: the epoch word is REQUESTED here and looked at only where a workgroup is about to write -- for the column
   // workgroups (the chain) behind their tile requests, so that its latency hides behind theirs.  (Not gated: the word read is `info`, ignored.)
   // (two scalars in front of the argument list, not an LmGate: an aggregate argument ends the kernel-argument preload for everything behind it,
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
       if (tid < 256 && !open_out) {  // a folded tile starts from conv(Afix) (A is not read: nothing of the previous solve survives), a tile in A from A
         // (ONE stream of sixteen requests from a base chosen once -- written as `fold ? fix2d(Afix[at]) : A[at]` the compiler made it sixteen branches, each
         //  with its own load and its own wait: sixteen memory round trips in a row, 14.4 us for a launch whose chain takes 13.2)
-        const long long* const src = fold ? fx.Afix : reinterpret_cast<const long long*>(A);
+        const long long* const src = fold ? fxA : reinterpret_cast<const long long*>(A);
         long long raw[2][2][4];
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc)
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
 #endif
     if constexpr (FX != 0) {
       if (open_out) {  // (the same 2^-24 grid as every other term of the open block: exact integer adds, any order)
-        unsigned long long* const Ai = reinterpret_cast<unsigned long long*>(const_cast<long long*>(fx.Afix));
+        unsigned long long* const Ai = reinterpret_cast<unsigned long long*>(const_cast<long long*>(fxA));
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc)
 #pragma unroll
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
   const bool own = b > 0;
   const bool uo = own && updc;
   // step 0 takes the right-hand side from rhs_in (the caller's b stays intact), later steps continue in rhs
-  const double* rsrc = (k0 == 0) ? rhs_in : rhs;
+  const double* rsrc = (k0 == 0 && FX == 0) ? rhs_in : rhs;  // (deterministic mode: launch 0 takes the right-hand side from bfix, see below)
   double rold = 0.0;  // the right-hand-side entry this thread updates at the end (threads 8 r of a row-half workgroup)
   [[maybe_unused]] bool rhs_open = false;  // (deterministic mode: its row block is still open -- the update goes to bfix as an integer)
   {
@@ -767,8 +773,8 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     const double* pP = uo ? &A[(size_t)kp * ld + row0] : pC;  // L[k+b][k-1]
     STAMP(15);
     [[maybe_unused]] longlong2 fd[NI], fb[NI / 2];  // (FX == 3: fixed-point images of the diagonal tile and of the own half, converted behind the requests)
-    const long long* fC = FX == 3 ? &fx.Afix[(size_t)k0 * ld + k0] : nullptr;
-    const long long* fB = FX == 3 ? (own ? &fx.Afix[(size_t)k0 * ld + row0] : fC) : nullptr;
+    const long long* fC = FX == 3 ? &fxA[(size_t)k0 * ld + k0] : nullptr;
+    const long long* fB = FX == 3 ? (own ? &fxA[(size_t)k0 * ld + row0] : fC) : nullptr;
     if constexpr (FX == 3) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
     STAMP(16);
     load_tile_nt<NT>(pQ, ld, tq);
     STAMP(17);
-    double rv = (tid < NB) ? (FX == 3 ? fix2d(fx.bfix[k0 + tid]) : rsrc[k0 + tid]) : 0.0;
+    double rv = (tid < NB) ? (FX == 3 ? fix2d(fxb[k0 + tid]) : rsrc[k0 + tid]) : 0.0;
 #pragma unroll
     for (int i = 0; i < NI / 2; ++i) {  // the own half: 32 rows x 64 columns, 16 d2 per column
       const int p = tid + NT * i, c = p >> 4, r = 32 * half + 2 * (p & 15);
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
       // they start from conv(bfix); else they live in `rhs`.  (The bfix request is unconditional like every other of this prologue: a load under an `if`
       // makes the compiler drain the requests in front of it first.)
       const int rblk = row0 / NB;
-      const double rf = fix2d(fx.bfix[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0]);
+      const double rf = fix2d(fxb[own ? row0 + 32 * half + ((tid & 255) >> 3) : k0]);
       rhs_open = own && rblk >= fx.fold_hi;
       if (own && !rhs_open && rblk >= fx.fold_lo) rold = rf;
     }
@@ -978,7 +984,7 @@ __global__ __launch_bounds__(kStepThreads) void chol_step_t(const int* gate_word
       if constexpr (FX != 0) {
         if (rhs_open) {
           if (!(fabs(sacc) < 4.0e11)) *fx.detbad = 1.0;
-          else atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<long long*>(fx.bfix)) + row0 + myrow, (unsigned long long)__double2ll_rn(-sacc * kStepFixScale));
+          else atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<long long*>(fxb)) + row0 + myrow, (unsigned long long)__double2ll_rn(-sacc * kStepFixScale));
         } else {
           rhs[row0 + myrow] = rold - sacc;
         }
@@ -1310,7 +1316,7 @@ int enqueue_all(double* A, int ld, const double* b, double* x, int* info, double
         const int fin_k = ov ? ov->fin[k] : nb, fin_km1 = (ov && k > 0) ? ov->fin[k - 1] : nb;
         StepFix fx{fixed->Afix, fixed->bfix, fixed->detbad, k == 0 ? 0 : (k == 1 ? 1 : fin_km1), k == 0 ? 1 : fin_k};
         const int mode = (k >= fx.fold_lo && k < fx.fold_hi) ? 3 : 1;  // (launches 0 and 1 always fold their own block; later ones when fin[k - 1] == k)
-#define PPO_STEP_FX(OV_, FX_) hipLaunchKernelGGL((chol_step_t<OV_, FX_>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, y, y, x, info, 0, inv, o, fx)
+#define PPO_STEP_FX(OV_, FX_) hipLaunchKernelGGL((chol_step_t<OV_, FX_>), grid, dim3(kStepThreads), 0, s, gate.epoch_word, gate.expect, A, ld, k0, reinterpret_cast<const double*>(fixed->Afix), y, x, info, 0, inv, o, fx)
         if (o.npair_wg > 0) {
           if (mode == 3) PPO_STEP_FX(true, 3);
           else PPO_STEP_FX(true, 1);
@@ -1372,7 +1378,7 @@ int chol_factor_solve_overlapped(double* A, int ld, double* x, int* info, double
 // Deterministic mode (StepFix): the system was summed as fixed-point integers into fixed.Afix / fixed.bfix; A is the factorisation's own array and
 // needs no initialisation.  ov (may be NULL): an overlapped reduction whose pair workgroups add to the fixed-point arrays (ov->ctx.S == Afix).
 int chol_factor_solve_fixed(double* A, int ld, double* x, int* info, double* ws, const CholFixed& fixed, const CholOverlap* ov, LmGate gate, hipStream_t stream, int n_active) {
-  if (ld % NB != 0 || kStepThreads != 512 || !fixed.Afix || !fixed.bfix || (ov && (!ov->fin || !ov->cb_start))) return PPO_BA_ERR_ARG;
+  if (ld % NB != 0 || kStepThreads != 512 || !fixed.Afix || fixed.bfix != fixed.Afix + (size_t)ld * ld || (ov && (!ov->fin || !ov->cb_start))) return PPO_BA_ERR_ARG;
   if (ld == 0) return PPO_BA_OK;
   return enqueue_all(A, ld, nullptr, x, info, ws, stream, ov, gate, n_active, &fixed);
 }
