@@ -1334,7 +1334,11 @@ def test_overlapped_reduction_solves_the_same_system_on_randomly_structured_wind
         for x in xs[1:]:
             dev = np.linalg.norm(x - xs[0]) / np.linalg.norm(xs[0])
             worst = max(worst, dev)
-            assert dev < 1e-9, (cfg, kw, elim, dev)
+            # (deterministic mode: a trailing update that reaches a column block while it is still open goes to the fixed-point array, i.e. is rounded to its 2^-24
+            #  grid like every other term there -- which blocks are open when depends on the schedule.  With the cuboids kept in the dense system, lambda = 10, its
+            #  smallest diagonal entries are ~10: one grid step is 6e-9 of them.  Measured worst over these windows 8.3e-9; a pose update off by 1e-8 of its norm is
+            #  two orders below the 1e-7 noise of the delta = 1e-9 Jacobians that made the system)
+            assert dev < (2e-8 if det else 1e-9), (cfg, kw, elim, dev)
     print("worst relative deviation of the pose update: %.1e" % worst)
 
 
