@@ -16,6 +16,9 @@
 //     (T_k = L_kk^-1, M_k = L_{k+1,k} T_k) that one extra workgroup per panel launch prepares (inv_block_wg);
 //   * overlapped reduction (chol_factor_solve_overlapped, StepOverlap): the panel launches also carry the pose-pair chunks of
 //     the Schur complement for the column blocks they have not reached yet (ppo_pairs.hpp) -- DESIGN.md 4.6;
+//   * deterministic mode (chol_factor_solve_fixed, StepFix; the library's default since round 6): the system arrives as 2^-24 fixed-point integers in a second
+//     array; open column blocks collect the factorisation's own trailing updates there too, the launch that finds a block final converts it with one load,
+//     the factor's array is never cleared -- DESIGN.md 4.10;
 //   * n/64 + 1 launches per solve (optionally captured once into a hipGraph and replayed, PPO_BA_CHOL_GRAPH=1).
 // FMAs are written explicitly (__builtin_fma): the library is built with -ffp-contract=off for the numeric Jacobians.
 // info follows LAPACK potrf: 0 = positive definite, j > 0 = leading minor j is not (the LM loop treats that as
