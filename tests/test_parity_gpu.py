@@ -1288,15 +1288,20 @@ def test_overlapped_reduction_equals_the_plain_one(hip_hooks, monkeypatch, cfg, 
         assert np.mean(ra.mono_level != rb.mono_level) < 1e-4
 
 
-def _reduced_solution(hip_hooks, solver):
+def _reduced_solution(hip_hooks, solver, with_system=False):
     lib = hip_hooks.lib
     n = C.c_int32()
     lib.ppo_ba_debug_set_lambda.argtypes = [C.c_void_p, C.c_double]
     assert lib.ppo_ba_debug_set_lambda(solver.h, 10.0) == 0  # (of the order of the first lambda of these windows: 1e-5 max diag H)
     assert lib.ppo_ba_debug_reduced(solver.h, None, None, None, C.byref(n)) == 0
     x = np.zeros(n.value)
-    assert lib.ppo_ba_debug_reduced(solver.h, None, None, x.ctypes.data_as(B.c_dp), None) == 0
-    return x
+    if not with_system:
+        assert lib.ppo_ba_debug_reduced(solver.h, None, None, x.ctypes.data_as(B.c_dp), None) == 0
+        return x
+    S = np.zeros((n.value, n.value))
+    b = np.zeros(n.value)
+    assert lib.ppo_ba_debug_reduced(solver.h, S.ctypes.data_as(B.c_dp), b.ctypes.data_as(B.c_dp), x.ctypes.data_as(B.c_dp), None) == 0
+    return x, S, b
 
 
 @pytest.mark.parametrize("det", [1, 0], ids=["deterministic", "atomics"])
@@ -1305,7 +1310,8 @@ def test_overlapped_reduction_solves_the_same_system_on_randomly_structured_wind
     reduction and through the overlapped one (test hook PPO_BA_DEBUG_OVERLAP), on windows of random size and composition that the
     overlapped path would not normally take (two to six 64-column blocks; fixed points, fixed observers, stereo, planes with vertical /
     parallel edges, cuboids with corners, empty classes, both elimination modes -- tools/random_sweep.py) and on configurations 3 and 4:
-    the pose updates agree to 1e-9 of their norm, in every schedule."""
+    the pose updates agree to 1e-9 of their norm in every schedule (floating-point sums); in deterministic mode every schedule solves a system within
+    the rounding of the fixed-point grid of the plain one (bound derived below) and the pose updates agree to 2e-7."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("random_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "random_sweep.py"))
     rs = importlib.util.module_from_spec(spec)
@@ -1317,7 +1323,7 @@ def test_overlapped_reduction_solves_the_same_system_on_randomly_structured_wind
         cfg["n_points"] *= 3
         cases.append((cfg, kw, elim))
     cases += [("cfg3", dict(seed=3, stereo_frac=0.25, with_corners=True, fixed_observer_frac=0.1), 1), ("cfg4", dict(seed=1), 1), ("cfg4", dict(seed=2), 0)]
-    worst = 0.0
+    worst = worst_fill = 0.0
     for cfg, kw, elim in cases:
         P = synth.make_problem(cfg, **kw)
         xs = []
@@ -1328,17 +1334,38 @@ def test_overlapped_reduction_solves_the_same_system_on_randomly_structured_wind
             else:
                 monkeypatch.delenv("PPO_BA_DEBUG_OVERLAP", raising=False)
             s = hip_hooks.create(P, B.default_options(eliminate_cuboids=elim, deterministic=det))
-            xs.append(_reduced_solution(hip_hooks, s))
+            if dbg is None and det:
+                x0, S0, b0 = _reduced_solution(hip_hooks, s, with_system=True)
+                xs.append(x0)
+            else:
+                xs.append(_reduced_solution(hip_hooks, s))
             s.close()
         assert np.all(np.isfinite(xs[0])) and np.linalg.norm(xs[0]) > 0
         for x in xs[1:]:
             dev = np.linalg.norm(x - xs[0]) / np.linalg.norm(xs[0])
             worst = max(worst, dev)
-            # (deterministic mode: a trailing update that reaches a column block while it is still open goes to the fixed-point array, i.e. is rounded to its 2^-24
-            #  grid like every other term there -- which blocks are open when depends on the schedule.  With the cuboids kept in the dense system, lambda = 10, its
-            #  smallest diagonal entries are ~10: one grid step is 6e-9 of them.  Measured worst over these windows 8.3e-9; a pose update off by 1e-8 of its norm is
-            #  two orders below the 1e-7 noise of the delta = 1e-9 Jacobians that made the system)
-            assert dev < (2e-8 if det else 1e-9), (cfg, kw, elim, dev)
+            if det:
+                # Deterministic mode: a trailing update that reaches a column block while that block is still OPEN (the reduction has not finished it) is added to
+                # the block's 2^-24 fixed-point image like every other term there, i.e. rounded to that grid by at most half a step; a block takes at most one such
+                # update per panel launch before it, and which blocks are open when is what the schedule decides.  So every overlapped schedule solves EXACTLY
+                # (up to the floating-point round-off of a Cholesky) a system (S + dS) x = b + db with |dS_ij|, |db_i| <= panels * 2^-25 -- checked here as a
+                # bound on the residual of its x against the plain schedule's S and b, row by row: |S x - b|_i <= eps (|x|_1 + 1) + round-off.
+                n = S0.shape[0]
+                panels = (n + 63) // 64
+                eps = panels * 2.0 ** -25
+                resid = np.abs(S0 @ x - b0).max()
+                roundoff = 8 * n * np.finfo(float).eps * np.abs(S0).max() * np.abs(x).max()
+                assert resid <= eps * (np.abs(x).sum() + 1.0) + roundoff, (cfg, kw, elim, resid, eps * (np.abs(x).sum() + 1.0), roundoff)
+                worst_fill = max(worst_fill, resid / (eps * (np.abs(x).sum() + 1.0) + roundoff))
+                # ... and what that does to the pose update (x' - x = S^-1 (S x' - b): the residual above times the conditioning of the window): with lambda = 10
+                # on a diagonal whose smallest entries are ~10, one grid step is 6e-9 of them.  Worst over these 33 windows x 3 schedules: 6.0e-8 of the update's
+                # norm (configuration 4 seed 2 with the cuboids kept in the dense system, 19 panels; 2.3e-8 on the random windows) -- the mode is bit-reproducible,
+                # so these numbers are the same in every run.  The noise of the delta = 1e-9 Jacobians that made the system is 1e-7.
+                assert dev < 2e-7, (cfg, kw, elim, dev)
+            else:
+                assert dev < 1e-9, (cfg, kw, elim, dev)
+    if det:
+        print("worst residual / its bound: %.2e" % worst_fill)
     print("worst relative deviation of the pose update: %.1e" % worst)
 
 
