@@ -40,14 +40,14 @@ extern "C" {
 #define PPO_API
 #endif
 
-#define PPO_BA_ABI_VERSION 2  /* 2: the 9-D camera-object edge (cub3d_*), th_cub3d_norm */
+#define PPO_BA_ABI_VERSION 3  /* 2: the 9-D camera-object edge (cub3d_*), th_cub3d_norm; 3: ppo_ba_stats.deterministic_fell_back, options.deterministic defaults to 1 */
 
 /* return codes: 0 ok, <0 error, >0 early termination */
 enum {
   PPO_BA_OK = 0,
   PPO_BA_ABORTED = 1,        /* *stop_flag became non-zero (Optimizer.cc:2723-2725, 2732-2734) */
   PPO_BA_ERR_ARG = -1,       /* null pointer, negative size, index out of range */
-  PPO_BA_ERR_NONFINITE = -2, /* NaN/Inf in the inputs; deterministic mode: a term of the first linearisation outside the fixed-point range */
+  PPO_BA_ERR_NONFINITE = -2, /* NaN/Inf in the inputs */
   PPO_BA_ERR_NOMEM = -3,
   PPO_BA_ERR_HIP = -4,       /* no device, kernel or runtime failure */
   PPO_BA_ERR_SOLVER = -5,    /* dense factorisation backend failure (not "matrix not positive") */
@@ -196,6 +196,8 @@ typedef struct ppo_ba_options {
   int32_t deterministic;    /* 1 (default since round 6): every sum that crosses a wave adds 2^-24 fixed-point INTEGERS (exact, hence independent
                              * of the order the atomics arrive in): two runs on the same device and build give bit-identical results, like the
                              * single-threaded reference.  This is the mode every strict parity test runs and the mode bench.py times.
+                             * The integers cover +-4e11: a window with a FINITE term beyond that (the reference sums doubles and takes it) leaves
+                             * this mode at that linearisation and continues as deterministic = 0 (ppo_ba_stats.deterministic_fell_back).
                              * 0: the same sums as floating-point atomics (run-to-run differences ~1e-9 in chi2 that flat directions of a
                              * window amplify); ~1 % faster at the BASELINE size.  Any other value -> PPO_BA_ERR_ARG */
   int32_t solver;           /* PPO_SOLVER_* */
@@ -251,6 +253,11 @@ typedef struct ppo_ba_stats {
    * the events cost a few us each).  linearize = k_linearize_all (incl. speculated and repeated ones), schur = reduction to the
    * pose system, factor = dense factor + solve, backsub = landmark back-substitution + state update, chi2 = trial chi2 + publish */
   double ms_linearize, ms_schur, ms_factor, ms_backsub, ms_chi2;
+  /* 1: options.deterministic was set, but a finite term of a committed state's linearisation did not fit the fixed-point range (|v| >= 4e11):
+   * from that linearisation on -- and for the rest of the handle's life -- the sums are the floating-point atomics of deterministic = 0 (the reference
+   * sums doubles and takes such a window without complaint; nothing of the abandoned linearisation is used).  0 otherwise. */
+  int32_t deterministic_fell_back;
+  int32_t pad_;
 } ppo_ba_stats;
 
 /* caller-allocated output buffers; any pointer may be NULL to skip that output */

@@ -169,6 +169,7 @@ struct ppo_ba_solver {
   const volatile uint8_t* stop_ptr = nullptr;
   bool stop_agreed = false;
   bool acc_fixed = false;  // deterministic mode: acc[ACC_CHI2 / ACC_SCALE] currently hold fixed-point integers
+  bool fell_back = false;  // the handle has left the deterministic mode (leave_fixed_point)
 };
 
 namespace {
@@ -822,6 +823,25 @@ void frozen_iteration(ppo_ba_solver* s, int pass, int iteration) {
 // that copy is in flight the NEXT iteration's linearisation is already queued on the trial state (an accepted trial is
 // the common case), so the device never idles on the host's decision; a rejected trial re-linearises the kept state.
 // `may_speculate` is false on the last iteration of a pass (the outlier classification or the caller comes next).
+// Deterministic mode: a FINITE term of the linearisation of the COMMITTED state did not fit the fixed-point range (+-4e11 at 2^-24).  The reference sums
+// such a window in doubles without complaint (block_solver.hpp:461-481), so this is not an error: the handle leaves the deterministic mode for good
+// and the caller of this function linearises the same state again with floating-point sums (stats.deterministic_fell_back tells).  Nothing of the
+// abandoned attempt is used: both linearisation buffers and the accumulator block are cleared by the next launch_linearize, S by the next reduction.
+// (A TRIAL state whose linearisation does not fit is rejected like a failed factorisation -- k_decide / lm_iteration, info 1 << 29 -- and the pass goes on
+// from the kept state in the mode it is in.)  Sharded runs: the flags are summed over the ranks before anyone looks, so every rank leaves together.
+void leave_fixed_point(ppo_ba_solver* s) {
+  s->g.det = 0;
+  s->fell_back = true;
+  s->stats.deterministic_fell_back = 1;
+  s->acc_fixed = false;
+  s->fix_pending = false;
+  s->pending_fix = DecideFix{};
+  s->g.lin_raw = 0;
+  s->g.lin_tag_word = nullptr;
+  s->lin_valid = false;
+  s->S_is_zero = false;
+  s->lin_clean[0] = s->lin_clean[1] = false;
+}
 int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const volatile uint8_t* stop, ppo_ba_iter_stat& it) {
   const bool fresh = !s->lin_valid;
   const bool defer = s->g.det && !s->comm.active();  // (deterministic, one rank: the conversions ride in the hand-over launch, fetch_acc_enqueue)
@@ -834,11 +854,12 @@ int lm_iteration(ppo_ba_solver* s, int iteration, bool may_speculate, const vola
   double currentChi;
   if (fresh || iteration == 0) {
     RC_TRY(fetch_acc(s, false, iteration == 0));
-    // deterministic mode: a finite addend of THIS linearisation (the committed state) did not fit the fixed-point range -- its system is
-    // incomplete and there is no earlier state to fall back to
     currentChi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
     if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) currentChi = std::numeric_limits<double>::quiet_NaN();  // (a non-finite term of chi2: NaN in the reference's arithmetic -- frozen, below)
-    else if (s->g.det && s->h_pinned[ACC_DETRANGE] != 0.0) return PPO_BA_ERR_NONFINITE;
+    else if (s->g.det && s->h_pinned[ACC_DETRANGE] != 0.0) {  // a finite addend of THIS linearisation (the committed state) did not fit the fixed-point range
+      leave_fixed_point(s);
+      return lm_iteration(s, iteration, may_speculate, stop, it);  // (once: g.det is 0 now)
+    }
   } else {
     currentChi = s->chi_cur;  // computeActiveErrors of the state the previous trial produced (levenberg.cpp:72-75)
   }
@@ -1061,7 +1082,10 @@ struct SolverDev {
     RC_TRY(fetch_acc(s, false));
     m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
     if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) m.chi_cur = m.ini_chi = std::numeric_limits<double>::quiet_NaN();
-    else if (s->g.det && s->h_pinned[ACC_DETRANGE] != 0.0) return PPO_BA_ERR_NONFINITE;
+    else if (s->g.det && s->h_pinned[ACC_DETRANGE] != 0.0) {
+      leave_fixed_point(s);
+      return relinearize(m);
+    }
     hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
     HIP_TRY(hipGetLastError());
     s->g.ctl = s->d_ctl.p;
@@ -1080,7 +1104,10 @@ int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
   RC_TRY(launch_linearize(s, -1, true, true, s->g.det != 0));  // (deterministic mode: converted by the hand-over launch of fetch_acc)
   RC_TRY(launch_maxdiag(s));
   RC_TRY(fetch_acc(s, false, true));
-  if (s->g.det && s->h_pinned[ACC_DETBAD] == 0.0 && s->h_pinned[ACC_DETRANGE] != 0.0) return PPO_BA_ERR_NONFINITE;  // (as lm_iteration: the committed state's system is incomplete, nothing to fall back to)
+  if (s->g.det && s->h_pinned[ACC_DETBAD] == 0.0 && s->h_pinned[ACC_DETRANGE] != 0.0) {  // (as lm_iteration: floating-point sums from here on)
+    leave_fixed_point(s);
+    return optimize_pipelined(s, pass, iterations);
+  }
   if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) {  // chi2 of the estimate is NaN: the window is frozen for this pass (frozen_iteration)
     s->lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
     s->ni = 2;
@@ -2120,6 +2147,7 @@ int ppo_ba_run(ppo_ba_handle s, const volatile uint8_t* stop, ppo_ba_stats* stat
   const int n_red = s->stats.n_reduced;
   std::memset(&s->stats, 0, sizeof(s->stats));
   s->stats.n_reduced = n_red;
+  s->stats.deterministic_fell_back = s->fell_back ? 1 : 0;  // (a handle that left the fixed-point sums stays out: leave_fixed_point)
   s->ph_used = 0;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {

@@ -71,6 +71,7 @@ class CStats(C.Structure):
         ("n_reduced", C.c_int32), ("n_active_edges_pass1", C.c_int32), ("n_active_edges_pass2", C.c_int32),
         ("wall_ms_total", C.c_double), ("wall_ms_pass1", C.c_double), ("wall_ms_pass2", C.c_double), ("wall_ms_classify", C.c_double),
         ("ms_linearize", C.c_double), ("ms_schur", C.c_double), ("ms_factor", C.c_double), ("ms_backsub", C.c_double), ("ms_chi2", C.c_double),
+        ("deterministic_fell_back", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -334,7 +335,7 @@ class Solver:
 def default_options(**over):
     """The reference's constants (comments on ppo_ba_options in include/ppo_ba.h)."""
     o = COptions()
-    o.abi_version = 2
+    o.abi_version = 3
     o.iters_pass1, o.iters_pass2 = 5, 10
     o.lm_tau, o.lm_max_trials, o.lm_lower, o.lm_upper = 1e-5, 10, 1.0 / 3.0, 2.0 / 3.0
     o.numeric_delta, o.jacobian_mode = 1e-9, 0

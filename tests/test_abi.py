@@ -55,7 +55,7 @@ def test_warmup_fails_loudly_without_a_gpu():
 
 def test_version_and_strerror():
     lib = B.load_library()
-    assert lib.ppo_ba_version() == 2  # 2: the 9-D camera-object edge (cub3d_*)
+    assert lib.ppo_ba_version() == 3  # 3: ppo_ba_stats.deterministic_fell_back, options.deterministic defaults to 1
     assert lib.ppo_ba_strerror(0) == b"ok"
     assert b"HIP" in lib.ppo_ba_strerror(-4)
 
@@ -77,7 +77,7 @@ def test_default_options_match_reference_constants():
 def test_struct_sizes_match_header():
     # sizes derived from the C declarations: guards against silent layout drift between header and ctypes mirror
     assert C.sizeof(B.CIterStat) == 4 * 4 + 3 * 8 + 2 * 4
-    assert C.sizeof(B.CStats) == 8 + 64 * C.sizeof(B.CIterStat) + 4 * 4 + 9 * 8
+    assert C.sizeof(B.CStats) == 8 + 64 * C.sizeof(B.CIterStat) + 4 * 4 + 9 * 8 + 2 * 4
     assert C.sizeof(B.CResult) == 24 * 8
     # ... and against the library itself: sizeof() of every ABI struct as the C compiler laid it out
     lib = B.load_library()

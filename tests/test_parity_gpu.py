@@ -584,18 +584,46 @@ def test_nan_residual_freezes_the_window_like_the_reference(oracle, hip, lm, det
     so.close(); sh.close()
 
 
-def test_out_of_range_term_is_an_error_in_deterministic_mode(hip):
-    """A FINITE term that does not fit the 2^-24 fixed-point range (+-4e11) cannot enter the integer sums: the deterministic mode reports it
-    (PPO_BA_ERR_NONFINITE, include/ppo_ba.h) instead of computing with an incomplete system; the floating-point-atomics mode takes the same window."""
-    P = synth.make_problem("small", seed=4)
-    info = P["mono_info"].copy(); info[0] = 1e16; P.set("mono_info", info)  # weight rho1 * Omega ~ 1e8, times J^2 ~ 1e5: beyond 4e11
-    sd = hip.create(P, B.default_options())
-    with pytest.raises(RuntimeError):
-        sd.run()
-    sd.close()
-    sa = hip.create(P, B.default_options(**ATOMICS))
-    assert len(sa.run()["iters"]) > 0
+@pytest.mark.parametrize("lm", [0, 1], ids=["lm-on-device", "lm-on-host"])
+def test_out_of_range_term_leaves_the_deterministic_mode(hip, lm):
+    """A FINITE term that does not fit the 2^-24 fixed-point range (+-4e11) cannot enter the integer sums.  The reference sums doubles and takes such a window,
+    so the handle leaves the deterministic mode at that linearisation and goes on with floating-point sums (ppo_ba_stats.deterministic_fell_back, include/ppo_ba.h).
+    The window: points only, every information matrix times 2^28 and every Huber width times 2^14 -- the SAME problem in other units (chi2, H, b, lambda all
+    scale by exactly 2^28), so it is as well conditioned as the original and its terms (J^2 Omega ~ 1e13) are out of range.  The handle that fell back follows
+    a handle created with deterministic = 0 (same schedule, chi2 history to 1e-7, poses to 1e-7), also on a second run after a reset, and ends where the
+    deterministic run of the unscaled window ends; a window whose terms fit never leaves."""
+    P0 = synth.make_problem(dict(n_kf=8, n_points=300, n_planes=0, n_cuboids=0), seed=4)
+    P = synth.make_problem(dict(n_kf=8, n_points=300, n_planes=0, n_cuboids=0), seed=4)
+    k = 2.0 ** 28
+    P.set("mono_info", P["mono_info"] * k)
+    P.set("mono_huber", P["mono_huber"] * 2.0 ** 14)
+    scaled = dict(lm_control=lm, chi2_mono=5.991 * k, chi2_stereo=7.815 * k)
+    sa = hip.create(P, B.default_options(**scaled, **ATOMICS))
+    sta = sa.run()
+    ra = sa.read()
     sa.close()
+    assert sta["deterministic_fell_back"] == 0 and len(sta["iters"]) > 0
+    s0 = hip.create(P0, B.default_options(lm_control=lm))
+    st0 = s0.run()
+    r0 = s0.read()
+    s0.close()
+    assert st0["deterministic_fell_back"] == 0
+    sd = hip.create(P, B.default_options(**scaled))
+    for rep in range(2):
+        std = sd.run()
+        rd = sd.read()
+        assert std["deterministic_fell_back"] == 1
+        assert [(i["trials"], i["accepted"]) for i in std["iters"]] == [(i["trials"], i["accepted"]) for i in sta["iters"]]
+        np.testing.assert_allclose([i["chi2_after"] for i in std["iters"]], [i["chi2_after"] for i in sta["iters"]], rtol=1e-7)
+        np.testing.assert_allclose(rd.pose_qt, ra.pose_qt, atol=1e-7)
+        np.testing.assert_allclose(rd.point_xyz, ra.point_xyz, atol=1e-6)
+        # ... and the unscaled window in deterministic mode: the same problem
+        assert [(i["trials"], i["accepted"]) for i in std["iters"]] == [(i["trials"], i["accepted"]) for i in st0["iters"]]
+        np.testing.assert_allclose([i["chi2_after"] / k for i in std["iters"]], [i["chi2_after"] for i in st0["iters"]], rtol=1e-7)
+        np.testing.assert_allclose(rd.pose_qt, r0.pose_qt, atol=1e-7)
+        np.testing.assert_array_equal(rd.mono_level, r0.mono_level)
+        sd.reset()
+    sd.close()
 
 
 def test_block_cache_survives_changing_shapes(oracle, hip):
