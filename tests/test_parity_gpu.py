@@ -584,6 +584,17 @@ def test_nan_residual_freezes_the_window_like_the_reference(oracle, hip, lm, det
     so.close(); sh.close()
 
 
+def _window_in_other_units():
+    """A points-only window, and the same window with every information matrix times 2^28 and every Huber width times 2^14 (chi2, H, b and lambda all scale by
+    exactly 2^28: the same problem, as well conditioned, with terms J^2 Omega ~ 1e13 -- beyond the fixed-point range); the options that go with the second."""
+    P0 = synth.make_problem(dict(n_kf=8, n_points=300, n_planes=0, n_cuboids=0), seed=4)
+    P = synth.make_problem(dict(n_kf=8, n_points=300, n_planes=0, n_cuboids=0), seed=4)
+    k = 2.0 ** 28
+    P.set("mono_info", P["mono_info"] * k)
+    P.set("mono_huber", P["mono_huber"] * 2.0 ** 14)
+    return P0, P, k, dict(chi2_mono=5.991 * k, chi2_stereo=7.815 * k)
+
+
 @pytest.mark.parametrize("lm", [0, 1], ids=["lm-on-device", "lm-on-host"])
 def test_out_of_range_term_leaves_the_deterministic_mode(hip, lm):
     """A FINITE term that does not fit the 2^-24 fixed-point range (+-4e11) cannot enter the integer sums.  The reference sums doubles and takes such a window,
@@ -592,12 +603,8 @@ def test_out_of_range_term_leaves_the_deterministic_mode(hip, lm):
     scale by exactly 2^28), so it is as well conditioned as the original and its terms (J^2 Omega ~ 1e13) are out of range.  The handle that fell back follows
     a handle created with deterministic = 0 (same schedule, chi2 history to 1e-7, poses to 1e-7), also on a second run after a reset, and ends where the
     deterministic run of the unscaled window ends; a window whose terms fit never leaves."""
-    P0 = synth.make_problem(dict(n_kf=8, n_points=300, n_planes=0, n_cuboids=0), seed=4)
-    P = synth.make_problem(dict(n_kf=8, n_points=300, n_planes=0, n_cuboids=0), seed=4)
-    k = 2.0 ** 28
-    P.set("mono_info", P["mono_info"] * k)
-    P.set("mono_huber", P["mono_huber"] * 2.0 ** 14)
-    scaled = dict(lm_control=lm, chi2_mono=5.991 * k, chi2_stereo=7.815 * k)
+    P0, P, k, scaled = _window_in_other_units()
+    scaled["lm_control"] = lm
     sa = hip.create(P, B.default_options(**scaled, **ATOMICS))
     sta = sa.run()
     ra = sa.read()
@@ -893,6 +900,27 @@ def test_landmark_sharding_gives_the_single_rank_answer(hip_hooks, cfg, kw, worl
     # every rank holds the same poses bit for bit (identical inputs to the redundant factorisation)
     for st, r in res[1:]:
         np.testing.assert_array_equal(r.pose_qt, res[0][1].pose_qt)
+
+
+def test_sharded_ranks_leave_the_deterministic_mode_together(hip_hooks):
+    """The out-of-range flags are summed over the ranks before any rank looks at them (csrc/ppo_solver.hip: fetch_acc_enqueue), so every rank leaves the fixed-point
+    sums at the same linearisation (leave_fixed_point) and the collectives stay matched: two ranks on the window of
+    test_out_of_range_term_leaves_the_deterministic_mode end where one rank ends, with the same schedule."""
+    hip = hip_hooks
+    _, P, _, scaled = _window_in_other_units()
+    s = hip.create(P, B.default_options(**scaled))
+    st1, r1 = s.run(), s.read()
+    s.close()
+    assert st1["deterministic_fell_back"] == 1
+    res = _run_sharded_in_process(hip, P, 2, key=7311, **scaled)
+    for st, r in res:
+        assert st["deterministic_fell_back"] == 1
+        assert [(i["trials"], i["accepted"], i["result"]) for i in st["iters"]] == [(i["trials"], i["accepted"], i["result"]) for i in st1["iters"]]
+        for a, b in zip(st["iters"], st1["iters"]):
+            assert abs(a["chi2_after"] - b["chi2_after"]) <= 1e-6 * abs(b["chi2_after"])
+        np.testing.assert_allclose(r.pose_qt, r1.pose_qt, atol=1e-7)
+        assert np.array_equal(r.mono_level, r1.mono_level)
+    np.testing.assert_array_equal(res[1][1].pose_qt, res[0][1].pose_qt)
 
 
 def _full_size_against_oracle(oracle, hip, P, with_spread, hip_only=None):
