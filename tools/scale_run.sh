@@ -6,10 +6,10 @@
 #   3. the same with options.solve_on_owner = 1 (reduce to rank 0, solve there, broadcast x)
 #   4. the weak-scaling configuration cfg5w (50 000 points per rank)
 # Every bench line carries config.multi_gpu (ms of the exchange steps of one solve attempt, timed alone) next to the headline rate.
-#   tools/scale_run.sh [round tag, default r05] [steps, default 20]
+#   tools/scale_run.sh [round tag, default r06] [steps, default 20]
 set -u
 cd "$(dirname "$0")/.."
-TAG=${1:-r05}
+TAG=${1:-r06}
 STEPS=${2:-20}
 OUT=profiles/${TAG}_scale.txt
 NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
