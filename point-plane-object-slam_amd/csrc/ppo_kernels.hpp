@@ -1632,7 +1632,25 @@ __device__ __forceinline__ void zero_ranges_body(const ZeroPlan& zp, size_t t0, 
 // (k_publish) Workgroup 0 hands the accumulator block and the factorisation flag to the host; when the next linearisation is
 // queued right behind (speculation), the remaining workgroups clear its accumulation ranges in the same launch and
 // workgroup 0 clears the accumulator block after copying it.
-__global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restrict__ info, double* host, unsigned long long seq, ZeroPlan zp) {
+// The head of a pass on the device (round 6, device LM control): the hand-over launch behind the first linearisation of a pass also INITIALISES the control
+// record -- lambda = tau * max diag H (computeLambdaInit, levenberg.cpp:166-180), chi2 of the estimate, _ni = 2, the epoch the first batch is queued under --
+// so that the host queues that batch without waiting for the numbers (it learns them from the mapped block like everything else; the queue used to sit idle
+// for ~24 us in front of k_ctl_set, twice per call).  The special cases of a head stay on the host: when a flag of the deterministic mode is up (a NaN chi2:
+// frozen window; a term out of range: the handle leaves the fixed-point sums) the record is NOT written, its epoch stays the old one, and everything the
+// host queued behind this launch finds itself dead; the host sees the flags with the first records it waits for (ppo_solver.hip: optimize_pipelined).
+struct HeadInit {
+  LmCtl* ctl;  // NULL: no head rides in this hand-over
+  LmCtl m;     // the record to write: everything but lambda, chi_cur, ini_chi
+  double tau;
+};
+__device__ __forceinline__ void head_init_record(const HeadInit& hi, double chi2, double maxdiag, double f_bad, double f_range) {
+  if (hi.ctl == nullptr || f_bad != 0.0 || f_range != 0.0) return;
+  LmCtl m = hi.m;
+  m.chi_cur = m.ini_chi = chi2 + m.cubpl;
+  m.lambda = hi.tau * maxdiag;
+  *hi.ctl = m;
+}
+__global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restrict__ info, double* host, unsigned long long seq, ZeroPlan zp, HeadInit hi) {
   const int t = threadIdx.x;
   if (blockIdx.x > 0) {
     zero_ranges_body(zp, (size_t)(blockIdx.x - 1) * 64 + t, (size_t)(gridDim.x - 1) * 64);
@@ -1642,6 +1660,8 @@ __global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restri
   __syncthreads();
   double v = 0.0;
   if (t < ACC_N) { v = acc[t]; host[t] = v; }
+  if (t == 0) head_init_record(hi, v, acc[ACC_MAXDIAG], acc[ACC_DETBAD], acc[ACC_DETRANGE]);
+  __syncthreads();  // (thread 0 has read the flags)
   if (t == ACC_DETBAD || t == ACC_DETRANGE) acc[t] = 0.0;  // deterministic mode: "an addend did not fit" has been handed over; armed again for the next launches
   if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
   __threadfence_system();
@@ -1653,7 +1673,7 @@ __global__ __launch_bounds__(64) void k_publish(double* acc, const int* __restri
 // Deterministic mode, one rank (round 6): the hand-over itself folds the INTEGER partial sums of chi2 and of the scale and converts them, and the other
 // workgroups of its launch turn the ranges a linearisation in front of it summed into back into doubles (DecideFix; tag_word == NULL: unconditionally) --
 // the k_fold_acc + two k_fix_to_double launches this mode used to put in front of every hand-over are gone.
-__global__ __launch_bounds__(256) void k_publish_fix(double* acc, const int* __restrict__ info, double* host, unsigned long long seq, DecideFix df) {
+__global__ __launch_bounds__(256) void k_publish_fix(double* acc, const int* __restrict__ info, double* host, unsigned long long seq, DecideFix df, HeadInit hi) {
   const int t = threadIdx.x;
   if (blockIdx.x > 0) {
     if (df.tag_word != nullptr && *df.tag_word != df.tag) return;
@@ -1674,6 +1694,8 @@ __global__ __launch_bounds__(256) void k_publish_fix(double* acc, const int* __r
   __threadfence();
   __syncthreads();
   if (t < ACC_N) host[t] = acc[t];
+  if (t == 0) head_init_record(hi, acc[ACC_CHI2], acc[ACC_MAXDIAG], acc[ACC_DETBAD], acc[ACC_DETRANGE]);
+  __syncthreads();  // (thread 0 has read the flags)
   if (t == ACC_DETBAD || t == ACC_DETRANGE) acc[t] = 0.0;  // handed over; armed again for the next launches
   if (t == ACC_N) host[ACC_N] = (double)(info ? *info : 0);
   __threadfence_system();

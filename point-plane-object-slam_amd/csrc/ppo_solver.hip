@@ -170,6 +170,11 @@ struct ppo_ba_solver {
   bool stop_agreed = false;
   bool acc_fixed = false;  // deterministic mode: acc[ACC_CHI2 / ACC_SCALE] currently hold fixed-point integers
   bool fell_back = false;  // the handle has left the deterministic mode (leave_fixed_point)
+  // device LM control: the head of a pass rides in the hand-over launch (ppo_kernels.hpp: HeadInit); the host has queued the first batch without
+  // looking at the numbers and looks when it first waits for records (head_arrived)
+  bool head_pending = false;
+  int head_special = 0;  // what head_arrived found: 0 nothing, 1 chi2 of the estimate is NaN (frozen window), 2 a term out of the fixed-point range
+  double head_chi = 0.0, head_lambda = 0.0;
 };
 
 namespace {
@@ -405,6 +410,8 @@ int reset_device(ppo_ba_solver* s) {
   s->have_system = false;
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->poisoned = false;  // (the stream has drained: whatever a timed-out batch had left queued is done, the next pass sets a fresh epoch)
+  s->head_pending = false;
+  s->head_special = 0;
   return PPO_BA_OK;
 }
 
@@ -709,7 +716,8 @@ int launch_update(ppo_ba_solver* s, double lambda) {
 
 // bring ACC_N accumulators (+ the factorisation info) to the host; sums over ranks first.  Split in two so that more work
 // can be queued behind the copy before the host blocks on it.
-int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false) {
+int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linearize = false, bool with_maxdiag = false, const HeadInit* head = nullptr) {
+  const HeadInit hi = head ? *head : HeadInit{};
   if (s->g.det && s->acc_fixed && !s->comm.active()) {
     // deterministic mode, one rank (round 6): ONE launch folds the integer sums, converts chi2 / scale, hands them over -- and its other workgroups
     // convert the ranges of a linearisation whose conversion was deferred to here (launch_linearize(..., defer_fix): s->pending_fix)
@@ -717,7 +725,7 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linea
     df.tag_word = nullptr;  // (the host queued that linearisation unconditionally: it ran)
     const size_t nconv = df.n[0] + df.n[1] + df.n[2] + df.n[3];
     const int nwg = nconv ? std::max(1, std::min(nblk((long)nconv, 1024), s->n_cu)) : 0;
-    hipLaunchKernelGGL(k_publish_fix, dim3(1 + nwg), dim3(256), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, df);
+    hipLaunchKernelGGL(k_publish_fix, dim3(1 + nwg), dim3(256), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, df, hi);
     s->pending_fix = DecideFix{};
     s->acc_fixed = false;
     (void)zero_for_next_linearize; (void)with_maxdiag;
@@ -742,7 +750,7 @@ int fetch_acc_enqueue(ppo_ba_solver* s, bool with_info, bool zero_for_next_linea
   }
   (void)zero_for_next_linearize;  // (the linearisation targets are double-buffered: nothing to clear behind the hand-over any more)
   ZeroPlan zp{};
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, zp);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s->stream, s->g.acc, (const int*)(with_info ? s->d_info.p : nullptr), s->h_pinned_dev, ++s->pub_seq, zp, hi);
   // (no event behind it: a hipEventRecord costs a 6-8 us bubble in the queue in front of the next kernel -- measured with
   //  tools/gap_report.py as idle time before k_reduce_stage1 in every iteration; the host's spin is backed up by the stream itself)
   return PPO_BA_OK;
@@ -1062,6 +1070,19 @@ int wait_for_records(ppo_ba_solver* s, unsigned long long seq) {
   return PPO_BA_OK;
 }
 // the device interface of lm_pipelined_pass (ppo_lm_host.hpp) on a solver
+// The head of a pipelined pass (HeadInit): the hand-over that initialised the control record on the device has arrived; what the host keeps of it, and whether the
+// device left the record alone (head_special: everything queued behind the head is dead then, optimize_pipelined takes it from there).
+constexpr int kHeadSpecial = 1001;  // wait_records: "the head did not start the pass" (not an error code: those are negative)
+int head_arrived(ppo_ba_solver* s) {
+  RC_TRY(fetch_acc_wait(s));
+  s->head_pending = false;
+  s->head_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
+  s->head_lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
+  s->head_special = 0;
+  if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) s->head_special = 1;
+  else if (s->g.det && s->h_pinned[ACC_DETRANGE] != 0.0) s->head_special = 2;
+  return PPO_BA_OK;
+}
 struct SolverDev {
   ppo_ba_solver* s;
   bool stop() { return stop_now(s); }
@@ -1072,7 +1093,13 @@ struct SolverDev {
     if (speculated) use_lin_buffer(s, s->lin_buf ^ 1);
   }
   int enqueue_trial(bool speculate, int n_publish, unsigned long long* seq) { return queue_trial(s, speculate, n_publish, seq); }
-  int wait_records(unsigned long long seq) { return wait_for_records(s, seq); }
+  int wait_records(unsigned long long seq) {
+    if (s->head_pending) {  // the first wait of a pass: the head's numbers first (they arrived long ago: the batch was queued behind them)
+      RC_TRY(head_arrived(s));
+      if (s->head_special) return kHeadSpecial;
+    }
+    return wait_for_records(s, seq);
+  }
   const double* record(unsigned long long seq) { return s->h_pinned + 16 + (seq % kRingSlots) * kRingSlotDoubles; }
   void set_epoch(int e) { s->epoch = e; s->g.epoch = e; }
   int restore_kept_errors() { return launch_chi2(s, s->st[s->cur]); }
@@ -1099,41 +1126,53 @@ struct SolverDev {
 };
 int optimize_pipelined(ppo_ba_solver* s, int pass, int iterations) {
   s->h_pinned[kStopMirror] = stop_now(s) ? 1.0 : 0.0;  // (the mirror the device reads: see wait_for_records)
-  // the head of the pass as lm_iteration does it: linearise the estimate, lambda from the largest diagonal entry (levenberg.cpp:166-180)
+  // The head of the pass as lm_iteration does it -- linearise the estimate, lambda from the largest diagonal entry (levenberg.cpp:166-180) -- except that the
+  // DEVICE writes the control record (HeadInit, riding in the hand-over launch) and the host queues the first batch right behind it.
   s->g.ctl = nullptr;
-  RC_TRY(launch_linearize(s, -1, true, true, s->g.det != 0));  // (deterministic mode: converted by the hand-over launch of fetch_acc)
+  LmCtl m{};  // the host's mirror of the record: what the device holds whenever nothing is queued (lambda, chi2: from the records, or from the head)
+  m.ni = 2;
+  m.cubpl = s->cubpl_rho_sum;
+  m.lm_upper = s->opt.lm_upper; m.lm_lower = s->opt.lm_lower;
+  m.max_trials = s->opt.lm_max_trials;
+  m.epoch = ++s->epoch;  // (larger than anything the record has held: a head that leaves the record alone leaves everything queued under this epoch dead)
+  const HeadInit head{s->d_ctl.p, m, s->opt.lm_tau};
+  RC_TRY(launch_linearize(s, -1, true, true, s->g.det != 0));  // (deterministic mode: converted by the hand-over launch)
   RC_TRY(launch_maxdiag(s));
-  RC_TRY(fetch_acc(s, false, true));
-  if (s->g.det && s->h_pinned[ACC_DETBAD] == 0.0 && s->h_pinned[ACC_DETRANGE] != 0.0) {  // (as lm_iteration: floating-point sums from here on)
-    leave_fixed_point(s);
-    return optimize_pipelined(s, pass, iterations);
-  }
-  if (s->g.det && s->h_pinned[ACC_DETBAD] != 0.0) {  // chi2 of the estimate is NaN: the window is frozen for this pass (frozen_iteration)
-    s->lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
+  RC_TRY(fetch_acc_enqueue(s, false, false, true, &head));
+  HIP_TRY(hipGetLastError());
+  s->head_pending = true;
+  s->head_special = 0;
+  s->g.ctl = s->d_ctl.p;
+  s->g.epoch = s->epoch;
+  int lookahead = kLookahead;
+  if (const char* e = PPO_DEV_ENV("PPO_BA_LOOKAHEAD")) lookahead = std::max(1, std::min(atoi(e), kLookahead));  // (A/B: 1 = a hand-over per trial)
+  SolverDev dev{s};
+  const TrialBook before = book_of(s);
+  const int trials0 = s->stats.n_trials;
+  int rc = lm_pipelined_pass(dev, pass, iterations, m, lookahead);  // (ppo_lm_host.hpp: the batch loop, also run on the CPU against a simulated device)
+  // (on an error return launches may still be queued: they are gated or harmless, the caller gives the handle up or resets it)
+  s->g.ctl = nullptr;
+  if (rc == PPO_BA_OK && s->head_pending) rc = head_arrived(s);  // (no batch was queued -- the stop flag, no iterations: the head's numbers all the same)
+  if ((rc == PPO_BA_OK || rc == kHeadSpecial) && s->head_special) {
+    // The device left the record alone: whatever was queued behind the head found its epoch missing and did nothing.  Drain it (rare path), take the
+    // bookkeeping back to the head, and do what the host-side head did in these cases.
+    const int what = s->head_special;
+    s->head_special = 0;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    restore_book(s, before);
+    if (what == 2) {  // a term of the estimate's linearisation out of the fixed-point range: floating-point sums from here on (as lm_iteration)
+      leave_fixed_point(s);
+      return optimize_pipelined(s, pass, iterations);
+    }
+    // chi2 of the estimate is NaN: the window is frozen for this pass (frozen_iteration)
+    s->lambda = s->head_lambda;
     s->ni = 2;
     s->nBad = 0;
     for (int i = 0; i < iterations && !stop_now(s); ++i) frozen_iteration(s, pass, i);
     s->lin_valid = false;
     return PPO_BA_OK;
   }
-  LmCtl m{};  // the host's mirror of the record: what the device holds whenever nothing is queued
-  m.chi_cur = m.ini_chi = s->h_pinned[ACC_CHI2] + s->cubpl_rho_sum;
-  m.lambda = s->opt.lm_tau * s->h_pinned[ACC_MAXDIAG];
-  m.ni = 2;
-  m.cubpl = s->cubpl_rho_sum;
-  m.lm_upper = s->opt.lm_upper; m.lm_lower = s->opt.lm_lower;
-  m.max_trials = s->opt.lm_max_trials;
-  m.epoch = ++s->epoch;
-  hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, s->stream, s->d_ctl.p, m);
-  HIP_TRY(hipGetLastError());
-  s->g.ctl = s->d_ctl.p;
-  s->g.epoch = s->epoch;
-  int lookahead = kLookahead;
-  if (const char* e = PPO_DEV_ENV("PPO_BA_LOOKAHEAD")) lookahead = std::max(1, std::min(atoi(e), kLookahead));  // (A/B: 1 = a hand-over per trial)
-  SolverDev dev{s};
-  const int rc = lm_pipelined_pass(dev, pass, iterations, m, lookahead);  // (ppo_lm_host.hpp: the batch loop, also run on the CPU against a simulated device)
-  // (on an error return launches may still be queued: they are gated or harmless, the caller gives the handle up or resets it)
-  s->g.ctl = nullptr;
+  if (s->stats.n_trials == trials0) { m.lambda = s->head_lambda; m.chi_cur = m.ini_chi = s->head_chi; }  // (no record came back: the mirror is the head)
   s->lambda = m.lambda; s->ni = m.ni; s->nBad = m.nbad; s->chi_cur = m.chi_cur;
   s->lin_valid = false;
   return rc;
